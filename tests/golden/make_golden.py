@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (it needs /root/reference); the GPU box and the
+test-suite only ever read the small .npz/.json files this script writes.  Nothing of
+the reference's source is copied: the reference modules are imported, driven with
+synthetic inputs, and their numeric outputs recorded.
+
+    python tests/golden/make_golden.py ops tiny init      # seconds
+    python tests/golden/make_golden.py traj64             # ~5 min
+    python tests/golden/make_golden.py traj128            # ~50 min (S=128, B=16, 100 steps)
+
+The reference's ``utils.py`` imports torchvision/torchfile at module top
+(reference utils.py:23-29) although the training step never uses them; both are
+absent here, so empty stand-in modules are registered before the import.  That is
+harness plumbing and touches nothing on the path being recorded.
+"""
+import json
+import os
+import sys
+import time
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REPO, "dwc-gan_amd", "hipdwc"))
+import synth  # noqa: E402  (the product's synthetic-batch generator; plain python, no HIP)
+
+warnings.filterwarnings("ignore")
+
+
+def import_reference():
+    for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchfile"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            if name == "torchfile":
+                m.load = lambda *a, **k: None
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.path.insert(0, REF)
+    import solver as ref_solver          # noqa
+    import networks.networks as ref_nets  # noqa
+    import networks.networks_v2 as ref_v2  # noqa
+    import gmm as ref_gmm                # noqa
+    import tools as ref_tools            # noqa
+    return ref_solver, ref_nets, ref_v2, ref_gmm, ref_tools
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def checksum(t):
+    t = t.detach().double()
+    return [float(t.sum()), float((t * t).sum())]
+
+
+LOSS_NAMES = ["loss_dis", "loss_dis_all", "loss_ds", "loss_gen_adv", "loss_gen_cycrecon_x",
+              "loss_gen_recon_c_fake", "loss_gen_recon_c_rand", "loss_gen_recon_c_real",
+              "loss_gen_recon_s_fake", "loss_gen_recon_s_rand", "loss_gen_recon_s_real",
+              "loss_gen_recon_x", "loss_gen_total", "loss_gen_vgg", "loss_kl_trg", "loss_kl_x"]
+
+
+def read_losses(trainer):
+    return {k: float(getattr(trainer, k)) for k in LOSS_NAMES}
+
+
+# ----------------------------------------------------------------------------------------
+# per-op goldens
+# ----------------------------------------------------------------------------------------
+def gen_ops(ref_nets, ref_gmm, ref_tools):
+    out = {}
+    g = torch.Generator().manual_seed(7)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g)
+
+    # (name, B, Cin, Cout, H, k, s, p, norm, act)
+    conv_cases = [
+        ("stem7_relu", 2, 3, 8, 12, 7, 1, 3, "none", "relu"),
+        ("down4_in_relu", 2, 8, 16, 12, 4, 2, 1, "in", "relu"),
+        ("res3_in_none", 2, 16, 16, 6, 3, 1, 1, "in", "none"),
+        ("res3_adain_relu", 3, 16, 16, 6, 3, 1, 1, "adain", "relu"),
+        ("up5_ln_relu", 3, 16, 8, 10, 5, 1, 2, "ln", "relu"),
+        ("up5_ln_relu_b1", 1, 16, 8, 10, 5, 1, 2, "ln", "relu"),
+        ("head7_tanh", 2, 8, 3, 12, 7, 1, 3, "none", "tanh"),
+        ("head7_sigmoid", 2, 8, 1, 12, 7, 1, 3, "none", "sigmoid"),
+        ("dis4_lrelu", 2, 3, 8, 12, 4, 2, 1, "none", "lrelu"),
+        ("dis4_lrelu_2x2", 2, 8, 8, 2, 4, 2, 1, "none", "lrelu"),
+    ]
+    for (name, B, ci, co, H, k, s, p, norm, act) in conv_cases:
+        blk = ref_nets.Conv2dBlock(ci, co, k, s, p, norm=norm, activation=act, pad_type="reflect")
+        with torch.no_grad():
+            blk.conv.weight.copy_(rnd(co, ci, k, k) * 0.2)
+            blk.conv.bias.copy_(rnd(co) * 0.1)
+            if norm == "ln":
+                blk.norm.gamma.copy_(torch.rand(co, generator=g))
+                blk.norm.beta.copy_(rnd(co) * 0.1)
+        x = rnd(B, ci, H, H).requires_grad_(True)
+        extra = {}
+        if norm == "adain":
+            aw = (rnd(B * co) * 0.5 + 1.0).requires_grad_(True)
+            ab = (rnd(B * co) * 0.5).requires_grad_(True)
+            blk.norm.weight, blk.norm.bias = aw, ab
+        y = blk(x)
+        gy = rnd(*y.shape)
+        (y * gy).sum().backward()
+        rec = {"x": x, "w": blk.conv.weight, "b": blk.conv.bias, "y": y, "gy": gy,
+               "dx": x.grad, "dw": blk.conv.weight.grad, "db": blk.conv.bias.grad}
+        if norm == "ln":
+            rec.update({"gamma": blk.norm.gamma, "beta": blk.norm.beta,
+                        "dgamma": blk.norm.gamma.grad, "dbeta": blk.norm.beta.grad})
+        if norm == "adain":
+            rec.update({"aw": aw, "ab": ab, "daw": aw.grad, "dab": ab.grad})
+        for kk, v in rec.items():
+            out["conv/%s/%s" % (name, kk)] = t2n(v)
+        out["conv/%s/meta" % name] = np.array([B, ci, co, H, k, s, p], dtype=np.int64)
+
+    # bilinear x2 upsample (reference networks_v2.py:154) and x0.5 pyramid (networks.py:113)
+    x = rnd(2, 4, 5, 6).requires_grad_(True)
+    y = torch.nn.Upsample(scale_factor=2, mode="bilinear")(x)
+    gy = rnd(*y.shape)
+    (y * gy).sum().backward()
+    for kk, v in {"x": x, "y": y, "gy": gy, "dx": x.grad}.items():
+        out["up2/%s" % kk] = t2n(v)
+    x = rnd(2, 3, 8, 12).requires_grad_(True)
+    y = torch.nn.functional.interpolate(x, scale_factor=0.5, mode="bilinear")
+    gy = rnd(*y.shape)
+    (y * gy).sum().backward()
+    for kk, v in {"x": x, "y": y, "gy": gy, "dx": x.grad}.items():
+        out["down2/%s" % kk] = t2n(v)
+
+    # GMM KL (reference gmm.py:13-22) and the L1 variant (gmm.py:33-41)
+    mus = [rnd(5, 8) for _ in range(8)]
+    lvs = [rnd(5, 8) * 0.3 for _ in range(8)]
+    c = (torch.rand(5, 8, generator=g) < 0.5).float() * 2 - 1
+    out["gmm/mus"] = t2n(torch.stack(mus))
+    out["gmm/logvars"] = t2n(torch.stack(lvs))
+    out["gmm/c"] = t2n(c)
+    out["gmm/kl"] = np.array(float(ref_gmm.gmm_kl_distance_sp(mus, lvs, c, torch.tensor(0.25))))
+    out["gmm/em"] = np.array(float(ref_gmm.gmm_earth_mover_distance_sp(mus, c)))
+
+    # style sampling layout (reference tools.py:65-70) under a fixed global seed
+    torch.manual_seed(99)
+    z = ref_tools.dist_sampling_split(c, 8, 0.5, torch.device("cpu"))
+    out["sample/c"] = t2n(c)
+    out["sample/z_seed99"] = t2n(z)
+
+    # discriminator losses on a tiny D (reference networks.py:116-170)
+    torch.manual_seed(5)
+    dparams = {"n_layer": 3, "gan_type": "lsgan", "dim": 4, "norm": "none", "activ": "lrelu",
+               "num_scales": 2, "pad_type": "reflect", "num_cls": 8, "image_size": 32,
+               "dataset": "CelebA"}
+    D = ref_nets.MsImageDis(3, dparams)
+    xf, xr = rnd(3, 3, 32, 32), rnd(3, 3, 32, 32)
+    lab = (torch.rand(3, 8, generator=g) < 0.5).float()
+    ld = D.calc_dis_loss(xf, xr, lab, lab, 1.0, 1.0)
+    lg = D.calc_gen_loss(xf, lab, 1.0, 1.0)
+    for kname, v in D.state_dict().items():
+        out["dis/sd/%s" % kname] = t2n(v)
+    out["dis/x_fake"], out["dis/x_real"], out["dis/label"] = t2n(xf), t2n(xr), t2n(lab)
+    out["dis/loss_dis"], out["dis/loss_gen"] = np.array(float(ld)), np.array(float(lg))
+    outs = D(xf)
+    for i, (src, cls) in enumerate(outs):
+        out["dis/out%d_src" % i], out["dis/out%d_cls" % i] = t2n(src), t2n(cls)
+
+    np.savez_compressed(os.path.join(HERE, "ops_golden.npz"), **out)
+    print("ops_golden.npz:", len(out), "arrays")
+
+
+# ----------------------------------------------------------------------------------------
+# whole-solver goldens
+# ----------------------------------------------------------------------------------------
+def build_ref_solver(ref_solver, cfg, seed=1234):
+    torch.manual_seed(seed)            # reference train.py:23
+    trainer = ref_solver.Solver(cfg, torch.device("cpu"), None)
+    trainer.copy_nets()                # reference train.py:87
+    return trainer
+
+
+def one_iteration(trainer, batch, cfg, it):
+    """The body of the reference training loop (reference train.py:102-111), n_critic=1."""
+    a = (batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+         batch["label_src"], batch["label_trg"], cfg, it)
+    trainer.dis_update(*a)
+    trainer.gen_update(*a)
+    trainer.smooth_moving()
+    trainer.update_learning_rate()
+    trainer.update_attention_status(it)
+
+
+def gen_tiny(ref_solver):
+    cfg = synth.make_config(image_size=32, tiny=True)
+    B = 3
+    trainer = build_ref_solver(ref_solver, cfg)
+    out = {}
+    for k, v in trainer.gen.state_dict().items():
+        out["init/gen/%s" % k] = t2n(v)
+    for k, v in trainer.dis.state_dict().items():
+        out["init/dis/%s" % k] = t2n(v)
+    batch = synth.make_batch(B, 32, seed=4321)
+    for k, v in batch.items():
+        out["batch/%s" % k] = t2n(v)
+    # state of the global CPU generator right after construction: lets a checker that is
+    # handed the recorded initial weights continue the random stream where the reference did
+    out["rng_state_after_init"] = torch.get_rng_state().numpy().copy()
+
+    # module outputs at the initial weights, eval-free (training mode, but with the RNG
+    # state saved/restored so the recorded step below starts from the post-init stream)
+    rng = torch.get_rng_state()
+    trainer.eval()  # dropout off for the deterministic module-level vectors
+    with torch.no_grad():
+        content, mus, lvs = trainer.gen.encode(batch["x_real"])
+        style = torch.cat(mus, 1)
+        tmu, tlv = trainer.gen.encode_txt(style, batch["txt"], batch["txt_lens"])
+        img, att = trainer.gen.decode(content, style)
+        d_out = trainer.dis(batch["x_real"])
+    trainer.train()
+    torch.set_rng_state(rng)
+    out["mod/content"] = t2n(content)
+    out["mod/style_mu"] = t2n(torch.stack(mus))
+    out["mod/style_logvar"] = t2n(torch.stack(lvs))
+    out["mod/txt_mu"] = t2n(torch.stack(tmu))
+    out["mod/txt_logvar"] = t2n(torch.stack(tlv))
+    out["mod/dec_img"], out["mod/dec_att"] = t2n(img), t2n(att)
+    for i, (src, cls) in enumerate(d_out):
+        out["mod/dis%d_src" % i], out["mod/dis%d_cls" % i] = t2n(src), t2n(cls)
+
+    losses = []
+    for it in range(3):
+        one_iteration(trainer, batch, cfg, it)
+        losses.append(read_losses(trainer))
+        if it == 0:
+            # gradients left on the parameters after the first iteration
+            # (D grads: from gen_update's backward, the last to touch them — reference
+            #  solver.py:239 leaves D weight grads behind; G grads: gen_update)
+            for k, p in trainer.gen.named_parameters():
+                if p.grad is not None:
+                    out["grad_it0/gen/%s" % k] = t2n(p.grad)
+            for k, v in trainer.gen.state_dict().items():
+                out["after_it0/gen/%s" % k] = t2n(v)
+            for k, v in trainer.dis.state_dict().items():
+                out["after_it0/dis/%s" % k] = t2n(v)
+            for k, v in trainer.gen_copy.state_dict().items():
+                out["ema_it0/gen/%s" % k] = t2n(v)
+    out["losses_json"] = np.frombuffer(json.dumps(losses).encode(), dtype=np.uint8)
+    out["init_ds_w"] = np.array(trainer.init_ds_w)
+    out["lr"] = np.array(trainer.gen_opt.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(HERE, "tiny_step.npz"), **out)
+    print("tiny_step.npz written; losses it0:", losses[0]["loss_dis_all"], losses[0]["loss_gen_total"])
+
+    # D-only gradient fixture: a dis_update from the same init, grads on D params
+    trainer = build_ref_solver(ref_solver, cfg)
+    a = (batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+         batch["label_src"], batch["label_trg"], cfg, 0)
+    # run dis_update but capture grads before the optimiser step by wrapping step()
+    grabbed = {}
+    real_step = trainer.dis_opt.step
+
+    def grab_then_step(*args, **kw):
+        for k, p in trainer.dis.named_parameters():
+            grabbed[k] = t2n(p.grad)
+        return real_step(*args, **kw)
+    trainer.dis_opt.step = grab_then_step
+    trainer.dis_update(*a)
+    np.savez_compressed(os.path.join(HERE, "tiny_dis_grads.npz"),
+                        loss_dis=np.array(float(trainer.loss_dis_all)), **grabbed)
+    print("tiny_dis_grads.npz written")
+
+
+def gen_init_checksums(ref_solver):
+    res = {}
+    for S in (64, 128):
+        cfg = synth.make_config(image_size=S)
+        trainer = build_ref_solver(ref_solver, cfg)
+        res["S%d" % S] = {
+            "gen": {k: checksum(v) for k, v in trainer.gen.state_dict().items()},
+            "dis": {k: checksum(v) for k, v in trainer.dis.state_dict().items()},
+            "n_gen": sum(p.numel() for p in trainer.gen.parameters()),
+            "n_dis": sum(p.numel() for p in trainer.dis.parameters()),
+        }
+    with open(os.path.join(HERE, "init_checksums.json"), "w") as f:
+        json.dump(res, f)
+    print("init_checksums.json written")
+
+
+def gen_traj(ref_solver, S, B, steps, lstm_dropout, tag, threads=None):
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = synth.make_config(image_size=S, lstm_dropout=lstm_dropout)
+    trainer = build_ref_solver(ref_solver, cfg)
+    batch = synth.make_batch(B, S, seed=1234)
+    rows, t0 = [], time.time()
+    path = os.path.join(HERE, "traj_%s.json" % tag)
+    for it in range(steps):
+        one_iteration(trainer, batch, cfg, it)
+        row = read_losses(trainer)
+        row["init_ds_w"] = trainer.init_ds_w
+        rows.append(row)
+        if it % 5 == 0 or it == steps - 1:
+            print("[%s] it %d  dis %.6f gen %.6f  (%.1fs)" % (
+                tag, it, row["loss_dis_all"], row["loss_gen_total"], time.time() - t0), flush=True)
+            with open(path, "w") as f:
+                json.dump({"S": S, "B": B, "seed": 1234, "batch_seed": 1234,
+                           "lstm_dropout": lstm_dropout, "torch": torch.__version__,
+                           "threads": torch.get_num_threads(), "rows": rows}, f)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["ops", "tiny", "init"]
+    ref_solver, ref_nets, ref_v2, ref_gmm, ref_tools = import_reference()
+    if "ops" in what:
+        gen_ops(ref_nets, ref_gmm, ref_tools)
+    if "tiny" in what:
+        gen_tiny(ref_solver)
+    if "init" in what:
+        gen_init_checksums(ref_solver)
+    if "traj64" in what:
+        gen_traj(ref_solver, 64, 4, 100, None, "s64_b4_default")
+        gen_traj(ref_solver, 64, 4, 100, 0.0, "s64_b4_nolstmdrop")
+    if "traj128" in what:
+        gen_traj(ref_solver, 128, 16, 100, 0.0, "s128_b16_nolstmdrop", threads=6)

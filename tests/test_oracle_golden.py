@@ -1,0 +1,204 @@
+"""Pins the CPU oracle (oracle/dwcgan_oracle.py) to vectors recorded from the imported,
+unmodified reference (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dwcgan_oracle as orc
+from oracle import np_defs
+from hipdwc import synth
+
+T = torch.from_numpy
+
+
+def close_scaled(a, b, rel, atol=1e-6, msg=""):
+    """max|a-b| <= rel * max|b| + atol: error measured against the tensor's own scale
+    (element-wise rtol is meaningless for gradients that are sums with heavy cancellation)."""
+    err = (a - b).abs().max().item()
+    lim = rel * b.abs().max().item() + atol
+    assert err <= lim, "%s: max err %.3e > %.3e" % (msg, err, lim)
+
+
+@pytest.fixture(scope="module")
+def ops(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_golden.npz"))
+
+
+CONV_CASES = {  # name -> (norm, act)
+    "stem7_relu": ("none", "relu"), "down4_in_relu": ("in", "relu"), "res3_in_none": ("in", "none"),
+    "res3_adain_relu": ("adain", "relu"), "up5_ln_relu": ("ln", "relu"), "up5_ln_relu_b1": ("ln", "relu"),
+    "head7_tanh": ("none", "tanh"), "head7_sigmoid": ("none", "sigmoid"), "dis4_lrelu": ("none", "lrelu"),
+    "dis4_lrelu_2x2": ("none", "lrelu"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONV_CASES))
+def test_conv_block_forward_backward(ops, name):
+    norm, act = CONV_CASES[name]
+    g = lambda k: T(ops["conv/%s/%s" % (name, k)])
+    B, ci, co, H, k, s, p = [int(v) for v in ops["conv/%s/meta" % name]]
+    x, w, b = g("x").requires_grad_(True), g("w").requires_grad_(True), g("b").requires_grad_(True)
+    kw = {}
+    if norm == "ln":
+        kw = dict(gamma=g("gamma").requires_grad_(True), beta=g("beta").requires_grad_(True))
+    if norm == "adain":
+        kw = dict(adain_w=g("aw").requires_grad_(True), adain_b=g("ab").requires_grad_(True))
+    y = orc.conv_block(x, w, b, s, p, norm=norm, act=act, **kw)
+    torch.testing.assert_close(y, g("y"), rtol=1e-5, atol=1e-5)
+    (y * g("gy")).sum().backward()
+    torch.testing.assert_close(x.grad, g("dx"), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(w.grad, g("dw"), rtol=1e-4, atol=2e-5)
+    if norm not in ("in", "adain", "ln"):   # bias grads behind a mean-subtracting norm are ~0 +- noise
+        torch.testing.assert_close(b.grad, g("db"), rtol=1e-4, atol=2e-5)
+    if norm == "ln":
+        torch.testing.assert_close(kw["gamma"].grad, g("dgamma"), rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(kw["beta"].grad, g("dbeta"), rtol=1e-4, atol=2e-5)
+    if norm == "adain":
+        torch.testing.assert_close(kw["adain_w"].grad, g("daw"), rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(kw["adain_b"].grad, g("dab"), rtol=1e-4, atol=2e-5)
+
+
+def test_resample(ops):
+    x = T(ops["up2/x"]).requires_grad_(True)
+    y = orc.upsample_bilinear2x(x)
+    torch.testing.assert_close(y, T(ops["up2/y"]), rtol=1e-6, atol=1e-6)
+    (y * T(ops["up2/gy"])).sum().backward()
+    torch.testing.assert_close(x.grad, T(ops["up2/dx"]), rtol=1e-5, atol=1e-6)
+    x = T(ops["down2/x"]).requires_grad_(True)
+    y = orc.downsample_half(x)
+    torch.testing.assert_close(y, T(ops["down2/y"]), rtol=1e-6, atol=1e-6)
+    (y * T(ops["down2/gy"])).sum().backward()
+    torch.testing.assert_close(x.grad, T(ops["down2/dx"]), rtol=1e-5, atol=1e-6)
+
+
+def test_gmm_and_sampling(ops):
+    mus, lvs, c = list(T(ops["gmm/mus"])), list(T(ops["gmm/logvars"])), T(ops["gmm/c"])
+    assert abs(float(orc.gmm_kl_sp(mus, lvs, c, torch.tensor(0.25))) - float(ops["gmm/kl"])) < 1e-4
+    assert abs(float(orc.gmm_em_sp(mus, c)) - float(ops["gmm/em"])) < 1e-5
+    torch.manual_seed(99)
+    z = orc.GlobalCpuNoise().style_sample(T(ops["sample/c"]), 8, 0.5)
+    assert torch.equal(z, T(ops["sample/z_seed99"]))   # same stream, same layout: bit-exact
+
+
+def test_discriminator(ops):
+    D = {k[len("dis/sd/"):]: T(ops[k]) for k in ops.files if k.startswith("dis/sd/")}
+    cfg = {"n_layer": 3, "num_scales": 2, "activ": "lrelu"}
+    xf, xr, lab = T(ops["dis/x_fake"]), T(ops["dis/x_real"]), T(ops["dis/label"])
+    outs = orc.dis_forward(D, xf, cfg)
+    for i, (src, cls) in enumerate(outs):
+        torch.testing.assert_close(src, T(ops["dis/out%d_src" % i]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(cls, T(ops["dis/out%d_cls" % i]), rtol=1e-5, atol=1e-6)
+    assert abs(float(orc.calc_dis_loss(D, xf, xr, lab, 1.0, 1.0, cfg)) - float(ops["dis/loss_dis"])) < 1e-5
+    assert abs(float(orc.calc_gen_loss(D, xf, lab, 1.0, 1.0, cfg)) - float(ops["dis/loss_gen"])) < 1e-5
+
+
+def test_numpy_definitions_agree_with_restatement():
+    """The torch restatement against the loop-level float64 definitions (small shapes)."""
+    g = torch.Generator().manual_seed(3)
+    for (ci, co, H, k, s, p) in [(3, 4, 7, 7, 1, 3), (4, 5, 8, 4, 2, 1), (4, 4, 5, 3, 1, 1), (4, 3, 6, 5, 1, 2),
+                                 (4, 2, 3, 1, 1, 0), (4, 3, 2, 4, 2, 1)]:
+        x = torch.randn(2, ci, H, H, generator=g)
+        w = torch.randn(co, ci, k, k, generator=g)
+        b = torch.randn(co, generator=g)
+        y = orc.conv_block(x, w, b, s, p)
+        ref = np_defs.conv2d_reflect(x.numpy().astype(np.float64), w.numpy().astype(np.float64),
+                                     b.numpy().astype(np.float64), s, p)
+        np.testing.assert_allclose(y.numpy(), ref, rtol=1e-4, atol=1e-4)
+    x = torch.randn(2, 3, 5, 4, generator=g) * 2 + 1
+    np.testing.assert_allclose(orc.instance_norm(x).numpy(), np_defs.instance_norm(x.numpy()), rtol=1e-4, atol=1e-5)
+    gam, bet = torch.rand(3, generator=g), torch.randn(3, generator=g)
+    np.testing.assert_allclose(orc.layer_norm_munit(x, gam, bet).numpy(),
+                               np_defs.layer_norm_munit(x.numpy(), gam.numpy(), bet.numpy()), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(orc.upsample_bilinear2x(x).numpy(), np_defs.upsample_bilinear2x(x.numpy()),
+                               rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------
+# whole-solver: tiny config, three iterations, against the reference's recorded run
+# ----------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiny_step.npz"))
+
+
+def _sd(npz, prefix):
+    return OrderedDict((k[len(prefix):], T(npz[k])) for k in npz.files if k.startswith(prefix))
+
+
+def test_tiny_modules(tiny):
+    cfg = synth.make_config(image_size=32, tiny=True)
+    G, D = _sd(tiny, "init/gen/"), _sd(tiny, "init/dis/")
+    x = T(tiny["batch/x_real"])
+    noise = orc.GlobalCpuNoise()
+    content, mus, lvs = orc.gen_encode(G, x, cfg["gen"], noise, training=False)
+    torch.testing.assert_close(content, T(tiny["mod/content"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.stack(mus), T(tiny["mod/style_mu"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.stack(lvs), T(tiny["mod/style_logvar"]), rtol=1e-4, atol=1e-5)
+    style = torch.cat(mus, 1)
+    tmu, tlv = orc.gen_encode_txt(G, style, T(tiny["batch/txt"]), T(tiny["batch/txt_lens"]), cfg["gen"], noise,
+                                  training=False)
+    torch.testing.assert_close(torch.stack(tmu), T(tiny["mod/txt_mu"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.stack(tlv), T(tiny["mod/txt_logvar"]), rtol=1e-4, atol=1e-5)
+    img, att = orc.gen_decode(G, content, style, cfg["gen"])
+    torch.testing.assert_close(img, T(tiny["mod/dec_img"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(att, T(tiny["mod/dec_att"]), rtol=1e-4, atol=1e-5)
+    for i, (src, cls) in enumerate(orc.dis_forward(D, x, cfg["dis"])):
+        torch.testing.assert_close(src, T(tiny["mod/dis%d_src" % i]), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(cls, T(tiny["mod/dis%d_cls" % i]), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("as_written", [False, True])
+def test_tiny_three_iterations(tiny, as_written):
+    cfg = synth.make_config(image_size=32, tiny=True)
+    batch = {k[len("batch/"):]: T(tiny[k]) for k in tiny.files if k.startswith("batch/")}
+    solver = orc.OracleSolver(cfg, _sd(tiny, "init/gen/"), _sd(tiny, "init/dis/"), as_written=as_written)
+    solver.copy_nets()
+    torch.set_rng_state(T(tiny["rng_state_after_init"]))
+    want = json.loads(bytes(tiny["losses_json"]).decode())
+    for it in range(3):
+        solver.iteration(batch, it)
+        for k, v in want[it].items():
+            assert abs(solver.losses[k] - v) <= 2e-4 * max(1.0, abs(v)), (it, k, solver.losses[k], v)
+        if it == 0:
+            for k, gref in _sd(tiny, "grad_it0/gen/").items():
+                # whole-network gradients at kaiming init: a few ReLU/IN near-ties flip between
+                # kernel implementations, so the bound is on the tensor's scale, not element-wise
+                close_scaled(solver.last_gen_grads[k], gref, 5e-3, msg=k)
+            absent = [k for k, g in solver.last_gen_grads.items() if g is None]
+            assert all(("grad_it0/gen/" + k) not in tiny.files for k in absent)
+            # Adam's first step moves every element by lr*sign(g) (m/sqrt(v) = g/|g|), so an
+            # element whose ~0 gradient changes sign differs by 2*lr; bound the max by that
+            # and require the bulk to agree far more tightly.
+            lr = cfg["lr"]
+            for P, prefix in ((solver.gen, "after_it0/gen/"), (solver.dis, "after_it0/dis/")):
+                off = total = 0
+                for k, pref in _sd(tiny, prefix).items():
+                    if k in P:
+                        d = (P[k].detach() - pref).abs()
+                        assert d.max().item() <= 2.05 * lr, (k, d.max().item())
+                        off += int((d > 1e-6).sum())
+                        total += d.numel()
+                assert off <= 0.02 * total, (prefix, off, total)
+            for k, pref in _sd(tiny, "ema_it0/gen/").items():
+                if k in solver.gen_copy:
+                    torch.testing.assert_close(solver.gen_copy[k], pref, rtol=1e-5, atol=1e-6, msg=k)
+    assert abs(solver.init_ds_w - float(tiny["init_ds_w"])) < 1e-12
+    # attention was on for iteration 0 and is off afterwards (reference solver.py:109-111)
+    assert solver.use_attention is False
+
+
+def test_tiny_dis_grads(tiny, golden_dir):
+    ref = np.load(os.path.join(golden_dir, "tiny_dis_grads.npz"))
+    cfg = synth.make_config(image_size=32, tiny=True)
+    batch = {k[len("batch/"):]: T(tiny[k]) for k in tiny.files if k.startswith("batch/")}
+    solver = orc.OracleSolver(cfg, _sd(tiny, "init/gen/"), _sd(tiny, "init/dis/"))
+    torch.set_rng_state(T(tiny["rng_state_after_init"]))
+    solver.dis_update(batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+                      batch["label_src"], batch["label_trg"])
+    assert abs(solver.losses["loss_dis_all"] - float(ref["loss_dis"])) < 1e-4
+    for k, g in solver.last_dis_grads.items():
+        close_scaled(g, T(ref[k]), 1e-3, msg=k)
