@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels of libdwcgan_hip.so (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dwcgan_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DWC_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return DWC_ELAUNCH; \
+    } while (0)
+
+static inline int dwc_ilog2_exact(int v) {  // -1 if v is not a power of two
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+__device__ __forceinline__ float dwc_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over the 256 threads of a block; result valid in every thread. `sm` >= 4 floats.
+__device__ __forceinline__ float dwc_block_sum_256(float v, float* sm) {
+    v = dwc_wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
+    switch (act) {
+        case DWC_ACT_RELU: return fmaxf(v, 0.f);
+        case DWC_ACT_LRELU: return v > 0.f ? v : 0.1f * v;
+        case DWC_ACT_TANH: return tanhf(v);
+        case DWC_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case DWC_ACT_HEADS: return ((ch & 3) == 3) ? 1.f / (1.f + expf(-v)) : tanhf(v);
+        default: return v;
+    }
+}
+
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float dwc_act_grad(float y, int act, int ch) {
+    switch (act) {
+        case DWC_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case DWC_ACT_LRELU: return y > 0.f ? 1.f : 0.1f;
+        case DWC_ACT_TANH: return 1.f - y * y;
+        case DWC_ACT_SIGMOID: return y * (1.f - y);
+        case DWC_ACT_HEADS: return ((ch & 3) == 3) ? y * (1.f - y) : 1.f - y * y;
+        default: return 1.f;
+    }
+}

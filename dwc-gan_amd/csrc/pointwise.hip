@@ -1,0 +1,421 @@
+// HBM-bound pointwise / reduction kernels around the conv stack (gfx950, fp32, NHWC).
+//   * activation backward + bias gradient      (autograd of reference networks.py:583-584, conv bias)
+//   * bilinear x2 upsample / 2x2 mean          (reference networks_v2.py:154, networks.py:113)
+//   * NCHW(3) <-> NHWC4 image boundary
+//   * attention blend                           (reference solver.py:148,161,170,179-180,192,330-331)
+//   * mean |a-b|                                (reference solver.py:113-114)
+//   * Adam (+coupled L2) and the EMA lerp       (reference solver.py:62-68, utils.py:52-54)
+// All use 16-byte accesses with the channel axis on the lanes and grid-stride loops.
+#include "dwc_common.h"
+
+namespace {
+
+int grid_for(size_t items, int cap = 4096) {
+    size_t b = (items + 255) / 256;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- activation backward + bias gradient ------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_partial(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ g, float* __restrict__ part, int rows, int C,
+                                                       int rows_per_chunk, int act) {
+    __shared__ f32x4 sm[256];
+    const int cq = C >> 2;
+    const int cqb = cq < 256 ? cq : 256;           // f4 columns handled by this block
+    const int groups = 256 / cqb;
+    const int col = blockIdx.y * 256 + threadIdx.x % cqb, rg = threadIdx.x / cqb;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(rows, r0 + rows_per_chunk);
+    f32x4 s = {0, 0, 0, 0};
+    for (int r = r0 + rg; r < r1; r += groups) {
+        const size_t i = (size_t)r * cq + col;
+        f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        if (act != DWC_ACT_NONE) {
+            const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] *= dwc_act_grad(yy[k], act, k);
+        }
+        if (g) reinterpret_cast<f32x4*>(g)[i] = d;
+        s += d;
+    }
+    if (!part) return;
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0) {
+        for (int k = 1; k < groups; ++k) s += sm[k * cqb + threadIdx.x % cqb];
+        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + col * 4) = s;
+    }
+}
+
+__global__ void colsum_final(const float* __restrict__ part, float* __restrict__ out, int chunks, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
+    out[c] = s;
+}
+
+void act_plan(int rows, int* chunks, int* rpc) {
+    int c = rows / 32;
+    if (c > 1024) c = 1024;
+    if (c < 1) c = 1;
+    *rpc = (rows + c - 1) / c;
+    *chunks = (rows + *rpc - 1) / *rpc;
+}
+
+// ---- bilinear x2 (align_corners=False), torch's tap rule ------------------------------------
+__device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+                                                             size_t total4) {
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;
+        size_t r = i / cq;
+        const int ox = r % (2 * W);
+        r /= (2 * W);
+        const int oy = r % (2 * H);
+        const size_t n = r / (2 * H);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        up_taps(oy, H, y0, y1, ly0, ly1);
+        up_taps(ox, W, x0, x1, lx0, lx1);
+        const size_t b = n * H * W;
+        const f32x4 p00 = xs[(b + (size_t)y0 * W + x0) * cq + c], p01 = xs[(b + (size_t)y0 * W + x1) * cq + c];
+        const f32x4 p10 = xs[(b + (size_t)y1 * W + x0) * cq + c], p11 = xs[(b + (size_t)y1 * W + x1) * cq + c];
+        reinterpret_cast<f32x4*>(y)[i] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+    }
+}
+
+// adjoint, gather form: every input pixel collects from the <=4x4 output pixels that read it
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int cq,
+                                                             size_t total4) {
+    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;
+        size_t r = i / cq;
+        const int ix = r % W;
+        r /= W;
+        const int iy = r % H;
+        const size_t n = r / H;
+        float wy[5], wx[5];
+        int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int a, b;
+            float l0, l1;
+            const int oy = oy0 + k, ox = ox0 + k;
+            wy[k] = 0.f;
+            wx[k] = 0.f;
+            if (oy >= 0 && oy < 2 * H) {
+                up_taps(oy, H, a, b, l0, l1);
+                wy[k] = (a == iy ? l0 : 0.f) + (b == iy ? l1 : 0.f);
+            }
+            if (ox >= 0 && ox < 2 * W) {
+                up_taps(ox, W, a, b, l0, l1);
+                wx[k] = (a == ix ? l0 : 0.f) + (b == ix ? l1 : 0.f);
+            }
+        }
+        f32x4 s = {0, 0, 0, 0};
+        const size_t base = n * (size_t)(2 * H) * (2 * W);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            if (wy[a] == 0.f) continue;
+            f32x4 row = {0, 0, 0, 0};
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+                if (wx[b] != 0.f) row += wx[b] * ds[(base + (size_t)(oy0 + a) * (2 * W) + (ox0 + b)) * cq + c];
+            s += wy[a] * row;
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+                                                           size_t total4) {
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;
+        size_t r = i / cq;
+        const int ox = r % Wo;
+        r /= Wo;
+        const int oy = r % Ho;
+        const size_t n = r / Ho;
+        const size_t b = (n * H + 2 * oy) * W + 2 * ox;
+        reinterpret_cast<f32x4*>(y)[i] = ((xs[b * cq + c] + xs[(b + 1) * cq + c]) + (xs[(b + W) * cq + c] + xs[(b + W + 1) * cq + c])) * 0.25f;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int cq,
+                                                           size_t total4) {
+    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;
+        size_t r = i / cq;
+        const int ix = r % W;
+        r /= W;
+        const int iy = r % H;
+        const size_t n = r / H;
+        reinterpret_cast<f32x4*>(dx)[i] = ds[((n * Ho + iy / 2) * Wo + ix / 2) * cq + c] * 0.25f;
+    }
+}
+
+// ---- image boundary ----------------------------------------------------------------------------
+__global__ void pack_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index over B*HW
+    if (i >= total) return;
+    const size_t n = i / HW, p = i % HW;
+    f32x4 v = {0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) v[c] = x[(n * C + c) * HW + p];
+    reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
+__global__ void unpack_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / HW, p = i % HW;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    for (int c = 0; c < C; ++c) y[(n * C + c) * HW + p] = v[c];
+}
+
+// ---- attention blend -----------------------------------------------------------------------------
+__global__ void blend_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ real, float* __restrict__ out, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const f32x4 h = reinterpret_cast<const f32x4*>(heads)[i];
+    const f32x4 r = reinterpret_cast<const f32x4*>(real)[i];
+    const float a = h[3], na = 1.f - h[3];
+    f32x4 o;
+    o[0] = h[0] * a + r[0] * na;
+    o[1] = h[1] * a + r[1] * na;
+    o[2] = h[2] * a + r[2] * na;
+    o[3] = 0.f;
+    reinterpret_cast<f32x4*>(out)[i] = o;
+}
+
+__global__ void blend_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ heads, const float* __restrict__ real,
+                                 float* __restrict__ dheads, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
+    const f32x4 h = reinterpret_cast<const f32x4*>(heads)[i];
+    const f32x4 r = reinterpret_cast<const f32x4*>(real)[i];
+    f32x4 o;
+    o[0] = d[0] * h[3];
+    o[1] = d[1] * h[3];
+    o[2] = d[2] * h[3];
+    o[3] = (d[0] * h[0] - d[0] * r[0]) + (d[1] * h[1] - d[1] * r[1]) + (d[2] * h[2] - d[2] * r[2]);
+    reinterpret_cast<f32x4*>(dheads)[i] = o;
+}
+
+// ---- mean |a-b| ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                         size_t n4, size_t n, int skip4) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 d = reinterpret_cast<const f32x4*>(a)[i] - reinterpret_cast<const f32x4*>(b)[i];
+        s += (fabsf(d[0]) + fabsf(d[1])) + (fabsf(d[2]) + (skip4 ? 0.f : fabsf(d[3])));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += fabsf(a[i] - b[i]);
+    s = dwc_block_sum_256(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, float* __restrict__ out, int blocks, float inv_n) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < blocks; i += 256) s += part[i];
+    s = dwc_block_sum_256(s, sm);
+    if (threadIdx.x == 0) out[0] = s * inv_n;
+}
+
+__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dout, float* __restrict__ da,
+                              float* __restrict__ db, size_t n, float inv_n, int skip4) {
+    const float sc = dout[0] * inv_n;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        float g = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
+        if (skip4 && (i & 3) == 3) g = 0.f;
+        if (da) da[i] = g;
+        if (db) db[i] = -g;
+    }
+}
+
+// ---- optimiser -------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerp_torch(float start, float end, float w) {
+    // torch.lerp's two-branch form (ATen/native/Lerp.h)
+    return w < 0.5f ? start + w * (end - start) : end - (end - start) * (1.f - w);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float step_size, float beta1, float beta2, float eps, float wd, float bc2_sqrt) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = g[i] + wd * pi;
+        const float mi = lerp_torch(m[i], gi, 1.f - beta1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+__global__ void ema_kernel(const float* __restrict__ p, float* __restrict__ e, size_t n, float beta) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        e[i] = lerp_torch(p[i], e[i], beta);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dwc_act_bwd_bias_ws_bytes(int rows, int C) {
+    int chunks, rpc;
+    act_plan(rows, &chunks, &rpc);
+    return (size_t)chunks * C * sizeof(float);
+}
+
+int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
+                     void* stream) {
+    if (rows <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const int cq = C >> 2;
+    if (cq < 256 ? (256 % cq) != 0 : (cq % 256) != 0) return DWC_EINVAL;
+    if (act != DWC_ACT_NONE && !y) return DWC_EINVAL;
+    if (db && (!ws || ws_bytes < dwc_act_bwd_bias_ws_bytes(rows, C))) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int chunks, rpc;
+    act_plan(rows, &chunks, &rpc);
+    hipLaunchKernelGGL(act_bwd_partial, dim3(chunks, (cq + 255) / 256), dim3(256), 0, st, dy, y, g, db ? (float*)ws : nullptr,
+                       rows, C, rpc, act);
+    DWC_LAUNCH_CHECK();
+    if (db) {
+        hipLaunchKernelGGL(colsum_final, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, db, chunks, C);
+        DWC_LAUNCH_CHECK();
+    }
+    return DWC_OK;
+}
+
+int dwc_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4,
+                       total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4,
+                       total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_pack_nchw_to_nhwc4(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    if (C < 1 || C > 4 || B <= 0 || H <= 0 || W <= 0) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(pack_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_unpack_nhwc4_to_nchw(const float* x, float* y, int B, int C, int H, int W, void* stream) {
+    if (C < 1 || C > 4 || B <= 0 || H <= 0 || W <= 0) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(unpack_nhwc4_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, C, H * W, total);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_blend_fwd(const float* heads, const float* real, float* out, int npix, void* stream) {
+    if (npix <= 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, heads, real, out, (size_t)npix);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_blend_bwd(const float* dout, const float* heads, const float* real, float* dheads, int npix, void* stream) {
+    if (npix <= 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, dout, heads, real, dheads,
+                       (size_t)npix);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_l1_ws_bytes(size_t n) { return (size_t)grid_for(n / 4 + 1, 1024) * sizeof(float); }
+
+int dwc_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes,
+                    void* stream) {
+    if (n == 0 || (skip4 && (n & 3))) return DWC_EINVAL;
+    if (!ws || ws_bytes < dwc_l1_ws_bytes(n)) return DWC_EWORKSPACE;
+    const int blocks = grid_for(n / 4 + 1, 1024);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, st, a, b, (float*)ws, n / 4, n, skip4);
+    DWC_LAUNCH_CHECK();
+    const double count = skip4 ? (double)n * 0.75 : (double)n;
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, blocks, (float)(1.0 / count));
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_l1_mean_bwd(const float* a, const float* b, const float* dout, float* da, float* db, size_t n, int skip4,
+                    void* stream) {
+    if (n == 0 || (skip4 && (n & 3))) return DWC_EINVAL;
+    const double count = skip4 ? (double)n * 0.75 : (double)n;
+    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, dout, da, db, n,
+                       (float)(1.0 / count), skip4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, void* stream) {
+    if (n == 0 || step < 1) return DWC_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)((double)lr / bc1),
+                       beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_ema_lerp(const float* p, float* ema, size_t n, float beta, void* stream) {
+    if (n == 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, ema, n, beta);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

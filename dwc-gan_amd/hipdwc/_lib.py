@@ -1,0 +1,80 @@
+"""ctypes binding of libdwcgan_hip.so (C ABI declared in include/dwcgan_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a kernel call
+returns an error code, the caller gets an exception.  Nothing here touches the CPU oracle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdwcgan_hip.so")
+
+c_fp = ctypes.c_void_p   # device pointers travel as void*
+c_int = ctypes.c_int
+c_sz = ctypes.c_size_t
+c_f = ctypes.c_float
+
+# name -> (restype, argtypes): mirrors include/dwcgan_hip.h one to one
+SIGNATURES = {
+    "dwc_version": (c_int, []),
+    "dwc_weight_oihw_to_hwio": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_weight_oihw_to_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp]),
+    "dwc_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 5),
+    "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),
+    "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),
+    "dwc_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_instnorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
+    "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_layernorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
+    "dwc_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_upsample2x_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_upsample2x_bwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_avgpool2_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_avgpool2_bwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_pack_nchw_to_nhwc4": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_unpack_nhwc4_to_nchw": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_blend_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_blend_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_l1_ws_bytes": (c_sz, [c_sz]),
+    "dwc_l1_mean_fwd": (c_int, [c_fp, c_fp, c_fp, c_sz, c_int, c_fp, c_sz, c_fp]),
+    "dwc_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "dwc_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_sz, c_f, c_f, c_f, c_f, c_f, c_int, c_fp]),
+    "dwc_ema_lerp": (c_int, [c_fp, c_fp, c_sz, c_f, c_fp]),
+}
+
+_ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
+           -3: "DWC_ELAUNCH (kernel launch failed)"}
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdwcgan_hip.so and attach prototypes.  Raises loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libdwcgan_hip.so not found at %s — build it with `make -C dwc-gan_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipKernelError("%s failed: %s" % (what, _ERRORS.get(rc, rc)))

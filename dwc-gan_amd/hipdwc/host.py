@@ -1,0 +1,110 @@
+"""Host-side glue of the training step: weight init, LR schedule, EMA, random draws.
+
+These follow reference utils.py:52-54 (moving_average), :220-231 (get_scheduler),
+:234-254 (weights_init) and the four places where the reference draws random numbers
+(tools.py:65-70, networks_v2.py:119, :222, :201/:236).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.optim import lr_scheduler
+
+
+# --------------------------------------------------------------------------------------
+# random draws
+# --------------------------------------------------------------------------------------
+class DeviceNoise:
+    """Default: draw on the tensor's own device, like the reference does on its GPU."""
+
+    def dropout(self, x, p, training=True):
+        return F.dropout(x, p=p, training=training)
+
+    def style_sample(self, mu, c_dim, stddev):
+        shape = (1, c_dim) + tuple(mu.shape)
+        draw = torch.normal(mu.expand(shape), torch.full_like(mu, stddev).expand(shape))
+        return draw.permute(0, 2, 3, 1).reshape(mu.shape[0], -1)
+
+
+class HostNoise:
+    """Parity mode: every draw is made on torch's global CPU generator with the calls, shapes
+    and order the reference makes when it runs on CPU, then moved to the device.  With the
+    same seed the HIP run then sees the same dropout masks and style samples as a CPU run
+    (reference or oracle)."""
+
+    def dropout(self, x, p, training=True):
+        if not training or p == 0:
+            return x
+        mask = F.dropout(torch.ones(tuple(x.shape), dtype=torch.float32), p=p, training=True)
+        return x * mask.to(x.device, non_blocking=True)
+
+    def style_sample(self, mu, c_dim, stddev):
+        m = mu.detach().to("cpu", torch.float32)
+        shape = (1, c_dim) + tuple(m.shape)
+        draw = torch.normal(m.expand(shape), torch.full_like(m, stddev).expand(shape))
+        return draw.permute(0, 2, 3, 1).reshape(m.shape[0], -1).to(mu.device)
+
+
+_NOISE = DeviceNoise()
+
+
+def noise():
+    return _NOISE
+
+
+def set_noise(source):
+    global _NOISE
+    _NOISE = source
+    return source
+
+
+# --------------------------------------------------------------------------------------
+# init / schedule / EMA
+# --------------------------------------------------------------------------------------
+def weights_init(init_type="gaussian"):
+    """Initialiser applied with Module.apply: touches modules whose class name starts with
+    Conv/Linear and that own a ``weight`` (i.e. nn.Conv2d / nn.Linear), zeroes their bias."""
+    fillers = {
+        "gaussian": lambda w: nn.init.normal_(w, 0.0, 0.02),
+        "xavier": lambda w: nn.init.xavier_normal_(w, gain=math.sqrt(2)),
+        "kaiming": lambda w: nn.init.kaiming_normal_(w, a=0, mode="fan_in"),
+        "orthogonal": lambda w: nn.init.orthogonal_(w, gain=math.sqrt(2)),
+        "default": lambda w: w,
+    }
+    if init_type not in fillers:
+        raise ValueError("Unsupported initialization: %s" % init_type)
+    fill = fillers[init_type]
+
+    def visit(m):
+        name = type(m).__name__
+        if (name.startswith("Conv") or name.startswith("Linear")) and hasattr(m, "weight"):
+            fill(m.weight.data)
+            if getattr(m, "bias", None) is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+    return visit
+
+
+def get_scheduler(optimizer, hp, iterations=-1):
+    policy = hp.get("lr_policy", "const")
+    if policy == "const":
+        return None
+    if policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=hp["step_size"], gamma=hp["gamma"], last_epoch=iterations)
+    if policy == "cosa":
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=hp["step_size"], eta_min=hp["eta_min"],
+                                              last_epoch=iterations)
+    raise NotImplementedError("learning rate policy [%s] is not implemented" % policy)
+
+
+@torch.no_grad()
+def moving_average(model, model_copy, beta=0.999):
+    """copy <- lerp(param, copy, beta) over parameters (buffers are not averaged)."""
+    src = [p.data for p in model.parameters()]
+    dst = [p.data for p in model_copy.parameters()]
+    if src and src[0].is_cuda:
+        # dst + (1-beta)*(src-dst) in torch.lerp's high-weight form, one fused multi-tensor call
+        torch._foreach_lerp_(dst, src, 1.0 - beta)
+    else:
+        for s, d in zip(src, dst):
+            d.copy_(torch.lerp(s, d, beta))

@@ -1,0 +1,421 @@
+"""torch.autograd wrappers around the HIP kernels (C ABI in include/dwcgan_hip.h).
+
+Tensors keep the reference's logical NCHW shapes but live channels-last in memory
+(``torch.channels_last``), which is exactly the NHWC layout the kernels stream.  Every
+function here requires device tensors; there is no CPU path (use the oracle for that,
+from tests only).
+"""
+import weakref
+
+import torch
+
+from . import _lib
+
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "heads": 5}
+
+
+# --------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------
+def _require_device(t):
+    if not t.is_cuda:
+        raise RuntimeError("dwc-gan_amd HIP op called with a CPU tensor: the product path has no CPU "
+                           "fallback (the CPU oracle lives under oracle/ and is for tests only)")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Per-device scratch arena handed to the kernels (grown on demand, never shrunk).
+    Kernels on one stream run in order, so one arena per device is enough."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def cl(x):
+    """channels-last contiguous fp32 view/copy of a 4-D tensor."""
+    if x.dtype != torch.float32:
+        raise TypeError("fp32 only")
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D NCHW-shaped tensor")
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def empty_cl(b, c, h, w, device):
+    return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+# --------------------------------------------------------------------------------------
+# weight layouts, cached per parameter version
+# --------------------------------------------------------------------------------------
+_WCACHE = weakref.WeakKeyDictionary()
+
+
+def _prepped(w, kind, cout_pad, cin_pad, stride):
+    """Re-laid-out copy of an OIHW weight; recomputed only when the parameter changed
+    (optimizer steps bump ``_version``)."""
+    ent = None
+    try:
+        ent = _WCACHE.get(w)
+    except TypeError:
+        pass
+    key = (kind, cout_pad, cin_pad, stride)
+    if ent is not None and ent.get(key, (None, None))[0] == w._version:
+        return ent[key][1]
+    lib = _lib.load()
+    cout, cin, kh, kw = w.shape
+    wc = w.detach().contiguous()
+    out = torch.empty(kh * kw * cin_pad * cout_pad, dtype=torch.float32, device=w.device)
+    if kind == "hwio":
+        _lib.check(lib.dwc_weight_oihw_to_hwio(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
+                                               _stream()), "weight_oihw_to_hwio")
+    else:
+        _lib.check(lib.dwc_weight_oihw_to_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
+                                                cin_pad, _stream()), "weight_oihw_to_dgrad")
+    try:
+        _WCACHE.setdefault(w, {})[key] = (w._version, out)
+    except TypeError:
+        pass
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------
+class _Conv2d(torch.autograd.Function):
+    """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, act):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, Cx, H, W = x.shape
+        Cout, Cin, KH, KW = w.shape
+        if Cin > Cx:
+            raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
+        cop = _pad4(Cout)
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        w_hwio = _prepped(w, "hwio", cop, Cx, stride)
+        bias = None
+        if b is not None:
+            bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
+            bias = bias.contiguous()
+        y = empty_cl(B, cop, Ho, Wo, x.device)
+        _lib.check(lib.dwc_conv2d_fwd(x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW,
+                                      stride, pad, act, _stream()), "conv2d_fwd")
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, has_b = ctx.geom
+        dy = cl(dy)
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        rows = B * Ho * Wo
+        st = _stream()
+        dev = x.device
+        need_db = has_b and ctx.needs_input_grad[2]
+        g = dy
+        db = None
+        if act != 0 or need_db:
+            db_full = torch.empty(cop, dtype=torch.float32, device=dev) if need_db else None
+            g_out = empty_cl(B, cop, Ho, Wo, dev) if act != 0 else None
+            nws = lib.dwc_act_bwd_bias_ws_bytes(rows, cop)
+            ws = workspace(nws, dev)
+            _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
+                                            ws.numel(), st), "act_bwd_bias")
+            if g_out is not None:
+                g = g_out
+            if need_db:
+                db = db_full[:Cout]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            w_dg = _prepped(w, "dgrad", cop, Cx, stride)
+            dx = empty_cl(B, Cx, H, W, dev)
+            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, Cx, pad)
+            ws = workspace(nws, dev)
+            _lib.check(lib.dwc_conv2d_bwd_data(g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW,
+                                               stride, pad, ws.data_ptr(), ws.numel(), st), "conv2d_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
+            nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
+            ws = workspace(nws, dev)
+            _lib.check(lib.dwc_conv2d_bwd_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW,
+                                                 stride, pad, Cin, Cout, ws.data_ptr(), ws.numel(), st), "conv2d_bwd_weight")
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, b, stride, pad, act="none"):
+    """Reflect-padded convolution + bias + activation.  Returns Cout channels (a channel
+    slice of the 4-aligned buffer when Cout is not a multiple of 4)."""
+    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act])
+    return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
+
+
+def conv2d_padded(x, w, b, stride, pad, act="none"):
+    """As conv2d, but returns the 4-aligned channel buffer itself."""
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act])
+
+
+def linear(x, w, b, act="none"):
+    """nn.Linear (+ReLU) as a 1x1 convolution over a 1x1 image (reference networks.py:587-634).
+    Input width must be a power of two >= 4."""
+    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), b, 1, 0, act)
+    return y.reshape(x.shape[0], -1)
+
+
+# --------------------------------------------------------------------------------------
+# norms
+# --------------------------------------------------------------------------------------
+class _InstNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, relu, eps):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, C, H, W = x.shape
+        dev = x.device
+        if gamma is not None:
+            gamma, beta = gamma.contiguous(), beta.contiguous()
+        if residual is not None:
+            residual = cl(residual)
+        y = empty_cl(B, C, H, W, dev)
+        mean = torch.empty(B * C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
+        _lib.check(lib.dwc_instnorm_fwd(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
+                   "instnorm_fwd")
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.relu = int(relu)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        dy = cl(dy)
+        B, C, H, W = x.shape
+        dev = x.device
+        dx = empty_cl(B, C, H, W, dev)
+        dgamma = dbeta = None
+        if gamma is not None:
+            dgamma = torch.empty(B * C, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(B * C, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
+        _lib.check(lib.dwc_instnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
+                                        dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
+                                        ws.numel(), _stream()), "instnorm_bwd")
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
+
+
+def instance_norm(x, gamma=None, beta=None, residual=None, relu=False, eps=1e-5):
+    """IN / AdaIN (+ReLU) (+residual add).  gamma/beta: flat [B*C] per-sample scale/shift or None."""
+    return _InstNorm.apply(x, gamma, beta, residual, bool(relu), float(eps))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, eps):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, C, H, W = x.shape
+        dev = x.device
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = empty_cl(B, C, H, W, dev)
+        mean = torch.empty(B, dtype=torch.float32, device=dev)
+        inv = torch.empty(B, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
+        _lib.check(lib.dwc_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                         inv.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
+                   "layernorm_fwd")
+        ctx.save_for_backward(x, mean, inv, g, b)
+        ctx.relu, ctx.eps = int(relu), eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, mean, inv, g, b = ctx.saved_tensors
+        dy = cl(dy)
+        B, C, H, W = x.shape
+        dev = x.device
+        dx = empty_cl(B, C, H, W, dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
+        _lib.check(lib.dwc_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
+                                         b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
+                                         ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), _stream()), "layernorm_bwd")
+        return dx, dgamma, dbeta, None, None
+
+
+def layer_norm_munit(x, gamma, beta, relu=False, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, bool(relu), float(eps))
+
+
+# --------------------------------------------------------------------------------------
+# resampling
+# --------------------------------------------------------------------------------------
+class _Resample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, up):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, C, H, W = x.shape
+        ctx.shape, ctx.up = (B, C, H, W), up
+        if up:
+            y = empty_cl(B, C, 2 * H, 2 * W, x.device)
+            _lib.check(lib.dwc_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "upsample2x_fwd")
+        else:
+            y = empty_cl(B, C, H // 2, W // 2, x.device)
+            _lib.check(lib.dwc_avgpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "avgpool2_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, C, H, W = ctx.shape
+        dy = cl(dy)
+        dx = empty_cl(B, C, H, W, dy.device)
+        if ctx.up:
+            _lib.check(lib.dwc_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "upsample2x_bwd")
+        else:
+            _lib.check(lib.dwc_avgpool2_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "avgpool2_bwd")
+        return dx, None
+
+
+def upsample2x(x):
+    return _Resample.apply(x, True)
+
+
+def downsample_half(x):
+    return _Resample.apply(x, False)
+
+
+# --------------------------------------------------------------------------------------
+# image boundary / blend / L1
+# --------------------------------------------------------------------------------------
+class _Pack4(torch.autograd.Function):
+    """[B,3,H,W] (any strides) -> NHWC4 image [B,4,H,W] channels-last with a zero 4th plane."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_device(x)
+        lib = _lib.load()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        ctx.shape = (B, C, H, W)
+        y = empty_cl(B, 4, H, W, x.device)
+        _lib.check(lib.dwc_pack_nchw_to_nhwc4(x.data_ptr(), y.data_ptr(), B, C, H, W, _stream()), "pack")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, C, H, W = ctx.shape
+        dy = cl(dy)
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        _lib.check(lib.dwc_unpack_nhwc4_to_nchw(dy.data_ptr(), dx.data_ptr(), B, C, H, W, _stream()), "unpack")
+        return dx
+
+
+def pack_image(x):
+    """Bring an image batch to the internal NHWC4 form (no-op when it already is)."""
+    if x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    if x.shape[1] > 4:
+        raise ValueError("image tensors have at most 4 channels")
+    return _Pack4.apply(x)
+
+
+class _Blend(torch.autograd.Function):
+    """x = img*att + real*(1-att) on NHWC4 tensors (att = plane 3 of `heads`); plane 3 of the result is 0."""
+
+    @staticmethod
+    def forward(ctx, heads, real):
+        _require_device(heads)
+        lib = _lib.load()
+        heads, real = cl(heads), cl(real)
+        B, C, H, W = heads.shape
+        out = empty_cl(B, 4, H, W, heads.device)
+        _lib.check(lib.dwc_blend_fwd(heads.data_ptr(), real.data_ptr(), out.data_ptr(), B * H * W, _stream()), "blend_fwd")
+        ctx.save_for_backward(heads, real)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        heads, real = ctx.saved_tensors
+        dout = cl(dout)
+        B, C, H, W = heads.shape
+        dh = empty_cl(B, 4, H, W, heads.device)
+        _lib.check(lib.dwc_blend_bwd(dout.data_ptr(), heads.data_ptr(), real.data_ptr(), dh.data_ptr(), B * H * W, _stream()),
+                   "blend_bwd")
+        return dh, None
+
+
+def attention_blend(heads, real):
+    return _Blend.apply(heads, real)
+
+
+class _L1Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, skip4):
+        _require_device(a)
+        lib = _lib.load()
+        if a.shape != b.shape:
+            raise ValueError("shape mismatch")
+        if a.dim() == 4:
+            a, b = cl(a), cl(b)
+        else:
+            a, b = a.contiguous(), b.contiguous()
+        n = a.numel()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = workspace(lib.dwc_l1_ws_bytes(n), a.device)
+        _lib.check(lib.dwc_l1_mean_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, int(skip4), ws.data_ptr(), ws.numel(),
+                                       _stream()), "l1_mean_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.skip4 = int(skip4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        dout = dout.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.dwc_l1_mean_bwd(a.data_ptr(), b.data_ptr(), dout.data_ptr(), _p(da), _p(db), a.numel(), ctx.skip4,
+                                       _stream()), "l1_mean_bwd")
+        return da, db, None
+
+
+def l1_mean(a, b, image=False):
+    """mean |a-b| (reference solver.py:113-114).  image=True: NHWC4 images, 4th plane ignored."""
+    return _L1Mean.apply(a, b, bool(image))

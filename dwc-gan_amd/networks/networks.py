@@ -1,0 +1,314 @@
+"""MI355X-native building blocks and discriminator behind the reference's ``networks.networks`` API.
+
+Same class names, constructor signatures, method names and ``state_dict`` keys as
+reference networks/networks.py (so ``from networks.networks import MsImageDis`` and reference
+checkpoints keep working), but every forward/backward runs on the hand-written gfx950
+kernels of libdwcgan_hip.so (``hipdwc.ops``).  ``nn.Conv2d`` / ``nn.Linear`` objects are kept
+only as parameter containers: that preserves the key names *and* makes construction consume
+the random stream exactly like the reference, so a seeded build has identical initial weights.
+
+Internally activations are channels-last (NHWC) and the 3-channel images travel as NHWC4.
+Reflect padding is never materialised (it is an index rule inside the conv kernels), the
+activation is fused into the conv epilogue or the norm's apply pass, and ResBlock's
+residual add is fused into its second norm.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from hipdwc import ops
+
+_CONV_ACTS = ("relu", "lrelu", "tanh", "sigmoid", "none")
+
+
+# --------------------------------------------------------------------------------------
+# normalisation layers
+# --------------------------------------------------------------------------------------
+class AdaptiveInstanceNorm2d(nn.Module):
+    """Instance norm whose per-sample scale (``weight``) and shift (``bias``) are assigned from
+    outside before each call (reference networks.py:693-722).  The running buffers exist only
+    for checkpoint compatibility; like the reference's, they never influence the output."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = None
+        self.bias = None
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x, relu=False, residual=None):
+        if self.weight is None or self.bias is None:
+            raise AssertionError("Please assign weight and bias before calling AdaIN!")
+        return ops.instance_norm(x, self.weight, self.bias, residual=residual, relu=relu, eps=self.eps)
+
+    def __repr__(self):
+        return "%s(%d)" % (type(self).__name__, self.num_features)
+
+
+class LayerNorm(nn.Module):
+    """MUNIT's LayerNorm: per-sample statistics over C*H*W with the unbiased std and eps added
+    to the std; gamma ~ U(0,1), beta = 0 (reference networks.py:725-752)."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True):
+        super().__init__()
+        self.num_features, self.affine, self.eps = num_features, affine, eps
+        if affine:
+            self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
+            self.beta = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x, relu=False):
+        if not self.affine:
+            one = torch.ones(self.num_features, device=x.device)
+            return ops.layer_norm_munit(x, one, torch.zeros_like(one), relu=relu, eps=self.eps)
+        return ops.layer_norm_munit(x, self.gamma, self.beta, relu=relu, eps=self.eps)
+
+
+class _PlainInstanceNorm(nn.InstanceNorm2d):
+    """nn.InstanceNorm2d(affine=False) as a marker/parameter-less container (reference networks.py:545)."""
+
+    def forward(self, x, relu=False, residual=None):
+        return ops.instance_norm(x, None, None, residual=residual, relu=relu, eps=self.eps)
+
+
+# --------------------------------------------------------------------------------------
+# basic blocks
+# --------------------------------------------------------------------------------------
+class Conv2dBlock(nn.Module):
+    """pad -> conv -> norm -> activation (reference networks.py:524-585) as at most two fused passes."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, norm="none", activation="relu",
+                 pad_type="zero"):
+        super().__init__()
+        if pad_type not in ("reflect", "replicate", "zero"):
+            raise AssertionError("Unsupported padding type: {}".format(pad_type))
+        if pad_type != "reflect" and padding > 0:
+            raise NotImplementedError("the HIP conv kernels implement reflect padding (the only mode the shipped "
+                                      "configs use); got pad_type=%r" % pad_type)
+        if activation not in _CONV_ACTS:
+            raise NotImplementedError("activation %r is not on the HIP path" % activation)
+        self.use_bias = True
+        self.stride, self.padding = stride, padding
+        self.norm_kind, self.act_kind = norm, activation
+        # norm is created before the conv, as in the reference: LayerNorm draws its gamma then
+        if norm == "in":
+            self.norm = _PlainInstanceNorm(output_dim)
+        elif norm == "ln":
+            self.norm = LayerNorm(output_dim)
+        elif norm == "adain":
+            self.norm = AdaptiveInstanceNorm2d(output_dim)
+        elif norm == "none":
+            self.norm = None
+        else:
+            raise NotImplementedError("normalization %r is not on the HIP path" % norm)
+        if self.norm is not None and activation not in ("relu", "none"):
+            raise NotImplementedError("norm followed by %r is not fused" % activation)
+        self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)  # parameter container
+
+    def forward(self, x, residual=None):
+        if x.shape[1] < 4:
+            x = ops.pack_image(x)
+        if self.norm is None:
+            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, self.act_kind)
+            return y if residual is None else y + residual
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, "none")
+        relu = self.act_kind == "relu"
+        if self.norm_kind == "ln":
+            y = self.norm(y, relu=relu)
+            return y if residual is None else y + residual
+        return self.norm(y, relu=relu, residual=residual)
+
+
+class ResBlock(nn.Module):
+    """x + conv-norm(conv-norm-act(x)) (reference networks.py:509-522); the add rides on the second norm."""
+
+    def __init__(self, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        self.model = nn.Sequential(
+            Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation=activation, pad_type=pad_type),
+            Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation="none", pad_type=pad_type))
+
+    def forward(self, x):
+        return self.model[1](self.model[0](x), residual=x)
+
+
+class ResBlocks(nn.Module):
+    def __init__(self, num_blocks, dim, norm="in", activation="relu", pad_type="zero"):
+        super().__init__()
+        self.model = nn.Sequential(*[ResBlock(dim, norm=norm, activation=activation, pad_type=pad_type)
+                                     for _ in range(num_blocks)])
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class LinearBlock(nn.Module):
+    """Linear (+ReLU) (reference networks.py:587-634) on the 1x1-conv kernel."""
+
+    def __init__(self, input_dim, output_dim, norm="none", activation="relu"):
+        super().__init__()
+        if norm != "none":
+            raise NotImplementedError("LinearBlock norm %r is not on the HIP path" % norm)
+        if activation not in ("relu", "none"):
+            raise NotImplementedError("LinearBlock activation %r is not on the HIP path" % activation)
+        self.act_kind = activation
+        self.norm = None
+        self.fc = nn.Linear(input_dim, output_dim, bias=True)
+
+    def forward(self, x):
+        return ops.linear(x, self.fc.weight, self.fc.bias, self.act_kind)
+
+
+class MLP(nn.Module):
+    """style -> AdaIN parameters (reference networks.py:491-503)."""
+
+    def __init__(self, input_dim, output_dim, dim, n_blk, norm="none", activ="relu"):
+        super().__init__()
+        dims = [input_dim] + [dim] * (n_blk - 1) + [output_dim]
+        blocks = [LinearBlock(dims[i], dims[i + 1], norm=norm if i < n_blk - 1 else "none",
+                              activation=activ if i < n_blk - 1 else "none") for i in range(n_blk)]
+        self.model = nn.Sequential(*blocks)
+
+    def forward(self, x):
+        return self.model(x.reshape(x.size(0), -1))
+
+
+class Upsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='bilinear') stand-in without parameters."""
+
+    def forward(self, x):
+        return ops.upsample2x(x)
+
+
+# --------------------------------------------------------------------------------------
+# encoders / decoder shared with networks_v2
+# --------------------------------------------------------------------------------------
+class ContentEncoder(nn.Module):
+    """7x7 stem, n_downsample stride-2 convs (channel cap 256), n_res IN ResBlocks
+    (reference networks.py:428-446)."""
+
+    def __init__(self, n_downsample, n_res, input_dim, dim, norm, activ, pad_type):
+        super().__init__()
+        layers = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for _ in range(n_downsample):
+            nxt = min(dim * 2, 256)
+            layers.append(Conv2dBlock(dim, nxt, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type))
+            dim = nxt
+        layers.append(ResBlocks(n_res, dim, norm=norm, activation=activ, pad_type=pad_type))
+        self.model = nn.Sequential(*layers)
+        self.output_dim = dim
+
+    def forward(self, x):
+        return self.model(ops.pack_image(x) if x.shape[1] < 4 else x)
+
+
+class Decoder(nn.Module):
+    """AdaIN ResBlocks -> n_upsample x [bilinear x2, 5x5 conv, LN, act] -> tanh image head and
+    sigmoid attention head (reference networks.py:449-475 / networks_v2.py:144-169).
+
+    The two 7x7 heads read the same feature map, so they run as ONE 4-channel convolution
+    (planes 0-2 tanh, plane 3 sigmoid); ``forward`` hands back the usual (image, attention)
+    pair as channel views of that NHWC4 buffer, ``forward_nhwc4`` the buffer itself."""
+
+    def __init__(self, n_upsample, n_res, dim, output_dim, res_norm="adain", activ="relu", pad_type="zero",
+                 use_attention=False):
+        super().__init__()
+        self.use_attention = use_attention
+        self.output_dim = output_dim
+        layers = [ResBlocks(n_res, dim, res_norm, activ, pad_type=pad_type)]
+        for _ in range(n_upsample):
+            layers += [Upsample2x(), Conv2dBlock(dim, dim // 2, 5, 1, 2, norm="ln", activation=activ, pad_type=pad_type)]
+            dim //= 2
+        self.model = nn.Sequential(*layers)
+        self.image_content = Conv2dBlock(dim, output_dim, 7, 1, 3, norm="none", activation="tanh", pad_type=pad_type)
+        self.image_attention = Conv2dBlock(dim, 1, 7, 1, 3, norm="none", activation="sigmoid", pad_type=pad_type)
+
+    def forward_nhwc4(self, x):
+        feats = self.model(x)
+        if self.output_dim != 3:
+            raise NotImplementedError("fused heads assume a 3-channel image")
+        w = torch.cat([self.image_content.conv.weight, self.image_attention.conv.weight], 0)
+        b = torch.cat([self.image_content.conv.bias, self.image_attention.conv.bias], 0)
+        return ops.conv2d_padded(feats, w, b, 1, 3, "heads")
+
+    def forward(self, x):
+        heads = self.forward_nhwc4(x)
+        return heads[:, :3], (heads[:, 3:4] if self.use_attention else None)
+
+
+# --------------------------------------------------------------------------------------
+# discriminator
+# --------------------------------------------------------------------------------------
+class MsImageDis(nn.Module):
+    """Multi-scale discriminator (reference networks.py:43-170): per scale n_layer x
+    [reflect-pad 1, 4x4 stride-2 conv, LeakyReLU(0.1)], a 1x1 'src' head and a full-extent
+    'cls' head; the next scale sees the 2x2-mean image."""
+
+    def __init__(self, input_dim, params, device=None):
+        super().__init__()
+        self.n_layer, self.gan_type, self.dim = params["n_layer"], params["gan_type"], params["dim"]
+        self.norm, self.activ, self.num_scales = params["norm"], params["activ"], params["num_scales"]
+        self.pad_type, self.num_cls, self.input_dim = params["pad_type"], params["num_cls"], input_dim
+        self.image_size, self.dataset = params["image_size"], params["dataset"]
+        self.device = device if device is not None else torch.device("cpu")
+        self.cnns_feat, self.cnns_src, self.cnns_cls = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for s in range(self.num_scales):
+            feat, src, cls = self._make_net(self.image_size // (2 ** s))
+            self.cnns_feat.append(feat)
+            self.cnns_src.append(src)
+            self.cnns_cls.append(cls)
+
+    def _make_net(self, im_size):
+        dim, chain, prev = self.dim, [], self.input_dim
+        for l in range(self.n_layer):
+            chain.append(Conv2dBlock(prev, dim, 4, 2, 1, norm="none" if l == 0 else self.norm, activation=self.activ,
+                                     pad_type=self.pad_type))
+            prev, dim = dim, min(dim * 2, 512)
+        src = nn.Conv2d(prev, 1, 1, 1, 0)
+        cls = nn.Conv2d(prev, self.num_cls, kernel_size=im_size // (2 ** self.n_layer), stride=1, padding=0, bias=False)
+        return nn.Sequential(*chain), src, cls
+
+    def forward(self, x, use_multiscales=True):
+        x = ops.pack_image(x)
+        outputs = []
+        for s in range(self.num_scales):
+            h = self.cnns_feat[s](x)
+            src = ops.conv2d(h, self.cnns_src[s].weight, self.cnns_src[s].bias, 1, 0)
+            cls = ops.conv2d(h, self.cnns_cls[s].weight, None, 1, 0)
+            outputs.append([src, cls.reshape(cls.size(0), -1)])
+            if not use_multiscales:
+                break
+            if s + 1 < self.num_scales:
+                x = ops.downsample_half(x)
+        return outputs
+
+    def _classification_loss(self, logit, target, dataset="CelebA"):
+        if dataset in ("CelebA", "CUB200"):
+            return F.binary_cross_entropy_with_logits(logit, target, reduction="mean")
+        return F.cross_entropy(logit, target)
+
+    def _gan_term(self, out, target_is_real):
+        if self.gan_type == "lsgan":
+            return torch.mean((out - (1.0 if target_is_real else 0.0)) ** 2)
+        if self.gan_type == "nsgan":
+            tgt = torch.ones_like(out) if target_is_real else torch.zeros_like(out)
+            return F.binary_cross_entropy(torch.sigmoid(out), tgt)
+        if self.gan_type == "wgan":
+            return -torch.mean(out) if target_is_real else torch.mean(out)
+        raise AssertionError("Unsupported GAN type: {}".format(self.gan_type))
+
+    def calc_dis_loss(self, input_fake, input_real, fake_cls, real_cls, weight_gan=1.0, weight_cls=1.0):
+        """D objective (reference networks.py:116-146)."""
+        loss = 0.0
+        for (src_f, _), (src_r, cls_r) in zip(self.forward(input_fake), self.forward(input_real)):
+            loss = loss + (self._gan_term(src_f, False) + self._gan_term(src_r, True)) * weight_gan
+            loss = loss + self._classification_loss(cls_r, real_cls, self.dataset) * weight_cls
+        return loss
+
+    def calc_gen_loss(self, input_fake, target_cls, weight_gan=1.0, weight_cls=1.0):
+        """G-side adversarial objective (reference networks.py:148-170)."""
+        loss = 0
+        for src_f, cls_f in self.forward(input_fake):
+            loss = loss + self._gan_term(src_f, True) * weight_gan
+            loss = loss + self._classification_loss(cls_f, target_cls, self.dataset) * weight_cls
+        return loss

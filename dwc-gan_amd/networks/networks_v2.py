@@ -1,0 +1,172 @@
+"""MI355X-native generator behind the reference's ``networks.networks_v2`` API.
+
+``AdaINGen_v2`` keeps the constructor, ``encode`` / ``encode_txt`` / ``decode`` methods, attribute
+names and ``state_dict`` keys of reference networks/networks_v2.py:9-95; the conv / norm /
+upsample stacks run on libdwcgan_hip.so through ``hipdwc.ops``.  The text encoder
+(Embedding + bi-LSTM, ~0% of the FLOPs) stays on stock PyTorch-ROCm as SURVEY.md section 8(a)
+row a12 scopes it, with the reference's batch-mixing ``view`` reproduced on purpose.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from hipdwc import host, ops
+from .networks import ContentEncoder, MLP, Conv2dBlock, ResBlocks, AdaptiveInstanceNorm2d, Decoder  # noqa: F401
+
+
+class StyleEncoder(nn.Module):
+    """Image -> per-attribute (mu, logvar) heads (reference networks_v2.py:98-141): 7x7 stem,
+    n_downsample stride-2 convs without norm, global average pool, optional 2-layer mapping
+    with dropout 0.1, then num_class pairs of Linear(dim -> c_dim)."""
+
+    def __init__(self, n_downsample, input_dim, dim, norm, activ, pad_type, c_dim, num_class, use_map=False):
+        super().__init__()
+        self.num_class, self.use_map, self.c_dim = num_class, use_map, c_dim
+        convs = [Conv2dBlock(input_dim, dim, 7, 1, 3, norm=norm, activation=activ, pad_type=pad_type)]
+        for i in range(n_downsample):
+            nxt = dim * 2 if i < 2 else dim
+            convs.append(Conv2dBlock(dim, nxt, 4, 2, 1, norm=norm, activation=activ, pad_type=pad_type))
+            dim = nxt
+        convs.append(nn.AdaptiveAvgPool2d(1))
+        self.model = nn.Sequential(*convs)
+        if use_map:
+            self.mapping = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(inplace=True), nn.Dropout(p=0.1),
+                                         nn.Linear(dim, dim), nn.ReLU(inplace=True))
+        self.fcs, self.fcvars = nn.ModuleList(), nn.ModuleList()
+        for _ in range(num_class):           # interleaved creation order matters for seeded init
+            self.fcs.append(nn.Linear(dim, c_dim))
+            self.fcvars.append(nn.Linear(dim, c_dim))
+        self.output_dim = dim
+
+    def forward(self, x):
+        h = ops.pack_image(x) if x.shape[1] < 4 else x
+        for blk in list(self.model)[:-1]:
+            h = blk(h)
+        f = h.mean(dim=(2, 3))                                   # global average pool over <=4x4 pixels
+        if self.use_map:
+            f = ops.linear(f, self.mapping[0].weight, self.mapping[0].bias, "relu")
+            f = host.noise().dropout(f, self.mapping[2].p, self.training)
+            f = ops.linear(f, self.mapping[3].weight, self.mapping[3].bias, "relu")
+        # the 2*num_class heads share their input: one [2*num_class*c_dim, dim] product
+        w = torch.cat([m.weight for m in self.fcs] + [m.weight for m in self.fcvars], 0)
+        b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
+        out = ops.linear(f, w, b)
+        k, c = self.num_class, self.c_dim
+        mus = [out[:, i * c:(i + 1) * c] for i in range(k)]
+        lvs = [out[:, (k + i) * c:(k + i + 1) * c] for i in range(k)]
+        return mus, lvs
+
+
+class TxtEncoder(nn.Module):
+    """Command text + current style -> per-attribute (mu, logvar) (reference networks_v2.py:171-254)."""
+
+    def __init__(self, vocab, embed_dim=512, hidden_size=512, c_dim=8, num_class=8, num_layers=1, dropout_in=0.1,
+                 dropout_out=0.1, bidirectional=True, pretrained_embed=None):
+        super().__init__()
+        self.vocab, self.embed_dim, self.hidden_size = vocab, embed_dim, hidden_size
+        self.num_layers, self.dropout_in, self.dropout_out = num_layers, dropout_in, dropout_out
+        self.bidirectional, self.num_class, self.style_dim = bidirectional, num_class, c_dim * num_class
+        self.embed_tokens = nn.Embedding(vocab.size, embed_dim, vocab.padding_idx)
+        if pretrained_embed is not None:
+            table = np.zeros((vocab.size, embed_dim))
+            for i, word in enumerate(vocab.itos):
+                table[i] = pretrained_embed[word] if word in pretrained_embed else \
+                    np.random.normal(scale=0.6, size=(embed_dim,))
+            self.embed_tokens.load_state_dict({"weight": torch.from_numpy(table)})
+            self.embed_tokens.weight.requires_grad = False
+        self.lstm = nn.LSTM(input_size=embed_dim + self.style_dim, hidden_size=hidden_size, num_layers=num_layers,
+                            dropout=dropout_out if num_layers > 1 else 0.0, bidirectional=bidirectional)
+        feat = hidden_size * num_layers * (4 if bidirectional else 2)
+        self.fcs, self.fcvars = nn.ModuleList(), nn.ModuleList()
+        for _ in range(num_class):
+            self.fcs.append(nn.Linear(feat, c_dim))
+            self.fcvars.append(nn.Linear(feat, c_dim))
+
+    def forward(self, style_ord, src_tokens, src_lengths):
+        noise = host.noise()
+        tokens = src_tokens.transpose(1, 0)
+        seq_len, bsz = tokens.shape
+        lens_host = src_lengths.detach().to("cpu")               # kept on the host: no device sync per call
+        lens_sorted, order_host = torch.sort(lens_host, descending=True)
+        order = order_host.to(tokens.device)
+        emb = self.embed_tokens(tokens.index_select(1, order))
+        emb = noise.dropout(emb, self.dropout_in, self.training)
+        sty = style_ord.index_select(0, order)
+        packed = nn.utils.rnn.pack_padded_sequence(torch.cat([emb, sty.expand(seq_len, -1, -1)], -1),
+                                                   lens_sorted.tolist())
+        dirs = 2 if self.bidirectional else 1
+        zeros = emb.new_zeros(dirs * self.num_layers, bsz, self.hidden_size)
+        outs, (h_n, c_n) = self.lstm(packed, (zeros, zeros))
+        if self.training and self.dropout_out > 0:
+            # the reference drops out the (unused) padded memory here and thereby advances the
+            # random stream (reference networks_v2.py:235-236); keep the stream aligned
+            mem, _ = nn.utils.rnn.pad_packed_sequence(outs)
+            noise.dropout(mem, self.dropout_out, True)
+        if self.bidirectional:
+            h_n = h_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
+            c_n = c_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
+        unsort = torch.sort(order_host)[1].to(tokens.device)
+        h_n, c_n = h_n.index_select(1, unsort), c_n.index_select(1, unsort)
+        # reference networks_v2.py:249: concatenating along the BATCH axis and then viewing as
+        # (batch, -1) interleaves samples of the local batch; reproduced, not fixed
+        feat = torch.cat([h_n, c_n], dim=1).view(bsz, -1)
+        mus = [fc(feat) for fc in self.fcs]
+        lvs = [fc(feat) for fc in self.fcvars]
+        return mus, lvs
+
+
+class AdaINGen_v2(nn.Module):
+    """Style/content auto-encoder with AdaIN injection (reference networks_v2.py:9-95)."""
+
+    def __init__(self, input_dim, vocab, params, pretrained_embed=None):
+        super().__init__()
+        p = params
+        style_dim = p["c_dim"] * p["num_cls"]
+        self.enc_style = StyleEncoder(p["style_downsample"], input_dim, p["dim"], norm="none", activ=p["activ"],
+                                      pad_type=p["pad_type"], c_dim=p["c_dim"], num_class=p["num_cls"],
+                                      use_map=p["use_map"])
+        self.enc_content = ContentEncoder(p["content_downsample"], p["n_res"], input_dim, p["dim"], "in", p["activ"],
+                                          pad_type=p["pad_type"])
+        self.dec = Decoder(p["content_downsample"], p["n_res"], self.enc_content.output_dim, input_dim,
+                           res_norm="adain", activ=p["activ"], pad_type=p["pad_type"],
+                           use_attention=p["use_attention"])
+        self.enc_txt = TxtEncoder(vocab, p["embed_dim"], p["hidden_size"], p["c_dim"], p["num_cls"], p["num_layers"],
+                                  p["dropout_in"], p["dropout_out"], pretrained_embed=pretrained_embed)
+        self.mlp = MLP(style_dim, self.get_num_adain_params(self.dec), p["mlp_dim"], 3, norm="none", activ=p["activ"])
+
+    # -- reference API -------------------------------------------------------------------
+    def forward(self, images):
+        content, mus, _ = self.encode(images)
+        return self.decode(content, mus)
+
+    def encode(self, images):
+        x = ops.pack_image(images)
+        mus, logvar = self.enc_style(x)
+        return self.enc_content(x), mus, logvar
+
+    def encode_txt(self, style_ord, txt_org2trg, txt_lens):
+        return self.enc_txt(style_ord, txt_org2trg, txt_lens)
+
+    def decode(self, content, style):
+        self.assign_adain_params(self.mlp(style), self.dec)
+        return self.dec(content)
+
+    # -- internal 4-plane image API used by the solver ------------------------------------
+    def decode_nhwc4(self, content, style):
+        """As decode(), returning the fused NHWC4 head buffer (planes 0-2 image, plane 3 attention)."""
+        self.assign_adain_params(self.mlp(style), self.dec)
+        return self.dec.forward_nhwc4(content)
+
+    def assign_adain_params(self, adain_params, model):
+        """Hand each AdaIN layer, in module order, its slice of the MLP output: first C columns ->
+        bias (shift), next C -> weight (scale), both flattened to B*C (reference networks_v2.py:78-87)."""
+        col = 0
+        for m in model.modules():
+            if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
+                c = m.num_features
+                m.bias = adain_params[:, col:col + c].contiguous().view(-1)
+                m.weight = adain_params[:, col + c:col + 2 * c].contiguous().view(-1)
+                col += 2 * c
+
+    def get_num_adain_params(self, model):
+        return sum(2 * m.num_features for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d")

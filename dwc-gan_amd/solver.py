@@ -1,0 +1,302 @@
+"""MI355X-native trainer behind the reference's ``solver.Solver`` API (reference solver.py:22-413).
+
+Drop-in for ``from solver import Solver`` in the reference's train.py: same constructor, the
+same ``dis_update`` / ``gen_update`` / ``smooth_moving`` / ``update_learning_rate`` /
+``update_attention_status`` / ``sample`` / ``copy_nets`` / ``resume`` / ``save`` /
+``init_network`` methods and the same ``loss_*`` attributes, with the generator and
+discriminator running on the hand-written gfx950 kernels (``networks.networks{,_v2}``).
+
+Differences from the reference that do not change any number it produces:
+  * work the reference computes and then discards is not computed: the generator is not
+    back-propagated in the D step (its gradients are zeroed at solver.py:153 before use), D's
+    weight gradients are not formed in the G step (zeroed at solver.py:319 before use), and the
+    ``x_fake2`` decode (only ever used detached, solver.py:181) keeps no tape;
+  * images travel as NHWC4 buffers end to end (plane 3 is padding or the attention map).
+"""
+import contextlib
+import copy
+import os
+
+import torch
+from torch import nn
+
+from gmm import gmm_kl_distance_sp, gmm_earth_mover_distance_sp
+from hipdwc import host, ops
+from hipdwc.host import get_scheduler, moving_average, weights_init
+from networks.networks import MsImageDis
+from networks.networks_v2 import AdaINGen_v2
+from tools import dist_sampling_split
+
+try:                                   # the reference's own vocabulary when dropped into its tree
+    from vocab import Vocab
+except ImportError:                    # stand-alone: only the sizes/indices matter on this path
+    class Vocab(object):
+        """102 tokens: PAD=0, BOS=1, EOS=2, UNK=3 + 98 words (reference vocab.py:5,177-185)."""
+
+        def __init__(self, dataset="CelebA", with_SE=True):
+            self.itos = ["<_>", "<bos>", "<eos>", "<unk>"] + ["w%d" % i for i in range(98)]
+            self.stoi = {w: i for i, w in enumerate(self.itos)}
+            self.size, self.padding_idx, self.unk_idx, self.start_idx, self.end_idx = len(self.itos), 0, 3, 1, 2
+
+
+@contextlib.contextmanager
+def _frozen(module):
+    """Run a block with ``module``'s parameters excluded from autograd (their gradients would be discarded)."""
+    flags = [(p, p.requires_grad) for p in module.parameters()]
+    for p, _ in flags:
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in flags:
+            p.requires_grad_(f)
+
+
+class Solver(nn.Module):
+    def __init__(self, configs, device=None, pretrained_embed=None):
+        super().__init__()
+        self.device = device if device is not None else torch.device("cpu")
+        self.configs = configs
+        self.vocab = Vocab(dataset=configs["dataset"])
+        self.gen = AdaINGen_v2(configs["input_dim"], self.vocab, configs["gen"], pretrained_embed=pretrained_embed)
+        self.dis = MsImageDis(configs["input_dim"], configs["dis"], self.device)
+        self.instancenorm = nn.InstanceNorm2d(512, affine=False)
+        self.print_network(self.dis, "D")
+        self.print_network(self.gen, "G")
+
+        self.num_cls, self.c_dim = configs["gen"]["num_cls"], configs["c_dim"]
+        self.dist_mode = configs["dist_mode"]
+        self.use_attention = configs["gen"]["use_attention"]
+        self.att_status = self.use_attention
+        self.ds_iter = configs["ds_iter"]
+        self.display_size = int(configs["display_size"])
+        self.dataset, self.stddev = configs["dataset"], configs["stddev"]
+        self.sigma = torch.tensor(self.stddev ** 2).to(self.device)
+        self.d_reg_every, self.rnd_step = 16, 3
+        self.init_ds_w = configs["ds_w"]
+        self.lr_policy = configs["lr_policy"]
+
+        adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
+        self.dis_opt = torch.optim.Adam([p for p in self.dis.parameters() if p.requires_grad], **adam)
+        self.gen_opt = torch.optim.Adam([p for p in self.gen.parameters() if p.requires_grad], **adam)
+        self.dis_scheduler = get_scheduler(self.dis_opt, configs)
+        self.gen_scheduler = get_scheduler(self.gen_opt, configs)
+
+        self.apply(weights_init(configs["init"]))      # whole solver first ...
+        self.dis.apply(weights_init("gaussian"))       # ... then D again (reference solver.py:73-74)
+        self.criterionL1 = torch.nn.L1Loss()
+
+        if configs.get("vgg_w", 0) > 0:
+            raise NotImplementedError(
+                "vgg_w > 0 needs the VGG16 perceptual network (reference solver.py:79-83), which is outside the "
+                "hot path built here (SURVEY.md section 8(f)); run with vgg_w: 0")
+
+    # ---- bookkeeping -----------------------------------------------------------------------
+    def print_network(self, model, name):
+        print("The number of parameters in {}: {}".format(name, sum(p.numel() for p in model.parameters())))
+
+    def copy_nets(self):
+        self.gen_copy = copy.deepcopy(self.gen)
+        self.dis_copy = copy.deepcopy(self.dis)
+
+    def smooth_moving(self):
+        moving_average(self.gen, self.gen_copy)
+        moving_average(self.dis, self.dis_copy)
+
+    def update_learning_rate(self):
+        if self.lr_policy == "cosa":
+            floor = self.configs["eta_min"]
+            if self.dis_opt.param_groups[0]["lr"] == floor or self.gen_opt.param_groups[0]["lr"] == floor:
+                self.configs["step_size"] *= self.configs["t_mult"]
+                self.dis_scheduler = get_scheduler(self.dis_opt, self.configs)
+                self.gen_scheduler = get_scheduler(self.gen_opt, self.configs)
+        for sched in (self.dis_scheduler, self.gen_scheduler):
+            if sched is not None:
+                sched.step()
+
+    def update_attention_status(self, iters):
+        if self.att_status:
+            self.use_attention = iters >= 10000
+
+    # ---- small losses ------------------------------------------------------------------------
+    def recon_criterion(self, x, y):
+        if x.dim() == 4 and x.shape[1] == 4 and y.shape[1] == 4:
+            return ops.l1_mean(x, y, image=True)
+        if x.dim() == 4:
+            return ops.l1_mean(x, y)
+        return torch.mean(torch.abs(x - y))
+
+    def criterion_l1(self, a, z):
+        a = torch.cat(a, dim=1) if isinstance(a, (list, tuple)) else a
+        z = torch.cat(z, dim=1) if isinstance(z, (list, tuple)) else z
+        return self.criterionL1(a, z)
+
+    def style_replace(self, c_src, c_trg, z_src, z_trg):
+        keep = (c_src == c_trg).repeat_interleave(self.c_dim, dim=1)
+        return torch.where(keep, z_src, z_trg)
+
+    def _decode(self, content, style, x_real4):
+        """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out."""
+        heads = self.gen.decode_nhwc4(content, style)
+        return ops.attention_blend(heads, x_real4) if self.use_attention else heads
+
+    def forward(self, x_real, txt_src2trg, txt_lens):
+        x4 = ops.pack_image(x_real)
+        content, style_src, _ = self.gen.encode(x4)
+        style_txt, _ = self.gen.encode_txt(torch.cat(style_src, dim=1), txt_src2trg, txt_lens)
+        return self._decode(content, torch.cat(style_txt, dim=1), x4)[:, :3]
+
+    # ---- D step (reference solver.py:317-353) ---------------------------------------------------
+    def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters):
+        if configs["gp_w"] > 0.0 or configs["use_r1"]:
+            raise NotImplementedError("gradient / R1 penalties need double backward through the HIP ops "
+                                      "(off in the shipped config: gp_w 0, use_r1 False)")
+        self.dis_opt.zero_grad()
+        x4 = ops.pack_image(x_real)
+        with torch.no_grad():
+            content, style_real, _ = self.gen.encode(x4)
+            style_real = torch.cat(style_real, dim=1)
+            style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
+            style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
+            x_fake = self._decode(content, torch.cat(style_txt, dim=1), x4)
+            x_fake1 = self._decode(content, style1, x4)
+        gw, cw = configs["gan_w"], configs["cls_w"]
+        self.loss_dis = self.dis.calc_dis_loss(x_fake, x4, label_trg, label_src, gw, cw) + \
+            self.dis.calc_dis_loss(x_fake1, x4, label_trg, label_src, gw, cw)
+        self.loss_dis_all = self.loss_dis
+        self.loss_dis_all.backward()
+        self.dis_opt.step()
+
+    # ---- G step (reference solver.py:151-240) ---------------------------------------------------
+    def gen_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters):
+        self.gen_opt.zero_grad()
+        gen, cfg = self.gen, configs
+        x4 = ops.pack_image(x_real)
+        with _frozen(self.dis):
+            content_real, style_real, logvar = gen.encode(x4)
+            s_real = torch.cat(style_real, dim=1)
+            # within-domain reconstruction
+            x_rec = self._decode(content_real, s_real, x4)
+            content_rec, style_rec, _ = gen.encode(x_rec)
+            # cross-domain via the text command
+            style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)
+            s_txt = torch.cat(style_txt, dim=1)
+            x_fake = self._decode(content_real, s_txt, x4)
+            # two random styles for the diversity term; the second is only a detached target
+            style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
+            x_fake1 = self._decode(content_real, style1, x4)
+            style2 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
+            with torch.no_grad():
+                x_fake2 = self._decode(content_real, style2, x4)
+            self.loss_ds = ops.l1_mean(x_fake1, x_fake2, image=True)
+            content_rand, style_rand, _ = gen.encode(x_fake1)
+            self.init_ds_w = max(self.init_ds_w - 1 / 1e5, 0.0)
+            content_fake, style_fake, _ = gen.encode(x_fake)
+            cyc = cfg["recon_x_cyc_w"] > 0
+            if cyc:
+                x_cycle = self._decode(content_fake, s_real, x4)
+
+            self.loss_gen_recon_x = ops.l1_mean(x_rec, x4, image=True)
+            self.loss_gen_recon_c_real = ops.l1_mean(content_rec, content_real)
+            self.loss_gen_recon_c_fake = ops.l1_mean(content_fake, content_real)
+            self.loss_gen_recon_c_rand = ops.l1_mean(content_rand, content_real)
+            self.loss_gen_recon_s_real = self.criterion_l1(style_rec, style_real)
+            self.loss_gen_recon_s_fake = self.criterion_l1(style_fake, style_txt)
+            self.loss_gen_recon_s_rand = self.criterion_l1(style_rand, style1)
+            self.loss_gen_cycrecon_x = ops.l1_mean(x_cycle, x4, image=True) if cyc else 0
+
+            self.loss_gen_adv = self.dis.calc_gen_loss(x_fake, label_trg, cfg["gan_w"], cfg["cls_w"]) + \
+                self.dis.calc_gen_loss(x_fake1, label_trg, cfg["gan_w"], cfg["cls_w"])
+
+            if self.dist_mode == "kls":
+                self.loss_kl_x = gmm_kl_distance_sp(style_real, logvar, c_src, self.sigma)
+                self.loss_kl_trg = gmm_kl_distance_sp(style_txt, logvar_txt, c_trg, self.sigma)
+            else:
+                self.loss_kl_x = gmm_earth_mover_distance_sp(style_real, c_src)
+                self.loss_kl_trg = gmm_earth_mover_distance_sp(style_txt, c_trg)
+            self.loss_gen_vgg = 0
+
+            self.loss_gen_total = self.loss_gen_adv + \
+                cfg["recon_x_w"] * self.loss_gen_recon_x + \
+                cfg["recon_c_w"] * self.loss_gen_recon_c_real + \
+                cfg["recon_c_w"] * self.loss_gen_recon_c_fake + \
+                cfg["recon_c_w"] * self.loss_gen_recon_c_rand + \
+                cfg["recon_s_w"] * self.loss_gen_recon_s_real + \
+                cfg["recon_s_w"] * self.loss_gen_recon_s_fake + \
+                cfg["recon_s_w"] * self.loss_gen_recon_s_rand + \
+                cfg["recon_x_cyc_w"] * self.loss_gen_cycrecon_x + \
+                cfg["kl_w"] * self.loss_kl_x + \
+                cfg["kl_w"] * self.loss_kl_trg + \
+                cfg["vgg_w"] * self.loss_gen_vgg - \
+                self.init_ds_w * self.loss_ds
+            self.loss_gen_total.backward()
+        self.gen_opt.step()
+
+    # ---- visualisation path (reference solver.py:249-289), batched instead of per image ---------
+    @torch.no_grad()
+    def sample(self, x_real, txt_src2trg, txt_lens):
+        self.eval()
+        outs = {"rec": [], "trg": [], "sam": [], "att": []}
+        for i in range(x_real.size(0)):
+            x4 = ops.pack_image(x_real[i:i + 1])
+            content, style_real, _ = self.gen.encode(x4)
+            style_real = torch.cat(style_real, dim=1)
+            style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg[i:i + 1], txt_lens[i:i + 1])
+            style_txt = torch.cat(style_txt, dim=1)
+            sign = lambda s: torch.where(s.view(1, self.num_cls, self.c_dim).mean(2) < 0, -1.0, 1.0)
+            mus_real, mus_txt = sign(style_real), sign(style_txt)
+            z = dist_sampling_split(mus_txt, self.c_dim, self.stddev, self.device)
+            z = self.style_replace(mus_real, mus_txt, style_real, z)
+            h_trg = self.gen.decode_nhwc4(content, style_txt)
+            outs["rec"].append(self._decode(content, style_real, x4)[:, :3])
+            outs["trg"].append((ops.attention_blend(h_trg, x4) if self.use_attention else h_trg)[:, :3])
+            outs["sam"].append(self._decode(content, z, x4)[:, :3])
+            outs["att"].append(h_trg[:, 3:4].expand(-1, 3, -1, -1))
+        res = [x_real, torch.cat(outs["rec"]), torch.cat(outs["trg"]), torch.cat(outs["sam"])]
+        if self.use_attention:
+            res.append((torch.cat(outs["att"]) - 0.5) / 0.5)
+        self.train()
+        return res
+
+    # ---- checkpoints (reference solver.py:359-413; file names/keys kept) ------------------------
+    @staticmethod
+    def _latest(dirname, key):
+        if not os.path.exists(dirname):
+            return None
+        files = sorted(os.path.join(dirname, f) for f in os.listdir(dirname)
+                       if os.path.isfile(os.path.join(dirname, f)) and key in f and ".pt" in f)
+        return files[-1] if files else None
+
+    def resume(self, checkpoint_dir, configs):
+        name = self._latest(checkpoint_dir, "gen")
+        self.gen.load_state_dict(torch.load(name, map_location="cpu")["a"])
+        iterations = int(name[-15:-7]) if "avg" in name else int(name[-11:-3])
+        name = self._latest(checkpoint_dir, "dis")
+        self.dis.load_state_dict(torch.load(name, map_location="cpu")["b"])
+        self.dis_scheduler = get_scheduler(self.dis_opt, configs, iterations)
+        self.gen_scheduler = get_scheduler(self.gen_opt, configs, iterations)
+        for _ in range(iterations):
+            self.gen_scheduler.step()
+            self.dis_scheduler.step()
+        print("Resume from iteration %d" % iterations)
+        return iterations
+
+    def init_network(self, gen_path, dis_path):
+        gen_dict = torch.load(gen_path, map_location="cpu")["a"]
+        dis_dict = torch.load(dis_path, map_location="cpu")["b"]
+        sd = self.dis.state_dict()
+        sd.update({k: v for k, v in dis_dict.items() if k in sd})
+        self.dis.load_state_dict(sd)
+        sg = self.gen.state_dict()
+        sg.update({k: v for k, v in gen_dict.items() if k in sg and "embed_tokens" not in k})
+        self.gen.load_state_dict(sg)
+        print("Initial model loaded...")
+
+    def save(self, snapshot_dir, iterations):
+        tag = "%08d" % (iterations + 1)
+        torch.save({"a": self.gen.state_dict()}, os.path.join(snapshot_dir, "gen_%s.pt" % tag))
+        torch.save({"b": self.dis.state_dict()}, os.path.join(snapshot_dir, "dis_%s.pt" % tag))
+        torch.save({"a": self.gen_copy.state_dict()}, os.path.join(snapshot_dir, "gen_%s_avg.pt" % tag))
+        torch.save({"b": self.dis_copy.state_dict()}, os.path.join(snapshot_dir, "dis_%s_avg.pt" % tag))
+        torch.save({"gen": self.gen_opt.state_dict(), "dis": self.dis_opt.state_dict()},
+                   os.path.join(snapshot_dir, "optimizer.pt"))

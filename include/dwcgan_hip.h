@@ -1,0 +1,145 @@
+/*
+ * dwcgan_hip.h — C ABI of libdwcgan_hip.so: the gfx950 (MI355X) kernels under the DWC-GAN
+ * training hot path.
+ *
+ * The reference has no native/FFI layer: its boundary is the Python import contract
+ * `solver.Solver`, `networks.networks`, `networks.networks_v2`, and every
+ * heavy operation is a torch.nn call.  Each entry point below replaces one of those torch
+ * dispatch sites (cited per function as reference file:line); the Python mirror in
+ * dwc-gan_amd/ binds them with ctypes.
+ *
+ * Conventions
+ *  - all tensors are dense fp32 in HBM, activations NHWC: x[n][h][w][c]
+ *  - conv weights are handed over in the state_dict layout OIHW and re-laid-out on device by
+ *    the dwc_weight_* entry points into the layouts the kernels stream ("HWIO": [kh][kw][ci][co])
+ *  - channel counts on the data path must be multiples of 4 (16-byte vector accesses); the
+ *    3-channel images travel as NHWC4 with a zero 4th plane
+ *  - pointers are borrowed device pointers; the library never allocates, frees or synchronises;
+ *    scratch is passed in by the caller (`ws`, `ws_bytes`); `stream` is a hipStream_t
+ *  - return value: 0 on success, a negative DWC_E* code otherwise; nothing throws
+ *  - thread-safe per stream (no global mutable state)
+ */
+#ifndef DWCGAN_HIP_H
+#define DWCGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DWC_OK 0
+#define DWC_EINVAL (-1)   /* unsupported shape / argument */
+#define DWC_EWORKSPACE (-2) /* scratch buffer too small */
+#define DWC_ELAUNCH (-3)  /* hipLaunch failed */
+
+/* activation codes fused into conv epilogues (reference networks.py:556-571) */
+#define DWC_ACT_NONE 0
+#define DWC_ACT_RELU 1
+#define DWC_ACT_LRELU 2    /* slope 0.1, reference networks.py:559 */
+#define DWC_ACT_TANH 3
+#define DWC_ACT_SIGMOID 4
+#define DWC_ACT_HEADS 5    /* channels 0..2 tanh, channel 3 sigmoid: image_content+image_attention
+                              fused into one 4-channel conv (reference networks_v2.py:159-160) */
+
+int dwc_version(void);
+
+/* ---- weight re-layout -------------------------------------------------------------------- */
+/* OIHW -> HWIO with Cin padded to cin_pad and Cout padded to cout_pad (zero fill). */
+int dwc_weight_oihw_to_hwio(const float* w_oihw, float* w_hwio, int Cout, int Cin, int KH, int KW,
+                            int cout_pad, int cin_pad, void* stream);
+/* OIHW -> data-gradient layout.
+ *   stride 1: [kh'][kw'][co][ci] = W[co][ci][KH-1-kh'][KW-1-kw']
+ *   stride 2 (4x4 kernel only): [ph][pw][th][tw][co][ci] = W[co][ci][ph+2*th][pw+2*tw]
+ * co padded to cout_pad, ci to cin_pad. */
+int dwc_weight_oihw_to_dgrad(const float* w_oihw, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+                             int stride, int cout_pad, int cin_pad, void* stream);
+
+/* ---- convolution (replaces nn.ReflectionPad2d + nn.Conv2d [+ activation];
+ *      reference networks.py:579-585, call sites networks.py:432-441,514-515,90-98,
+ *      networks_v2.py:106-112,155,159-160; also nn.Linear as a 1x1 conv, networks.py:595) ---- */
+/* y = act(conv(reflect_pad(x, pad), w) + bias).  x:[B,H,W,Cin] y:[B,Ho,Wo,Cout], w HWIO. */
+int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float* y,
+                   int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                   int act, void* stream);
+/* dx = d/dx of the above (pre-activation gradient dy:[B,Ho,Wo,Cout], w in dgrad layout).
+ * Needs scratch for the padded gradient image when pad>0. */
+size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int pad);
+int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dx,
+                        int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                        void* ws, size_t ws_bytes, void* stream);
+/* dw (written in OIHW, the state_dict layout, [Cout_real][Cin_real][KH][KW]) from x and dy.
+ * Cin/Cout are the padded data-path channel counts, cin_real/cout_real the parameter's. */
+size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                      int stride, int pad);
+int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw,
+                          int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                          int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
+/* g = dy * act'(y) and db[c] = sum over rows of g (rows = B*Ho*Wo).  db may be NULL. */
+size_t dwc_act_bwd_bias_ws_bytes(int rows, int C);
+int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- instance norm / AdaIN (reference networks.py:545 nn.InstanceNorm2d and
+ *      networks.py:706-719 AdaptiveInstanceNorm2d; residual add networks.py:518-522) --------- */
+/* y = relu?( (x-mean[n,c])*rstd[n,c]*gamma[n,c] + beta[n,c] ) + residual?
+ * gamma/beta: [B*C] or NULL (plain IN).  mean/rstd [B*C] are outputs kept for the backward. */
+size_t dwc_instnorm_ws_bytes(int B, int HW, int C);
+int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
+                     float* y, float* mean, float* rstd, int B, int HW, int C, float eps, int relu,
+                     void* ws, size_t ws_bytes, void* stream);
+/* dx (and dgamma/dbeta [B*C] when gamma != NULL) given dy w.r.t. the (pre-residual) output. */
+int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                     int B, int HW, int C, int relu, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- MUNIT LayerNorm (reference networks.py:736-752: per-sample mean, UNBIASED std,
+ *      (x-mean)/(std+eps), per-channel gamma/beta) ------------------------------------------ */
+size_t dwc_layernorm_ws_bytes(int B, int HW, int C);
+int dwc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                      float* mean, float* inv, int B, int HW, int C, float eps, int relu,
+                      void* ws, size_t ws_bytes, void* stream);
+int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* inv,
+                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
+                      int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- resampling (reference networks_v2.py:154 nn.Upsample(x2, bilinear);
+ *      networks.py:113 F.interpolate(x0.5, bilinear) == 2x2 mean) ---------------------------- */
+int dwc_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int dwc_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+int dwc_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- image boundary: NCHW 3-channel <-> NHWC4 ------------------------------------------- */
+int dwc_pack_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int C, int H, int W, void* stream);
+int dwc_unpack_nhwc4_to_nchw(const float* x_nhwc4, float* y_nchw, int B, int C, int H, int W, void* stream);
+
+/* ---- attention blend (reference solver.py:148,161,170,179-180,192,330-331):
+ *      out[...,0:3] = img*att + real*(1-att) on NHWC4 images (att = channel 3 of `heads`) ------ */
+int dwc_blend_fwd(const float* heads, const float* real, float* out, int npix, void* stream);
+int dwc_blend_bwd(const float* dout, const float* heads, const float* real, float* dheads, int npix,
+                  void* stream);
+
+/* ---- mean |a-b| (reference solver.py:113-114) ----------------------------------------------
+ * skip4 != 0: the buffers are NHWC4 images; every 4th element (the pad / attention plane) is
+ * ignored and the mean is over the 3 image planes only (n*3/4 elements). */
+size_t dwc_l1_ws_bytes(size_t n);
+int dwc_l1_mean_fwd(const float* a, const float* b, float* out_scalar, size_t n, int skip4, void* ws,
+                    size_t ws_bytes, void* stream);
+/* da = sign(a-b) * dout[0] / count, db = -da (either may be NULL) */
+int dwc_l1_mean_bwd(const float* a, const float* b, const float* dout_scalar, float* da, float* db,
+                    size_t n, int skip4, void* stream);
+
+/* ---- fused Adam (+coupled L2) + EMA (reference solver.py:62-68,240,353; utils.py:52-54) ----- */
+/* One launch over a flat parameter arena.  p,g,m,v,ema: [n].  step is the 1-based Adam step.
+ * ema may be NULL.  ema update is the reference's lerp(param, ema, beta) AFTER the step only when
+ * do_ema != 0 (the reference runs it once per iteration, after both optimisers). */
+int dwc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, void* stream);
+int dwc_ema_lerp(const float* p, float* ema, size_t n, float beta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DWCGAN_HIP_H */

@@ -1,0 +1,354 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and against the
+vectors recorded from the reference.  Run on the MI355X box with ``pytest -m gpu``.
+
+Tolerances (fp32 end to end): single ops are compared on the tensor's own scale,
+max|hip - ref| <= 2e-5 * max|ref| (+1e-6); whole-network gradients at kaiming init 5e-3 of scale
+(a handful of ReLU/IN near-ties flip between any two implementations, the CPU oracle vs the
+CPU reference show the same spread); scalar losses 2e-4 relative.
+"""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hipdwc import host, ops, synth          # noqa: E402
+from oracle import dwcgan_oracle as orc      # noqa: E402
+
+T = torch.from_numpy
+DEV = "cuda:0"
+
+
+def close(a, b, rel=2e-5, atol=1e-6, msg=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    lim = rel * b.abs().max().item() + atol
+    assert err <= lim, "%s: max err %.3e > %.3e" % (msg, err, lim)
+
+
+def dev(t, grad=False):
+    return t.detach().clone().to(DEV).requires_grad_(grad)
+
+
+# (B, Cin, Cout, H, k, stride, pad, act)
+CONV_SHAPES = [
+    (2, 4, 64, 32, 7, 1, 3, "relu"),        # stem on an NHWC4 image
+    (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
+    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv, BN=128 path, 2 N tiles
+    (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
+    (2, 128, 64, 24, 5, 1, 2, "none"),      # BN=64 path, non power-of-two spatial size
+    (2, 64, 4, 32, 7, 1, 3, "heads"),       # fused tanh/sigmoid heads, BN=32 path
+    (3, 4, 64, 16, 4, 2, 1, "lrelu"),       # D stem
+    (3, 512, 512, 2, 4, 2, 1, "lrelu"),     # D tail on a 2x2 map (reflect pad on tiny maps)
+    (3, 512, 8, 4, 4, 1, 0, "none"),        # cls head: 'valid' full-extent conv
+    (3, 512, 4, 4, 1, 1, 0, "none"),        # src head 1x1 (Cout 1 padded to 4)
+    (5, 64, 256, 1, 1, 1, 0, "relu"),       # Linear as 1x1 conv, M = 5 rows
+    (2, 8, 16, 12, 3, 1, 1, "sigmoid"),     # small channel counts (tiny config)
+    (1, 16, 32, 6, 4, 2, 1, "tanh"),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_conv_forward_backward(shape):
+    B, ci, co, H, k, s, p, act = shape
+    g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)))
+    x = torch.randn(B, ci, H, H, generator=g)
+    w = torch.randn(co, ci, k, k, generator=g) * (1.0 / (ci * k * k) ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    if act == "heads":
+        pre = orc.conv_block(xr, wr, br, s, p)
+        yr = torch.cat([torch.tanh(pre[:, :3]), torch.sigmoid(pre[:, 3:4])], 1)
+    else:
+        yr = orc.conv_block(xr, wr, br, s, p, act=act)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+    yd = ops.conv2d(xd, wd, bd, s, p, act)
+    close(yd, yr, msg="y")
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=5e-5, msg="dx")
+    close(wd.grad, wr.grad, rel=5e-5, msg="dw")
+    close(bd.grad, br.grad, rel=5e-5, msg="db")
+
+
+def test_conv_no_bias_and_cout_not_multiple_of_4():
+    g = torch.Generator().manual_seed(1)
+    x, w = torch.randn(2, 16, 9, 9, generator=g), torch.randn(3, 16, 3, 3, generator=g) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = orc.conv_block(xr, wr, None, 1, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd, wd = dev(x, True), dev(w, True)
+    yd = ops.conv2d(xd, wd, None, 1, 1)
+    assert yd.shape == yr.shape
+    close(yd, yr)
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=5e-5)
+    close(wd.grad, wr.grad, rel=5e-5)
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 256, 16), (3, 64, 32), (1, 128, 8), (2, 8, 6), (2, 512, 2)])
+@pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res"])
+def test_instance_norm(B, C, H, mode):
+    g = torch.Generator().manual_seed(B * 1000 + C + H)
+    x = torch.randn(B, C, H, H, generator=g) * 2 + 0.7
+    res = torch.randn(B, C, H, H, generator=g) if mode.endswith("res") else None
+    ga = (torch.randn(B * C, generator=g) * 0.5 + 1) if mode.startswith("adain") else None
+    be = torch.randn(B * C, generator=g) if mode.startswith("adain") else None
+    relu = mode.endswith("relu")
+    leaves = [t.clone().requires_grad_(True) for t in (x, res, ga, be) if t is not None]
+    it = iter(leaves)
+    xr = next(it)
+    rr = next(it) if res is not None else None
+    gr, br = (next(it), next(it)) if ga is not None else (None, None)
+    yr = orc.adain(xr, gr, br) if ga is not None else orc.instance_norm(xr)
+    if relu:
+        yr = torch.clamp_min(yr, 0)
+    if rr is not None:
+        yr = yr + rr
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd = dev(x, True)
+    rd = dev(res, True) if res is not None else None
+    gd, bd = (dev(ga, True), dev(be, True)) if ga is not None else (None, None)
+    yd = ops.instance_norm(xd, gd, bd, residual=rd, relu=relu)
+    close(yd, yr, rel=3e-5, msg="y")
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=2e-4, msg="dx")
+    if rd is not None:
+        close(rd.grad, rr.grad, msg="dres")
+    if gd is not None:
+        close(gd.grad, gr.grad, rel=1e-4, msg="dgamma")
+        close(bd.grad, br.grad, rel=1e-4, msg="dbeta")
+
+
+@pytest.mark.parametrize("B,C,H", [(3, 128, 16), (1, 64, 32), (2, 8, 10)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_layer_norm(B, C, H, relu):
+    g = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, H, generator=g) * 1.5 - 0.3
+    ga, be = torch.rand(C, generator=g), torch.randn(C, generator=g) * 0.1
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, ga, be)]
+    yr = orc.layer_norm_munit(xr, gr, br)
+    if relu:
+        yr = torch.clamp_min(yr, 0)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd, gd, bd = dev(x, True), dev(ga, True), dev(be, True)
+    yd = ops.layer_norm_munit(xd, gd, bd, relu=relu)
+    close(yd, yr, rel=3e-5, msg="y")
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=2e-4, msg="dx")
+    close(gd.grad, gr.grad, rel=1e-4, msg="dgamma")
+    close(bd.grad, br.grad, rel=1e-4, msg="dbeta")
+
+
+def test_resample_and_golden(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "ops_golden.npz"))
+    g = torch.Generator().manual_seed(3)
+    for (B, C, H, W) in [(2, 4, 5, 6), (1, 64, 16, 16), (2, 8, 1, 3)]:
+        x = torch.randn(B, C, H, W, generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = orc.upsample_bilinear2x(xr)
+        gy = torch.randn(yr.shape, generator=g)
+        (yr * gy).sum().backward()
+        xd = dev(x, True)
+        yd = ops.upsample2x(xd)
+        close(yd, yr, rel=1e-6)
+        (yd * gy.to(DEV)).sum().backward()
+        close(xd.grad, xr.grad, rel=1e-6)
+    xd = dev(T(gold["up2/x"]), True)
+    yd = ops.upsample2x(xd)
+    close(yd, T(gold["up2/y"]), rel=1e-6, msg="golden up2")
+    (yd * T(gold["up2/gy"]).to(DEV)).sum().backward()
+    close(xd.grad, T(gold["up2/dx"]), rel=1e-6, msg="golden up2 dx")
+    for (B, C, H, W) in [(2, 4, 8, 12), (1, 64, 16, 16)]:
+        x = torch.randn(B, C, H, W, generator=g)
+        xr = x.clone().requires_grad_(True)
+        yr = orc.downsample_half(xr)
+        gy = torch.randn(yr.shape, generator=g)
+        (yr * gy).sum().backward()
+        xd = dev(x, True)
+        yd = ops.downsample_half(xd)
+        close(yd, yr, rel=1e-6)
+        (yd * gy.to(DEV)).sum().backward()
+        close(xd.grad, xr.grad, rel=1e-6)
+
+
+def test_pack_blend_l1():
+    g = torch.Generator().manual_seed(11)
+    x3 = torch.randn(2, 3, 8, 8, generator=g)
+    xd = dev(x3, True)
+    x4 = ops.pack_image(xd)
+    assert x4.shape == (2, 4, 8, 8) and x4.is_contiguous(memory_format=torch.channels_last)
+    close(x4[:, :3], x3, rel=0, atol=0)
+    assert float(x4[:, 3].abs().max()) == 0.0
+    gy = torch.randn(2, 4, 8, 8, generator=g)
+    (x4 * gy.to(DEV)).sum().backward()
+    close(xd.grad, gy[:, :3], rel=0, atol=0)
+    # blend
+    heads = torch.cat([torch.tanh(torch.randn(2, 3, 8, 8, generator=g)), torch.sigmoid(torch.randn(2, 1, 8, 8, generator=g))], 1)
+    real = torch.cat([x3, torch.zeros(2, 1, 8, 8)], 1)
+    hr = heads.clone().requires_grad_(True)
+    outr = hr[:, :3] * hr[:, 3:4] + real[:, :3] * (1 - hr[:, 3:4])
+    go = torch.randn(outr.shape, generator=g)
+    (outr * go).sum().backward()
+    hd = dev(heads, True)
+    outd = ops.attention_blend(hd, dev(real))
+    close(outd[:, :3], outr, rel=1e-6)
+    (outd[:, :3] * go.to(DEV)).sum().backward()
+    close(hd.grad, hr.grad, rel=1e-5)
+    # l1, plain and image flavour, odd sizes
+    for shape, image in [((2, 256, 8, 8), False), ((3, 4, 9, 7), True), ((5, 64), False)]:
+        a, b = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        lr_ = (ar[:, :3] - br[:, :3]).abs().mean() if image else (ar - br).abs().mean()
+        (lr_ * 3.0).backward()
+        ad, bd = dev(a, True), dev(b, True)
+        ld = ops.l1_mean(ad, bd, image=image)
+        assert abs(float(ld) - float(lr_)) <= 1e-6 * max(1.0, abs(float(lr_)))
+        (ld * 3.0).backward()
+        close(ad.grad, ar.grad, rel=1e-6)
+        close(bd.grad, br.grad, rel=1e-6)
+
+
+def test_golden_conv_blocks(golden_dir):
+    """The reference's own Conv2dBlock vectors (conv + norm + activation, forward and backward)."""
+    import networks.networks as nets
+    gold = np.load(os.path.join(golden_dir, "ops_golden.npz"))
+    cases = {"stem7_relu": ("none", "relu"), "down4_in_relu": ("in", "relu"), "res3_in_none": ("in", "none"),
+             "res3_adain_relu": ("adain", "relu"), "up5_ln_relu": ("ln", "relu"), "up5_ln_relu_b1": ("ln", "relu"),
+             "head7_tanh": ("none", "tanh"), "head7_sigmoid": ("none", "sigmoid"), "dis4_lrelu": ("none", "lrelu"),
+             "dis4_lrelu_2x2": ("none", "lrelu")}
+    for name, (norm, act) in cases.items():
+        gg = lambda k: T(gold["conv/%s/%s" % (name, k)])
+        B, ci, co, H, k, s, p = [int(v) for v in gold["conv/%s/meta" % name]]
+        blk = nets.Conv2dBlock(ci, co, k, s, p, norm=norm, activation=act, pad_type="reflect").to(DEV)
+        with torch.no_grad():
+            blk.conv.weight.copy_(gg("w"))
+            blk.conv.bias.copy_(gg("b"))
+            if norm == "ln":
+                blk.norm.gamma.copy_(gg("gamma"))
+                blk.norm.beta.copy_(gg("beta"))
+        x = dev(gg("x"), True)
+        if norm == "adain":
+            blk.norm.weight, blk.norm.bias = dev(gg("aw"), True), dev(gg("ab"), True)
+        y = blk(x)
+        close(y, gg("y"), rel=5e-5, atol=2e-6, msg=name + " y")
+        (y * gg("gy").to(DEV)).sum().backward()
+        close(x.grad, gg("dx"), rel=3e-4, atol=2e-6, msg=name + " dx")
+        close(blk.conv.weight.grad, gg("dw"), rel=3e-4, atol=2e-6, msg=name + " dw")
+        if norm == "none":
+            close(blk.conv.bias.grad, gg("db"), rel=3e-4, atol=2e-6, msg=name + " db")
+        if norm == "ln":
+            close(blk.norm.gamma.grad, gg("dgamma"), rel=3e-4, msg=name + " dgamma")
+            close(blk.norm.beta.grad, gg("dbeta"), rel=3e-4, msg=name + " dbeta")
+        if norm == "adain":
+            close(blk.norm.weight.grad, gg("daw"), rel=3e-4, msg=name + " daw")
+            close(blk.norm.bias.grad, gg("dab"), rel=3e-4, msg=name + " dab")
+
+
+# ----------------------------------------------------------------------------------------
+# whole modules / solver on the tiny config, against the reference's recorded run
+# ----------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return np.load(os.path.join(golden_dir, "tiny_step.npz"))
+
+
+def _tiny_solver(tiny):
+    from solver import Solver
+    cfg = synth.make_config(image_size=32, tiny=True)
+    torch.manual_seed(1234)
+    s = Solver(cfg, torch.device(DEV), None).to(DEV)
+    s.copy_nets()
+    assert torch.equal(torch.get_rng_state(), T(tiny["rng_state_after_init"]))
+    batch = {k[len("batch/"):]: T(tiny[k]) for k in tiny.files if k.startswith("batch/")}
+    return s, cfg, {k: v.to(DEV) for k, v in batch.items()}
+
+
+def test_tiny_modules_vs_reference(tiny):
+    s, cfg, batch = _tiny_solver(tiny)
+    s.eval()
+    with torch.no_grad():
+        content, mus, lvs = s.gen.encode(batch["x_real"])
+        close(content, T(tiny["mod/content"]), rel=1e-4, msg="content")
+        close(torch.stack(mus), T(tiny["mod/style_mu"]), rel=1e-4, msg="style mu")
+        close(torch.stack(lvs), T(tiny["mod/style_logvar"]), rel=1e-4, msg="style logvar")
+        style = torch.cat(mus, 1)
+        tmu, tlv = s.gen.encode_txt(style, batch["txt"], batch["txt_lens"])
+        close(torch.stack(tmu), T(tiny["mod/txt_mu"]), rel=1e-4, msg="txt mu")
+        close(torch.stack(tlv), T(tiny["mod/txt_logvar"]), rel=1e-4, msg="txt logvar")
+        img, att = s.gen.decode(content, style)
+        close(img, T(tiny["mod/dec_img"]), rel=1e-4, msg="image")
+        close(att, T(tiny["mod/dec_att"]), rel=1e-4, msg="attention")
+        for i, (src, cls) in enumerate(s.dis(batch["x_real"])):
+            close(src, T(tiny["mod/dis%d_src" % i]), rel=1e-4, msg="dis src")
+            close(cls, T(tiny["mod/dis%d_cls" % i]), rel=1e-4, msg="dis cls")
+
+
+def test_tiny_three_iterations_vs_reference(tiny):
+    """Same seed, same random stream (HostNoise), three full iterations: every loss scalar the
+    reference printed, its G gradients and its post-Adam weights after iteration 0."""
+    want = json.loads(bytes(tiny["losses_json"]).decode())
+    host.set_noise(host.HostNoise())
+    try:
+        s, cfg, batch = _tiny_solver(tiny)
+        a = (batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"], batch["label_src"],
+             batch["label_trg"], cfg)
+        for it in range(3):
+            s.dis_update(*a, it)
+            s.gen_update(*a, it)
+            if it == 0:
+                grads = {k: p.grad.detach().clone() for k, p in s.gen.named_parameters() if p.grad is not None}
+            s.smooth_moving()
+            s.update_learning_rate()
+            s.update_attention_status(it)
+            for k, v in want[it].items():
+                got = float(getattr(s, k))
+                assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), (it, k, got, v)
+            if it == 0:
+                ref_g = {k[len("grad_it0/gen/"):]: T(tiny[k]) for k in tiny.files if k.startswith("grad_it0/gen/")}
+                assert set(grads.keys()) == set(ref_g.keys())
+                for k, gref in ref_g.items():
+                    close(grads[k], gref, rel=5e-3, msg=k)
+                lr, off, total = cfg["lr"], 0, 0
+                for prefix, mod in (("after_it0/gen/", s.gen), ("after_it0/dis/", s.dis)):
+                    sd = mod.state_dict()
+                    for k in tiny.files:
+                        if k.startswith(prefix) and "running_" not in k:
+                            d = (sd[k[len(prefix):]].cpu() - T(tiny[k])).abs()
+                            assert d.max().item() <= 2.05 * lr, k
+                            off += int((d > 1e-6).sum())
+                            total += d.numel()
+                assert off <= 0.02 * total
+        assert abs(s.init_ds_w - float(tiny["init_ds_w"])) < 1e-12
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
+def test_tiny_dis_gradients_vs_reference(tiny, golden_dir):
+    ref = np.load(os.path.join(golden_dir, "tiny_dis_grads.npz"))
+    host.set_noise(host.HostNoise())
+    try:
+        s, cfg, batch = _tiny_solver(tiny)
+        grabbed = {}
+        real_step = s.dis_opt.step
+
+        def grab(*a, **k):
+            grabbed.update({n: p.grad.detach().clone() for n, p in s.dis.named_parameters()})
+            return real_step(*a, **k)
+        s.dis_opt.step = grab
+        s.dis_update(batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+                     batch["label_src"], batch["label_trg"], cfg, 0)
+        assert abs(float(s.loss_dis_all) - float(ref["loss_dis"])) < 2e-4
+        for k, g in grabbed.items():
+            close(g, T(ref[k]), rel=2e-3, msg=k)
+    finally:
+        host.set_noise(host.DeviceNoise())
