@@ -487,24 +487,24 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     return launch_gemm(g, w_hwio, 0, 1, o, bias, act, (hipStream_t)stream);
 }
 
-size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int pad) {
-    if (pad == 0) return 0;
-    return (size_t)B * (H + 2 * pad) * (W + 2 * pad) * Cin * sizeof(float);
+int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || pad < 0 || pad >= H || pad >= W) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dxp, dx, B, H, W, C / 4,
+                       pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
 }
 
-int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W, int Cin, int Cout, int KH,
-                        int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp, int B, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int stride, int pad, void* stream) {
     // here the gathered tensor is dy (Cout channels) and the produced one is dx (Cin channels)
     if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, stride, pad)) return DWC_EINVAL;
     if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3)) return DWC_EINVAL;
     if (stride == 2 && !(KH == 4 && KW == 4 && pad == 1 && !(H & 1) && !(W & 1))) return DWC_EINVAL;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    float* target = dx;
-    if (pad > 0) {
-        if (ws_bytes < dwc_conv2d_bwd_data_ws_bytes(B, H, W, Cin, pad) || !ws) return DWC_EWORKSPACE;
-        target = (float*)ws;
-    }
+    float* target = dxp;
     hipStream_t st = (hipStream_t)stream;
     Gather g;
     g.src = dy; g.SH = Ho; g.SW = Wo; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
@@ -528,13 +528,7 @@ int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dx, int B,
         o.os = 2;
         rc = launch_gemm(g, w_dgrad, (size_t)4 * Cout * Cin, 4, o, nullptr, DWC_ACT_NONE, st);
     }
-    if (rc != DWC_OK) return rc;
-    if (pad > 0) {
-        const size_t total = (size_t)B * H * W * (Cin / 4);
-        hipLaunchKernelGGL(fold_reflect_kernel, dim3((total + 255) / 256), dim3(256), 0, st, target, dx, B, H, W, Cin / 4, pad);
-        DWC_LAUNCH_CHECK();
-    }
-    return DWC_OK;
+    return rc;
 }
 
 size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

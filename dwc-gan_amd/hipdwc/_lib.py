@@ -20,8 +20,8 @@ SIGNATURES = {
     "dwc_weight_oihw_to_hwio": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_weight_oihw_to_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp]),
-    "dwc_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 5),
-    "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
+    "dwc_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),
     "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),

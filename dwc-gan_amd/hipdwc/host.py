@@ -17,6 +17,7 @@ from torch.optim import lr_scheduler
 # --------------------------------------------------------------------------------------
 class DeviceNoise:
     """Default: draw on the tensor's own device, like the reference does on its GPU."""
+    align_stream = False     # draws whose result is unused may be skipped
 
     def dropout(self, x, p, training=True):
         return F.dropout(x, p=p, training=training)
@@ -32,6 +33,7 @@ class HostNoise:
     and order the reference makes when it runs on CPU, then moved to the device.  With the
     same seed the HIP run then sees the same dropout masks and style samples as a CPU run
     (reference or oracle)."""
+    align_stream = True      # reproduce even the draws whose result the reference throws away
 
     def dropout(self, x, p, training=True):
         if not training or p == 0:

@@ -58,6 +58,45 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class KernelTimer:
+    """Optional per-launch timing of the conv GEMM kernels with HIP events recorded on the
+    launch stream (torch's current stream IS the stream the C ABI launches on).  bench.py
+    switches it on for one timed step to obtain the live roofline figure; off by default."""
+
+    def __init__(self):
+        self.spans = []   # (kernel tag, algorithmic flops, start event, end event)
+
+    def run(self, tag, flops, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn()
+        b.record()
+        self.spans.append((tag, flops, a, b))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, flops, a, b in self.spans:
+            ent = out.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            ent["launches"] += 1
+            ent["ms"] += a.elapsed_time(b)
+            ent["flops"] += flops
+        return out
+
+
+TIMER = None   # set to a KernelTimer to collect spans
+
+
+def _timed(tag, flops, fn):
+    return fn() if TIMER is None else TIMER.run(tag, flops, fn)
+
+
+def _gemm_tag(n_cols):
+    """Name of the conv_gemm_kernel instantiation the library picks for an N-column product."""
+    return "conv_gemm_kernel<%d>" % (128 if n_cols > 64 else (64 if n_cols > 32 else 32))
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -65,19 +104,20 @@ def _pad4(n):
 # --------------------------------------------------------------------------------------
 # weight layouts, cached per parameter version
 # --------------------------------------------------------------------------------------
-_WCACHE = weakref.WeakKeyDictionary()
+_WCACHE = {}   # id(tensor) -> (weakref to it, {layout key: (version, prepared tensor)})
 
 
 def _prepped(w, kind, cout_pad, cin_pad, stride):
     """Re-laid-out copy of an OIHW weight; recomputed only when the parameter changed
     (optimizer steps bump ``_version``)."""
-    ent = None
-    try:
-        ent = _WCACHE.get(w)
-    except TypeError:
-        pass
+    slot = _WCACHE.get(id(w))
+    if slot is None or slot[0]() is not w:
+        wid = id(w)
+        slot = (weakref.ref(w, lambda _r, wid=wid: _WCACHE.pop(wid, None)), {})
+        _WCACHE[wid] = slot
+    ent = slot[1]
     key = (kind, cout_pad, cin_pad, stride)
-    if ent is not None and ent.get(key, (None, None))[0] == w._version:
+    if ent.get(key, (None, None))[0] == w._version:
         return ent[key][1]
     lib = _lib.load()
     cout, cin, kh, kw = w.shape
@@ -89,10 +129,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     else:
         _lib.check(lib.dwc_weight_oihw_to_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
                                                 cin_pad, _stream()), "weight_oihw_to_dgrad")
-    try:
-        _WCACHE.setdefault(w, {})[key] = (w._version, out)
-    except TypeError:
-        pass
+    ent[key] = (w._version, out)
     return out
 
 
@@ -120,8 +157,11 @@ class _Conv2d(torch.autograd.Function):
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
             bias = bias.contiguous()
         y = empty_cl(B, cop, Ho, Wo, x.device)
-        _lib.check(lib.dwc_conv2d_fwd(x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW,
-                                      stride, pad, act, _stream()), "conv2d_fwd")
+        flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
+        st = _stream()
+        _lib.check(_timed(_gemm_tag(cop), flops, lambda: lib.dwc_conv2d_fwd(
+            x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, st)),
+            "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         return y
@@ -154,16 +194,23 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)
-            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, Cx, pad)
-            ws = workspace(nws, dev)
-            _lib.check(lib.dwc_conv2d_bwd_data(g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW,
-                                               stride, pad, ws.data_ptr(), ws.numel(), st), "conv2d_bwd_data")
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            if pad == 0:
+                target = dx.data_ptr()
+            else:   # gradient of the padded image goes to scratch, then is folded back
+                target = workspace(B * (H + 2 * pad) * (W + 2 * pad) * Cx * 4, dev).data_ptr()
+            _lib.check(_timed(_gemm_tag(Cx), flops, lambda: lib.dwc_conv2d_bwd_data(
+                g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, st)), "conv2d_bwd_data")
+            if pad > 0:
+                _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1]:
             dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
             nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
             ws = workspace(nws, dev)
-            _lib.check(lib.dwc_conv2d_bwd_weight(x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW,
-                                                 stride, pad, Cin, Cout, ws.data_ptr(), ws.numel(), st), "conv2d_bwd_weight")
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
+                x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
+                ws.numel(), st)), "conv2d_bwd_weight")
         return dx, dw, db, None, None, None
 
 

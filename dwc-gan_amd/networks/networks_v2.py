@@ -6,6 +6,8 @@ upsample stacks run on libdwcgan_hip.so through ``hipdwc.ops``.  The text encode
 (Embedding + bi-LSTM, ~0% of the FLOPs) stays on stock PyTorch-ROCm as SURVEY.md section 8(a)
 row a12 scopes it, with the reference's batch-mixing ``view`` reproduced on purpose.
 """
+import warnings
+
 import numpy as np
 import torch
 from torch import nn
@@ -96,10 +98,30 @@ class TxtEncoder(nn.Module):
                                                    lens_sorted.tolist())
         dirs = 2 if self.bidirectional else 1
         zeros = emb.new_zeros(dirs * self.num_layers, bsz, self.hidden_size)
-        outs, (h_n, c_n) = self.lstm(packed, (zeros, zeros))
-        if self.training and self.dropout_out > 0:
+        if self.training and self.dropout_out > 0 and self.num_layers > 1:
+            # Stacked LSTM = one layer at a time with the inter-layer dropout drawn by the noise
+            # source (bit-identical to nn.LSTM(dropout=p) on CPU, stream consumption included),
+            # so that parity runs can replay the mask that a stock nn.LSTM would draw privately.
+            data, batch_sizes, hs, cs = packed.data, packed.batch_sizes, [], []
+            z1 = zeros[:dirs]
+            for l in range(self.num_layers):
+                names = ["%s_l%d%s" % (n, l, suf) for suf in (("", "_reverse") if self.bidirectional else ("",))
+                         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    data, hy, cy = torch._VF.lstm(data, batch_sizes, (z1, z1), [getattr(self.lstm, n) for n in names],
+                                                  True, 1, 0.0, True, self.bidirectional)
+                hs.append(hy)
+                cs.append(cy)
+                if l + 1 < self.num_layers:
+                    data = noise.dropout(data, self.dropout_out, True)
+            h_n, c_n = torch.cat(hs, 0), torch.cat(cs, 0)
+            outs = nn.utils.rnn.PackedSequence(data, batch_sizes)
+        else:
+            outs, (h_n, c_n) = self.lstm(packed, (zeros, zeros))
+        if self.training and self.dropout_out > 0 and noise.align_stream:
             # the reference drops out the (unused) padded memory here and thereby advances the
-            # random stream (reference networks_v2.py:235-236); keep the stream aligned
+            # random stream (reference networks_v2.py:235-236); parity mode keeps the stream aligned
             mem, _ = nn.utils.rnn.pad_packed_sequence(outs)
             noise.dropout(mem, self.dropout_out, True)
         if self.bidirectional:

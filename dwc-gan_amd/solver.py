@@ -75,6 +75,7 @@ class Solver(nn.Module):
         self.d_reg_every, self.rnd_step = 16, 3
         self.init_ds_w = configs["ds_w"]
         self.lr_policy = configs["lr_policy"]
+        self.grad_sync = None      # set to hipdwc.dp.GradAllReduce for multi-GPU data parallel
 
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
         self.dis_opt = torch.optim.Adam([p for p in self.dis.parameters() if p.requires_grad], **adam)
@@ -165,6 +166,8 @@ class Solver(nn.Module):
             self.dis.calc_dis_loss(x_fake1, x4, label_trg, label_src, gw, cw)
         self.loss_dis_all = self.loss_dis
         self.loss_dis_all.backward()
+        if self.grad_sync is not None:      # data parallel: average D's gradients over the ranks
+            self.grad_sync(self.dis_opt.param_groups[0]["params"])
         self.dis_opt.step()
 
     # ---- G step (reference solver.py:151-240) ---------------------------------------------------
@@ -230,6 +233,8 @@ class Solver(nn.Module):
                 cfg["vgg_w"] * self.loss_gen_vgg - \
                 self.init_ds_w * self.loss_ds
             self.loss_gen_total.backward()
+        if self.grad_sync is not None:      # data parallel: average G's gradients over the ranks
+            self.grad_sync(self.gen_opt.param_groups[0]["params"])
         self.gen_opt.step()
 
     # ---- visualisation path (reference solver.py:249-289), batched instead of per image ---------

@@ -63,12 +63,15 @@ int dwc_weight_oihw_to_dgrad(const float* w_oihw, float* w_dgrad, int Cout, int 
 int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float* y,
                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                    int act, void* stream);
-/* dx = d/dx of the above (pre-activation gradient dy:[B,Ho,Wo,Cout], w in dgrad layout).
- * Needs scratch for the padded gradient image when pad>0. */
-size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int pad);
-int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dx,
+/* Data gradient, step 1: gradient w.r.t. the reflect-PADDED input image,
+ * dxp:[B,H+2*pad,W+2*pad,Cin], from the pre-activation gradient dy:[B,Ho,Wo,Cout]
+ * (w in dgrad layout).  With pad == 0 this already is dx. */
+int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp,
                         int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                        void* ws, size_t ws_bytes, void* stream);
+                        void* stream);
+/* Data gradient, step 2: adjoint of the reflect padding — fold dxp back onto dx:[B,H,W,C]. */
+int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad,
+                            void* stream);
 /* dw (written in OIHW, the state_dict layout, [Cout_real][Cin_real][KH][KW]) from x and dy.
  * Cin/Cout are the padded data-path channel counts, cin_real/cout_real the parameter's. */
 size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW,
