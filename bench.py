@@ -30,7 +30,7 @@ IMAGE_SIZE = 128
 PER_GPU_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ALGO_GFLOP_PER_IMAGE = 569.6           # BASELINE.md section 4 / SURVEY.md 8(d): necessary fwd+bwd conv+linear work
-DOMINANT = "conv_gemm_kernel<128>"     # the 128x128x32 implicit-GEMM tile (forward and data-gradient launches)
+DOMINANT = "conv_gemm_kernel"          # the implicit-GEMM conv kernel (all tile instantiations; forward + data-gradient launches)
 
 
 def run_iteration(trainer, batch, cfg, it):

@@ -28,6 +28,9 @@ LAYERS = [
     ("down4x4 64>128 @128", 64, 128, 128, 4, 2, 1),
     ("down4x4 128>256 @64", 128, 256, 64, 4, 2, 1),
     ("D 4x4 256>512 @16", 256, 512, 16, 4, 2, 1),
+    ("D 4x4 512>512 @8", 512, 512, 8, 4, 2, 1),
+    ("D 4x4 128>256 @32", 128, 256, 32, 4, 2, 1),
+    ("style 4x4 256>256 @8", 256, 256, 8, 4, 2, 1),
 ]
 
 
@@ -49,8 +52,11 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
     print("B=%d  fp32 MFMA peak %.1f TF" % (B, PEAK_TF))
     for name, ci, co, H, k, s, p in LAYERS:
+        if only not in name:
+            continue
         x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=torch.channels_last)
         w = torch.randn(co, ci, k, k, device=dev) * 0.05
         b = torch.zeros(co, device=dev)
@@ -59,15 +65,17 @@ def main():
         dy = torch.randn_like(y)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
-        w_hwio = ops._prepped(w, "hwio", co, ci, s)
+        w_hwio = ops._prepped(w, "fwd", co, ci, s)
         w_dg = ops._prepped(w, "dgrad", co, ci, s)
-        ws = ops.workspace(lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, H, ci, co, k, k, s, p), dev)
+        ws = ops.workspace(max(lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, H, ci, co, k, k, s, p),
+                               lib.dwc_conv2d_fwd_ws_bytes(B, H, H, ci, co, k, k, s, p),
+                               lib.dwc_conv2d_bwd_data_ws_bytes(B, H, H, ci, co, k, k, s, p)), dev)
         dxp = torch.empty(B * (H + 2 * p) * (H + 2 * p) * ci, device=dev)
         flops = 2.0 * B * Ho * Ho * co * ci * k * k
         tf = timeit(lambda: lib.dwc_conv2d_fwd(x.data_ptr(), w_hwio.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci, co,
-                                               k, k, s, p, 1, st))
+                                               k, k, s, p, 1, ws.data_ptr(), ws.numel(), st))
         td = timeit(lambda: lib.dwc_conv2d_bwd_data(dy.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), B, H, H, ci, co, k, k, s,
-                                                    p, st))
+                                                    p, ws.data_ptr(), ws.numel(), st))
         tw = timeit(lambda: lib.dwc_conv2d_bwd_weight(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, H, ci, co, k, k, s, p,
                                                       ci, co, ws.data_ptr(), ws.numel(), st))
         print("%-22s %7.2f GFLOP | fwd %8.1f us %5.1f TF (%4.1f%%) | dgrad %8.1f us %5.1f TF | wgrad %8.1f us %5.1f TF" % (

@@ -12,15 +12,22 @@
 // The data gradient is the same kernel with another index rule (see dwc_conv2d_bwd_data);
 // the weight gradient contracts over m instead (conv_wgrad_kernel).
 //
-// Tiling: 256 threads = 4 waves, block tile 128(M) x BN(N) x 32(K); each wave owns TMxTN
-// 32x32 accumulator tiles (16 VGPRs each).  Operands are staged global -> registers -> LDS
-// (16-byte vectors along the channel axis) with the next K-slab's loads issued before the
-// MFMAs of the current one.
+// Tiling: 256 threads = 4 waves, block tile BM x BN x 32(K); each wave owns TMxTN 32x32
+// accumulator tiles (16 VGPRs each).  Operands are staged global -> registers -> LDS
+// (16-byte vectors along the channel axis) into a double-buffered LDS tile: the next K-slab's
+// global loads are issued before the MFMAs of the current one and there is ONE barrier per slab.
+// Tile shape is picked per problem so that every CU holds >= 2 workgroups whenever the grid
+// allows it (one wave per SIMD cannot hide its own LDS/barrier latency), and products with few
+// output tiles but a long K (the discriminator tails, M = B*16 rows) are split along K into
+// partial images that a small epilogue kernel sums (+bias, +activation) in a fixed order.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "dwc_common.h"
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int A_LD = BK + 4;  // row stride (floats) of the A tile: 36 -> conflict-free b128 reads
 
@@ -28,6 +35,7 @@ struct Gather {        // how GEMM row m / column k address the source tensor
     const float* src;  // [B][SH][SW][SC]
     int SH, SW, SC, logSC;
     int OH, OW;        // pixel grid enumerated by m (per image)
+    int logOW, logOHW; // log2 of OW and OH*OW when both are powers of two, else -1
     int KH, KW, kw_magic;
     int mul, kstep, off_h, off_w;  // src_h = oh*mul + kh*kstep + off_h
     int reflect;       // 1: reflect at the border, 0: zero outside
@@ -45,13 +53,16 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * (n - 1) - i : i;
 }
 
-template <int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
-                                                        Scatter o, const float* __restrict__ bias, int act,
-                                                        int tiles_n) {
+                                                        Scatter o, const float* __restrict__ bias, int act, int tiles_n,
+                                                        int kt_per_split, size_t part_stride) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    __shared__ __attribute__((aligned(16))) float sA[BM * A_LD];
-    __shared__ __attribute__((aligned(16))) float sB[BK * BN];
+    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+    constexpr int A_TILE = BM * A_LD, B_TILE = BN * A_LD;   // both tiles are [row][k] with the padded stride
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    float* sA = smem;
+    float* sB = smem + 2 * A_TILE;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -72,18 +83,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     const int cls = blockIdx.z;  // stride-2 data gradient: output parity class
     wmat += (size_t)cls * w_class_stride;
     const int oph = cls >> 1, opw = cls & 1;
+    const int split = blockIdx.y;
 
     // ---- per-thread gather rows (fixed for the whole K loop) ----
+    // Rows past M / N are clamped to the last valid one (their results are dropped by the
+    // epilogue) and the weight matrix is zero-padded along K to a multiple of 32, so the
+    // staging loads need no masks in reflect mode and one in-bounds select in zero mode.
     const int arow = t >> 3;        // + 32*i
     const int acol = (t & 7) * 4;   // k offset inside the slab
-    int a_bh[4], a_bw[4], a_img[4];
-    bool a_ok[4];
+    int a_bh[A_PASSES], a_bw[A_PASSES], a_img[A_PASSES];
     const int ohw = g.OH * g.OW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + arow + 32 * i;
-        a_ok[i] = m < g.M;
-        const int mm = a_ok[i] ? m : 0;
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int mm = min(m0 + arow + 32 * i, g.M - 1);
         const int n = mm / ohw;
         const int rem = mm - n * ohw;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
@@ -91,52 +103,79 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
         a_bw[i] = ow * g.mul + g.off_w;
         a_img[i] = n * g.SH * g.SW;
     }
-    // B tile: rows k, BN/4 float4 per row
-    constexpr int B_F4 = BN / 4;
-    constexpr int B_ROWS_PER_PASS = 256 / B_F4;
-    constexpr int B_PASSES = BK / B_ROWS_PER_PASS;
-    const int brow = t / B_F4, bcol = (t % B_F4) * 4;
+    const int Kp = (g.K + BK - 1) / BK * BK;   // padded row length of the [N][Kp] weight matrix
+    const float* b_ptr[B_PASSES];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = wmat + (size_t)min(n0 + arow + 32 * p, o.N - 1) * Kp + acol;
 
-    f32x4 ra[4], rb[B_PASSES];
-    const int nk = (g.K + BK - 1) / BK;
+    f32x4 ra[A_PASSES], rb[B_PASSES];
+    const int nk_all = Kp / BK;
+    const int kt0 = split * kt_per_split;
+    const int kt1 = min(nk_all, kt0 + kt_per_split);
+    const int n_taps = g.KH * g.KW;
 
-    auto load_slab = [&](int kt) {
-        const int kg = kt * BK + acol;
-        const bool kok = kg < g.K;
-        const int tap = kg >> g.logSC;
-        const int ci = kg & (g.SC - 1);
+    // Gather addressing is strength-reduced: with >= 32 source channels a K-slab lies inside ONE
+    // filter tap, so the per-row source offsets (reflect / bounds rule applied) are recomputed
+    // only when the slab index crosses into the next tap — a wave-uniform event — and the slabs
+    // of that tap just step along the channel axis.  The vector ALU shares its issue port with
+    // the matrix pipe, so address arithmetic left in the slab loop costs MFMA issue slots.
+    int cur_tap = -1;                       // wave-uniform
+    int a_off[A_PASSES];                    // element offset of (row i, current tap, channel acol)
+    bool a_inb[A_PASSES];
+    const bool tap_uniform = g.SC >= BK;
+    auto row_offsets = [&](int tap) {
         const int kh = (tap * g.kw_magic) >> 16;
         const int kw = tap - kh * g.KW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PASSES; ++i) {
             int h = a_bh[i] + kh * g.kstep;
             int w = a_bw[i] + kw * g.kstep;
-            bool ok = a_ok[i] && kok;
+            bool inb = true;
             if (g.reflect) {
                 h = reflect_idx(h, g.SH);
                 w = reflect_idx(w, g.SW);
             } else {
-                ok = ok && h >= 0 && h < g.SH && w >= 0 && w < g.SW;
+                inb = h >= 0 && h < g.SH && w >= 0 && w < g.SW;
+                h = min(max(h, 0), g.SH - 1);
+                w = min(max(w, 0), g.SW - 1);
             }
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(g.src + (((size_t)(a_img[i] + h * g.SW + w)) << g.logSC) + ci);
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            const int k = kt * BK + brow + p * B_ROWS_PER_PASS;
-            const int n = n0 + bcol;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < g.K && n < o.N) v = *reinterpret_cast<const f32x4*>(wmat + (size_t)k * o.N + n);
-            rb[p] = v;
+            a_off[i] = (a_img[i] + h * g.SW + w) << g.logSC;
+            a_inb[i] = inb;
         }
     };
-    auto store_slab = [&]() {
+    auto load_slab = [&](int kt) {
+        int ci;
+        if (tap_uniform) {
+            const int kg0 = kt * BK;
+            const int tap = min(kg0 >> g.logSC, n_taps - 1);   // K tail: any valid tap (weights there are 0)
+            if (tap != cur_tap) {
+                row_offsets(tap);
+                cur_tap = tap;
+            }
+            ci = (kg0 & (g.SC - 1)) + acol;
+        } else {   // few channels (image stems, tiny configs): a slab spans several taps, one per 4-wide group
+            const int kg = kt * BK + acol;
+            row_offsets(min(kg >> g.logSC, n_taps - 1));
+            ci = kg & (g.SC - 1);
+        }
+        // the loaded values are not touched here (the out-of-bounds zeroing happens in store_slab):
+        // any use would make the compiler wait for the loads before the MFMAs they are meant to hide under
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sA[(arow + 32 * i) * A_LD + acol]) = ra[i];
+        for (int i = 0; i < A_PASSES; ++i) ra[i] = *reinterpret_cast<const f32x4*>(g.src + a_off[i] + ci);
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            *reinterpret_cast<f32x4*>(&sB[(brow + p * B_ROWS_PER_PASS) * BN + bcol]) = rb[p];
+        for (int p = 0; p < B_PASSES; ++p) rb[p] = *reinterpret_cast<const f32x4*>(b_ptr[p] + kt * BK);
+    };
+    auto store_slab = [&](int buf) {
+        float* a = sA + buf * A_TILE;
+        float* b = sB + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            f32x4 v = ra[i];
+            if (!g.reflect && !a_inb[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&a[(arow + 32 * i) * A_LD + acol]) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<f32x4*>(&b[(arow + 32 * p) * A_LD + acol]) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -147,39 +186,54 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_slab(0);
-    store_slab();
-    __syncthreads();
+    // fragment addresses: lane (l31, hi) of MFMA step (q, j) contracts k = 8q + 4hi + j for BOTH operands,
+    // so each operand is one ds_read_b128 per 4 MFMA steps
+    const int a_frag = (wm * TM * 32 + l31) * A_LD + 4 * hi;
+    const int b_frag = (wn * TN * 32 + l31) * A_LD + 4 * hi;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_slab(kt + 1);
-        // 16 MFMA k-steps; lane half `hi` of step (q,j) contracts k = 8q + 4hi + j for both operands
+    if (kt0 < kt1) {
+        load_slab(kt0);
+        store_slab(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) load_slab(kt + 1);
+            const float* a = sA + buf * A_TILE + a_frag;
+            const float* b = sB + buf * B_TILE + b_frag;
+            f32x4 fa[2][TM], fb[2][TN];      // fragment double buffer: q+1 is fetched while q is multiplied
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 a4[TM];
+            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const f32x4*>(&sA[((wm * TM + i) * 32 + l31) * A_LD + 8 * q + 4 * hi]);
+            for (int n = 0; n < TN; ++n) fb[0][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b[TN];
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
 #pragma unroll
-                for (int n = 0; n < TN; ++n) b[n] = sB[(8 * q + 4 * hi + j) * BN + (wn * TN + n) * 32 + l31];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
+                        fa[(q + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD + 8 * (q + 1));
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][j], b[n], acc[i][n], 0, 0, 0);
+                        fb[(q + 1) & 1][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD + 8 * (q + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][j], fb[q & 1][n][j], acc[i][n], 0, 0, 0);
             }
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            store_slab();
+            // the other buffer was last read one iteration ago, behind the barrier below: safe to refill
+            if (kt + 1 < kt1) store_slab(buf ^ 1);
             __syncthreads();
+            buf ^= 1;
         }
     }
 
-    // ---- epilogue: bias + activation, scatter rows ----
+
+    // ---- epilogue: (bias + activation) or raw split-K partial, scatter rows ----
+    const bool partial = part_stride != 0;
+    float* dst = o.dst + (size_t)split * part_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -196,11 +250,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
                 const int col = n0 + (wn * TN + n) * 32 + l31;
                 if (col < o.N) {
                     float v = acc[i][n][r];
-                    if (bias) v += bias[col];
-                    o.dst[prow * o.N + col] = dwc_act_apply(v, act, col);
+                    if (!partial) {
+                        if (bias) v += bias[col];
+                        v = dwc_act_apply(v, act, col);
+                    }
+                    dst[prow * o.N + col] = v;
                 }
             }
         }
+    }
+}
+
+// dst[i] = act(sum_s part[s][i] + bias[i % N]), fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst,
+                                                            const float* __restrict__ bias, size_t total4, size_t stride4, int splits,
+                                                            int N, int act) {
+    const int nq = N >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+        for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part)[(size_t)z * stride4 + i];
+        const int c4 = i % nq;
+        if (bias) s += reinterpret_cast<const f32x4*>(bias)[c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = dwc_act_apply(s[k], act, c4 * 4 + k);
+        reinterpret_cast<f32x4*>(dst)[i] = s;
     }
 }
 
@@ -211,8 +284,10 @@ template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* __restrict__ dy, int N, float* __restrict__ slab,
                                                          int m_chunk) {
     static_assert(WM * WN == 4 && WM * TM * 32 == 128 && WN * TN * 32 == BN, "tile shape");
-    __shared__ __attribute__((aligned(16))) float sA[32 * 128];  // [m][k]
-    __shared__ __attribute__((aligned(16))) float sB[32 * BN];   // [m][n]
+    constexpr int A_TILE = 32 * 128, B_TILE = 32 * BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    float* sA = smem;               // [buf][m][k]
+    float* sB = smem + 2 * A_TILE;  // [buf][m][n]
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -221,10 +296,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     const int m_begin = blockIdx.z * m_chunk;
     const int m_end = min(g.M, m_begin + m_chunk);
 
-    // A^T tile: thread owns one 4-wide k group (fixed tap / channel) and rows (t>>5)+8i
+    // A^T tile: thread owns one 4-wide k group (fixed tap / channel) and rows (t>>5)+8i.
+    // k >= K (tile tail) is clamped to a valid tap: those output rows are never stored.
     const int kg = k0 + (t & 31) * 4;
-    const bool kok = kg < g.K;
-    const int tap = kg >> g.logSC;
+    const int tap = min(kg >> g.logSC, g.KH * g.KW - 1);
     const int ci = kg & (g.SC - 1);
     const int kh = (tap * g.kw_magic) >> 16;
     const int kw = tap - kh * g.KW;
@@ -237,36 +312,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     const int ohw = g.OH * g.OW;
 
     f32x4 ra[4], rb[B_PASSES];
+    const int bcol_c = min(n0 + bcol, N - 4);    // columns past N are never stored: clamp instead of masking
     auto load_slab = [&](int mb) {
+        // rows past the end of this m-chunk must contribute nothing: the dY operand is zeroed for
+        // them, the gathered x operand may then be anything finite (row index clamped)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = mb + arow + 8 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (kok && m < m_end) {
-                const int n = m / ohw;
+            const int m = min(mb + arow + 8 * i, g.M - 1);
+            int n, oh, ow;
+            if (g.logOW >= 0) {                   // power-of-two pixel grid: shifts instead of divisions
+                n = m >> g.logOHW;
+                const int rem = m & (ohw - 1);
+                oh = rem >> g.logOW;
+                ow = rem & (g.OW - 1);
+            } else {
+                n = m / ohw;
                 const int rem = m - n * ohw;
-                const int oh = rem / g.OW, ow = rem - oh * g.OW;
-                const int h = reflect_idx(oh * g.mul + dh, g.SH);
-                const int w = reflect_idx(ow * g.mul + dw, g.SW);
-                v = *reinterpret_cast<const f32x4*>(g.src + (((size_t)((n * g.SH + h) * g.SW + w)) << g.logSC) + ci);
+                oh = rem / g.OW;
+                ow = rem - oh * g.OW;
             }
-            ra[i] = v;
+            const int h = reflect_idx(oh * g.mul + dh, g.SH);
+            const int w = reflect_idx(ow * g.mul + dw, g.SW);
+            ra[i] = *reinterpret_cast<const f32x4*>(g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci);
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
             const int m = mb + brow + p * B_ROWS_PER_PASS;
-            const int n = n0 + bcol;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end && n < N) v = *reinterpret_cast<const f32x4*>(dy + (size_t)m * N + n);
+            f32x4 v = *reinterpret_cast<const f32x4*>(dy + (size_t)min(m, g.M - 1) * N + bcol_c);
+            if (m >= m_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
             rb[p] = v;
         }
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](int buf) {
+        float* a = sA + buf * A_TILE;
+        float* b = sB + buf * B_TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&sA[(arow + 8 * i) * 128 + (t & 31) * 4]) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&a[(arow + 8 * i) * 128 + (t & 31) * 4]) = ra[i];
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p)
-            *reinterpret_cast<f32x4*>(&sB[(brow + p * B_ROWS_PER_PASS) * BN + bcol]) = rb[p];
+            *reinterpret_cast<f32x4*>(&b[(brow + p * B_ROWS_PER_PASS) * BN + bcol]) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -279,29 +363,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
 
     if (m_begin < m_end) {
         load_slab(m_begin);
-        store_slab();
+        store_slab(0);
         __syncthreads();
+        int buf = 0;
         for (int mb = m_begin; mb < m_end; mb += 32) {
             if (mb + 32 < m_end) load_slab(mb + 32);
+            const float* a = sA + buf * A_TILE;
+            const float* b = sB + buf * B_TILE;
+            // operand double buffer: step s+1 is fetched from LDS while step s is multiplied
+            float av[2][TM], bv[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[0][i] = a[hi * 128 + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bv[0][n] = b[hi * BN + (wn * TN + n) * 32 + l31];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int ml = 2 * s + hi;
-                float a[TM], b[TN];
+                if (s < 15) {
+                    const int ml = 2 * (s + 1) + hi;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = sA[ml * 128 + (wm * TM + i) * 32 + l31];
+                    for (int i = 0; i < TM; ++i) av[(s + 1) & 1][i] = a[ml * 128 + (wm * TM + i) * 32 + l31];
 #pragma unroll
-                for (int n = 0; n < TN; ++n) b[n] = sB[ml * BN + (wn * TN + n) * 32 + l31];
+                    for (int n = 0; n < TN; ++n) bv[(s + 1) & 1][n] = b[ml * BN + (wn * TN + n) * 32 + l31];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[n], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][n], acc[i][n], 0, 0, 0);
             }
+            if (mb + 32 < m_end) store_slab(buf ^ 1);
             __syncthreads();
-            if (mb + 32 < m_end) {
-                store_slab();
-                __syncthreads();
-            }
+            buf ^= 1;
         }
     }
     float* out = slab + (size_t)blockIdx.z * g.K * N;
@@ -359,43 +451,44 @@ __global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restr
     reinterpret_cast<f32x4*>(dx)[idx] = s;
 }
 
-__global__ void weight_to_hwio_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW,
-                                      int cout_pad, int cin_pad) {
+// Weight layouts streamed by conv_gemm_kernel: one row per GEMM column n, K contiguous and
+// zero-padded to a multiple of 32 ("[N][Kp]"), so the B tile is staged exactly like the A tile.
+//   forward : row = co, k = (kh*KW + kw)*cin_pad + ci                      value W[co][ci][kh][kw]
+//   dgrad s1: row = ci, k = (kh'*KW + kw')*cout_pad + co                   value W[co][ci][KH-1-kh'][KW-1-kw']
+//   dgrad s2: [class ph*2+pw] row = ci, k = (th*2 + tw)*cout_pad + co      value W[co][ci][ph+2th][pw+2tw]  (4x4 kernel)
+__global__ void weight_prepare_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KHW,
+                                          int cout_pad, int cin_pad, int Kp) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)KH * KW * cin_pad * cout_pad;
-    if (idx >= total) return;
-    const int co = idx % cout_pad;
-    size_t r = idx / cout_pad;
-    const int ci = r % cin_pad;
-    const int tap = r / cin_pad;
+    if (idx >= (size_t)cout_pad * Kp) return;
+    const int k = idx % Kp, co = idx / Kp;
+    const int ci = k % cin_pad, tap = k / cin_pad;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KH * KW + tap];
+    if (co < Cout && ci < Cin && tap < KHW) v = w[((size_t)co * Cin + ci) * KHW + tap];
     out[idx] = v;
 }
 
-// stride 1: out[kh'][kw'][co][ci] = W[co][ci][KH-1-kh'][KW-1-kw']
-// stride 2: out[ph][pw][th][tw][co][ci] = W[co][ci][ph+2th][pw+2tw]   (KH=KW=4)
-__global__ void weight_to_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW,
-                                       int stride, int cout_pad, int cin_pad) {
+__global__ void weight_prepare_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                            int stride, int cout_pad, int cin_pad, int Kp) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)KH * KW * cin_pad * cout_pad;
-    if (idx >= total) return;
-    const int ci = idx % cin_pad;
-    size_t r = idx / cin_pad;
-    const int co = r % cout_pad;
-    const int tapo = r / cout_pad;
+    const size_t per_class = (size_t)cin_pad * Kp;
+    const int classes = stride == 1 ? 1 : 4;
+    if (idx >= per_class * classes) return;
+    const int cls = idx / per_class;
+    const size_t r = idx % per_class;
+    const int k = r % Kp, ci = r / Kp;
+    const int co = k % cout_pad, tapo = k / cout_pad;
     int kh, kw;
+    bool ok = co < Cout && ci < Cin;
     if (stride == 1) {
+        ok = ok && tapo < KH * KW;
         kh = KH - 1 - tapo / KW;
         kw = KW - 1 - tapo % KW;
     } else {
-        const int tw = tapo & 1, th = (tapo >> 1) & 1, pw = (tapo >> 2) & 1, ph = (tapo >> 3) & 1;
-        kh = ph + 2 * th;
-        kw = pw + 2 * tw;
+        ok = ok && tapo < 4;
+        kh = (cls >> 1) + 2 * (tapo >> 1);
+        kw = (cls & 1) + 2 * (tapo & 1);
     }
-    float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KH * KW + kh * KW + kw];
-    out[idx] = v;
+    out[idx] = ok ? w[((size_t)co * Cin + ci) * KH * KW + kh * KW + kw] : 0.f;
 }
 
 int kw_magic_for(int KW, int max_tap) {
@@ -405,21 +498,102 @@ int kw_magic_for(int KW, int max_tap) {
     return magic;
 }
 
-int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int classes, const Scatter& o, const float* bias,
-                int act, hipStream_t st) {
-    const int tiles_m = (g.M + BM - 1) / BM;
-    if (o.N > 64) {
-        const int tn = (o.N + 127) / 128;
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 2, 2, 2>), dim3(tiles_m * tn, 1, classes), dim3(256), 0, st, g, w,
-                           w_class_stride, o, bias, act, tn);
-    } else if (o.N > 32) {
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 2, 2, 2, 1>), dim3(tiles_m, 1, classes), dim3(256), 0, st, g, w,
-                           w_class_stride, o, bias, act, 1);
-    } else {
-        hipLaunchKernelGGL((conv_gemm_kernel<32, 4, 1, 1, 1>), dim3(tiles_m, 1, classes), dim3(256), 0, st, g, w,
-                           w_class_stride, o, bias, act, 1);
+// ---- tile / split selection ------------------------------------------------------------------
+constexpr int NUM_CU = 256;
+struct Plan {
+    int bm, bn, splits, kt_per_split;
+};
+
+// Cost model (relative time): the busiest CU runs ceil(blocks/256) workgroups back to back at the
+// MFMA rate; a lone workgroup on a CU (one wave per SIMD) only reaches ~0.55 of that rate because
+// nothing covers its barrier / LDS-read latency, two or more co-resident reach ~0.75; smaller
+// tiles re-read more operand bytes per flop (factor f).
+Plan plan_gemm(int M, int N, int K, int classes) {
+    struct Cand { int bm, bn, resident; float f; };
+    // f: measured MFMA-rate ratio of each tile against 128x128 at >= 2 workgroups per CU (r01 kernel_bench)
+    static const Cand all[] = {{128, 128, 2, 1.0f}, {128, 64, 2, 0.75f}, {64, 64, 4, 0.7f}, {128, 32, 4, 0.6f}};
+    const int nk = (K + BK - 1) / BK;
+    Plan best = {128, 32, 1, nk};
+    float best_cost = 3.0e38f;
+    auto valid = [N](const Cand& c) {
+        if (N <= 32) return c.bn == 32;
+        if (N <= 64) return c.bn == 64;
+        return c.bn != 32;
+    };
+    // development knob: DWC_GEMM_TILE=128x128|128x64|64x64 pins the tile where it is valid for this N
+    const char* force = getenv("DWC_GEMM_TILE");
+    const Cand* pinned = nullptr;
+    if (force)
+        for (const Cand& c : all) {
+            char tag[16];
+            snprintf(tag, sizeof tag, "%dx%d", c.bm, c.bn);
+            if (valid(c) && strcmp(tag, force) == 0) pinned = &c;
+        }
+    for (const Cand& c : all) {
+        if (!valid(c) || (pinned && pinned != &c)) continue;
+        const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
+        const long per_cu = (blocks + NUM_CU - 1) / NUM_CU;
+        const float eff = (per_cu >= 2 && c.resident >= 2) ? 0.75f : 0.55f;
+        const float cost = (float)per_cu * c.bm * c.bn / (c.f * eff);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = {c.bm, c.bn, 1, nk};
+        }
     }
+    // split-K: too few output tiles to fill the chip but a long contraction
+    const long blocks = (long)((M + best.bm - 1) / best.bm) * ((N + best.bn - 1) / best.bn) * classes;
+    if (blocks < NUM_CU / 2 && nk >= 8) {
+        int s = (int)((2 * NUM_CU + blocks - 1) / blocks);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 32) s = 32;
+        if (s >= 2) {
+            best.kt_per_split = (nk + s - 1) / s;
+            best.splits = (nk + best.kt_per_split - 1) / best.kt_per_split;
+        }
+    }
+    return best;
+}
+
+size_t gemm_ws_bytes(int M, int N, int K, int classes, size_t dst_elems) {
+    const Plan p = plan_gemm(M, N, K, classes);
+    return p.splits > 1 ? (size_t)p.splits * dst_elems * sizeof(float) : 0;
+}
+
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+void launch_variant(const Gather& g, const float* w, size_t wcs, int classes, const Scatter& o, const float* bias, int act,
+                    const Plan& p, size_t part_stride, hipStream_t st) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (o.N + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, TM, TN>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0, st,
+                       g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+}
+
+int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int classes, Scatter o, const float* bias, int act,
+                size_t dst_elems, void* ws, size_t ws_bytes, hipStream_t st) {
+    Plan p = plan_gemm(g.M, o.N, g.K, classes);
+    float* final_dst = o.dst;
+    size_t part_stride = 0;
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < (size_t)p.splits * dst_elems * sizeof(float)) {
+            p.splits = 1;   // not enough scratch: run un-split (slower, same result up to summation order)
+            p.kt_per_split = (g.K + BK - 1) / BK;
+        } else {
+            o.dst = (float*)ws;
+            part_stride = dst_elems;
+        }
+    }
+    if (p.bm == 128 && p.bn == 128) launch_variant<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+    else if (p.bm == 128 && p.bn == 64) launch_variant<128, 64, 2, 2, 2, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+    else if (p.bm == 64 && p.bn == 64) launch_variant<64, 64, 2, 2, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+    else launch_variant<128, 32, 4, 1, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
     DWC_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const size_t total4 = dst_elems / 4;
+        size_t blocks = (total4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, final_dst, bias, total4,
+                           total4, p.splits, o.N, act);
+        DWC_LAUNCH_CHECK();
+    }
     return DWC_OK;
 }
 
@@ -433,7 +607,8 @@ bool conv_args_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int st
 }
 
 void wgrad_plan(int M, int K, int N, int* splits, int* chunk) {
-    const int tiles = ((K + 127) / 128) * ((N + (N > 64 ? 127 : (N > 32 ? 63 : 31))) / (N > 64 ? 128 : (N > 32 ? 64 : 32)));
+    const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    const int tiles = ((K + 127) / 128) * ((N + bn - 1) / bn);
     int want = (1024 + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int c = (M + want - 1) / want;
@@ -443,48 +618,119 @@ void wgrad_plan(int M, int K, int N, int* splits, int* chunk) {
     *splits = (M + c - 1) / c;
 }
 
+struct FwdGeom {
+    Gather g;
+    Scatter o;
+    size_t dst_elems;
+};
+
+bool fwd_geom(const float* x, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, FwdGeom* f) {
+    if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return false;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    Gather& g = f->g;
+    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
+    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
+    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
+    if (g.kw_magic < 0) return false;
+    g.mul = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
+    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
+    g.logOW = dwc_ilog2_exact(Wo); g.logOHW = dwc_ilog2_exact(Ho * Wo);
+    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
+    f->o.dst = y; f->o.N = Cout; f->o.OHf = Ho; f->o.OWf = Wo; f->o.os = 1;
+    f->dst_elems = (size_t)g.M * Cout;
+    return true;
+}
+
+struct BwdGeom {
+    Gather g;
+    Scatter o;
+    size_t dst_elems, wcs;
+    int classes;
+};
+
+bool bwd_geom(const float* dy, float* dxp, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+              BwdGeom* f) {
+    // here the gathered tensor is dy (Cout channels) and the produced one is dx (Cin channels)
+    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, stride, pad)) return false;
+    if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3)) return false;
+    if (stride == 2 && !(KH == 4 && KW == 4 && pad == 1 && !(H & 1) && !(W & 1))) return false;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    Gather& g = f->g;
+    g.src = dy; g.SH = Ho; g.SW = Wo; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
+    g.reflect = 0; g.logOW = g.logOHW = -1;
+    f->o.dst = dxp; f->o.N = Cin; f->o.OHf = Hp; f->o.OWf = Wp;
+    f->dst_elems = (size_t)B * Hp * Wp * Cin;
+    if (stride == 1) {
+        g.OH = Hp; g.OW = Wp; g.KH = KH; g.KW = KW;
+        g.kw_magic = kw_magic_for(KW, KH * KW + 64);
+        if (g.kw_magic < 0) return false;
+        g.mul = 1; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1);
+        g.M = B * Hp * Wp; g.K = KH * KW * Cout;
+        f->o.os = 1; f->classes = 1; f->wcs = 0;
+    } else {
+        g.OH = Hp / 2; g.OW = Wp / 2; g.KH = 2; g.KW = 2;
+        g.kw_magic = kw_magic_for(2, 64);
+        g.mul = 1; g.kstep = -1; g.off_h = 0; g.off_w = 0;
+        g.M = B * (Hp / 2) * (Wp / 2); g.K = 4 * Cout;
+        f->o.os = 2; f->classes = 4; f->wcs = (size_t)Cin * ((4 * Cout + BK - 1) / BK * BK);
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
 
-int dwc_version(void) { return 1; }
+int dwc_version(void) { return 2; }
 
-int dwc_weight_oihw_to_hwio(const float* w, float* out, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,
-                            void* stream) {
+size_t dwc_weight_prepared_elems(int Cout, int Cin, int KH, int KW, int stride, int cout_pad, int cin_pad, int for_dgrad) {
+    if (!for_dgrad) return (size_t)cout_pad * ((KH * KW * cin_pad + BK - 1) / BK * BK);
+    if (stride == 1) return (size_t)cin_pad * ((KH * KW * cout_pad + BK - 1) / BK * BK);
+    return (size_t)4 * cin_pad * ((4 * cout_pad + BK - 1) / BK * BK);
+}
+
+int dwc_weight_prepare_fwd(const float* w, float* out, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,
+                           void* stream) {
     if (cout_pad < Cout || cin_pad < Cin) return DWC_EINVAL;
-    const size_t total = (size_t)KH * KW * cin_pad * cout_pad;
-    hipLaunchKernelGGL(weight_to_hwio_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
-                       KH, KW, cout_pad, cin_pad);
+    const int Kp = (KH * KW * cin_pad + BK - 1) / BK * BK;
+    const size_t total = (size_t)cout_pad * Kp;
+    hipLaunchKernelGGL(weight_prepare_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
+                       KH * KW, cout_pad, cin_pad, Kp);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_weight_oihw_to_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, int stride, int cout_pad,
+int dwc_weight_prepare_dgrad(const float* w, float* out, int Cout, int Cin, int KH, int KW, int stride, int cout_pad,
                              int cin_pad, void* stream) {
     if (cout_pad < Cout || cin_pad < Cin) return DWC_EINVAL;
     if (stride == 2 && !(KH == 4 && KW == 4)) return DWC_EINVAL;
     if (stride != 1 && stride != 2) return DWC_EINVAL;
-    const size_t total = (size_t)KH * KW * cin_pad * cout_pad;
-    hipLaunchKernelGGL(weight_to_dgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin,
-                       KH, KW, stride, cout_pad, cin_pad);
+    const int Kp = ((stride == 1 ? KH * KW : 4) * cout_pad + BK - 1) / BK * BK;
+    const size_t total = (size_t)(stride == 1 ? 1 : 4) * cin_pad * Kp;
+    hipLaunchKernelGGL(weight_prepare_dgrad_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, Cout,
+                       Cin, KH, KW, stride, cout_pad, cin_pad, Kp);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
+size_t dwc_conv2d_fwd_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    FwdGeom f;
+    if (!fwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return 0;
+    return gemm_ws_bytes(f.g.M, Cout, f.g.K, 1, f.dst_elems);
+}
+
 int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                   int KH, int KW, int stride, int pad, int act, void* stream) {
-    if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return DWC_EINVAL;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    Gather g;
-    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
-    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-    if (g.kw_magic < 0) return DWC_EINVAL;
-    g.mul = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
-    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
-    Scatter o;
-    o.dst = y; o.N = Cout; o.OHf = Ho; o.OWf = Wo; o.os = 1;
-    return launch_gemm(g, w_hwio, 0, 1, o, bias, act, (hipStream_t)stream);
+                   int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
+    return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    BwdGeom f;
+    if (!bwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return 0;
+    return gemm_ws_bytes(f.g.M, Cin, f.g.K, f.classes, f.dst_elems);
 }
 
 int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream) {
@@ -497,38 +743,10 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
 }
 
 int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp, int B, int H, int W, int Cin, int Cout, int KH,
-                        int KW, int stride, int pad, void* stream) {
-    // here the gathered tensor is dy (Cout channels) and the produced one is dx (Cin channels)
-    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, stride, pad)) return DWC_EINVAL;
-    if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3)) return DWC_EINVAL;
-    if (stride == 2 && !(KH == 4 && KW == 4 && pad == 1 && !(H & 1) && !(W & 1))) return DWC_EINVAL;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    float* target = dxp;
-    hipStream_t st = (hipStream_t)stream;
-    Gather g;
-    g.src = dy; g.SH = Ho; g.SW = Wo; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
-    g.reflect = 0;
-    Scatter o;
-    o.dst = target; o.N = Cin; o.OHf = Hp; o.OWf = Wp;
-    int rc;
-    if (stride == 1) {
-        g.OH = Hp; g.OW = Wp; g.KH = KH; g.KW = KW;
-        g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-        if (g.kw_magic < 0) return DWC_EINVAL;
-        g.mul = 1; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1);
-        g.M = B * Hp * Wp; g.K = KH * KW * Cout;
-        o.os = 1;
-        rc = launch_gemm(g, w_dgrad, 0, 1, o, nullptr, DWC_ACT_NONE, st);
-    } else {
-        g.OH = Hp / 2; g.OW = Wp / 2; g.KH = 2; g.KW = 2;
-        g.kw_magic = kw_magic_for(2, 64);
-        g.mul = 1; g.kstep = -1; g.off_h = 0; g.off_w = 0;
-        g.M = B * (Hp / 2) * (Wp / 2); g.K = 4 * Cout;
-        o.os = 2;
-        rc = launch_gemm(g, w_dgrad, (size_t)4 * Cout * Cin, 4, o, nullptr, DWC_ACT_NONE, st);
-    }
-    return rc;
+                        int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    BwdGeom f;
+    if (!bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
+    return launch_gemm(f.g, w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
@@ -540,18 +758,12 @@ size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, in
 
 int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
                           int KW, int stride, int pad, int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
-    if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return DWC_EINVAL;
+    FwdGeom f;
+    if (!fwd_geom(x, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
     if (cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
     if (!ws || ws_bytes < dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cin, Cout, KH, KW, stride, pad)) return DWC_EWORKSPACE;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
-    Gather g;
-    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
-    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-    if (g.kw_magic < 0) return DWC_EINVAL;
-    g.mul = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
-    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
+    const Gather& g = f.g;
     int splits, chunk;
     wgrad_plan(g.M, g.K, Cout, &splits, &chunk);
     float* slab = (float*)ws;

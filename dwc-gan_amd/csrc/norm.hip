@@ -320,27 +320,55 @@ __global__ __launch_bounds__(256) void ln_bwd_partial(const float* __restrict__ 
     }
 }
 
-// sample sums -> sums[n*2..], channel sums -> dgamma/dbeta
-__global__ void ln_bwd_final(const float* __restrict__ part_s, const float* __restrict__ part_c, float* __restrict__ sums,
-                             float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int chunks) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < B) {
-        double a = 0, b = 0;
-        for (int k = 0; k < chunks; ++k) {
-            a += part_s[(size_t)(idx * chunks + k) * 2];
-            b += part_s[(size_t)(idx * chunks + k) * 2 + 1];
+// blocks [0, B): per-sample sums -> sums[n*2..];  blocks [B, B + ceil(C/64)): channel sums -> dgamma/dbeta.
+// 1024 threads; fixed summation order.
+__global__ __launch_bounds__(1024) void ln_bwd_final(const float* __restrict__ part_s, const float* __restrict__ part_c,
+                                                     float* __restrict__ sums, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int B, int C, int chunks) {
+    __shared__ float sm[2][16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if ((int)blockIdx.x < B) {
+        const int n = blockIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int k = threadIdx.x; k < chunks; k += 1024) {
+            a += part_s[(size_t)(n * chunks + k) * 2];
+            b += part_s[(size_t)(n * chunks + k) * 2 + 1];
         }
-        sums[idx * 2] = (float)a;
-        sums[idx * 2 + 1] = (float)b;
+        a = dwc_wave_sum(a);
+        b = dwc_wave_sum(b);
+        if (cl == 0) {
+            sm[0][g][0] = a;
+            sm[1][g][0] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 16; ++k) {
+                a += sm[0][k][0];
+                b += sm[1][k][0];
+            }
+            sums[n * 2] = a;
+            sums[n * 2 + 1] = b;
+        }
+        return;
     }
-    if (idx < C) {
-        double a = 0, b = 0;
-        for (int k = 0; k < B * chunks; ++k) {
-            a += part_c[(size_t)k * 2 * C + idx];
-            b += part_c[(size_t)k * 2 * C + C + idx];
+    const int c = ((int)blockIdx.x - B) * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int k = g; k < B * chunks; k += 16) {
+            a += part_c[(size_t)k * 2 * C + c];
+            b += part_c[(size_t)k * 2 * C + C + c];
         }
-        dgamma[idx] = (float)a;
-        dbeta[idx] = (float)b;
+    sm[0][g][cl] = a;
+    sm[1][g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            a += sm[0][k][cl];
+            b += sm[1][k][cl];
+        }
+        dgamma[c] = a;
+        dbeta[c] = b;
     }
 }
 
@@ -466,8 +494,8 @@ int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
     hipLaunchKernelGGL(ln_bwd_partial, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, part_s, part_c, HW,
                        C, rs.rows_per_chunk, relu);
     DWC_LAUNCH_CHECK();
-    const int n = B > C ? B : C;
-    hipLaunchKernelGGL(ln_bwd_final, dim3((n + 63) / 64), dim3(64), 0, st, part_s, part_c, sums, dgamma, dbeta, B, C, rs.chunks);
+    hipLaunchKernelGGL(ln_bwd_final, dim3(B + (C + 63) / 64), dim3(1024), 0, st, part_s, part_c, sums, dgamma, dbeta, B, C,
+                       rs.chunks);
     DWC_LAUNCH_CHECK();
     const size_t total4 = (size_t)B * HW * (C / 4);
     hipLaunchKernelGGL(ln_bwd_apply, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,

@@ -49,12 +49,21 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const float* __restrict__
     }
 }
 
-__global__ void colsum_final(const float* __restrict__ part, float* __restrict__ out, int chunks, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] = sum_k part[k][c]; 64 channels x 16 chunk-lanes per block, fixed summation order
+__global__ __launch_bounds__(1024) void colsum_final(const float* __restrict__ part, float* __restrict__ out, int chunks, int C) {
+    __shared__ float sm[16][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int k = g; k < chunks; k += 16) s += part[(size_t)k * C + c];
+    sm[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += sm[k][cl];
+        out[c] = s;
+    }
 }
 
 void act_plan(int rows, int* chunks, int* rpc) {
@@ -303,7 +312,7 @@ int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int r
                        rows, C, rpc, act);
     DWC_LAUNCH_CHECK();
     if (db) {
-        hipLaunchKernelGGL(colsum_final, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)ws, db, chunks, C);
+        hipLaunchKernelGGL(colsum_final, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)ws, db, chunks, C);
         DWC_LAUNCH_CHECK();
     }
     return DWC_OK;

@@ -17,10 +17,13 @@ c_f = ctypes.c_float
 # name -> (restype, argtypes): mirrors include/dwcgan_hip.h one to one
 SIGNATURES = {
     "dwc_version": (c_int, []),
-    "dwc_weight_oihw_to_hwio": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
-    "dwc_weight_oihw_to_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
-    "dwc_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp]),
-    "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp]),
+    "dwc_weight_prepared_elems": (c_sz, [c_int] * 8),
+    "dwc_weight_prepare_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_weight_prepare_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_conv2d_fwd_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
     "dwc_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),

@@ -22,6 +22,10 @@ class DeviceNoise:
     def dropout(self, x, p, training=True):
         return F.dropout(x, p=p, training=training)
 
+    def dropout_mask(self, shape, p, device):
+        """Scaled keep-mask (0 or 1/(1-p)) drawn now, to be multiplied in later."""
+        return F.dropout(torch.ones(tuple(shape), dtype=torch.float32, device=device), p=p, training=True)
+
     def style_sample(self, mu, c_dim, stddev):
         shape = (1, c_dim) + tuple(mu.shape)
         draw = torch.normal(mu.expand(shape), torch.full_like(mu, stddev).expand(shape))
@@ -38,8 +42,12 @@ class HostNoise:
     def dropout(self, x, p, training=True):
         if not training or p == 0:
             return x
-        mask = F.dropout(torch.ones(tuple(x.shape), dtype=torch.float32), p=p, training=True)
-        return x * mask.to(x.device, non_blocking=True)
+        return x * self.dropout_mask(x.shape, p, x.device)
+
+    def dropout_mask(self, shape, p, device):
+        """Same stream consumption as F.dropout on a CPU tensor of that shape (one bernoulli_ call)."""
+        mask = F.dropout(torch.ones(tuple(shape), dtype=torch.float32), p=p, training=True)
+        return mask.to(device, non_blocking=True)
 
     def style_sample(self, mu, c_dim, stddev):
         m = mu.detach().to("cpu", torch.float32)

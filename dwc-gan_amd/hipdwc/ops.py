@@ -92,11 +92,6 @@ def _timed(tag, flops, fn):
     return fn() if TIMER is None else TIMER.run(tag, flops, fn)
 
 
-def _gemm_tag(n_cols):
-    """Name of the conv_gemm_kernel instantiation the library picks for an N-column product."""
-    return "conv_gemm_kernel<%d>" % (128 if n_cols > 64 else (64 if n_cols > 32 else 32))
-
-
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -122,13 +117,14 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     lib = _lib.load()
     cout, cin, kh, kw = w.shape
     wc = w.detach().contiguous()
-    out = torch.empty(kh * kw * cin_pad * cout_pad, dtype=torch.float32, device=w.device)
-    if kind == "hwio":
-        _lib.check(lib.dwc_weight_oihw_to_hwio(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
-                                               _stream()), "weight_oihw_to_hwio")
+    n = lib.dwc_weight_prepared_elems(cout, cin, kh, kw, stride, cout_pad, cin_pad, int(kind == "dgrad"))
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    if kind == "fwd":
+        _lib.check(lib.dwc_weight_prepare_fwd(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
+                                              _stream()), "weight_prepare_fwd")
     else:
-        _lib.check(lib.dwc_weight_oihw_to_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
-                                                cin_pad, _stream()), "weight_oihw_to_dgrad")
+        _lib.check(lib.dwc_weight_prepare_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
+                                                cin_pad, _stream()), "weight_prepare_dgrad")
     ent[key] = (w._version, out)
     return out
 
@@ -151,7 +147,7 @@ class _Conv2d(torch.autograd.Function):
         cop = _pad4(Cout)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        w_hwio = _prepped(w, "hwio", cop, Cx, stride)
+        w_hwio = _prepped(w, "fwd", cop, Cx, stride)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -159,9 +155,11 @@ class _Conv2d(torch.autograd.Function):
         y = empty_cl(B, cop, Ho, Wo, x.device)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
         st = _stream()
-        _lib.check(_timed(_gemm_tag(cop), flops, lambda: lib.dwc_conv2d_fwd(
-            x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, st)),
-            "conv2d_fwd")
+        nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
+        wsp = workspace(nws, x.device).data_ptr() if nws else None
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
+            x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
+            st)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         return y
@@ -195,12 +193,15 @@ class _Conv2d(torch.autograd.Function):
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)
             flops = 2.0 * rows * Cout * Cin * KH * KW
-            if pad == 0:
-                target = dx.data_ptr()
-            else:   # gradient of the padded image goes to scratch, then is folded back
-                target = workspace(B * (H + 2 * pad) * (W + 2 * pad) * Cx * 4, dev).data_ptr()
-            _lib.check(_timed(_gemm_tag(Cx), flops, lambda: lib.dwc_conv2d_bwd_data(
-                g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, st)), "conv2d_bwd_data")
+            # scratch arena: [gradient of the padded image (folded back below)] [split-K partials]
+            pad_bytes = 0 if pad == 0 else (B * (H + 2 * pad) * (W + 2 * pad) * Cx * 4 + 255) // 256 * 256
+            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
+            base = workspace(pad_bytes + nws, dev).data_ptr() if pad_bytes + nws else 0
+            target = dx.data_ptr() if pad == 0 else base
+            wsp = base + pad_bytes if nws else None
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
+                g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st)),
+                "conv2d_bwd_data")
             if pad > 0:
                 _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1]:

@@ -297,18 +297,34 @@ class MsImageDis(nn.Module):
             return -torch.mean(out) if target_is_real else torch.mean(out)
         raise AssertionError("Unsupported GAN type: {}".format(self.gan_type))
 
-    def calc_dis_loss(self, input_fake, input_real, fake_cls, real_cls, weight_gan=1.0, weight_cls=1.0):
-        """D objective (reference networks.py:116-146)."""
+    @staticmethod
+    def split_outputs(outputs, sizes):
+        """Outputs of ONE forward over a concatenated batch -> per-segment output lists (the
+        discriminator has no cross-sample op, so this equals separate forwards)."""
+        parts = [[] for _ in sizes]
+        for src, cls in outputs:
+            for p, s, c in zip(parts, torch.split(src, sizes), torch.split(cls, sizes)):
+                p.append([s, c])
+        return parts
+
+    def dis_loss_terms(self, outs_fake, outs_real, real_cls, weight_gan=1.0, weight_cls=1.0):
         loss = 0.0
-        for (src_f, _), (src_r, cls_r) in zip(self.forward(input_fake), self.forward(input_real)):
+        for (src_f, _), (src_r, cls_r) in zip(outs_fake, outs_real):
             loss = loss + (self._gan_term(src_f, False) + self._gan_term(src_r, True)) * weight_gan
             loss = loss + self._classification_loss(cls_r, real_cls, self.dataset) * weight_cls
         return loss
 
-    def calc_gen_loss(self, input_fake, target_cls, weight_gan=1.0, weight_cls=1.0):
-        """G-side adversarial objective (reference networks.py:148-170)."""
+    def gen_loss_terms(self, outs_fake, target_cls, weight_gan=1.0, weight_cls=1.0):
         loss = 0
-        for src_f, cls_f in self.forward(input_fake):
+        for src_f, cls_f in outs_fake:
             loss = loss + self._gan_term(src_f, True) * weight_gan
             loss = loss + self._classification_loss(cls_f, target_cls, self.dataset) * weight_cls
         return loss
+
+    def calc_dis_loss(self, input_fake, input_real, fake_cls, real_cls, weight_gan=1.0, weight_cls=1.0):
+        """D objective (reference networks.py:116-146)."""
+        return self.dis_loss_terms(self.forward(input_fake), self.forward(input_real), real_cls, weight_gan, weight_cls)
+
+    def calc_gen_loss(self, input_fake, target_cls, weight_gan=1.0, weight_cls=1.0):
+        """G-side adversarial objective (reference networks.py:148-170)."""
+        return self.gen_loss_terms(self.forward(input_fake), target_cls, weight_gan, weight_cls)

@@ -40,14 +40,19 @@ class StyleEncoder(nn.Module):
             self.fcvars.append(nn.Linear(dim, c_dim))
         self.output_dim = dim
 
-    def forward(self, x):
+    def forward(self, x, drop_mask=None):
+        """``drop_mask``: optional pre-drawn scaled keep-mask for the mapping dropout (lets a caller
+        that batches several encodes draw the masks in the reference's order)."""
         h = ops.pack_image(x) if x.shape[1] < 4 else x
         for blk in list(self.model)[:-1]:
             h = blk(h)
         f = h.mean(dim=(2, 3))                                   # global average pool over <=4x4 pixels
         if self.use_map:
             f = ops.linear(f, self.mapping[0].weight, self.mapping[0].bias, "relu")
-            f = host.noise().dropout(f, self.mapping[2].p, self.training)
+            if self.training and self.mapping[2].p > 0:
+                if drop_mask is None:
+                    drop_mask = host.noise().dropout_mask(f.shape, self.mapping[2].p, f.device)
+                f = f * drop_mask
             f = ops.linear(f, self.mapping[3].weight, self.mapping[3].bias, "relu")
         # the 2*num_class heads share their input: one [2*num_class*c_dim, dim] product
         w = torch.cat([m.weight for m in self.fcs] + [m.weight for m in self.fcvars], 0)
@@ -161,10 +166,17 @@ class AdaINGen_v2(nn.Module):
         content, mus, _ = self.encode(images)
         return self.decode(content, mus)
 
-    def encode(self, images):
+    def encode(self, images, drop_mask=None):
         x = ops.pack_image(images)
-        mus, logvar = self.enc_style(x)
+        mus, logvar = self.enc_style(x, drop_mask=drop_mask)
         return self.enc_content(x), mus, logvar
+
+    def draw_encode_mask(self, batch, device):
+        """The dropout mask one ``encode`` of ``batch`` images would draw (None when nothing is drawn)."""
+        es = self.enc_style
+        if not (es.use_map and es.training and es.mapping[2].p > 0):
+            return None
+        return host.noise().dropout_mask((batch, es.mapping[0].out_features), es.mapping[2].p, device)
 
     def encode_txt(self, style_ord, txt_org2trg, txt_lens):
         return self.enc_txt(style_ord, txt_org2trg, txt_lens)

@@ -154,16 +154,21 @@ class Solver(nn.Module):
                                       "(off in the shipped config: gp_w 0, use_r1 False)")
         self.dis_opt.zero_grad()
         x4 = ops.pack_image(x_real)
+        B = x4.shape[0]
         with torch.no_grad():
             content, style_real, _ = self.gen.encode(x4)
             style_real = torch.cat(style_real, dim=1)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
-            x_fake = self._decode(content, torch.cat(style_txt, dim=1), x4)
-            x_fake1 = self._decode(content, style1, x4)
+            # both fakes in ONE decoder pass (AdaIN parameters are per sample)
+            fakes = self._decode(torch.cat([content, content]), torch.cat([torch.cat(style_txt, dim=1), style1]),
+                                 torch.cat([x4, x4]))
         gw, cw = configs["gan_w"], configs["cls_w"]
-        self.loss_dis = self.dis.calc_dis_loss(x_fake, x4, label_trg, label_src, gw, cw) + \
-            self.dis.calc_dis_loss(x_fake1, x4, label_trg, label_src, gw, cw)
+        # ONE discriminator pass over [x_fake, x_fake1, x_real]; D(x_real) enters both loss terms as
+        # in the reference (which evaluates it twice, with identical values)
+        o_fake, o_fake1, o_real = self.dis.split_outputs(self.dis(torch.cat([fakes, x4])), [B, B, B])
+        self.loss_dis = self.dis.dis_loss_terms(o_fake, o_real, label_src, gw, cw) + \
+            self.dis.dis_loss_terms(o_fake1, o_real, label_src, gw, cw)
         self.loss_dis_all = self.loss_dis
         self.loss_dis_all.backward()
         if self.grad_sync is not None:      # data parallel: average D's gradients over the ranks
@@ -176,25 +181,34 @@ class Solver(nn.Module):
         gen, cfg = self.gen, configs
         x4 = ops.pack_image(x_real)
         with _frozen(self.dis):
-            content_real, style_real, logvar = gen.encode(x4)
+            # The reference runs its encodes/decodes one after another (solver.py:155-192).  The three
+            # decodes of content_real and the three re-encodes are independent across samples, so
+            # they run here as ONE 3B-sample pass each (larger GEMMs, a third of the launches); the
+            # random draws are still made in the reference's order, the masks just get applied later.
+            B = x4.shape[0]
+            content_real, style_real, logvar = gen.encode(x4)                    # draw: mapping dropout
             s_real = torch.cat(style_real, dim=1)
-            # within-domain reconstruction
-            x_rec = self._decode(content_real, s_real, x4)
-            content_rec, style_rec, _ = gen.encode(x_rec)
-            # cross-domain via the text command
-            style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)
+            mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
+            style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)   # draws of the text encoder
             s_txt = torch.cat(style_txt, dim=1)
-            x_fake = self._decode(content_real, s_txt, x4)
-            # two random styles for the diversity term; the second is only a detached target
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
-            x_fake1 = self._decode(content_real, style1, x4)
             style2 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
-            with torch.no_grad():
+            mask_rand = gen.draw_encode_mask(B, x4.device)                       # draw of encode(x_fake1)
+            mask_fake = gen.draw_encode_mask(B, x4.device)                       # draw of encode(x_fake)
+
+            # decode [within-domain reconstruction | text-driven fake | random-style fake]
+            x_all = self._decode(torch.cat([content_real] * 3), torch.cat([s_real, s_txt, style1]), torch.cat([x4] * 3))
+            x_rec, x_fake, x_fake1 = torch.split(x_all, B)
+            with torch.no_grad():                                                # only ever used detached
                 x_fake2 = self._decode(content_real, style2, x4)
             self.loss_ds = ops.l1_mean(x_fake1, x_fake2, image=True)
-            content_rand, style_rand, _ = gen.encode(x_fake1)
             self.init_ds_w = max(self.init_ds_w - 1 / 1e5, 0.0)
-            content_fake, style_fake, _ = gen.encode(x_fake)
+            masks = None if mask_rec is None else torch.cat([mask_rec, mask_fake, mask_rand])
+            content_all, style_all, _ = gen.encode(x_all, drop_mask=masks)
+            content_rec, content_fake, content_rand = torch.split(content_all, B)
+            style_rec = [m[:B] for m in style_all]
+            style_fake = [m[B:2 * B] for m in style_all]
+            style_rand = [m[2 * B:] for m in style_all]
             cyc = cfg["recon_x_cyc_w"] > 0
             if cyc:
                 x_cycle = self._decode(content_fake, s_real, x4)
@@ -208,8 +222,9 @@ class Solver(nn.Module):
             self.loss_gen_recon_s_rand = self.criterion_l1(style_rand, style1)
             self.loss_gen_cycrecon_x = ops.l1_mean(x_cycle, x4, image=True) if cyc else 0
 
-            self.loss_gen_adv = self.dis.calc_gen_loss(x_fake, label_trg, cfg["gan_w"], cfg["cls_w"]) + \
-                self.dis.calc_gen_loss(x_fake1, label_trg, cfg["gan_w"], cfg["cls_w"])
+            o_fake, o_fake1 = self.dis.split_outputs(self.dis(x_all[B:]), [B, B])   # one pass over [x_fake, x_fake1]
+            self.loss_gen_adv = self.dis.gen_loss_terms(o_fake, label_trg, cfg["gan_w"], cfg["cls_w"]) + \
+                self.dis.gen_loss_terms(o_fake1, label_trg, cfg["gan_w"], cfg["cls_w"])
 
             if self.dist_mode == "kls":
                 self.loss_kl_x = gmm_kl_distance_sp(style_real, logvar, c_src, self.sigma)

@@ -11,7 +11,7 @@
  * Conventions
  *  - all tensors are dense fp32 in HBM, activations NHWC: x[n][h][w][c]
  *  - conv weights are handed over in the state_dict layout OIHW and re-laid-out on device by
- *    the dwc_weight_* entry points into the layouts the kernels stream ("HWIO": [kh][kw][ci][co])
+ *    the dwc_weight_prepare_* entry points into the K-contiguous layouts the kernels stream
  *  - channel counts on the data path must be multiples of 4 (16-byte vector accesses); the
  *    3-channel images travel as NHWC4 with a zero 4th plane
  *  - pointers are borrowed device pointers; the library never allocates, frees or synchronises;
@@ -45,30 +45,37 @@ extern "C" {
 
 int dwc_version(void);
 
-/* ---- weight re-layout -------------------------------------------------------------------- */
-/* OIHW -> HWIO with Cin padded to cin_pad and Cout padded to cout_pad (zero fill). */
-int dwc_weight_oihw_to_hwio(const float* w_oihw, float* w_hwio, int Cout, int Cin, int KH, int KW,
-                            int cout_pad, int cin_pad, void* stream);
-/* OIHW -> data-gradient layout.
- *   stride 1: [kh'][kw'][co][ci] = W[co][ci][KH-1-kh'][KW-1-kw']
- *   stride 2 (4x4 kernel only): [ph][pw][th][tw][co][ci] = W[co][ci][ph+2*th][pw+2*tw]
- * co padded to cout_pad, ci to cin_pad. */
-int dwc_weight_oihw_to_dgrad(const float* w_oihw, float* w_dgrad, int Cout, int Cin, int KH, int KW,
+/* ---- weight re-layout --------------------------------------------------------------------
+ * The GEMM kernels stream weights as one row per GEMM column with K contiguous and
+ * zero-padded to a multiple of 32:
+ *   forward : [co][ (kh*KW+kw)*cin_pad + ci ]               = W[co][ci][kh][kw]
+ *   dgrad s1: [ci][ (kh'*KW+kw')*cout_pad + co ]            = W[co][ci][KH-1-kh'][KW-1-kw']
+ *   dgrad s2: [ph*2+pw][ci][ (th*2+tw)*cout_pad + co ]      = W[co][ci][ph+2*th][pw+2*tw]   (4x4 only)
+ * dwc_weight_prepared_elems gives the float count of the prepared buffer. */
+size_t dwc_weight_prepared_elems(int Cout, int Cin, int KH, int KW, int stride, int cout_pad, int cin_pad,
+                                 int for_dgrad);
+int dwc_weight_prepare_fwd(const float* w_oihw, float* w_prepared, int Cout, int Cin, int KH, int KW,
+                           int cout_pad, int cin_pad, void* stream);
+int dwc_weight_prepare_dgrad(const float* w_oihw, float* w_prepared, int Cout, int Cin, int KH, int KW,
                              int stride, int cout_pad, int cin_pad, void* stream);
 
 /* ---- convolution (replaces nn.ReflectionPad2d + nn.Conv2d [+ activation];
  *      reference networks.py:579-585, call sites networks.py:432-441,514-515,90-98,
  *      networks_v2.py:106-112,155,159-160; also nn.Linear as a 1x1 conv, networks.py:595) ---- */
-/* y = act(conv(reflect_pad(x, pad), w) + bias).  x:[B,H,W,Cin] y:[B,Ho,Wo,Cout], w HWIO. */
-int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float* y,
+/* y = act(conv(reflect_pad(x, pad), w) + bias).  x:[B,H,W,Cin] y:[B,Ho,Wo,Cout], w prepared by dwc_weight_prepare_fwd.
+ * Scratch (dwc_conv2d_fwd_ws_bytes) is only used when the product is split along K (few output
+ * tiles, long contraction); with less scratch than that the kernel runs un-split. */
+size_t dwc_conv2d_fwd_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dwc_conv2d_fwd(const float* x, const float* w_prepared, const float* bias, float* y,
                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                   int act, void* stream);
+                   int act, void* ws, size_t ws_bytes, void* stream);
 /* Data gradient, step 1: gradient w.r.t. the reflect-PADDED input image,
  * dxp:[B,H+2*pad,W+2*pad,Cin], from the pre-activation gradient dy:[B,Ho,Wo,Cout]
- * (w in dgrad layout).  With pad == 0 this already is dx. */
+ * (w in dgrad layout).  With pad == 0 this already is dx.  Scratch as for the forward. */
+size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
 int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp,
                         int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-                        void* stream);
+                        void* ws, size_t ws_bytes, void* stream);
 /* Data gradient, step 2: adjoint of the reflect padding — fold dxp back onto dx:[B,H,W,C]. */
 int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad,
                             void* stream);
