@@ -191,41 +191,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     const int a_frag = (wm * TM * 32 + l31) * A_LD + 4 * hi;
     const int b_frag = (wn * TN * 32 + l31) * A_LD + 4 * hi;
 
+    // Skewed slab pipeline.  A slab is four 8-deep K-groups q0..q3 (TM*TN*4 MFMAs each).  Per iteration:
+    //     global loads of slab kt+1 -> registers
+    //     frags(q1) | MFMA(q0) ; frags(q2) | MFMA(q1)
+    //     registers -> LDS[other buffer]            (those loads have had two MFMA groups to land)
+    //     frags(q3) | MFMA(q2)
+    //     barrier                                   (other buffer complete; this buffer fully read)
+    //     frags(q0 of slab kt+1) | MFMA(q3)         (q3 was fetched before the barrier)
+    // so neither the LDS-store phase nor the first LDS read after the barrier leaves the matrix
+    // pipe without queued work.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int set, int buf, int q) {
+        const float* a = sA + buf * A_TILE + a_frag + 8 * q;
+        const float* b = sB + buf * B_TILE + b_frag + 8 * q;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD);
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][j], fb[set][n][j], acc[i][n], 0, 0, 0);
+    };
+
     if (kt0 < kt1) {
         load_slab(kt0);
         store_slab(0);
         __syncthreads();
         int buf = 0;
+        load_frags(0, 0, 0);
         for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) load_slab(kt + 1);
-            const float* a = sA + buf * A_TILE + a_frag;
-            const float* b = sB + buf * B_TILE + b_frag;
-            f32x4 fa[2][TM], fb[2][TN];      // fragment double buffer: q+1 is fetched while q is multiplied
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD);
-#pragma unroll
-            for (int n = 0; n < TN; ++n) fb[0][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < 3) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        fa[(q + 1) & 1][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD + 8 * (q + 1));
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        fb[(q + 1) & 1][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD + 8 * (q + 1));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int n = 0; n < TN; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][j], fb[q & 1][n][j], acc[i][n], 0, 0, 0);
-            }
-            // the other buffer was last read one iteration ago, behind the barrier below: safe to refill
-            if (kt + 1 < kt1) store_slab(buf ^ 1);
+            const bool more = kt + 1 < kt1;
+            if (more) load_slab(kt + 1);
+            load_frags(1, buf, 1);
+            mfma_group(0);
+            load_frags(0, buf, 2);
+            mfma_group(1);
+            if (more) store_slab(buf ^ 1);
+            load_frags(1, buf, 3);
+            mfma_group(0);
             __syncthreads();
+            if (more) load_frags(0, buf ^ 1, 0);
+            mfma_group(1);
             buf ^= 1;
         }
     }
@@ -361,38 +373,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Same skewed pipeline as conv_gemm_kernel: a slab is four groups of four MFMA steps; the
+    // operands of group g+1 are fetched from LDS while group g is multiplied, the registers->LDS
+    // store of the next slab sits between groups 1 and 2, and group 3 (fetched before the barrier)
+    // is multiplied after it while the next slab's group 0 is being fetched.
+    float av[2][4][TM], bv[2][4][TN];
+    auto load_ops = [&](int set, int buf, int grp) {
+        const float* a = sA + buf * A_TILE + (wm * TM) * 32 + l31;
+        const float* b = sB + buf * B_TILE + (wn * TN) * 32 + l31;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ml = 2 * (4 * grp + s) + hi;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[set][s][i] = a[ml * 128 + i * 32];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) bv[set][s][n] = b[ml * BN + n * 32];
+        }
+    };
+    auto mfma_ops = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][s][i], bv[set][s][n], acc[i][n], 0, 0, 0);
+    };
     if (m_begin < m_end) {
         load_slab(m_begin);
         store_slab(0);
         __syncthreads();
         int buf = 0;
+        load_ops(0, 0, 0);
         for (int mb = m_begin; mb < m_end; mb += 32) {
-            if (mb + 32 < m_end) load_slab(mb + 32);
-            const float* a = sA + buf * A_TILE;
-            const float* b = sB + buf * B_TILE;
-            // operand double buffer: step s+1 is fetched from LDS while step s is multiplied
-            float av[2][TM], bv[2][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[0][i] = a[hi * 128 + (wm * TM + i) * 32 + l31];
-#pragma unroll
-            for (int n = 0; n < TN; ++n) bv[0][n] = b[hi * BN + (wn * TN + n) * 32 + l31];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s < 15) {
-                    const int ml = 2 * (s + 1) + hi;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) av[(s + 1) & 1][i] = a[ml * 128 + (wm * TM + i) * 32 + l31];
-#pragma unroll
-                    for (int n = 0; n < TN; ++n) bv[(s + 1) & 1][n] = b[ml * BN + (wn * TN + n) * 32 + l31];
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][n], acc[i][n], 0, 0, 0);
-            }
-            if (mb + 32 < m_end) store_slab(buf ^ 1);
+            const bool more = mb + 32 < m_end;
+            if (more) load_slab(mb + 32);
+            load_ops(1, buf, 1);
+            mfma_ops(0);
+            load_ops(0, buf, 2);
+            mfma_ops(1);
+            if (more) store_slab(buf ^ 1);
+            load_ops(1, buf, 3);
+            mfma_ops(0);
             __syncthreads();
+            if (more) load_ops(0, buf ^ 1, 0);
+            mfma_ops(1);
             buf ^= 1;
         }
     }

@@ -223,12 +223,18 @@ class Decoder(nn.Module):
         self.image_content = Conv2dBlock(dim, output_dim, 7, 1, 3, norm="none", activation="tanh", pad_type=pad_type)
         self.image_attention = Conv2dBlock(dim, 1, 7, 1, 3, norm="none", activation="sigmoid", pad_type=pad_type)
 
-    def forward_nhwc4(self, x):
+    def forward_nhwc4(self, x, attention_used=True):
+        """``attention_used=False``: the caller will not read plane 3, so the attention head is taken
+        off the tape — its parameters then get NO gradient (not a zero one), exactly like the
+        reference, whose optimiser skips gradient-less parameters (no weight decay / momentum)."""
         feats = self.model(x)
         if self.output_dim != 3:
             raise NotImplementedError("fused heads assume a 3-channel image")
-        w = torch.cat([self.image_content.conv.weight, self.image_attention.conv.weight], 0)
-        b = torch.cat([self.image_content.conv.bias, self.image_attention.conv.bias], 0)
+        wa, ba = self.image_attention.conv.weight, self.image_attention.conv.bias
+        if not attention_used:
+            wa, ba = wa.detach(), ba.detach()
+        w = torch.cat([self.image_content.conv.weight, wa], 0)
+        b = torch.cat([self.image_content.conv.bias, ba], 0)
         return ops.conv2d_padded(feats, w, b, 1, 3, "heads")
 
     def forward(self, x):

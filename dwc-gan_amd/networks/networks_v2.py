@@ -186,10 +186,10 @@ class AdaINGen_v2(nn.Module):
         return self.dec(content)
 
     # -- internal 4-plane image API used by the solver ------------------------------------
-    def decode_nhwc4(self, content, style):
+    def decode_nhwc4(self, content, style, attention_used=True):
         """As decode(), returning the fused NHWC4 head buffer (planes 0-2 image, plane 3 attention)."""
         self.assign_adain_params(self.mlp(style), self.dec)
-        return self.dec.forward_nhwc4(content)
+        return self.dec.forward_nhwc4(content, attention_used=attention_used)
 
     def assign_adain_params(self, adain_params, model):
         """Hand each AdaIN layer, in module order, its slice of the MLP output: first C columns ->

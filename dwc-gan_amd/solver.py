@@ -138,7 +138,7 @@ class Solver(nn.Module):
 
     def _decode(self, content, style, x_real4):
         """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out."""
-        heads = self.gen.decode_nhwc4(content, style)
+        heads = self.gen.decode_nhwc4(content, style, attention_used=self.use_attention)
         return ops.attention_blend(heads, x_real4) if self.use_attention else heads
 
     def forward(self, x_real, txt_src2trg, txt_lens):

@@ -324,5 +324,9 @@ if __name__ == "__main__":
     if "traj64" in what:
         gen_traj(ref_solver, 64, 4, 100, None, "s64_b4_default")
         gen_traj(ref_solver, 64, 4, 100, 0.0, "s64_b4_nolstmdrop")
+    if "traj64_threads4" in what:
+        # the SAME reference run with another CPU thread count (different reduction order inside
+        # the library kernels): measures how fast two fp32 evaluations of this GAN drift apart
+        gen_traj(ref_solver, 64, 4, 100, None, "s64_b4_default_threads4", threads=4)
     if "traj128" in what:
         gen_traj(ref_solver, 128, 16, 100, 0.0, "s128_b16_nolstmdrop", threads=6)

@@ -307,6 +307,11 @@ def test_tiny_three_iterations_vs_reference(tiny):
             s.gen_update(*a, it)
             if it == 0:
                 grads = {k: p.grad.detach().clone() for k, p in s.gen.named_parameters() if p.grad is not None}
+            if it == 1:
+                # attention is off from iteration 1: the head must get NO gradient (Adam then skips it,
+                # SURVEY section 7 quirk viii) rather than a zero one
+                assert s.gen.dec.image_attention.conv.weight.grad is None
+                assert s.gen.dec.image_attention.conv.bias.grad is None
             s.smooth_moving()
             s.update_learning_rate()
             s.update_attention_status(it)
