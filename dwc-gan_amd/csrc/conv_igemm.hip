@@ -37,7 +37,7 @@ struct Gather {        // how GEMM row m / column k address the source tensor
     int OH, OW;        // pixel grid enumerated by m (per image)
     int logOW, logOHW; // log2 of OW and OH*OW when both are powers of two, else -1
     int KH, KW, kw_magic;
-    int mul, kstep, off_h, off_w;  // src_h = oh*mul + kh*kstep + off_h
+    int mul_h, mul_w, kstep, off_h, off_w;  // src_h = oh*mul_h + kh*kstep + off_h (same for w)
     int reflect;       // 1: reflect at the border, 0: zero outside
     int M, K;
 };
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
         const int n = mm / ohw;
         const int rem = mm - n * ohw;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        a_bh[i] = oh * g.mul + g.off_h;
-        a_bw[i] = ow * g.mul + g.off_w;
+        a_bh[i] = oh * g.mul_h + g.off_h;
+        a_bw[i] = ow * g.mul_w + g.off_w;
         a_img[i] = n * g.SH * g.SW;
     }
     const int Kp = (g.K + BK - 1) / BK * BK;   // padded row length of the [N][Kp] weight matrix
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
                 oh = rem / g.OW;
                 ow = rem - oh * g.OW;
             }
-            const int h = reflect_idx(oh * g.mul + dh, g.SH);
-            const int w = reflect_idx(ow * g.mul + dw, g.SW);
+            const int h = reflect_idx(oh * g.mul_h + dh, g.SH);
+            const int w = reflect_idx(ow * g.mul_w + dw, g.SW);
             ra[i] = *reinterpret_cast<const f32x4*>(g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci);
         }
 #pragma unroll
@@ -649,6 +649,30 @@ struct FwdGeom {
     size_t dst_elems;
 };
 
+// general forward geometry: separate strides / reflect pads per axis (the plain entry points pass
+// the same value twice; the "wide" 8-pixels-per-row form of the image heads uses stride_w = 8)
+bool fwd_geom_ex(const float* x, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw, int ph,
+                 int pw, FwdGeom* f) {
+    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || sh < 1 || sw < 1) return false;
+    if (dwc_ilog2_exact(Cin) < 2 || (Cout & 3) || Cout <= 0) return false;
+    if (ph < 0 || pw < 0 || ph >= H || pw >= W || H + 2 * ph < KH || W + 2 * pw < KW) return false;
+    const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
+    // the furthest gathered index must stay inside the single reflection: i <= 2*(n-1)
+    if ((Ho - 1) * sh - ph + KH - 1 > 2 * (H - 1) || (Wo - 1) * sw - pw + KW - 1 > 2 * (W - 1)) return false;
+    Gather& g = f->g;
+    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
+    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
+    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
+    if (g.kw_magic < 0) return false;
+    g.mul_h = sh; g.mul_w = sw; g.kstep = 1; g.off_h = -ph; g.off_w = -pw; g.reflect = 1;
+    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
+    g.logOW = dwc_ilog2_exact(Wo); g.logOHW = dwc_ilog2_exact(Ho * Wo);
+    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
+    f->o.dst = y; f->o.N = Cout; f->o.OHf = Ho; f->o.OWf = Wo; f->o.os = 1;
+    f->dst_elems = (size_t)g.M * Cout;
+    return true;
+}
+
 bool fwd_geom(const float* x, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, FwdGeom* f) {
     if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return false;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
@@ -657,7 +681,7 @@ bool fwd_geom(const float* x, float* y, int B, int H, int W, int Cin, int Cout, 
     g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
     g.kw_magic = kw_magic_for(KW, KH * KW + 64);
     if (g.kw_magic < 0) return false;
-    g.mul = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
+    g.mul_h = g.mul_w = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
     g.M = B * Ho * Wo; g.K = KH * KW * Cin;
     g.logOW = dwc_ilog2_exact(Wo); g.logOHW = dwc_ilog2_exact(Ho * Wo);
     if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
@@ -690,13 +714,13 @@ bool bwd_geom(const float* dy, float* dxp, int B, int H, int W, int Cin, int Cou
         g.OH = Hp; g.OW = Wp; g.KH = KH; g.KW = KW;
         g.kw_magic = kw_magic_for(KW, KH * KW + 64);
         if (g.kw_magic < 0) return false;
-        g.mul = 1; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1);
+        g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1);
         g.M = B * Hp * Wp; g.K = KH * KW * Cout;
         f->o.os = 1; f->classes = 1; f->wcs = 0;
     } else {
         g.OH = Hp / 2; g.OW = Wp / 2; g.KH = 2; g.KW = 2;
         g.kw_magic = kw_magic_for(2, 64);
-        g.mul = 1; g.kstep = -1; g.off_h = 0; g.off_w = 0;
+        g.mul_h = g.mul_w = 1; g.kstep = -1; g.off_h = 0; g.off_w = 0;
         g.M = B * (Hp / 2) * (Wp / 2); g.K = 4 * Cout;
         f->o.os = 2; f->classes = 4; f->wcs = (size_t)Cin * ((4 * Cout + BK - 1) / BK * BK);
     }
@@ -750,6 +774,56 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     FwdGeom f;
     if (!fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
     return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// forward / weight gradient with per-axis stride and reflect pad (no scratch on the forward: never split)
+int dwc_conv2d_fwd_ex(const float* x, const float* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin,
+                      int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom_ex(x, y, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f)) return DWC_EINVAL;
+    return launch_gemm(f.g, w_prepared, 0, 1, f.o, bias, act, f.dst_elems, nullptr, 0, (hipStream_t)stream);
+}
+
+static int wgrad_launch(const FwdGeom& f, const float* dy, float* dw_oihw, int Cin, int Cout, int KHW, int cin_real, int cout_real,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    const Gather& g = f.g;
+    int splits, chunk;
+    wgrad_plan(g.M, g.K, Cout, &splits, &chunk);
+    if (!ws || ws_bytes < (size_t)splits * g.K * Cout * sizeof(float)) return DWC_EWORKSPACE;
+    float* slab = (float*)ws;
+    const int tk = (g.K + 127) / 128;
+    if (Cout > 64) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy,
+                           Cout, slab, chunk);
+    } else if (Cout > 32) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1, 1, 1>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    }
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)g.K * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
+                       cin_real, cout_real);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_conv2d_bwd_weight_ex_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w,
+                                         int pad_h, int pad_w) {
+    FwdGeom f;
+    if (!fwd_geom_ex(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f)) return 0;
+    int splits, chunk;
+    wgrad_plan(f.g.M, f.g.K, Cout, &splits, &chunk);
+    return (size_t)splits * f.g.K * Cout * sizeof(float);
+}
+
+int dwc_conv2d_bwd_weight_ex(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
+                             int KW, int stride_h, int stride_w, int pad_h, int pad_w, int cin_real, int cout_real, void* ws,
+                             size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom_ex(x, nullptr, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f)) return DWC_EINVAL;
+    if (cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
+    return wgrad_launch(f, dy, dw_oihw, Cin, Cout, KH * KW, cin_real, cout_real, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t dwc_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

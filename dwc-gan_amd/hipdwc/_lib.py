@@ -27,6 +27,9 @@ SIGNATURES = {
     "dwc_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_fwd_ex": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 12 + [c_fp]),
+    "dwc_conv2d_bwd_weight_ex_ws_bytes": (c_sz, [c_int] * 11),
+    "dwc_conv2d_bwd_weight_ex": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 13 + [c_fp, c_sz, c_fp]),
     "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "dwc_instnorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),

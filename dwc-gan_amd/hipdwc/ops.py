@@ -227,6 +227,83 @@ def conv2d_padded(x, w, b, stride, pad, act="none"):
     return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act])
 
 
+class _HeadsConvWide(torch.autograd.Function):
+    """The fused 4-channel image heads (tanh x3 + sigmoid) as a "wide" convolution: 8 horizontally
+    adjacent output pixels x 4 channels = 32 output channels of a KHx(KW+7), stride-(1,8) filter
+    bank whose p-th copy is the real filter shifted right by p taps.  The product then fills a
+    32-wide MFMA tile (2x zero work instead of 8x).  The [B,H,W/8,32] result IS the NHWC4 image."""
+
+    @staticmethod
+    def forward(ctx, x, w4, b4):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, C, H, W = x.shape
+        co, ci, KH, KW = w4.shape
+        assert co == 4 and ci == C and W % 8 == 0
+        pad = KH // 2
+        wd = w4.detach()
+        wide = torch.stack([torch.nn.functional.pad(wd, (p, 7 - p)) for p in range(8)]).reshape(32, C, KH, KW + 7)
+        w_prep = _prepped(wide, "fwd", 32, C, 1)
+        bias = b4.detach().repeat(8).contiguous()
+        y = empty_cl(B, 4, H, W, x.device)
+        st = _stream()
+        flops = 2.0 * B * H * W * 4 * C * KH * KW
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_ex(
+            x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad,
+            ACT["heads"], st)), "conv2d_fwd_ex")
+        ctx.save_for_backward(x, w4, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w4, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        _, _, KH, KW = w4.shape
+        pad = KH // 2
+        dev = x.device
+        st = _stream()
+        dy = cl(dy)
+        rows = B * H * W
+        g = empty_cl(B, 4, H, W, dev)
+        db = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, 4), dev)
+        _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), db.data_ptr(), rows, 4, ACT["heads"],
+                                        ws.data_ptr(), ws.numel(), st), "act_bwd_bias")
+        dx = dw = None
+        flops = 2.0 * rows * 4 * C * KH * KW
+        if ctx.needs_input_grad[0]:        # data gradient: the ordinary 4-channel formulation (N = C columns)
+            w_dg = _prepped(w4, "dgrad", 4, C, 1)
+            dx = empty_cl(B, C, H, W, dev)
+            pad_bytes = (B * (H + 2 * pad) * (W + 2 * pad) * C * 4 + 255) // 256 * 256
+            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, C, 4, KH, KW, 1, pad)
+            base = workspace(pad_bytes + nws, dev).data_ptr()
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
+                g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, 4, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
+                st)), "conv2d_bwd_data")
+            _lib.check(lib.dwc_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+        if ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
+            dwide = torch.empty((32, C, KH, KW + 7), dtype=torch.float32, device=dev)
+            nws = lib.dwc_conv2d_bwd_weight_ex_ws_bytes(B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad)
+            ws = workspace(nws, dev)
+            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight_ex(
+                x.data_ptr(), g.data_ptr(), dwide.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad, C, 32, ws.data_ptr(),
+                ws.numel(), st)), "conv2d_bwd_weight_ex")
+            dv = dwide.view(8, 4, C, KH, KW + 7)
+            dw = dv[0, :, :, :, 0:KW].clone()
+            for p in range(1, 8):
+                dw += dv[p, :, :, :, p:p + KW]
+        return dx, dw, (db if ctx.needs_input_grad[2] else None)
+
+
+def conv2d_heads(x, w4, b4):
+    """tanh/sigmoid image heads: [B,C,H,W] features, [4,C,7,7] weights -> NHWC4 image [B,4,H,W]."""
+    if x.shape[3] % 8 == 0 and w4.shape[2] == w4.shape[3] == 7:
+        return _HeadsConvWide.apply(x, w4, b4)
+    return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads"])
+
+
 def linear(x, w, b, act="none"):
     """nn.Linear (+ReLU) as a 1x1 convolution over a 1x1 image (reference networks.py:587-634).
     Input width must be a power of two >= 4."""

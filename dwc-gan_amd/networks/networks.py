@@ -235,7 +235,7 @@ class Decoder(nn.Module):
             wa, ba = wa.detach(), ba.detach()
         w = torch.cat([self.image_content.conv.weight, wa], 0)
         b = torch.cat([self.image_content.conv.bias, ba], 0)
-        return ops.conv2d_padded(feats, w, b, 1, 3, "heads")
+        return ops.conv2d_heads(feats, w, b)
 
     def forward(self, x):
         heads = self.forward_nhwc4(x)

@@ -86,6 +86,19 @@ size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, in
 int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw,
                           int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                           int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
+/* Forward / weight gradient with per-axis stride and reflect pad.  Used for the image heads
+ * (reference networks_v2.py:159-160): 8 horizontally adjacent output pixels x 4 channels are
+ * computed as 32 "wide" output channels of a 7x14, stride-(1,8) convolution, so that the
+ * 4-channel product fills a 32-wide MFMA tile (2x padding instead of 8x). */
+int dwc_conv2d_fwd_ex(const float* x, const float* w_prepared, const float* bias, float* y,
+                      int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                      int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream);
+size_t dwc_conv2d_bwd_weight_ex_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                         int stride_h, int stride_w, int pad_h, int pad_w);
+int dwc_conv2d_bwd_weight_ex(const float* x, const float* dy, float* dw_oihw,
+                             int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride_h, int stride_w, int pad_h, int pad_w,
+                             int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
 /* g = dy * act'(y) and db[c] = sum over rows of g (rows = B*Ho*Wo).  db may be NULL. */
 size_t dwc_act_bwd_bias_ws_bytes(int rows, int C);
 int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act,

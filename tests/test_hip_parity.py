@@ -77,6 +77,27 @@ def test_conv_forward_backward(shape):
     close(bd.grad, br.grad, rel=5e-5, msg="db")
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 32), (1, 16, 9, 24), (2, 8, 6, 12)])
+def test_fused_image_heads(B, C, H, W):
+    """tanh x3 + sigmoid heads as one conv; W % 8 == 0 takes the 'wide' 32-column formulation."""
+    g = torch.Generator().manual_seed(B + C + H + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(4, C, 7, 7, generator=g) * (1.0 / (C * 49) ** 0.5)
+    b = torch.randn(4, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = orc.conv_block(xr, wr, br, 1, 3)
+    yr = torch.cat([torch.tanh(pre[:, :3]), torch.sigmoid(pre[:, 3:4])], 1)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+    yd = ops.conv2d_heads(xd, wd, bd)
+    close(yd, yr, msg="y")
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=5e-5, msg="dx")
+    close(wd.grad, wr.grad, rel=5e-5, msg="dw")
+    close(bd.grad, br.grad, rel=5e-5, msg="db")
+
+
 def test_conv_no_bias_and_cout_not_multiple_of_4():
     g = torch.Generator().manual_seed(1)
     x, w = torch.randn(2, 16, 9, 9, generator=g), torch.randn(3, 16, 3, 3, generator=g) * 0.1
