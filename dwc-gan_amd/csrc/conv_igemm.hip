@@ -13,9 +13,9 @@
 // the weight gradient contracts over m instead (conv_wgrad_kernel).
 //
 // Tiling: 256 threads = 4 waves, block tile BM x BN x 32(K); each wave owns TMxTN 32x32
-// accumulator tiles (16 VGPRs each).  Operands are staged global -> registers -> LDS
-// (16-byte vectors along the channel axis) into a double-buffered LDS tile: the next K-slab's
-// global loads are issued before the MFMAs of the current one and there is ONE barrier per slab.
+// accumulator tiles (16 VGPRs each).  Operands are staged global -> LDS directly (16-byte
+// vectors along the channel axis) into a double-buffered LDS tile: the next K-slab's loads are
+// issued before the MFMAs of the current one and there is ONE barrier per slab.
 // Tile shape is picked per problem so that every CU holds >= 2 workgroups whenever the grid
 // allows it (one wave per SIMD cannot hide its own LDS/barrier latency), and products with few
 // output tiles but a long K (the discriminator tails, M = B*16 rows) are split along K into
@@ -29,7 +29,6 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int A_LD = BK + 4;  // row stride (floats) of the A tile: 36 -> conflict-free b128 reads
 
 struct Gather {        // how GEMM row m / column k address the source tensor
     const float* src;  // [B][SH][SW][SC]
@@ -53,23 +52,33 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * (n - 1) - i : i;
 }
 
+// ------------------------------------------------------------------------------------------
+// Forward / data-gradient GEMM.  Staging is DIRECT global->LDS (global_load_lds_dwordx4): no
+// staging registers, no ds_write pass.  A wave instruction deposits 64 x 16 B contiguously, i.e.
+// 8 rows x 128 B of an UNPADDED [row][32] tile; bank conflicts of the ds_read_b128 fragment reads
+// are avoided by an XOR swizzle of the 16-byte chunk index with ((row >> 1) & 7), applied on the
+// SOURCE address (which K-chunk a lane fetches) and again on the read.  Out-of-bounds taps of the
+// zero-padded data gradient fetch from a zero page.  (Measured against the register-staged
+// variant this replaced, r01: 5x5 256->128 @64^2 113 -> 130 TFLOP/s, 3x3 256->256 @32^2 94 -> 98.)
+// ------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float g_zero_page[64];
+
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
-                                                        Scatter o, const float* __restrict__ bias, int act, int tiles_n,
-                                                        int kt_per_split, size_t part_stride) {
+                                                             Scatter o, const float* __restrict__ bias, int act, int tiles_n,
+                                                             int kt_per_split, size_t part_stride) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-    constexpr int A_TILE = BM * A_LD, B_TILE = BN * A_LD;   // both tiles are [row][k] with the padded stride
+    constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
     float* sA = smem;
     float* sB = smem + 2 * A_TILE;
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // XCD-aware tile order: blocks that share an XCD (id % 8) walk neighbouring tiles
     int bid = blockIdx.x;
     {
         const int nb = gridDim.x;
@@ -80,17 +89,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     }
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int cls = blockIdx.z;  // stride-2 data gradient: output parity class
+    const int cls = blockIdx.z;
     wmat += (size_t)cls * w_class_stride;
     const int oph = cls >> 1, opw = cls & 1;
     const int split = blockIdx.y;
 
-    // ---- per-thread gather rows (fixed for the whole K loop) ----
-    // Rows past M / N are clamped to the last valid one (their results are dropped by the
-    // epilogue) and the weight matrix is zero-padded along K to a multiple of 32, so the
-    // staging loads need no masks in reflect mode and one in-bounds select in zero mode.
-    const int arow = t >> 3;        // + 32*i
-    const int acol = (t & 7) * 4;   // k offset inside the slab
+    const int arow = t >> 3;                              // tile row this lane stages (+32 per pass)
+    const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 4;  // LOGICAL k offset fetched into physical chunk t&7
     int a_bh[A_PASSES], a_bw[A_PASSES], a_img[A_PASSES];
     const int ohw = g.OH * g.OW;
 #pragma unroll
@@ -103,27 +108,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
         a_bw[i] = ow * g.mul_w + g.off_w;
         a_img[i] = n * g.SH * g.SW;
     }
-    const int Kp = (g.K + BK - 1) / BK * BK;   // padded row length of the [N][Kp] weight matrix
+    const int Kp = (g.K + BK - 1) / BK * BK;
     const float* b_ptr[B_PASSES];
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = wmat + (size_t)min(n0 + arow + 32 * p, o.N - 1) * Kp + acol;
 
-    f32x4 ra[A_PASSES], rb[B_PASSES];
     const int nk_all = Kp / BK;
     const int kt0 = split * kt_per_split;
     const int kt1 = min(nk_all, kt0 + kt_per_split);
     const int n_taps = g.KH * g.KW;
 
-    // Gather addressing is strength-reduced: with >= 32 source channels a K-slab lies inside ONE
-    // filter tap, so the per-row source offsets (reflect / bounds rule applied) are recomputed
-    // only when the slab index crosses into the next tap — a wave-uniform event — and the slabs
-    // of that tap just step along the channel axis.  The vector ALU shares its issue port with
-    // the matrix pipe, so address arithmetic left in the slab loop costs MFMA issue slots.
-    int cur_tap = -1;                       // wave-uniform
-    int a_off[A_PASSES];                    // element offset of (row i, current tap, channel acol)
-    bool a_inb[A_PASSES];
+    int cur_tap = -1;
+    const float* a_src[A_PASSES];     // per-row source of the current tap (zero page when out of bounds)
     const bool tap_uniform = g.SC >= BK;
-    auto row_offsets = [&](int tap) {
+    auto row_sources = [&](int tap, int ci) {
         const int kh = (tap * g.kw_magic) >> 16;
         const int kw = tap - kh * g.KW;
 #pragma unroll
@@ -139,43 +137,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
                 h = min(max(h, 0), g.SH - 1);
                 w = min(max(w, 0), g.SW - 1);
             }
-            a_off[i] = (a_img[i] + h * g.SW + w) << g.logSC;
-            a_inb[i] = inb;
+            const float* p = g.src + ((a_img[i] + h * g.SW + w) << g.logSC) + ci;
+            a_src[i] = inb ? p : g_zero_page;   // (no channel offset is ever added to the zero page, see stage_slab)
         }
     };
-    auto load_slab = [&](int kt) {
-        int ci;
+    // issue the direct loads of slab kt into LDS buffer `buf`
+    auto stage_slab = [&](int kt, int buf) {
+        int coff;   // channel offset added to a_src (0 when the source is the zero page)
         if (tap_uniform) {
             const int kg0 = kt * BK;
-            const int tap = min(kg0 >> g.logSC, n_taps - 1);   // K tail: any valid tap (weights there are 0)
+            const int tap = min(kg0 >> g.logSC, n_taps - 1);
             if (tap != cur_tap) {
-                row_offsets(tap);
+                row_sources(tap, acol);
                 cur_tap = tap;
             }
-            ci = (kg0 & (g.SC - 1)) + acol;
-        } else {   // few channels (image stems, tiny configs): a slab spans several taps, one per 4-wide group
+            coff = kg0 & (g.SC - 1);
+        } else {
             const int kg = kt * BK + acol;
-            row_offsets(min(kg >> g.logSC, n_taps - 1));
-            ci = kg & (g.SC - 1);
+            row_sources(min(kg >> g.logSC, n_taps - 1), kg & (g.SC - 1));
+            coff = 0;
         }
-        // the loaded values are not touched here (the out-of-bounds zeroing happens in store_slab):
-        // any use would make the compiler wait for the loads before the MFMAs they are meant to hide under
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) ra[i] = *reinterpret_cast<const f32x4*>(g.src + a_off[i] + ci);
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) rb[p] = *reinterpret_cast<const f32x4*>(b_ptr[p] + kt * BK);
-    };
-    auto store_slab = [&](int buf) {
-        float* a = sA + buf * A_TILE;
-        float* b = sB + buf * B_TILE;
+        float* la = sA + buf * A_TILE + wave * (8 * BK);
+        float* lb = sB + buf * B_TILE + wave * (8 * BK);
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            f32x4 v = ra[i];
-            if (!g.reflect && !a_inb[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&a[(arow + 32 * i) * A_LD + acol]) = v;
+            const float* s = a_src[i];
+            if (s != g_zero_page) s += coff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(la + i * 32 * BK), 16, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) *reinterpret_cast<f32x4*>(&b[(arow + 32 * p) * A_LD + acol]) = rb[p];
+        for (int p = 0; p < B_PASSES; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[p] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(lb + p * 32 * BK), 16, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -186,28 +180,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment addresses: lane (l31, hi) of MFMA step (q, j) contracts k = 8q + 4hi + j for BOTH operands,
-    // so each operand is one ds_read_b128 per 4 MFMA steps
-    const int a_frag = (wm * TM * 32 + l31) * A_LD + 4 * hi;
-    const int b_frag = (wn * TN * 32 + l31) * A_LD + 4 * hi;
-
-    // Skewed slab pipeline.  A slab is four 8-deep K-groups q0..q3 (TM*TN*4 MFMAs each).  Per iteration:
-    //     global loads of slab kt+1 -> registers
-    //     frags(q1) | MFMA(q0) ; frags(q2) | MFMA(q1)
-    //     registers -> LDS[other buffer]            (those loads have had two MFMA groups to land)
-    //     frags(q3) | MFMA(q2)
-    //     barrier                                   (other buffer complete; this buffer fully read)
-    //     frags(q0 of slab kt+1) | MFMA(q3)         (q3 was fetched before the barrier)
-    // so neither the LDS-store phase nor the first LDS read after the barrier leaves the matrix
-    // pipe without queued work.
+    // fragment reads: logical chunk 2q+hi of row r sits in physical chunk (2q+hi) ^ ((r>>1)&7)
+    const int fsw = (l31 >> 1) & 7;
+    int frag_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag_off[q] = ((2 * q + hi) ^ fsw) * 4;
+    const int a_row = (wm * TM * 32 + l31) * BK;
+    const int b_row = (wn * TN * 32 + l31) * BK;
     f32x4 fa[2][TM], fb[2][TN];
     auto load_frags = [&](int set, int buf, int q) {
-        const float* a = sA + buf * A_TILE + a_frag + 8 * q;
-        const float* b = sB + buf * B_TILE + b_frag + 8 * q;
+        const float* a = sA + buf * A_TILE + a_row + frag_off[q];
+        const float* b = sB + buf * B_TILE + b_row + frag_off[q];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * A_LD);
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK);
 #pragma unroll
-        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * A_LD);
+        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * BK);
     };
     auto mfma_group = [&](int set) {
 #pragma unroll
@@ -220,30 +207,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     };
 
     if (kt0 < kt1) {
-        load_slab(kt0);
-        store_slab(0);
+        stage_slab(kt0, 0);
         __syncthreads();
         int buf = 0;
         load_frags(0, 0, 0);
         for (int kt = kt0; kt < kt1; ++kt) {
             const bool more = kt + 1 < kt1;
-            if (more) load_slab(kt + 1);
+            if (more) stage_slab(kt + 1, buf ^ 1);       // other buffer: fully read before the last barrier
             load_frags(1, buf, 1);
             mfma_group(0);
             load_frags(0, buf, 2);
             mfma_group(1);
-            if (more) store_slab(buf ^ 1);
             load_frags(1, buf, 3);
             mfma_group(0);
-            __syncthreads();
+            __syncthreads();                              // waits for the direct loads (vmcnt) and this buffer's reads
             if (more) load_frags(0, buf ^ 1, 0);
             mfma_group(1);
             buf ^= 1;
         }
     }
 
-
-    // ---- epilogue: (bias + activation) or raw split-K partial, scatter rows ----
     const bool partial = part_stride != 0;
     float* dst = o.dst + (size_t)split * part_stride;
 #pragma unroll
@@ -323,11 +306,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     const int brow = t / B_F4, bcol = (t % B_F4) * 4;
     const int ohw = g.OH * g.OW;
 
-    f32x4 ra[4], rb[B_PASSES];
     const int bcol_c = min(n0 + bcol, N - 4);    // columns past N are never stored: clamp instead of masking
-    auto load_slab = [&](int mb) {
-        // rows past the end of this m-chunk must contribute nothing: the dY operand is zeroed for
-        // them, the gathered x operand may then be anything finite (row index clamped)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // Direct global->LDS staging (global_load_lds_dwordx4): lane t deposits its 16 bytes at float
+    // offset 4*t of the pass, which IS [row][k] / [row][n] order for these unpadded tiles (the MFMA
+    // operands are read along the lanes, so no swizzle is needed).  Rows past the end of this
+    // m-chunk must contribute nothing: their dY operand comes from the zero page, the gathered x
+    // operand may then be anything finite (row index clamped).
+    auto stage_slab = [&](int mb, int buf) {
+        float* la = sA + buf * A_TILE + wave_u * 256;
+        float* lb = sB + buf * B_TILE + wave_u * 256;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = min(mb + arow + 8 * i, g.M - 1);
@@ -345,24 +333,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
             }
             const int h = reflect_idx(oh * g.mul_h + dh, g.SH);
             const int w = reflect_idx(ow * g.mul_w + dw, g.SW);
-            ra[i] = *reinterpret_cast<const f32x4*>(g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci);
+            const float* s = g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(la + i * 8 * 128), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p) {
             const int m = mb + brow + p * B_ROWS_PER_PASS;
-            f32x4 v = *reinterpret_cast<const f32x4*>(dy + (size_t)min(m, g.M - 1) * N + bcol_c);
-            if (m >= m_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            rb[p] = v;
+            const float* s = m < m_end ? dy + (size_t)m * N + bcol_c : g_zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(lb + p * B_ROWS_PER_PASS * BN), 16, 0, 0);
         }
-    };
-    auto store_slab = [&](int buf) {
-        float* a = sA + buf * A_TILE;
-        float* b = sB + buf * B_TILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&a[(arow + 8 * i) * 128 + (t & 31) * 4]) = ra[i];
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            *reinterpret_cast<f32x4*>(&b[(brow + p * B_ROWS_PER_PASS) * BN + bcol]) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -400,19 +381,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][s][i], bv[set][s][n], acc[i][n], 0, 0, 0);
     };
     if (m_begin < m_end) {
-        load_slab(m_begin);
-        store_slab(0);
+        stage_slab(m_begin, 0);
         __syncthreads();
         int buf = 0;
         load_ops(0, 0, 0);
         for (int mb = m_begin; mb < m_end; mb += 32) {
             const bool more = mb + 32 < m_end;
-            if (more) load_slab(mb + 32);
+            if (more) stage_slab(mb + 32, buf ^ 1);      // other buffer: fully read before the last barrier
             load_ops(1, buf, 1);
             mfma_ops(0);
             load_ops(0, buf, 2);
             mfma_ops(1);
-            if (more) store_slab(buf ^ 1);
             load_ops(1, buf, 3);
             mfma_ops(0);
             __syncthreads();
