@@ -508,14 +508,16 @@ struct Plan {
     int bm, bn, splits, kt_per_split;
 };
 
-// Cost model (relative time): the busiest CU runs ceil(blocks/256) workgroups back to back at the
-// MFMA rate; a lone workgroup on a CU (one wave per SIMD) only reaches ~0.55 of that rate because
-// nothing covers its barrier / LDS-read latency, two or more co-resident reach ~0.75; smaller
-// tiles re-read more operand bytes per flop (factor f).
+// Cost model (relative time of the busiest CU).  A CU holds up to `resident` workgroups of a
+// tile shape (LDS / VGPR limits of the direct-to-LDS kernel); it receives n = ceil(blocks/256)
+// of them and works through them `resident` at a time.  A full group runs at the tile's measured
+// MFMA-rate factor f (relative to 128x128 at 2 WG/CU, r01 kernel_bench: 130 / 108 / ~95 TFLOP/s);
+// a trailing partial group runs at reduced efficiency because fewer waves per SIMD are left to
+// cover barrier / LDS latency (one WG alone: 0.62).  This is what makes 768 tiles of 128x128
+// (1.5 groups) lose to 1536 tiles of 128x64 (exactly 2 groups) for the 3B-batched 3x3 convs.
 Plan plan_gemm(int M, int N, int K, int classes) {
     struct Cand { int bm, bn, resident; float f; };
-    // f: measured MFMA-rate ratio of each tile against 128x128 at >= 2 workgroups per CU (r01 kernel_bench)
-    static const Cand all[] = {{128, 128, 2, 1.0f}, {128, 64, 2, 0.75f}, {64, 64, 4, 0.7f}, {128, 32, 4, 0.6f}};
+    static const Cand all[] = {{128, 128, 2, 1.0f}, {128, 64, 3, 0.85f}, {64, 64, 5, 0.72f}, {128, 32, 4, 0.5f}};
     const int nk = (K + BK - 1) / BK;
     Plan best = {128, 32, 1, nk};
     float best_cost = 3.0e38f;
@@ -536,9 +538,11 @@ Plan plan_gemm(int M, int N, int K, int classes) {
     for (const Cand& c : all) {
         if (!valid(c) || (pinned && pinned != &c)) continue;
         const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
-        const long per_cu = (blocks + NUM_CU - 1) / NUM_CU;
-        const float eff = (per_cu >= 2 && c.resident >= 2) ? 0.75f : 0.55f;
-        const float cost = (float)per_cu * c.bm * c.bn / (c.f * eff);
+        const long n = (blocks + NUM_CU - 1) / NUM_CU;
+        const long full = n / c.resident, rem = n % c.resident;
+        const float tile = (float)c.bm * c.bn / c.f;
+        float cost = (float)full * c.resident * tile;
+        if (rem) cost += (float)rem * tile / (rem == 1 ? 0.62f : 0.9f);
         if (cost < best_cost) {
             best_cost = cost;
             best = {c.bm, c.bn, 1, nk};
