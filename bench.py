@@ -31,6 +31,10 @@ PER_GPU_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ALGO_GFLOP_PER_IMAGE = 569.6           # BASELINE.md section 4 / SURVEY.md 8(d): necessary fwd+bwd conv+linear work
 DOMINANT = "conv_gemm_kernel"          # the implicit-GEMM conv kernel (all tile instantiations; forward + data-gradient launches)
+# HBM-side bytes per launch of that kernel from the PMC passes committed as profiles/r01_pmc_hbm_traffic.json
+# (rocprofv3 --pmc FETCH_SIZE and, separately, WRITE_SIZE, same command; FETCH_SIZE doubled per the gfx950 note
+# in MI355X_MICROARCH.md).  A profile-time constant: bench.py cannot read PMCs itself.
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 259838976
 
 
 def run_iteration(trainer, batch, cfg, it):
@@ -140,7 +144,8 @@ def main():
         if dom and dom["ms"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": DOMINANT_TRAFFIC_BYTES_PER_LAUNCH,
                     "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
         out = {
@@ -154,7 +159,8 @@ def main():
                        "parallelism": "dp%d" % world},
             "whole_step_tflops": round(ALGO_GFLOP_PER_IMAGE * value / 1e3, 2),
             "whole_step_frac_of_fp32_mfma_peak": round(ALGO_GFLOP_PER_IMAGE * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),
-            "loss_dis_all": round(float(trainer.loss_dis_all), 5), "loss_gen_total": round(float(trainer.loss_gen_total), 5),
+            "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
+            "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
             "roofline": roof,
             "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
