@@ -139,7 +139,25 @@ def main():
         images = PER_GPU_BATCH * world * args.steps
         value = images / elapsed
         spans = timer.summary() if timer is not None else {}
-        dom = spans.get(DOMINANT)
+
+        def total(pred):
+            ent = {"launches": 0, "ms": 0.0, "flops": 0.0}
+            for tag, v in spans.items():
+                if pred(tag):
+                    for k in ent:
+                        ent[k] += v[k]
+            return ent
+
+        def rate(ent):
+            return None if ent["ms"] <= 0 else {
+                "launches": ent["launches"], "ms": round(ent["ms"], 3),
+                "tflops": round(ent["flops"] / (ent["ms"] * 1e-3) / 1e12, 2),
+                "frac_of_fp32_mfma_peak": round(ent["flops"] / (ent["ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+
+        dom = total(lambda t: t.endswith(DOMINANT))
+        # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)
+        decode_stack = {"forward": rate(total(lambda t: t == "decode/conv_gemm_kernel")),
+                        "backward": rate(total(lambda t: t.startswith("bwd:decode/")))}
         roof = None
         if dom and dom["ms"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -162,6 +180,7 @@ def main():
             "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
             "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
             "roofline": roof,
+            "decode_conv_stack": decode_stack,
             "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
         }

@@ -86,10 +86,29 @@ class KernelTimer:
 
 
 TIMER = None   # set to a KernelTimer to collect spans
+SCOPE = ""     # optional label (e.g. "decode") prefixed to the span tags of launches made inside it
 
 
-def _timed(tag, flops, fn):
-    return fn() if TIMER is None else TIMER.run(tag, flops, fn)
+class scope:
+    """``with ops.scope("decode"): ...`` labels the kernel spans recorded inside (profiling only)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global SCOPE
+        self.prev, SCOPE = SCOPE, self.name
+
+    def __exit__(self, *exc):
+        global SCOPE
+        SCOPE = self.prev
+
+
+def _timed(tag, flops, fn, scope_name=None):
+    if TIMER is None:
+        return fn()
+    s = SCOPE if scope_name is None else scope_name
+    return TIMER.run((s + "/" + tag) if s else tag, flops, fn)
 
 
 def _pad4(n):
@@ -162,6 +181,7 @@ class _Conv2d(torch.autograd.Function):
             st)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
+        ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
         return y
 
     @staticmethod
@@ -200,8 +220,8 @@ class _Conv2d(torch.autograd.Function):
             target = dx.data_ptr() if pad == 0 else base
             wsp = base + pad_bytes if nws else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
-                g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st)),
-                "conv2d_bwd_data")
+                g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st),
+                scope_name=ctx.bscope), "conv2d_bwd_data")
             if pad > 0:
                 _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1]:
@@ -211,7 +231,7 @@ class _Conv2d(torch.autograd.Function):
             flops = 2.0 * rows * Cout * Cin * KH * KW
             _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
                 x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
-                ws.numel(), st)), "conv2d_bwd_weight")
+                ws.numel(), st), scope_name=ctx.bscope), "conv2d_bwd_weight")
         return dx, dw, db, None, None, None
 
 
@@ -253,6 +273,7 @@ class _HeadsConvWide(torch.autograd.Function):
             x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad,
             ACT["heads"], st)), "conv2d_fwd_ex")
         ctx.save_for_backward(x, w4, y)
+        ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
         return y
 
     @staticmethod
@@ -281,7 +302,7 @@ class _HeadsConvWide(torch.autograd.Function):
             base = workspace(pad_bytes + nws, dev).data_ptr()
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
                 g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, 4, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
-                st)), "conv2d_bwd_data")
+                st), scope_name=ctx.bscope), "conv2d_bwd_data")
             _lib.check(lib.dwc_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
             dwide = torch.empty((32, C, KH, KW + 7), dtype=torch.float32, device=dev)
@@ -289,7 +310,7 @@ class _HeadsConvWide(torch.autograd.Function):
             ws = workspace(nws, dev)
             _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight_ex(
                 x.data_ptr(), g.data_ptr(), dwide.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad, C, 32, ws.data_ptr(),
-                ws.numel(), st)), "conv2d_bwd_weight_ex")
+                ws.numel(), st), scope_name=ctx.bscope), "conv2d_bwd_weight_ex")
             dv = dwide.view(8, 4, C, KH, KW + 7)
             dw = dv[0, :, :, :, 0:KW].clone()
             for p in range(1, 8):

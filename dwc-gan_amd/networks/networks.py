@@ -227,7 +227,6 @@ class Decoder(nn.Module):
         """``attention_used=False``: the caller will not read plane 3, so the attention head is taken
         off the tape — its parameters then get NO gradient (not a zero one), exactly like the
         reference, whose optimiser skips gradient-less parameters (no weight decay / momentum)."""
-        feats = self.model(x)
         if self.output_dim != 3:
             raise NotImplementedError("fused heads assume a 3-channel image")
         wa, ba = self.image_attention.conv.weight, self.image_attention.conv.bias
@@ -235,7 +234,8 @@ class Decoder(nn.Module):
             wa, ba = wa.detach(), ba.detach()
         w = torch.cat([self.image_content.conv.weight, wa], 0)
         b = torch.cat([self.image_content.conv.bias, ba], 0)
-        return ops.conv2d_heads(feats, w, b)
+        with ops.scope("decode"):        # label for the profiler's decode-stack roofline figure
+            return ops.conv2d_heads(self.model(x), w, b)
 
     def forward(self, x):
         heads = self.forward_nhwc4(x)

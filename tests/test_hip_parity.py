@@ -359,6 +359,42 @@ def test_tiny_three_iterations_vs_reference(tiny):
         host.set_noise(host.DeviceNoise())
 
 
+@pytest.mark.parametrize("S,B", [(128, 2), (256, 1)])
+def test_full_size_iteration_vs_oracle(S, B):
+    """The shipped network sizes (dim 64, 4 ResBlocks, 5-layer 2-scale D) at 128x128 and at the 256x256 of
+    BASELINE configs[4]: one full iteration, every loss scalar against the CPU oracle run from the same
+    weights, batch and random stream.  Exercises the real layer shapes (128x128 tiles, split-K tails,
+    wide heads) that the tiny configuration cannot."""
+    from solver import Solver
+    cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(1234)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        s.copy_nets()
+        rng = torch.get_rng_state()
+        batch = synth.make_batch(B, S, seed=11)
+        oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in s.gen.state_dict().items()},
+                                  {k: v.cpu() for k, v in s.dis.state_dict().items()})
+        oracle.copy_nets()
+        oracle.iteration(batch, 0)
+        torch.set_rng_state(rng)
+        db = {k: v.to(DEV) for k, v in batch.items()}
+        a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
+        s.dis_update(*a)
+        s.gen_update(*a)
+        for k, want in oracle.losses.items():
+            got = float(torch.as_tensor(getattr(s, k)).detach())
+            assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), (k, got, want)
+        # gradients of a few representative tensors (stem, ResBlock, 5x5, heads, style MLP)
+        for name in ("enc_content.model.0.conv.weight", "dec.model.0.model.1.model.0.conv.weight",
+                     "dec.model.2.conv.weight", "dec.image_content.conv.weight", "mlp.model.2.fc.weight"):
+            g_hip = dict(s.gen.named_parameters())[name].grad
+            close(g_hip, oracle.last_gen_grads[name], rel=1e-2, msg=name)   # whole-network gradient, 1-2 samples
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
 def test_tiny_dis_gradients_vs_reference(tiny, golden_dir):
     ref = np.load(os.path.join(golden_dir, "tiny_dis_grads.npz"))
     host.set_noise(host.HostNoise())
