@@ -70,8 +70,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-gpu-batch", type=int, default=PER_GPU_BATCH,
+                    help="development knob; the contract workload (and the default) is 16")
     args = ap.parse_args()
 
+    per_gpu_batch = args.per_gpu_batch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -106,7 +109,7 @@ def main():
     init_dis = {k: v.detach().cpu().clone() for k, v in trainer.dis.state_dict().items()}
 
     # fresh batch per iteration, pre-generated on the device (4 distinct, cycled)
-    batches = [synth.make_batch(PER_GPU_BATCH, IMAGE_SIZE, seed=1000 * rank + i, device=dev) for i in range(4)]
+    batches = [synth.make_batch(per_gpu_batch, IMAGE_SIZE, seed=1000 * rank + i, device=dev) for i in range(4)]
     for b in batches:
         b["txt_lens"] = b["txt_lens"].cpu()                  # lengths stay on the host (pack_padded_sequence needs them there)
 
@@ -136,7 +139,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        images = PER_GPU_BATCH * world * args.steps
+        images = per_gpu_batch * world * args.steps
         value = images / elapsed
         spans = timer.summary() if timer is not None else {}
 
@@ -173,7 +176,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CelebA-shaped 128x128, per-GPU batch 16, fp32, full iteration "
                                    "(dis_update + gen_update + EMA + LR step), vgg_w=0",
-                       "image_size": IMAGE_SIZE, "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
+                       "image_size": IMAGE_SIZE, "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world,
                        "parallelism": "dp%d" % world},
             "whole_step_tflops": round(ALGO_GFLOP_PER_IMAGE * value / 1e3, 2),
             "whole_step_frac_of_fp32_mfma_peak": round(ALGO_GFLOP_PER_IMAGE * value / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world), 4),

@@ -63,6 +63,15 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) float g_zero_page[64];
 
+// Workgroup barrier that also retires this wave's outstanding direct-to-LDS loads.  hipcc's
+// __syncthreads() already drains vmcnt when an LDS-DMA is in flight (checked in the ISA: every
+// s_barrier is preceded by s_waitcnt vmcnt(0) lgkmcnt(0)); the explicit wait makes the kernels
+// independent of that compiler behaviour.
+__device__ __forceinline__ void lds_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
                                                              Scatter o, const float* __restrict__ bias, int act, int tiles_n,
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
 
     if (kt0 < kt1) {
         stage_slab(kt0, 0);
-        __syncthreads();
+        lds_dma_barrier();
         int buf = 0;
         load_frags(0, 0, 0);
         for (int kt = kt0; kt < kt1; ++kt) {
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
             mfma_group(1);
             load_frags(1, buf, 3);
             mfma_group(0);
-            __syncthreads();                              // waits for the direct loads (vmcnt) and this buffer's reads
+            lds_dma_barrier();                            // direct loads landed (vmcnt), this buffer fully read
             if (more) load_frags(0, buf ^ 1, 0);
             mfma_group(1);
             buf ^= 1;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     };
     if (m_begin < m_end) {
         stage_slab(m_begin, 0);
-        __syncthreads();
+        lds_dma_barrier();
         int buf = 0;
         load_ops(0, 0, 0);
         for (int mb = m_begin; mb < m_end; mb += 32) {
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
             mfma_ops(1);
             load_ops(1, buf, 3);
             mfma_ops(0);
-            __syncthreads();
+            lds_dma_barrier();
             if (more) load_ops(0, buf ^ 1, 0);
             mfma_ops(1);
             buf ^= 1;

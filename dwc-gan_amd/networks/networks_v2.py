@@ -137,8 +137,13 @@ class TxtEncoder(nn.Module):
         # reference networks_v2.py:249: concatenating along the BATCH axis and then viewing as
         # (batch, -1) interleaves samples of the local batch; reproduced, not fixed
         feat = torch.cat([h_n, c_n], dim=1).view(bsz, -1)
-        mus = [fc(feat) for fc in self.fcs]
-        lvs = [fc(feat) for fc in self.fcvars]
+        # the 2*num_class heads read the same feature row: one [2*num_class*c_dim, feat] product
+        w = torch.cat([m.weight for m in self.fcs] + [m.weight for m in self.fcvars], 0)
+        b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
+        out = torch.nn.functional.linear(feat, w, b)
+        k, c = self.num_class, self.style_dim // self.num_class
+        mus = [out[:, i * c:(i + 1) * c] for i in range(k)]
+        lvs = [out[:, (k + i) * c:(k + i + 1) * c] for i in range(k)]
         return mus, lvs
 
 
