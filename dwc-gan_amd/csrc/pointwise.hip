@@ -288,6 +288,37 @@ __global__ void ema_kernel(const float* __restrict__ p, float* __restrict__ e, s
         e[i] = lerp_torch(p[i], e[i], beta);
 }
 
+// Multi-tensor forms: ONE launch walks every parameter tensor of a network.  Workgroup b handles
+// DWC_OPT_CHUNK consecutive elements of tensor chunk_tensor[b] starting at chunk_start[b]; tensors
+// whose gradient pointer is NULL are skipped entirely (torch.optim.Adam semantics for parameters
+// that received no gradient this step: no weight decay, no moment update, no step count).
+__global__ __launch_bounds__(256) void adam_multi_kernel(const dwc_adam_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
+                                                         const unsigned* __restrict__ chunk_start, float omb1, float beta2, float omb2,
+                                                         float eps, float wd) {
+    const dwc_adam_tensor d = tensors[chunk_tensor[blockIdx.x]];
+    if (!d.g) return;
+    const size_t i0 = chunk_start[blockIdx.x];
+    const size_t i1 = i0 + DWC_OPT_CHUNK < d.n ? i0 + DWC_OPT_CHUNK : d.n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float pi = d.p[i];
+        const float gi = d.g[i] + wd * pi;
+        const float mi = lerp_torch(d.m[i], gi, omb1);
+        const float vi = d.v[i] * beta2 + omb2 * gi * gi;
+        d.m[i] = mi;
+        d.v[i] = vi;
+        const float denom = sqrtf(vi) / d.bc2_sqrt + eps;
+        d.p[i] = pi - d.step_size * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_multi_kernel(const dwc_ema_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
+                                                        const unsigned* __restrict__ chunk_start, float beta) {
+    const dwc_ema_tensor d = tensors[chunk_tensor[blockIdx.x]];
+    const size_t i0 = chunk_start[blockIdx.x];
+    const size_t i1 = i0 + DWC_OPT_CHUNK < d.n ? i0 + DWC_OPT_CHUNK : d.n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) d.ema[i] = lerp_torch(d.p[i], d.ema[i], beta);
+}
+
 }  // namespace
 
 extern "C" {
@@ -416,6 +447,25 @@ int dwc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
     const double bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)((double)lr / bc1),
                        beta1, beta2, eps, weight_decay, (float)sqrt(bc2));
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_dev, const unsigned* chunk_start_dev, int n_chunks,
+                   double beta1, double beta2, double eps, double weight_decay, void* stream) {
+    if (n_chunks <= 0 || !tensors_dev || !chunk_tensor_dev || !chunk_start_dev) return DWC_EINVAL;
+    // hyper-parameters arrive as doubles and 1-beta is formed in double before the cast, as torch.optim.Adam does
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunk_tensor_dev,
+                       chunk_start_dev, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev, const unsigned* chunk_start_dev, int n_chunks,
+                  float beta, void* stream) {
+    if (n_chunks <= 0 || !tensors_dev || !chunk_tensor_dev || !chunk_start_dev) return DWC_EINVAL;
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, tensors_dev, chunk_tensor_dev,
+                       chunk_start_dev, beta);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

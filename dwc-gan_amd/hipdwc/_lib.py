@@ -51,6 +51,8 @@ SIGNATURES = {
     "dwc_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "dwc_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_sz, c_f, c_f, c_f, c_f, c_f, c_int, c_fp]),
     "dwc_ema_lerp": (c_int, [c_fp, c_fp, c_sz, c_f, c_fp]),
+    "dwc_adam_multi": (c_int, [c_fp, c_fp, c_fp, c_int] + [ctypes.c_double] * 4 + [c_fp]),
+    "dwc_ema_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_f, c_fp]),
 }
 
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",

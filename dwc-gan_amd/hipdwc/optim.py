@@ -1,0 +1,129 @@
+"""Multi-tensor Adam and EMA on the HIP kernels (``dwc_adam_multi`` / ``dwc_ema_multi``).
+
+``FusedAdam`` is a ``torch.optim.Adam`` (same constructor, ``param_groups``, ``state_dict`` layout,
+LR-scheduler compatibility) whose ``step()`` updates every parameter tensor of the group in ONE
+kernel launch instead of torch's ~12 multi-tensor launches: coupled L2 weight decay, bias-corrected
+moments, eps outside the sqrt, and parameters without a gradient skipped entirely — the behaviour
+of the optimiser the reference builds at solver.py:62-68 under torch >= 2 (SURVEY.md section 7, quirk viii).
+``FusedEMA`` is the reference's ``moving_average`` (utils.py:52-54) in one launch per network.
+On CPU tensors both fall back to ... nothing: they raise, like every other HIP op (the CPU
+restatement lives in oracle/).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CHUNK = 8192           # must equal DWC_OPT_CHUNK in include/dwcgan_hip.h
+
+_ADAM_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"),
+                     ("step_size", "<f4"), ("bc2_sqrt", "<f4")])      # struct dwc_adam_tensor
+_EMA_DT = np.dtype([("p", "<u8"), ("ema", "<u8"), ("n", "<u8")])      # struct dwc_ema_tensor
+
+
+def _chunk_maps(sizes, device):
+    tid, start = [], []
+    for i, n in enumerate(sizes):
+        for s in range(0, n, CHUNK):
+            tid.append(i)
+            start.append(s)
+    assert max(sizes) < 2 ** 31
+    return torch.tensor(tid, dtype=torch.int32, device=device), torch.tensor(start, dtype=torch.int32, device=device), len(tid)
+
+
+def _to_device_bytes(arr, device):
+    """Upload a descriptor array without stalling the host: pinned staging block (torch's caching host
+    allocator keeps it alive until the copy has executed) + asynchronous copy on the current stream."""
+    host = torch.from_numpy(arr.view(np.uint8).reshape(-1)).pin_memory()
+    return host.to(device, non_blocking=True)
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
+        self._maps = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure not supported")
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            if not params:
+                continue
+            dev = params[0].device
+            if not params[0].is_cuda:
+                raise RuntimeError("FusedAdam needs device parameters: the product path has no CPU fallback")
+            b1, b2 = group["betas"]
+            desc = np.zeros(len(params), dtype=_ADAM_DT)
+            keep = []          # keeps contiguous gradient copies alive until the launch is queued
+            for i, p in enumerate(params):
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam expects contiguous parameters")
+                desc[i]["p"], desc[i]["m"], desc[i]["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                desc[i]["n"] = p.numel()
+                g = p.grad
+                if g is None:
+                    continue                                  # g stays NULL: tensor skipped, step not advanced
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.to(torch.float32).contiguous()
+                    keep.append(g)
+                st["step"] += 1
+                t = float(st["step"])
+                desc[i]["g"] = g.data_ptr()
+                desc[i]["step_size"] = group["lr"] / (1.0 - b1 ** t)
+                desc[i]["bc2_sqrt"] = math.sqrt(1.0 - b2 ** t)
+            maps = self._maps.get(gi)
+            if maps is None or maps[3] != [p.numel() for p in params]:
+                sizes = [p.numel() for p in params]
+                tid, start, n = _chunk_maps(sizes, dev)
+                maps = (tid, start, n, sizes)
+                self._maps[gi] = maps
+            ddev = _to_device_bytes(desc, dev)
+            _lib.check(lib.dwc_adam_multi(ddev.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(), maps[2], b1, b2,
+                                          group["eps"], group["weight_decay"], torch.cuda.current_stream().cuda_stream),
+                       "adam_multi")
+            del keep
+            # the kernel wrote through raw pointers: tell autograd (and the prepared-weight cache in
+            # hipdwc.ops, which keys on the version counter) that these tensors changed
+            torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+        return None
+
+
+class FusedEMA:
+    """copy <- lerp(param, copy, beta) over the parameters of ``model`` / ``model_copy`` (buffers are not averaged)."""
+
+    def __init__(self, model, model_copy):
+        src = [p for p in model.parameters()]
+        dst = [p for p in model_copy.parameters()]
+        assert len(src) == len(dst) and all(a.shape == b.shape for a, b in zip(src, dst))
+        if not src[0].is_cuda:
+            raise RuntimeError("FusedEMA needs device parameters: the product path has no CPU fallback")
+        self.src, self.dst = src, dst
+        dev = src[0].device
+        desc = np.zeros(len(src), dtype=_EMA_DT)
+        for i, (a, b) in enumerate(zip(src, dst)):
+            if not (a.is_contiguous() and b.is_contiguous()):
+                raise RuntimeError("FusedEMA expects contiguous parameters")
+            desc[i]["p"], desc[i]["ema"], desc[i]["n"] = a.data_ptr(), b.data_ptr(), a.numel()
+        self.ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in zip(src, dst)]
+        self.desc = _to_device_bytes(desc, dev)
+        self.tid, self.start, self.n_chunks = _chunk_maps([p.numel() for p in src], dev)
+
+    def still_valid(self):
+        return all(a.data_ptr() == pa and b.data_ptr() == pb for (a, b), (pa, pb) in zip(zip(self.src, self.dst), self.ptrs))
+
+    @torch.no_grad()
+    def step(self, beta=0.999):
+        lib = _lib.load()
+        _lib.check(lib.dwc_ema_multi(self.desc.data_ptr(), self.tid.data_ptr(), self.start.data_ptr(), self.n_chunks,
+                                     beta, torch.cuda.current_stream().cuda_stream), "ema_multi")
+        torch.autograd.graph.increment_version(self.dst)

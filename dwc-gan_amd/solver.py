@@ -23,6 +23,7 @@ from torch import nn
 from gmm import gmm_kl_distance_sp, gmm_earth_mover_distance_sp
 from hipdwc import host, ops
 from hipdwc.host import get_scheduler, moving_average, weights_init
+from hipdwc.optim import FusedAdam, FusedEMA
 from networks.networks import MsImageDis
 from networks.networks_v2 import AdaINGen_v2
 from tools import dist_sampling_split
@@ -76,10 +77,13 @@ class Solver(nn.Module):
         self.init_ds_w = configs["ds_w"]
         self.lr_policy = configs["lr_policy"]
         self.grad_sync = None      # set to hipdwc.dp.GradAllReduce for multi-GPU data parallel
+        self._ema = None
 
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
-        self.dis_opt = torch.optim.Adam([p for p in self.dis.parameters() if p.requires_grad], **adam)
-        self.gen_opt = torch.optim.Adam([p for p in self.gen.parameters() if p.requires_grad], **adam)
+        # torch.optim.Adam subclasses (same param_groups / state_dict / scheduler interface) whose step()
+        # is one multi-tensor HIP launch per network
+        self.dis_opt = FusedAdam([p for p in self.dis.parameters() if p.requires_grad], **adam)
+        self.gen_opt = FusedAdam([p for p in self.gen.parameters() if p.requires_grad], **adam)
         self.dis_scheduler = get_scheduler(self.dis_opt, configs)
         self.gen_scheduler = get_scheduler(self.gen_opt, configs)
 
@@ -99,10 +103,18 @@ class Solver(nn.Module):
     def copy_nets(self):
         self.gen_copy = copy.deepcopy(self.gen)
         self.dis_copy = copy.deepcopy(self.dis)
+        self._ema = None
 
     def smooth_moving(self):
-        moving_average(self.gen, self.gen_copy)
-        moving_average(self.dis, self.dis_copy)
+        """EMA copies <- lerp(param, copy, 0.999) (reference solver.py:355-357, utils.py:52-54), one launch per net."""
+        if not next(self.gen.parameters()).is_cuda:
+            moving_average(self.gen, self.gen_copy)
+            moving_average(self.dis, self.dis_copy)
+            return
+        if self._ema is None or not all(e.still_valid() for e in self._ema):
+            self._ema = (FusedEMA(self.gen, self.gen_copy), FusedEMA(self.dis, self.dis_copy))
+        for e in self._ema:
+            e.step(0.999)
 
     def update_learning_rate(self):
         if self.lr_policy == "cosa":

@@ -162,6 +162,34 @@ int dwc_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
                   float beta2, float eps, float weight_decay, int step, void* stream);
 int dwc_ema_lerp(const float* p, float* ema, size_t n, float beta, void* stream);
 
+/* Multi-tensor forms: one launch for every parameter tensor of a network.  The descriptor arrays
+ * and the chunk maps live in DEVICE memory (the caller uploads them; gradient pointers and the
+ * per-tensor bias corrections change every step, the chunk maps never).  Workgroup b updates
+ * DWC_OPT_CHUNK consecutive elements of tensor chunk_tensor[b] starting at chunk_start[b].
+ * A tensor whose g is NULL is skipped entirely — Adam's behaviour for parameters without a
+ * gradient (SURVEY.md section 7 quirk viii).  step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t)
+ * with t that tensor's own step count. */
+#define DWC_OPT_CHUNK 8192
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    unsigned long long n;
+    float step_size;
+    float bc2_sqrt;
+} dwc_adam_tensor;
+typedef struct {
+    const float* p;
+    float* ema;
+    unsigned long long n;
+} dwc_ema_tensor;
+int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_dev,
+                   const unsigned* chunk_start_dev, int n_chunks, double beta1, double beta2, double eps,
+                   double weight_decay, void* stream);
+int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev,
+                  const unsigned* chunk_start_dev, int n_chunks, float beta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -239,6 +239,46 @@ def test_pack_blend_l1():
         close(bd.grad, br.grad, rel=1e-6)
 
 
+def test_fused_adam_and_ema_match_torch():
+    """Multi-tensor HIP Adam/EMA against torch.optim.Adam (CPU, single-tensor path) and torch.lerp:
+    odd sizes across the 8192-element chunking, a parameter that never gets a gradient (must be
+    skipped: no weight decay, no step count), another that gets one only on some steps."""
+    from hipdwc.optim import FusedAdam, FusedEMA
+    g = torch.Generator().manual_seed(0)
+    shapes = [(7,), (8192,), (8193,), (3, 5, 7, 7), (20000,), (64, 33), (11,)]
+    ref = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    hip = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    kw = dict(lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-4)
+    o_ref, o_hip = torch.optim.Adam(ref, foreach=False, **kw), FusedAdam(hip, **kw)
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(ref, hip)):
+            if i == 6 or (i == 2 and step % 2 == 1):       # no gradient at all / only on even steps
+                a.grad, b.grad = None, None
+                continue
+            gr = torch.randn(a.shape, generator=g)
+            a.grad, b.grad = gr.clone(), gr.to(DEV)
+        o_ref.step()
+        ver = [b._version for b in hip]
+        o_hip.step()
+        # the raw-pointer update must still bump autograd's version counters (the prepared-weight
+        # cache in hipdwc.ops keys on them): exactly the tensors that were updated
+        for i, b in enumerate(hip):
+            assert (b._version > ver[i]) == (b.grad is not None), i
+    for i, (a, b) in enumerate(zip(ref, hip)):
+        close(b, a, rel=2e-6, atol=1e-7, msg="param %d" % i)
+        if i != 6:
+            close(o_hip.state[b]["exp_avg"], o_ref.state[a]["exp_avg"], rel=2e-6, msg="m %d" % i)
+            close(o_hip.state[b]["exp_avg_sq"], o_ref.state[a]["exp_avg_sq"], rel=2e-6, msg="v %d" % i)
+            assert float(o_hip.state[b]["step"]) == float(o_ref.state[a]["step"])
+    assert torch.equal(hip[6].cpu(), ref[6].detach())       # untouched
+    assert set(o_hip.state_dict()["state"][0].keys()) == set(o_ref.state_dict()["state"][0].keys())
+    src, dst = torch.nn.ParameterList(hip), torch.nn.ParameterList([torch.nn.Parameter(torch.randn_like(p)) for p in hip])
+    want = [torch.lerp(a.detach().cpu(), b.detach().cpu(), 0.999) for a, b in zip(src, dst)]
+    FusedEMA(src, dst).step(0.999)
+    for w, b in zip(want, dst):
+        close(b, w, rel=1e-6, atol=1e-7, msg="ema")
+
+
 def test_golden_conv_blocks(golden_dir):
     """The reference's own Conv2dBlock vectors (conv + norm + activation, forward and backward)."""
     import networks.networks as nets
@@ -336,11 +376,16 @@ def test_tiny_three_iterations_vs_reference(tiny):
             s.smooth_moving()
             s.update_learning_rate()
             s.update_attention_status(it)
+            # iteration 0 sees the reference's own weights (2e-4).  From iteration 1 on every parameter has
+            # taken an Adam sign-descent step of +-lr, and entries whose true gradient is ~0 go either way
+            # under ANY change of summation order: the reference drifts from itself by 1e-4 / 5e-3 (relative,
+            # loss_gen_total) at iterations 1 / 2 when only its thread count changes (tests/test_trajectory.py).
+            tol = (2e-4, 5e-3, 2e-2)[it]
             for k, v in want[it].items():
-                got = float(getattr(s, k))
-                assert abs(got - v) <= 2e-4 * max(1.0, abs(v)), (it, k, got, v)
+                got = float(torch.as_tensor(getattr(s, k)).detach())
+                assert abs(got - v) <= tol * max(1.0, abs(v)), (it, k, got, v)
             if it == 0:
-                ref_g = {k[len("grad_it0/gen/"):]: T(tiny[k]) for k in tiny.files if k.startswith("grad_it0/gen/")}
+                ref_g ={k[len("grad_it0/gen/"):]: T(tiny[k]) for k in tiny.files if k.startswith("grad_it0/gen/")}
                 assert set(grads.keys()) == set(ref_g.keys())
                 for k, gref in ref_g.items():
                     close(grads[k], gref, rel=5e-3, msg=k)
