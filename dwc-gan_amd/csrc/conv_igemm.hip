@@ -63,6 +63,23 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) float g_zero_page[64];
 
+#ifdef DWC_CLOCK_PROBE   // development builds only (make PROBE=1): average shader clock seen by the GEMM kernels
+__device__ unsigned long long g_clock_probe[2];
+struct ClockProbe {
+    long long c0, r0;
+    __device__ ClockProbe() : c0(clock64()), r0(wall_clock64()) {}
+    __device__ ~ClockProbe() {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+            atomicAdd(&g_clock_probe[0], (unsigned long long)(clock64() - c0));
+            atomicAdd(&g_clock_probe[1], (unsigned long long)(wall_clock64() - r0));
+        }
+    }
+};
+#define DWC_PROBE() ClockProbe clock_probe_
+#else
+#define DWC_PROBE()
+#endif
+
 // Workgroup barrier that also retires this wave's outstanding direct-to-LDS loads.  hipcc's
 // __syncthreads() already drains vmcnt when an LDS-DMA is in flight (checked in the ISA: every
 // s_barrier is preceded by s_waitcnt vmcnt(0) lgkmcnt(0)); the explicit wait makes the kernels
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
                                                              Scatter o, const float* __restrict__ bias, int act, int tiles_n,
                                                              int kt_per_split, size_t part_stride) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    DWC_PROBE();
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
     constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
@@ -288,6 +306,7 @@ template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* __restrict__ dy, int N, float* __restrict__ slab,
                                                          int m_chunk) {
     static_assert(WM * WN == 4 && WM * TM * 32 == 128 && WN * TN * 32 == BN, "tile shape");
+    DWC_PROBE();
     constexpr int A_TILE = 32 * 128, B_TILE = 32 * BN;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
     float* sA = smem;               // [buf][m][k]
@@ -876,3 +895,14 @@ int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B
 }
 
 }  // extern "C"
+
+#ifdef DWC_CLOCK_PROBE
+extern "C" int dwc_debug_clock_probe(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 16) != hipSuccess) return DWC_ELAUNCH;
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_probe), z, 16) != hipSuccess) return DWC_ELAUNCH;
+    }
+    return 0;
+}
+#endif

@@ -65,13 +65,15 @@ class KernelTimer:
 
     def __init__(self):
         self.spans = []   # (kernel tag, algorithmic flops, start event, end event)
+        self.details = []  # problem shape of each span (benchmarks/step_breakdown.py)
 
-    def run(self, tag, flops, fn):
+    def run(self, tag, flops, fn, detail=""):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn()
         b.record()
         self.spans.append((tag, flops, a, b))
+        self.details.append(detail)
         return rc
 
     def summary(self):
@@ -104,11 +106,11 @@ class scope:
         SCOPE = self.prev
 
 
-def _timed(tag, flops, fn, scope_name=None):
+def _timed(tag, flops, fn, scope_name=None, detail=""):
     if TIMER is None:
         return fn()
     s = SCOPE if scope_name is None else scope_name
-    return TIMER.run((s + "/" + tag) if s else tag, flops, fn)
+    return TIMER.run((s + "/" + tag) if s else tag, flops, fn, detail)
 
 
 def _pad4(n):
@@ -178,7 +180,7 @@ class _Conv2d(torch.autograd.Function):
         wsp = workspace(nws, x.device).data_ptr() if nws else None
         _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
             x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
-            st)), "conv2d_fwd")
+            st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
@@ -209,6 +211,15 @@ class _Conv2d(torch.autograd.Function):
             if need_db:
                 db = db_full[:Cout]
         dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
+            nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            detail = "wgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
+            ws = workspace(nws, dev)
+            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
+                x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
+                ws.numel(), st), scope_name=ctx.bscope, detail=detail), "conv2d_bwd_weight")
         if ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)
@@ -221,17 +232,9 @@ class _Conv2d(torch.autograd.Function):
             wsp = base + pad_bytes if nws else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
                 g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st),
-                scope_name=ctx.bscope), "conv2d_bwd_data")
+                scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_bwd_data")
             if pad > 0:
                 _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
-            nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
-            ws = workspace(nws, dev)
-            flops = 2.0 * rows * Cout * Cin * KH * KW
-            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
-                x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
-                ws.numel(), st), scope_name=ctx.bscope), "conv2d_bwd_weight")
         return dx, dw, db, None, None, None
 
 
