@@ -458,7 +458,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
 }
 
 // reflect-pad adjoint: fold the padded gradient image back onto the un-padded one
-__global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restrict__ dx, int B, int H, int W, int C4, int pad) {
+__global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restrict__ dx, int B, int H, int W, int C4, int pad,
+                                    int Wp) {   // Wp: row pitch of gp in pixels (>= W + 2*pad)
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)B * H * W * C4;
     if (idx >= total) return;
@@ -468,7 +469,7 @@ __global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restr
     r /= W;
     const int h = r % H;
     const int n = r / H;
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int Hp = H + 2 * pad;
     int hs[3], ws[3], nh = 0, nw = 0;
     hs[nh++] = h + pad;
     if (h >= 1 && h <= pad) hs[nh++] = pad - h;
@@ -847,7 +848,48 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || pad < 0 || pad >= H || pad >= W) return DWC_EINVAL;
     const size_t total = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(fold_reflect_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dxp, dx, B, H, W, C / 4,
-                       pad);
+                       pad, W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+// Data gradient w.r.t. an NHWC4 IMAGE (stem convolutions, Cin = 4): N = 4 would fill 1/8 of a 32-wide MFMA tile, so
+// 8 horizontally adjacent pixels x 4 channels are produced as 32 columns of a KH x (KW+7), stride-(1,8) filter bank
+// (copy p = the flipped filter shifted right by p taps) applied to dY with the zero rule; the padded gradient image
+// lands in `ws` with a row pitch of ceil((W+2*pad)/8)*8 pixels and is folded onto dx (reflect-pad adjoint).
+static bool image_dgrad_geom(const float* dy, float* dxp, int B, int H, int W, int Cout, int KH, int KW, int pad, FwdGeom* f) {
+    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || pad <= 0 || 2 * pad != KH - 1 || 2 * pad != KW - 1) return false;
+    if (dwc_ilog2_exact(Cout) < 5 || pad >= H || pad >= W) return false;
+    const int Hp = H + 2 * pad, Wg = (W + 2 * pad + 7) / 8;
+    Gather& g = f->g;
+    g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
+    g.OH = Hp; g.OW = Wg; g.KH = KH; g.KW = KW + 7;
+    g.kw_magic = kw_magic_for(KW + 7, KH * (KW + 7) + 64);
+    if (g.kw_magic < 0) return false;
+    g.mul_h = 1; g.mul_w = 8; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1); g.reflect = 0;
+    g.M = B * Hp * Wg; g.K = KH * (KW + 7) * Cout;
+    g.logOW = g.logOHW = -1;
+    f->o.dst = dxp; f->o.N = 32; f->o.OHf = Hp; f->o.OWf = Wg; f->o.os = 1;
+    f->dst_elems = (size_t)g.M * 32;
+    return true;
+}
+
+size_t dwc_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad) {
+    FwdGeom f;
+    if (!image_dgrad_geom(nullptr, nullptr, B, H, W, Cout, KH, KW, pad, &f)) return 0;
+    return f.dst_elems * sizeof(float);
+}
+
+int dwc_conv2d_bwd_data_image(const float* dy, const float* w_wide, float* dx, int B, int H, int W, int Cout, int KH, int KW,
+                              int pad, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!image_dgrad_geom(dy, (float*)ws, B, H, W, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
+    if (!ws || ws_bytes < f.dst_elems * sizeof(float)) return DWC_EWORKSPACE;
+    const int rc = launch_gemm(f.g, w_wide, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, nullptr, 0, (hipStream_t)stream);
+    if (rc != DWC_OK) return rc;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dx, B, H,
+                       W, 1, pad, f.g.OW * 8);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -136,6 +136,16 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     if ent.get(key, (None, None))[0] == w._version:
         return ent[key][1]
     lib = _lib.load()
+    if kind == "dgrad_image":
+        # bank of 8 shifted copies of the flipped, transposed filter: [p*4 + ci][co][KH][KW+7] (dwc_conv2d_bwd_data_image);
+        # cout_pad = gathered (dY) channels, cin_pad = 4 image planes
+        co, ci, kh, kw = w.shape
+        wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
+        wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
+        bank = torch.stack([torch.nn.functional.pad(wf, (p, 7 - p)) for p in range(8)]).reshape(8 * cin_pad, cout_pad, kh, kw + 7)
+        out = _prepped(bank, "fwd", 8 * cin_pad, cout_pad, 1)
+        ent[key] = (w._version, out)
+        return out
     cout, cin, kh, kw = w.shape
     wc = w.detach().contiguous()
     n = lib.dwc_weight_prepared_elems(cout, cin, kh, kw, stride, cout_pad, cin_pad, int(kind == "dgrad"))
@@ -220,7 +230,19 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
                 x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
                 ws.numel(), st), scope_name=ctx.bscope, detail=detail), "conv2d_bwd_weight")
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and Cx == 4 and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
+                and (cop & (cop - 1)) == 0:
+            # gradient w.r.t. an NHWC4 image (7x7 stems): 8 pixels x 4 planes per GEMM row, see dwc_conv2d_bwd_data_image
+            w_img = _prepped(w, "dgrad_image", cop, 4, 1)
+            dx = empty_cl(B, 4, H, W, dev)
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            nws = lib.dwc_conv2d_bwd_data_image_ws_bytes(B, H, W, cop, KH, KW, pad)
+            ws = workspace(nws, dev)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_image(
+                g.data_ptr(), w_img.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
+                scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                "conv2d_bwd_data_image")
+        elif ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)
             flops = 2.0 * rows * Cout * Cin * KH * KW

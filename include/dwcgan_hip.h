@@ -79,6 +79,15 @@ int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp,
 /* Data gradient, step 2: adjoint of the reflect padding — fold dxp back onto dx:[B,H,W,C]. */
 int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad,
                             void* stream);
+/* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
+ * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).
+ * 8 adjacent pixels x 4 channels are produced as 32 GEMM columns.  w_wide: dwc_weight_prepare_fwd layout of the bank
+ * [32 = p*4+ci][Cout][KH][KW+7] whose copy p is the flipped filter W[co][ci][KH-1-kh][KW-1-kw] shifted right by p
+ * taps.  The padded gradient image is built in ws and folded onto dx (reflect-pad adjoint) by the same call. */
+size_t dwc_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
+int dwc_conv2d_bwd_data_image(const float* dy, const float* w_wide, float* dx,
+                              int B, int H, int W, int Cout, int KH, int KW, int pad,
+                              void* ws, size_t ws_bytes, void* stream);
 /* dw (written in OIHW, the state_dict layout, [Cout_real][Cin_real][KH][KW]) from x and dy.
  * Cin/Cout are the padded data-path channel counts, cin_real/cout_real the parameter's. */
 size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW,

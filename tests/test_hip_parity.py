@@ -37,7 +37,9 @@ def dev(t, grad=False):
 
 # (B, Cin, Cout, H, k, stride, pad, act)
 CONV_SHAPES = [
-    (2, 4, 64, 32, 7, 1, 3, "relu"),        # stem on an NHWC4 image
+    (2, 4, 64, 32, 7, 1, 3, "relu"),        # stem on an NHWC4 image (dx through the 8-pixels-wide image dgrad)
+    (1, 4, 64, 21, 7, 1, 3, "none"),        # same, odd size: padded width 27 -> pitch 32
+    (3, 4, 32, 16, 5, 1, 2, "lrelu"),       # same, 5x5 / 32 gathered channels
     (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
     (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv, BN=128 path, 2 N tiles
     (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
