@@ -1,0 +1,195 @@
+// Recurrent part of the text encoder's packed bi-LSTM (reference networks_v2.py:199-203,226-233: nn.LSTM over a
+// pack_padded_sequence) on the fp32 matrix cores.
+//
+// The input projections of all time steps are one library GEMM done by the caller; what is sequential is
+//     gates_t = xproj_t + h_{t-1} W_hh^T ;  c_t = f*c_{t-1} + i*g ;  h_t = o*tanh(c_t)
+// Stock ROCm runs this as two tiny launches per step per direction (a rocBLAS GEMM and a cell kernel, ~11 us).
+// Here one launch per step serves BOTH directions: workgroup (g, d) owns 16 hidden units of direction d, its four
+// waves hold the four gate tiles of v_mfma_f32_16x16x4_f32 ([B x H] . [H x 16], batch rows on M), the cell update is
+// fused behind an LDS exchange, and the kernel boundary is the only synchronisation (no spin barriers).
+//
+// Packed-sequence semantics by masking: sample b is active at step t iff t < len[b].  Inactive positions of out/c are
+// written as zeros, so "previous state" is simply the neighbouring time slot (t-1 forward, t+1 reverse): a reverse
+// sequence starts from zeros at its own last token exactly as nn.LSTM does on packed input.
+#include "dwc_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// K-labelling shared by both operands: lane (r = lane & 15, j = lane >> 4) takes k = 16*q + 4*j + i for the i-th MFMA
+// of block q, so that each lane fetches ONE 16-byte vector per block and operand.
+template <int MT>
+__device__ __forceinline__ void mfma_rows(const float* __restrict__ a_base, int row0, int a_rows, int a_pitch,
+                                          const float* __restrict__ b_row, bool b_valid, int K, int q0, int q1, f32x4 (&acc)[MT]) {
+    const int lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
+    for (int q = q0; q < q1; ++q) {
+        const int k = 16 * q + 4 * j;
+        const bool kin = k < K;           // K % 4 == 0: a vector is entirely inside or outside
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (kin && b_valid) bv = *reinterpret_cast<const f32x4*>(b_row + k);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int row = row0 + m * 16 + r;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (kin && row < a_rows) av = *reinterpret_cast<const f32x4*>(a_base + (size_t)row * a_pitch + k);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[m], 0, 0, 0);
+        }
+    }
+}
+
+// One time step of both directions.  grid (ceil(H/16), dirs), 256 threads.
+//   xproj [dirs][T][B][4H] (biases included)   w_hh [dirs][4H][H]   lens [B]
+//   out, c [dirs][T][B][H]   gates [dirs][T][B][4H] (activated i,f,g,o; kept for the backward)
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_step_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                     const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ c,
+                                                     float* __restrict__ gates, int T, int B, int H, int s) {
+    __shared__ float ex[4][MT * 16][17];
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, b0 = blockIdx.z * (MT * 16);
+    const int t = d == 0 ? s : T - 1 - s;
+    const int tp = d == 0 ? t - 1 : t + 1;                 // slot holding the previous state
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
+    const size_t dTB = (size_t)d * T * B;
+    const float* h_prev = (tp >= 0 && tp < T) ? out + (dTB + (size_t)tp * B) * H : nullptr;
+    const int unit = u0 + r;
+    const float* w_row = w_hh + ((size_t)d * 4 * H + (size_t)wave * H + min(unit, H - 1)) * H;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (h_prev) mfma_rows<MT>(h_prev, b0, B, H, w_row, unit < H, H, 0, (H + 15) / 16, acc);
+    // accumulator layout: column = lane & 15 (unit), rows 4*j + i (batch)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[m][i];
+    __syncthreads();
+    for (int p = threadIdx.x; p < MT * 256; p += 256) {
+        const int bl = p >> 4, b = b0 + bl, u = u0 + (p & 15);
+        if (b >= B || u >= H) continue;
+        const size_t row = dTB + (size_t)t * B + b;
+        const bool active = t < lens[b];
+        float hv = 0.f, cv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+        if (active) {
+            const float* xp = xproj + row * 4 * H + u;
+            gi = sigmoidf_(ex[0][bl][p & 15] + xp[0]);
+            gf = sigmoidf_(ex[1][bl][p & 15] + xp[H]);
+            gg = tanhf(ex[2][bl][p & 15] + xp[2 * H]);
+            go = sigmoidf_(ex[3][bl][p & 15] + xp[3 * H]);
+            const float cp = (tp >= 0 && tp < T) ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
+            cv = gf * cp + gi * gg;
+            hv = go * tanhf(cv);
+        }
+        out[row * H + u] = hv;
+        c[row * H + u] = cv;
+        float* gs = gates + row * 4 * H + u;
+        gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+    }
+}
+
+// One backward time step of both directions (time runs against the forward order).
+//   d_out, d_c [dirs][T][B][H] or NULL: gradients arriving at h_t / c_t from outside the recurrence
+//   w_hh_t [dirs][H][4H] (transposed)   dgates [dirs][T][B][4H] (output; the step processed before is read back)
+//   dc_carry [dirs][B][H] scratch, zero before the first step
+template <int MT>
+__global__ __launch_bounds__(256) void lstm_step_bwd(const float* __restrict__ d_out, const float* __restrict__ d_c,
+                                                     const float* __restrict__ w_hh_t,
+                                                     const int* __restrict__ lens, const float* __restrict__ c,
+                                                     const float* __restrict__ gates, float* __restrict__ dgates,
+                                                     float* __restrict__ dc_carry, int T, int B, int H, int s) {
+    __shared__ float ex[4][MT * 16][17];
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, b0 = blockIdx.z * (MT * 16);
+    const int t = d == 0 ? T - 1 - s : s;                   // forward direction walks back from the end
+    const int tn = d == 0 ? t + 1 : t - 1;                  // the step processed just before (later in forward order)
+    const int tp = d == 0 ? t - 1 : t + 1;                  // forward-order predecessor (its c enters f's gradient)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
+    const size_t dTB = (size_t)d * T * B;
+    const int unit = u0 + r;
+    // dh_rec[b][u] = sum_n dgates[tn][b][n] * W_hh[n][u]: contraction over 4H, split over the four waves
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tn >= 0 && tn < T) {
+        const int nq = (4 * H + 15) / 16, per = (nq + 3) / 4;
+        const float* a = dgates + (dTB + (size_t)tn * B) * 4 * H;
+        const float* w_row = w_hh_t + ((size_t)d * H + min(unit, H - 1)) * 4 * H;
+        mfma_rows<MT>(a, b0, B, 4 * H, w_row, unit < H, 4 * H, wave * per, min(nq, (wave + 1) * per), acc);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[m][i];
+    __syncthreads();
+    for (int p = threadIdx.x; p < MT * 256; p += 256) {
+        const int bl = p >> 4, b = b0 + bl, u = u0 + (p & 15);
+        if (b >= B || u >= H) continue;
+        const size_t row = dTB + (size_t)t * B + b;
+        const int len = lens[b];
+        float* dg = dgates + row * 4 * H + u;
+        if (t >= len) {                                      // inactive: nothing flows
+            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+            continue;
+        }
+        const size_t sb = ((size_t)d * B + b) * H + u;
+        float dh = ex[0][bl][p & 15] + ex[1][bl][p & 15] + ex[2][bl][p & 15] + ex[3][bl][p & 15];
+        float dc = dc_carry[sb];
+        if (d_out) dh += d_out[row * H + u];
+        if (d_c) dc += d_c[row * H + u];
+        const float* gs = gates + row * 4 * H + u;
+        const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
+        const float cv = c[row * H + u];
+        const bool has_prev = d == 0 ? tp >= 0 : tp < len;   // reverse: the state before the first step is zero
+        const float cp = has_prev ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
+        const float th = tanhf(cv);
+        dc += dh * go * (1.f - th * th);
+        dg[0] = dc * gg * gi * (1.f - gi);
+        dg[H] = dc * cp * gf * (1.f - gf);
+        dg[2 * H] = dc * gi * (1.f - gg * gg);
+        dg[3 * H] = dh * th * go * (1.f - go);
+        dc_carry[sb] = dc * gf;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
+                 int dirs, void* stream) {
+    if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
+    const int mt = min(4, (B + 15) / 16);
+    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < T; ++s) {
+        switch (mt) {
+            case 1: hipLaunchKernelGGL(lstm_step_fwd<1>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
+            case 2: hipLaunchKernelGGL(lstm_step_fwd<2>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
+            case 3: hipLaunchKernelGGL(lstm_step_fwd<3>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
+            default: hipLaunchKernelGGL(lstm_step_fwd<4>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
+        }
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_lstm_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c, const float* gates,
+                 float* dgates, float* dc_carry, int T, int B, int H, int dirs, void* stream) {
+    if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
+    const int mt = min(4, (B + 15) / 16);
+    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dc_carry, 0, (size_t)dirs * B * H * sizeof(float), st) != hipSuccess) return DWC_ELAUNCH;
+    for (int s = 0; s < T; ++s) {
+        switch (mt) {
+            case 1: hipLaunchKernelGGL(lstm_step_bwd<1>, grid, dim3(256), 0, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, dc_carry, T, B, H, s); break;
+            case 2: hipLaunchKernelGGL(lstm_step_bwd<2>, grid, dim3(256), 0, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, dc_carry, T, B, H, s); break;
+            case 3: hipLaunchKernelGGL(lstm_step_bwd<3>, grid, dim3(256), 0, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, dc_carry, T, B, H, s); break;
+            default: hipLaunchKernelGGL(lstm_step_bwd<4>, grid, dim3(256), 0, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, dc_carry, T, B, H, s); break;
+        }
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

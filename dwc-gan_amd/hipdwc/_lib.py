@@ -51,6 +51,8 @@ SIGNATURES = {
     "dwc_l1_ws_bytes": (c_sz, [c_sz]),
     "dwc_l1_mean_fwd": (c_int, [c_fp, c_fp, c_fp, c_sz, c_int, c_fp, c_sz, c_fp]),
     "dwc_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
+    "dwc_lstm_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp]),
+    "dwc_lstm_bwd": (c_int, [c_fp] * 8 + [c_int] * 4 + [c_fp]),
     "dwc_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_sz, c_f, c_f, c_f, c_f, c_f, c_int, c_fp]),
     "dwc_ema_lerp": (c_int, [c_fp, c_fp, c_sz, c_f, c_fp]),
     "dwc_adam_multi": (c_int, [c_fp, c_fp, c_fp, c_int] + [ctypes.c_double] * 4 + [c_fp]),

@@ -358,6 +358,69 @@ def linear(x, w, b, act="none"):
 
 
 # --------------------------------------------------------------------------------------
+# text encoder: one bidirectional LSTM layer over padded sequences with per-sample lengths
+# --------------------------------------------------------------------------------------
+class _LSTMBidir(torch.autograd.Function):
+    """Both directions of one nn.LSTM layer on a packed batch (reference networks_v2.py:226-233), zero initial state.
+    x:[T,B,I]; lens:[B] int32 on the device (sample b is active at steps t < lens[b]); w_ih:[2,4H,I], w_hh:[2,4H,H],
+    b_ih, b_hh:[2,4H] (direction 0 forward, 1 reverse).  Returns out (h_t) and c, both [2,T,B,H] with zeros at the
+    inactive slots.  The input projection and the four weight/input gradient products are library GEMMs; the T sequential
+    steps run in dwc_lstm_fwd / dwc_lstm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, lens, w_ih, w_hh, b_ih, b_hh):
+        _require_device(x)
+        lib = _lib.load()
+        T, B, I = x.shape
+        H = w_hh.shape[2]
+        dev = x.device
+        X = x.reshape(T * B, I)
+        xproj = torch.baddbmm((b_ih + b_hh).unsqueeze(1), X.unsqueeze(0).expand(2, -1, -1), w_ih.transpose(1, 2))   # [2,TB,4H]
+        w_hh_c = w_hh.contiguous()
+        out = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
+        c = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
+        gates = torch.empty((2, T, B, 4 * H), dtype=torch.float32, device=dev)
+        _lib.check(lib.dwc_lstm_fwd(xproj.data_ptr(), w_hh_c.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(),
+                                    gates.data_ptr(), T, B, H, 2, _stream()), "lstm_fwd")
+        ctx.save_for_backward(X, lens, w_ih, w_hh_c, out, c, gates)
+        ctx.shape = (T, B, I, H)
+        return out, c
+
+    @staticmethod
+    def backward(ctx, d_out, d_c):
+        lib = _lib.load()
+        X, lens, w_ih, w_hh, out, c, gates = ctx.saved_tensors
+        T, B, I, H = ctx.shape
+        dev = X.device
+        d_out = None if d_out is None else d_out.contiguous()
+        d_c = None if d_c is None else d_c.contiguous()
+        w_hh_t = w_hh.transpose(1, 2).contiguous()
+        dgates = torch.empty((2, T, B, 4 * H), dtype=torch.float32, device=dev)
+        carry = torch.empty((2, B, H), dtype=torch.float32, device=dev)
+        _lib.check(lib.dwc_lstm_bwd(_p(d_out), _p(d_c), w_hh_t.data_ptr(), lens.data_ptr(), c.data_ptr(), gates.data_ptr(),
+                                    dgates.data_ptr(), carry.data_ptr(), T, B, H, 2, _stream()), "lstm_bwd")
+        dG = dgates.view(2, T * B, 4 * H)
+        dGt = dG.transpose(1, 2)
+        dw_ih = torch.matmul(dGt, X) if ctx.needs_input_grad[2] else None                       # [2,4H,I]
+        db = dG.sum(1) if (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]) else None
+        dw_hh = None
+        if ctx.needs_input_grad[3]:
+            # state entering step t: the previous slot in processing order (zeros at the ends and past each length)
+            hprev = torch.zeros((2, T, B, H), dtype=torch.float32, device=dev)
+            hprev[0, 1:] = out[0, :-1]
+            hprev[1, :-1] = out[1, 1:]
+            dw_hh = torch.bmm(dGt, hprev.view(2, T * B, H))                                     # [2,4H,H]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.bmm(dG, w_ih).sum(0).view(T, B, I)
+        return dx, None, dw_ih, dw_hh, db, db
+
+
+def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh):
+    return _LSTMBidir.apply(x.contiguous(), lens, w_ih, w_hh, b_ih, b_hh)
+
+
+# --------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------
 class _InstNorm(torch.autograd.Function):

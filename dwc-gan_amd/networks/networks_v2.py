@@ -2,12 +2,11 @@
 
 ``AdaINGen_v2`` keeps the constructor, ``encode`` / ``encode_txt`` / ``decode`` methods, attribute
 names and ``state_dict`` keys of reference networks/networks_v2.py:9-95; the conv / norm /
-upsample stacks run on libdwcgan_hip.so through ``hipdwc.ops``.  The text encoder
-(Embedding + bi-LSTM, ~0% of the FLOPs) stays on stock PyTorch-ROCm as SURVEY.md section 8(a)
-row a12 scopes it, with the reference's batch-mixing ``view`` reproduced on purpose.
+upsample stacks run on libdwcgan_hip.so through ``hipdwc.ops``.  The text encoder's packed
+bi-LSTM runs its sequential part on the HIP recurrent kernels (``ops.lstm_bidir``; embedding lookup
+and the input / weight-gradient GEMMs are library calls), with the reference's batch-mixing
+``view`` reproduced on purpose.
 """
-import warnings
-
 import numpy as np
 import torch
 from torch import nn
@@ -64,6 +63,18 @@ class StyleEncoder(nn.Module):
         return mus, lvs
 
 
+def _packed_index(lens_sorted, t_max, bsz, device):
+    """Row of the PackedSequence data tensor that holds (t, b), for lengths sorted descending; slots past a sample's
+    length point at row 0 (their values are zero anyway).  [t_max*bsz] int64."""
+    idx = np.zeros((t_max, bsz), dtype=np.int64)
+    off = 0
+    for t in range(t_max):
+        n = sum(1 for v in lens_sorted if v > t)
+        idx[t, :n] = off + np.arange(n)
+        off += n
+    return torch.from_numpy(idx.reshape(-1)).to(device, non_blocking=True)
+
+
 class TxtEncoder(nn.Module):
     """Command text + current style -> per-attribute (mu, logvar) (reference networks_v2.py:171-254)."""
 
@@ -99,39 +110,41 @@ class TxtEncoder(nn.Module):
         emb = self.embed_tokens(tokens.index_select(1, order))
         emb = noise.dropout(emb, self.dropout_in, self.training)
         sty = style_ord.index_select(0, order)
-        packed = nn.utils.rnn.pack_padded_sequence(torch.cat([emb, sty.expand(seq_len, -1, -1)], -1),
-                                                   lens_sorted.tolist())
-        dirs = 2 if self.bidirectional else 1
-        zeros = emb.new_zeros(dirs * self.num_layers, bsz, self.hidden_size)
-        if self.training and self.dropout_out > 0 and self.num_layers > 1:
-            # Stacked LSTM = one layer at a time with the inter-layer dropout drawn by the noise
-            # source (bit-identical to nn.LSTM(dropout=p) on CPU, stream consumption included),
-            # so that parity runs can replay the mask that a stock nn.LSTM would draw privately.
-            data, batch_sizes, hs, cs = packed.data, packed.batch_sizes, [], []
-            z1 = zeros[:dirs]
-            for l in range(self.num_layers):
-                names = ["%s_l%d%s" % (n, l, suf) for suf in (("", "_reverse") if self.bidirectional else ("",))
-                         for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    data, hy, cy = torch._VF.lstm(data, batch_sizes, (z1, z1), [getattr(self.lstm, n) for n in names],
-                                                  True, 1, 0.0, True, self.bidirectional)
-                hs.append(hy)
-                cs.append(cy)
-                if l + 1 < self.num_layers:
+        # The packed bi-LSTM on the HIP recurrent kernels (hipdwc.ops.lstm_bidir): padded [T,B,*] tensors with per-sample
+        # lengths instead of a PackedSequence; T = longest sequence of the batch, as pack_padded_sequence would cut it.
+        lens_list = lens_sorted.tolist()
+        t_max = int(lens_list[0])
+        lens_dev = lens_sorted.to(torch.int32).to(tokens.device, non_blocking=True)
+        data = torch.cat([emb, sty.expand(seq_len, -1, -1)], -1)[:t_max]
+        last = (lens_sorted - 1).to(tokens.device, non_blocking=True)
+        cols = torch.arange(bsz, device=tokens.device)
+        suffixes = ("", "_reverse") if self.bidirectional else ("",)
+        if not self.bidirectional:
+            raise NotImplementedError("the HIP text encoder is bidirectional (the reference's only configuration)")
+        hs, cs = [], []
+        for l in range(self.num_layers):
+            par = {n: torch.stack([getattr(self.lstm, "%s_l%d%s" % (n, l, suf)) for suf in suffixes])
+                   for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
+            out, cell = ops.lstm_bidir(data, lens_dev, par["weight_ih"], par["weight_hh"], par["bias_ih"], par["bias_hh"])
+            # final states: forward direction at each sample's last token, reverse direction at t = 0
+            hs += [out[0][last, cols], out[1][0]]
+            cs += [cell[0][last, cols], cell[1][0]]
+            data = torch.cat([out[0], out[1]], -1)
+            if l + 1 < self.num_layers and self.training and self.dropout_out > 0:
+                # nn.LSTM(dropout=p) between the layers.  In parity mode the mask is drawn in PACKED order (the shape
+                # and stream consumption of a stock nn.LSTM on CPU) and scattered onto the padded layout.
+                if getattr(noise, "align_stream", False):
+                    mask = noise.dropout_mask((int(sum(lens_list)), data.shape[2]), self.dropout_out, data.device)
+                    data = data * mask.index_select(0, _packed_index(lens_list, t_max, bsz, data.device)).view(t_max, bsz, -1)
+                else:
                     data = noise.dropout(data, self.dropout_out, True)
-            h_n, c_n = torch.cat(hs, 0), torch.cat(cs, 0)
-            outs = nn.utils.rnn.PackedSequence(data, batch_sizes)
-        else:
-            outs, (h_n, c_n) = self.lstm(packed, (zeros, zeros))
+        h_n, c_n = torch.stack(hs), torch.stack(cs)
         if self.training and self.dropout_out > 0 and noise.align_stream:
             # the reference drops out the (unused) padded memory here and thereby advances the
             # random stream (reference networks_v2.py:235-236); parity mode keeps the stream aligned
-            mem, _ = nn.utils.rnn.pad_packed_sequence(outs)
-            noise.dropout(mem, self.dropout_out, True)
-        if self.bidirectional:
-            h_n = h_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
-            c_n = c_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
+            noise.dropout(data, self.dropout_out, True)
+        h_n = h_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
+        c_n = c_n.view(self.num_layers, 2, bsz, -1).transpose(1, 2).reshape(self.num_layers, bsz, -1)
         unsort = torch.sort(order_host)[1].to(tokens.device)
         h_n, c_n = h_n.index_select(1, unsort), c_n.index_select(1, unsort)
         # reference networks_v2.py:249: concatenating along the BATCH axis and then viewing as

@@ -163,6 +163,21 @@ int dwc_l1_mean_fwd(const float* a, const float* b, float* out_scalar, size_t n,
 int dwc_l1_mean_bwd(const float* a, const float* b, const float* dout_scalar, float* da, float* db,
                     size_t n, int skip4, void* stream);
 
+/* ---- text encoder: recurrent part of the packed bi-LSTM (reference networks_v2.py:199-203, 226-233; nn.LSTM over a
+ *      pack_padded_sequence).  The caller does the input projections of all steps as one GEMM; these run the T sequential
+ *      steps (one launch per step for both directions) with the cell update fused.  Packed semantics by masking: sample b is
+ *      active at step t iff t < lens[b]; inactive slots of out / c are written as zeros and a reverse sequence starts from
+ *      zeros at its own last token.  Gate order i, f, g, o as in torch.  H % 4 == 0. ---- */
+/* xproj:[dirs][T][B][4H] (x W_ih^T + b_ih + b_hh), w_hh:[dirs][4H][H], lens:[B] int32 (device).
+ * Outputs out (h_t), c: [dirs][T][B][H]; gates: [dirs][T][B][4H] activated gates kept for the backward. */
+int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates,
+                 int T, int B, int H, int dirs, void* stream);
+/* d_out / d_c: gradients arriving at h_t / c_t from outside the recurrence, [dirs][T][B][H] or NULL.
+ * w_hh_t:[dirs][H][4H] (transposed).  Output dgates:[dirs][T][B][4H] = gradient of the pre-activation gates, from which
+ * the caller forms dW_ih, dW_hh, db and dx with three GEMMs.  dc_carry:[dirs][B][H] scratch. */
+int dwc_lstm_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c,
+                 const float* gates, float* dgates, float* dc_carry, int T, int B, int H, int dirs, void* stream);
+
 /* ---- fused Adam (+coupled L2) + EMA (reference solver.py:62-68,240,353; utils.py:52-54) ----- */
 /* One launch over a flat parameter arena.  p,g,m,v,ema: [n].  step is the 1-based Adam step.
  * ema may be NULL.  ema update is the reference's lerp(param, ema, beta) AFTER the step only when

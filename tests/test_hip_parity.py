@@ -116,6 +116,49 @@ def test_conv_no_bias_and_cout_not_multiple_of_4():
     close(wd.grad, wr.grad, rel=5e-5)
 
 
+@pytest.mark.parametrize("T,B,I,H,lens", [
+    (7, 3, 12, 16, [7, 4, 1]),                        # tiny configuration, one sample of length 1
+    (40, 16, 364, 300, None),                         # the shipped text encoder, layer 0
+    (12, 20, 600, 300, None),                         # layer 1 input width, two 16-row tiles
+])
+def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens):
+    """One bidirectional layer on padded input + lengths against torch's nn.LSTM on the PackedSequence (what the
+    reference runs, networks_v2.py:226-233): outputs, final states, and every gradient."""
+    g = torch.Generator().manual_seed(T * 1000 + B + H)
+    if lens is None:
+        lens = sorted((int(v) for v in torch.randint(1, T + 1, (B,), generator=g)), reverse=True)
+        lens[0] = T
+    x = torch.randn(T, B, I, generator=g)
+    ref = torch.nn.LSTM(I, H, 1, bidirectional=True)
+    with torch.no_grad():
+        for prm in ref.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * (1.0 / H ** 0.5))
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, lens)
+    outs, (hn, cn) = ref(packed)
+    mem, _ = torch.nn.utils.rnn.pad_packed_sequence(outs, total_length=T)
+    g1, g2, g3 = torch.randn(mem.shape, generator=g), torch.randn(hn.shape, generator=g), torch.randn(cn.shape, generator=g)
+    ((mem * g1).sum() + (hn * g2).sum() + (cn * g3).sum()).backward()
+
+    xd = dev(x, True)
+    names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+    par = {n: [dev(getattr(ref, n + "_l0" + suf), True) for suf in ("", "_reverse")] for n in names}
+    lens_t = torch.tensor(lens)
+    out, cell = ops.lstm_bidir(xd, lens_t.to(torch.int32).to(DEV), *[torch.stack(par[n]) for n in names])
+    last, cols = (lens_t - 1).to(DEV), torch.arange(B, device=DEV)
+    mem_d = torch.cat([out[0], out[1]], -1)
+    hn_d = torch.stack([out[0][last, cols], out[1][0]])
+    cn_d = torch.stack([cell[0][last, cols], cell[1][0]])
+    close(mem_d, mem, rel=2e-5, msg="outputs")
+    close(hn_d, hn, rel=2e-5, msg="h_n")
+    close(cn_d, cn, rel=2e-5, msg="c_n")
+    ((mem_d * g1.to(DEV)).sum() + (hn_d * g2.to(DEV)).sum() + (cn_d * g3.to(DEV)).sum()).backward()
+    close(xd.grad, xr.grad, rel=1e-4, msg="dx")
+    for n in names:
+        for k, suf in enumerate(("", "_reverse")):
+            close(par[n][k].grad, getattr(ref, n + "_l0" + suf).grad, rel=1e-4, msg=n + suf)
+
+
 @pytest.mark.parametrize("B,C,H", [(2, 256, 16), (3, 64, 32), (1, 128, 8), (2, 8, 6), (2, 512, 2)])
 @pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res"])
 def test_instance_norm(B, C, H, mode):
