@@ -4,9 +4,10 @@
 // The input projections of all time steps are one library GEMM done by the caller; what is sequential is
 //     gates_t = xproj_t + h_{t-1} W_hh^T ;  c_t = f*c_{t-1} + i*g ;  h_t = o*tanh(c_t)
 // Stock ROCm runs this as two tiny launches per step per direction (a rocBLAS GEMM and a cell kernel, ~11 us).
-// Here one launch per step serves BOTH directions: workgroup (g, d) owns 16 hidden units of direction d, its four
-// waves hold the four gate tiles of v_mfma_f32_16x16x4_f32 ([B x H] . [H x 16], batch rows on M), the cell update is
-// fused behind an LDS exchange, and the kernel boundary is the only synchronisation (no spin barriers).
+// Here one launch per step serves BOTH directions: workgroup (g, d) owns 16 hidden units of direction d and computes
+// their four gate tiles with v_mfma_f32_16x16x4_f32 ([B x H] . [H x 16], batch rows on M; each wave a quarter of the
+// contraction), the cell update is fused behind an LDS exchange, and the kernel boundary is the only synchronisation
+// (no spin barriers).
 //
 // Packed-sequence semantics by masking: sample b is active at step t iff t < len[b].  Inactive positions of out/c are
 // written as zeros, so "previous state" is simply the neighbouring time slot (t-1 forward, t+1 reverse): a reverse
@@ -18,66 +19,102 @@ namespace {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // K-labelling shared by both operands: lane (r = lane & 15, j = lane >> 4) takes k = 16*q + 4*j + i for the i-th MFMA
-// of block q, so that each lane fetches ONE 16-byte vector per block and operand.
-template <int MT>
+// of block q, so that each lane fetches ONE 16-byte vector per block and operand.  Blocks [q0, q1) are processed in
+// chunks whose loads are all issued before the first MFMA (addresses clamped, out-of-range operands zeroed afterwards):
+// a step kernel is a chain of L2 latencies, so what matters is how many loads are in flight, not how many are issued.
+// NB operand sets: acc[n][m] += A[row0 + 16m + r][k] * Bn[k] for NB "B" rows (the four gates in the forward step).
+template <int MT, int NB>
 __device__ __forceinline__ void mfma_rows(const float* __restrict__ a_base, int row0, int a_rows, int a_pitch,
-                                          const float* __restrict__ b_row, bool b_valid, int K, int q0, int q1, f32x4 (&acc)[MT]) {
+                                          const float* const (&b_rows)[NB], bool b_valid, int K, int q0, int q1,
+                                          f32x4 (&acc)[NB][MT]) {
+    constexpr int CH = (MT * NB <= 2) ? 8 : ((MT + NB <= 6) ? 5 : 3);
     const int lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
-    for (int q = q0; q < q1; ++q) {
-        const int k = 16 * q + 4 * j;
-        const bool kin = k < K;           // K % 4 == 0: a vector is entirely inside or outside
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (kin && b_valid) bv = *reinterpret_cast<const f32x4*>(b_row + k);
+    const float* a_row[MT];
+    bool a_ok[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int row = row0 + m * 16 + r;
-            f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (kin && row < a_rows) av = *reinterpret_cast<const f32x4*>(a_base + (size_t)row * a_pitch + k);
+    for (int m = 0; m < MT; ++m) {
+        const int row = row0 + m * 16 + r;
+        a_ok[m] = row < a_rows;
+        a_row[m] = a_base + (size_t)min(row, a_rows - 1) * a_pitch;
+    }
+    for (int qc = q0; qc < q1; qc += CH) {
+        f32x4 av[CH][MT], bv[CH][NB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc[m], 0, 0, 0);
+        for (int u = 0; u < CH; ++u) {
+            const int kc = min(16 * (qc + u) + 4 * j, K - 4);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) bv[u][n] = *reinterpret_cast<const f32x4*>(b_rows[n] + kc);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[u][m] = *reinterpret_cast<const f32x4*>(a_row[m] + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const bool in = (qc + u < q1) && (16 * (qc + u) + 4 * j < K);   // K % 4 == 0: a vector is inside or outside
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const f32x4 b = (in && b_valid) ? bv[u][n] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const f32x4 a = (in && a_ok[m]) ? av[u][m] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc[n][m], 0, 0, 0);
+                }
+            }
         }
     }
 }
 
-// One time step of both directions.  grid (ceil(H/16), dirs), 256 threads.
+// One time step of both directions.  grid (ceil(H/16), dirs, row chunks), 256 threads.  Each wave takes a quarter of the
+// contraction for all four gates (so the whole operand fetch is one round of loads); the partial gate tiles meet in LDS.
 //   xproj [dirs][T][B][4H] (biases included)   w_hh [dirs][4H][H]   lens [B]
 //   out, c [dirs][T][B][H]   gates [dirs][T][B][4H] (activated i,f,g,o; kept for the backward)
 template <int MT>
 __global__ __launch_bounds__(256) void lstm_step_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                      const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ c,
                                                      float* __restrict__ gates, int T, int B, int H, int s) {
-    __shared__ float ex[4][MT * 16][17];
+    __shared__ float ex[4][4][MT * 16][17];                  // [wave][gate][batch row][unit]
     const int d = blockIdx.y, u0 = blockIdx.x * 16, b0 = blockIdx.z * (MT * 16);
     const int t = d == 0 ? s : T - 1 - s;
     const int tp = d == 0 ? t - 1 : t + 1;                 // slot holding the previous state
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
     const size_t dTB = (size_t)d * T * B;
-    const float* h_prev = (tp >= 0 && tp < T) ? out + (dTB + (size_t)tp * B) * H : nullptr;
+    const bool has_prev = tp >= 0 && tp < T;
     const int unit = u0 + r;
-    const float* w_row = w_hh + ((size_t)d * 4 * H + (size_t)wave * H + min(unit, H - 1)) * H;
-    f32x4 acc[MT];
+    f32x4 acc[4][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (h_prev) mfma_rows<MT>(h_prev, b0, B, H, w_row, unit < H, H, 0, (H + 15) / 16, acc);
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_prev) {
+        const float* w0 = w_hh + ((size_t)d * 4 * H + min(unit, H - 1)) * H;
+        const float* const w_rows[4] = {w0, w0 + (size_t)H * H, w0 + (size_t)2 * H * H, w0 + (size_t)3 * H * H};
+        const int nq = (H + 15) / 16, per = (nq + 3) / 4;
+        mfma_rows<MT, 4>(out + (dTB + (size_t)tp * B) * H, b0, B, H, w_rows, unit < H, H, wave * per, min(nq, (wave + 1) * per), acc);
+    }
     // accumulator layout: column = lane & 15 (unit), rows 4*j + i (batch)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[m][i];
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[wave][n][m * 16 + 4 * j + i][r] = acc[n][m][i];
     __syncthreads();
     for (int p = threadIdx.x; p < MT * 256; p += 256) {
-        const int bl = p >> 4, b = b0 + bl, u = u0 + (p & 15);
+        const int bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
         if (b >= B || u >= H) continue;
         const size_t row = dTB + (size_t)t * B + b;
         const bool active = t < lens[b];
         float hv = 0.f, cv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
         if (active) {
             const float* xp = xproj + row * 4 * H + u;
-            gi = sigmoidf_(ex[0][bl][p & 15] + xp[0]);
-            gf = sigmoidf_(ex[1][bl][p & 15] + xp[H]);
-            gg = tanhf(ex[2][bl][p & 15] + xp[2 * H]);
-            go = sigmoidf_(ex[3][bl][p & 15] + xp[3 * H]);
-            const float cp = (tp >= 0 && tp < T) ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
+            const float cp = has_prev ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
+            float pre[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) pre[n] = xp[(size_t)n * H] + ((ex[0][n][bl][ul] + ex[1][n][bl][ul]) + (ex[2][n][bl][ul] + ex[3][n][bl][ul]));
+            gi = sigmoidf_(pre[0]);
+            gf = sigmoidf_(pre[1]);
+            gg = tanhf(pre[2]);
+            go = sigmoidf_(pre[3]);
             cv = gf * cp + gi * gg;
             hv = go * tanhf(cv);
         }
@@ -107,19 +144,19 @@ __global__ __launch_bounds__(256) void lstm_step_bwd(const float* __restrict__ d
     const size_t dTB = (size_t)d * T * B;
     const int unit = u0 + r;
     // dh_rec[b][u] = sum_n dgates[tn][b][n] * W_hh[n][u]: contraction over 4H, split over the four waves
-    f32x4 acc[MT];
+    f32x4 acc[1][MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m) acc[0][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tn >= 0 && tn < T) {
         const int nq = (4 * H + 15) / 16, per = (nq + 3) / 4;
         const float* a = dgates + (dTB + (size_t)tn * B) * 4 * H;
-        const float* w_row = w_hh_t + ((size_t)d * H + min(unit, H - 1)) * 4 * H;
-        mfma_rows<MT>(a, b0, B, 4 * H, w_row, unit < H, 4 * H, wave * per, min(nq, (wave + 1) * per), acc);
+        const float* const w_rows[1] = {w_hh_t + ((size_t)d * H + min(unit, H - 1)) * 4 * H};
+        mfma_rows<MT, 1>(a, b0, B, 4 * H, w_rows, unit < H, 4 * H, wave * per, min(nq, (wave + 1) * per), acc);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[m][i];
+        for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[0][m][i];
     __syncthreads();
     for (int p = threadIdx.x; p < MT * 256; p += 256) {
         const int bl = p >> 4, b = b0 + bl, u = u0 + (p & 15);
