@@ -643,16 +643,33 @@ bool conv_args_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int st
     return true;
 }
 
+// Split of the pixel contraction of the weight gradient into `splits` ranges of `chunk` rows (a multiple of the
+// 32-row slab).  Every workgroup of a launch does the same amount of work, so the launch takes
+// rounds * (slabs per workgroup + prologue/epilogue) where a round is one full set of resident workgroups: the
+// split count is chosen to fill 1..4 rounds EXACTLY rather than to reach a fixed number of workgroups (29 ranges x
+// 36 tiles = 1044 workgroups is two rounds plus a third for the last 20).
 void wgrad_plan(int M, int K, int N, int* splits, int* chunk) {
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-    const int tiles = ((K + 127) / 128) * ((N + bn - 1) / bn);
-    int want = (1024 + tiles - 1) / tiles;
-    if (want < 1) want = 1;
-    int c = (M + want - 1) / want;
-    if (c < 256) c = 256;
-    c = (c + 31) / 32 * 32;
-    *chunk = c;
-    *splits = (M + c - 1) / c;
+    const long resident = bn == 128 ? 2 : (bn == 64 ? 3 : 4);       // workgroups per CU by LDS footprint
+    const long tiles = (long)((K + 127) / 128) * ((N + bn - 1) / bn);
+    const long slots = NUM_CU * resident;
+    const long slabs = (M + 31) / 32;
+    long best_cost = -1, best_c = slabs;
+    for (long r = 1; r <= 4; ++r) {
+        long s = r * slots / tiles;
+        if (s < 1) s = 1;
+        if (s > slabs / 8) s = slabs / 8 > 0 ? slabs / 8 : 1;       // at least 8 slabs per workgroup
+        const long c = (slabs + s - 1) / s;
+        const long s_eff = (slabs + c - 1) / c;
+        const long rounds = (tiles * s_eff + slots - 1) / slots;
+        const long cost = rounds * (c + 3);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_c = c;
+        }
+    }
+    *chunk = (int)best_c * 32;
+    *splits = (int)((slabs + best_c - 1) / best_c);
 }
 
 struct FwdGeom {
