@@ -39,6 +39,7 @@ struct Gather {        // how GEMM row m / column k address the source tensor
     int mul_h, mul_w, kstep, off_h, off_w;  // src_h = oh*mul_h + kh*kstep + off_h (same for w)
     int reflect;       // 1: reflect at the border, 0: zero outside
     int M, K;
+    int tap_t;         // 1: taps enumerated (kw, kh) instead of (kh, kw) — weights prepared from the transposed filter
 };
 
 struct Scatter {       // where GEMM row m lands in the destination tensor
@@ -89,12 +90,13 @@ __device__ __forceinline__ void lds_dma_barrier() {
     __syncthreads();
 }
 
+// One output tile (or, when part_stride != 0, its contribution from K-slabs [kt0, kt1_in)).  `bid`/`nb`: this
+// workgroup's linear tile index and the number of tiles of the launch; (oph, opw): parity class of a stride-2 gradient.
 template <int BM, int BN, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
-                                                             Scatter o, const float* __restrict__ bias, int act, int tiles_n,
-                                                             int kt_per_split, size_t part_stride) {
+__device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __restrict__ wmat, const Scatter& o,
+                                               const float* __restrict__ bias, int act, int tiles_n, int kt0, int kt1_in,
+                                               size_t part_offset, bool partial, int oph, int opw, int bid, int nb) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    DWC_PROBE();
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
     constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
@@ -106,20 +108,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if (nb >= 16) {
-            const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
-            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-        }
+    if (nb >= 16) {     // XCD-aware remap: the 32 CUs of one XCD walk neighbouring tiles
+        const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
     }
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int cls = blockIdx.z;
-    wmat += (size_t)cls * w_class_stride;
-    const int oph = cls >> 1, opw = cls & 1;
-    const int split = blockIdx.y;
 
     const int arow = t >> 3;                              // tile row this lane stages (+32 per pass)
     const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 4;  // LOGICAL k offset fetched into physical chunk t&7
@@ -141,16 +135,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
     for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = wmat + (size_t)min(n0 + arow + 32 * p, o.N - 1) * Kp + acol;
 
     const int nk_all = Kp / BK;
-    const int kt0 = split * kt_per_split;
-    const int kt1 = min(nk_all, kt0 + kt_per_split);
+    const int kt1 = min(nk_all, kt1_in);
     const int n_taps = g.KH * g.KW;
 
     int cur_tap = -1;
     const float* a_src[A_PASSES];     // per-row source of the current tap (zero page when out of bounds)
     const bool tap_uniform = g.SC >= BK;
     auto row_sources = [&](int tap, int ci) {
-        const int kh = (tap * g.kw_magic) >> 16;
-        const int kw = tap - kh * g.KW;
+        int kh = (tap * g.kw_magic) >> 16;
+        int kw = tap - kh * g.KW;
+        if (g.tap_t) {          // square filters only: the same decode gives (kw, kh)
+            const int x = kh;
+            kh = kw;
+            kw = x;
+        }
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             int h = a_bh[i] + kh * g.kstep;
@@ -254,8 +252,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
         }
     }
 
-    const bool partial = part_stride != 0;
-    float* dst = o.dst + (size_t)split * part_stride;
+    float* dst = o.dst + part_offset;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -281,6 +278,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
+                                                             Scatter o, const float* __restrict__ bias, int act, int tiles_n,
+                                                             int kt_per_split, size_t part_stride) {
+    DWC_PROBE();
+    const int cls = blockIdx.z, split = blockIdx.y;
+    conv_gemm_body<BM, BN, WM, WN, TM, TN>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
+                                           (split + 1) * kt_per_split, (size_t)split * part_stride, part_stride != 0, cls >> 1,
+                                           cls & 1, blockIdx.x, gridDim.x);
+}
+
+// Up to four small products with their own geometry, K range and weight matrix in ONE launch (blockIdx.z picks the
+// strip): the border ring of a data gradient, see dwc_conv2d_bwd_data_same.
+struct Strip {
+    Gather g;
+    Scatter o;
+    const float* w;
+    int kt0, kt1, tiles, tiles_n;
+};
+struct StripSet {
+    Strip s[4];
+};
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
+    const Strip& s = ss.s[blockIdx.z];
+    if ((int)blockIdx.x >= s.tiles) return;
+    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, s.kt0, s.kt1, 0, false, 0, 0,
+                                           blockIdx.x, s.tiles);
 }
 
 // dst[i] = act(sum_s part[s][i] + bias[i % N]), fixed summation order
@@ -689,6 +716,7 @@ bool fwd_geom_ex(const float* x, float* y, int B, int H, int W, int Cin, int Cou
     // the furthest gathered index must stay inside the single reflection: i <= 2*(n-1)
     if ((Ho - 1) * sh - ph + KH - 1 > 2 * (H - 1) || (Wo - 1) * sw - pw + KW - 1 > 2 * (W - 1)) return false;
     Gather& g = f->g;
+    g.tap_t = 0;
     g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
     g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
     g.kw_magic = kw_magic_for(KW, KH * KW + 64);
@@ -706,6 +734,7 @@ bool fwd_geom(const float* x, float* y, int B, int H, int W, int Cin, int Cout, 
     if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return false;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     Gather& g = f->g;
+    g.tap_t = 0;
     g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
     g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
     g.kw_magic = kw_magic_for(KW, KH * KW + 64);
@@ -735,6 +764,7 @@ bool bwd_geom(const float* dy, float* dxp, int B, int H, int W, int Cin, int Cou
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     const int Hp = H + 2 * pad, Wp = W + 2 * pad;
     Gather& g = f->g;
+    g.tap_t = 0;
     g.src = dy; g.SH = Ho; g.SW = Wo; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
     g.reflect = 0; g.logOW = g.logOHW = -1;
     f->o.dst = dxp; f->o.N = Cin; f->o.OHf = Hp; f->o.OWf = Wp;
@@ -870,6 +900,135 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
     return DWC_OK;
 }
 
+// dx += the border ring of the padded gradient image, folded back by the reflect rule.  dx already holds the interior;
+// the ring lives in four strips: top/bottom [B][pad][Wp][C], left/right [B][H][pad][C].  One thread per float4 of the
+// bands of dx that receive something (rows 1..pad and H-1-pad..H-2, the same columns).
+__global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict__ top, const float* __restrict__ bottom,
+                                 const float* __restrict__ left, const float* __restrict__ right, int B, int H, int W, int C4,
+                                 int pad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C4;
+    if (idx >= total) return;
+    const int c = idx % C4;
+    size_t r = idx / C4;
+    const int w = r % W;
+    r /= W;
+    const int h = r % H;
+    const int n = r / H;
+    const int Wp = W + 2 * pad;
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    if (nh == 1 && nw == 1) return;                       // interior pixel: nothing folds onto it
+    f32x4 s = reinterpret_cast<const f32x4*>(dx)[idx];
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            if (a == 0 && b == 0) continue;
+            const int rh = hs[a], rw = ws[b];
+            const f32x4* src;
+            if (rh < pad) src = reinterpret_cast<const f32x4*>(top) + ((size_t)(n * pad + rh) * Wp + rw) * C4;
+            else if (rh >= pad + H) src = reinterpret_cast<const f32x4*>(bottom) + ((size_t)(n * pad + rh - pad - H) * Wp + rw) * C4;
+            else if (rw < pad) src = reinterpret_cast<const f32x4*>(left) + ((size_t)(n * H + rh - pad) * pad + rw) * C4;
+            else src = reinterpret_cast<const f32x4*>(right) + ((size_t)(n * H + rh - pad) * pad + rw - pad - W) * C4;
+            s += src[c];
+        }
+    reinterpret_cast<f32x4*>(dx)[idx] = s;
+}
+
+// Data gradient of a stride-1 "same" reflect-padded convolution (2*pad == K-1, square filter) WITHOUT building the whole
+// padded gradient image: the interior is a zero-padded correlation of dY with the flipped filter over the H x W grid
+// (power-of-two geometry, no wasted rows), written straight into dx; the border ring of the padded image -- the only
+// part the reflect adjoint needs besides -- is four thin strips, each restricted to the filter rows (columns) that can
+// reach real dY pixels, computed by one extra launch and folded onto dx.  Ring work is pad*(KH+KW)/(KH*KW) of the
+// 2*pad*(H+W+2*pad)/(H*W) a full padded image would add: 4 % instead of 13 % for 3x3 on 32x32.
+struct SameDgrad {
+    Gather g;
+    Scatter o;
+    StripSet ss;
+    size_t ring_elems[4], dst_elems;
+    int max_tiles;
+};
+
+static bool same_dgrad_geom(const float* dy, const float* w_dg, const float* w_dg_t, float* dx, float* ring, int B, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int pad, SameDgrad* f) {
+    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
+    if (dwc_ilog2_exact(Cout) < 5 || (Cin & 3) || pad <= 0 || KH != KW || 2 * pad != KH - 1) return false;
+    const int Wp = W + 2 * pad;
+    const int magic = kw_magic_for(KW, KH * KW + 64);
+    if (magic < 0) return false;
+    auto base = [&](Gather& g, int OH, int OW, int off_h, int off_w, int tap_t) {
+        g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
+        g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW; g.kw_magic = magic;
+        g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = off_h; g.off_w = off_w; g.reflect = 0;
+        g.M = B * OH * OW; g.K = KH * KW * Cout; g.tap_t = tap_t;
+        g.logOW = dwc_ilog2_exact(OW); g.logOHW = dwc_ilog2_exact(OH * OW);
+        if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
+    };
+    // interior: padded coordinate (i+pad, j+pad) -> source offset -(K-1)+pad = -pad
+    base(f->g, H, W, -pad, -pad, 0);
+    f->o.dst = dx; f->o.N = Cin; f->o.OHf = H; f->o.OWf = W; f->o.os = 1;
+    f->dst_elems = (size_t)B * H * W * Cin;
+    // ring strips (padded coordinates): top rows [0,pad), bottom rows [pad+H, Hp), left/right columns of the rows between
+    const int spt = Cout / BK;                               // K-slabs per filter tap (Cout is a power of two >= 32)
+    const int geo[4][4] = {{pad, Wp, -(KH - 1), -(KW - 1)},
+                           {pad, Wp, -(KH - 1) + pad + H, -(KW - 1)},
+                           {H, pad, -(KH - 1) + pad, -(KW - 1)},
+                           {H, pad, -(KH - 1) + pad, -(KW - 1) + pad + W}};
+    float* p = ring;
+    f->max_tiles = 0;
+    for (int z = 0; z < 4; ++z) {
+        Strip& st = f->ss.s[z];
+        base(st.g, geo[z][0], geo[z][1], geo[z][2], geo[z][3], z >= 2);
+        st.o.dst = p; st.o.N = Cin; st.o.OHf = geo[z][0]; st.o.OWf = geo[z][1]; st.o.os = 1;
+        f->ring_elems[z] = (size_t)st.g.M * Cin;
+        p += f->ring_elems[z];
+        st.w = z < 2 ? w_dg : w_dg_t;
+        // strips 0 / 2 sit before the image: only the LAST pad filter rows (columns) reach real pixels; 1 / 3 the first
+        const int first = (z & 1) ? 0 : KH - pad;
+        st.kt0 = first * KW * spt;
+        st.kt1 = ((z & 1) ? pad : KH) * KW * spt;
+        st.tiles_n = (Cin + 63) / 64;
+        st.tiles = ((st.g.M + 63) / 64) * st.tiles_n;
+        if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
+    }
+    return true;
+}
+
+size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
+    SameDgrad f;
+    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f)) return 0;
+    size_t ring = 0;
+    for (int z = 0; z < 4; ++z) ring += f.ring_elems[z];
+    ring = (ring * sizeof(float) + 255) / 256 * 256;
+    return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
+}
+
+int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    SameDgrad f;
+    if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
+    size_t ring = 0;
+    for (int z = 0; z < 4; ++z) ring += f.ring_elems[z];
+    const size_t ring_bytes = (ring * sizeof(float) + 255) / 256 * 256;
+    if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_gemm(f.g, w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes, ws_bytes - ring_bytes, st);
+    if (rc != DWC_OK) return rc;
+    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 4), dim3(256), 0, st, f.ss);
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)B * H * W * (Cin / 4);
+    const float* r0 = (const float*)ws;
+    hipLaunchKernelGGL(fold_ring_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dx, r0, r0 + f.ring_elems[0],
+                       r0 + f.ring_elems[0] + f.ring_elems[1], r0 + f.ring_elems[0] + f.ring_elems[1] + f.ring_elems[2], B, H, W,
+                       Cin / 4, pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 // Data gradient w.r.t. an NHWC4 IMAGE (stem convolutions, Cin = 4): N = 4 would fill 1/8 of a 32-wide MFMA tile, so
 // 8 horizontally adjacent pixels x 4 channels are produced as 32 columns of a KH x (KW+7), stride-(1,8) filter bank
 // (copy p = the flipped filter shifted right by p taps) applied to dY with the zero rule; the padded gradient image
@@ -879,6 +1038,7 @@ static bool image_dgrad_geom(const float* dy, float* dxp, int B, int H, int W, i
     if (dwc_ilog2_exact(Cout) < 5 || pad >= H || pad >= W) return false;
     const int Hp = H + 2 * pad, Wg = (W + 2 * pad + 7) / 8;
     Gather& g = f->g;
+    g.tap_t = 0;
     g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
     g.OH = Hp; g.OW = Wg; g.KH = KH; g.KW = KW + 7;
     g.kw_magic = kw_magic_for(KW + 7, KH * (KW + 7) + 64);

@@ -148,6 +148,9 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
         return out
     cout, cin, kh, kw = w.shape
     wc = w.detach().contiguous()
+    if kind == "dgrad_t":           # dgrad layout of the filter with its two spatial axes swapped (taps enumerated kw-major)
+        wc = w.detach().transpose(2, 3).contiguous()
+        kind = "dgrad"
     n = lib.dwc_weight_prepared_elems(cout, cin, kh, kw, stride, cout_pad, cin_pad, int(kind == "dgrad"))
     out = torch.empty(n, dtype=torch.float32, device=w.device)
     if kind == "fwd":
@@ -242,6 +245,18 @@ class _Conv2d(torch.autograd.Function):
                 g.data_ptr(), w_img.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
                 scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                 "conv2d_bwd_data_image")
+        elif ctx.needs_input_grad[0] and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
+                and (cop & (cop - 1)) == 0:
+            # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
+            w_dg, w_dg_t = _prepped(w, "dgrad", cop, Cx, 1), _prepped(w, "dgrad_t", cop, Cx, 1)
+            dx = empty_cl(B, Cx, H, W, dev)
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            nws = lib.dwc_conv2d_bwd_data_same_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
+            ws = workspace(nws, dev)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_same(
+                g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
+                ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                "conv2d_bwd_data_same")
         elif ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)

@@ -79,6 +79,16 @@ int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp,
 /* Data gradient, step 2: adjoint of the reflect padding — fold dxp back onto dx:[B,H,W,C]. */
 int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad,
                             void* stream);
+/* Data gradient of a stride-1 "same" convolution (square filter, 2*pad == K-1: the 3x3 ResBlock, 5x5 upsampling and 7x7
+ * head convolutions, reference networks.py:514-515, networks_v2.py:155,159-160) in ONE call, dx:[B,H,W,Cin] final.
+ * The interior of the padded gradient image is computed on the H x W grid straight into dx; of the padding ring only
+ * four thin strips are formed (each restricted to the filter rows/columns that reach real dY pixels) and folded onto
+ * dx by the reflect rule.  w_dgrad: dwc_weight_prepare_dgrad of W; w_dgrad_t: the same of W with its two filter axes
+ * swapped.  Cout (channels of dy) a power of two >= 32. */
+size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
+int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
+                             int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                             void* ws, size_t ws_bytes, void* stream);
 /* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
  * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).
  * 8 adjacent pixels x 4 channels are produced as 32 GEMM columns.  w_wide: dwc_weight_prepare_fwd layout of the bank
