@@ -301,13 +301,16 @@ struct Strip {
 };
 struct StripSet {
     Strip s[4];
+    int kt_per_part;        // the K range of every strip is cut into gridDim.y parts (summed by fold_ring_kernel)
+    size_t part_stride;     // elements between the ring buffers of consecutive parts
 };
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
     const Strip& s = ss.s[blockIdx.z];
     if ((int)blockIdx.x >= s.tiles) return;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, s.kt0, s.kt1, 0, false, 0, 0,
-                                           blockIdx.x, s.tiles);
+    const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
+    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
+                                           blockIdx.y * ss.part_stride, false, 0, 0, blockIdx.x, s.tiles);
 }
 
 // dst[i] = act(sum_s part[s][i] + bias[i % N]), fixed summation order
@@ -901,20 +904,31 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
 }
 
 // dx += the border ring of the padded gradient image, folded back by the reflect rule.  dx already holds the interior;
-// the ring lives in four strips: top/bottom [B][pad][Wp][C], left/right [B][H][pad][C].  One thread per float4 of the
-// bands of dx that receive something (rows 1..pad and H-1-pad..H-2, the same columns).
-__global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict__ top, const float* __restrict__ bottom,
-                                 const float* __restrict__ left, const float* __restrict__ right, int B, int H, int W, int C4,
-                                 int pad) {
+// the ring lives in four strips: top/bottom [B][pad][Wp][C], left/right [B][H][pad][C], `parts` copies `part_stride`
+// apart (partial sums over K, added in order).  Only the bands of dx that receive something are visited: per image
+// 2*pad rows x W pixels (rows 1..pad, H-1-pad..H-2) then 2*pad columns x H pixels (skipping the rows already done).
+__global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict__ ring, size_t off_bottom, size_t off_left,
+                                 size_t off_right, int parts, size_t part_stride, int B, int H, int W, int C4, int pad) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)B * H * W * C4;
+    const int band = 2 * pad * (W + H);
+    const size_t total = (size_t)B * band * C4;
     if (idx >= total) return;
     const int c = idx % C4;
     size_t r = idx / C4;
-    const int w = r % W;
-    r /= W;
-    const int h = r % H;
-    const int n = r / H;
+    const int q = r % band;
+    const int n = r / band;
+    int h, w;
+    if (q < 2 * pad * W) {
+        const int br = q / W;
+        w = q - br * W;
+        h = br < pad ? 1 + br : H - 1 - pad + (br - pad);
+    } else {
+        const int q2 = q - 2 * pad * W, bc = q2 / H;
+        h = q2 - bc * H;
+        w = bc < pad ? 1 + bc : W - 1 - pad + (bc - pad);
+        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;   // covered by the row bands
+    }
+    if (h < 0 || h >= H || w < 0 || w >= W) return;
     const int Wp = W + 2 * pad;
     int hs[3], ws[3], nh = 0, nw = 0;
     hs[nh++] = h + pad;
@@ -923,20 +937,20 @@ __global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict
     ws[nw++] = w + pad;
     if (w >= 1 && w <= pad) ws[nw++] = pad - w;
     if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
-    if (nh == 1 && nw == 1) return;                       // interior pixel: nothing folds onto it
-    f32x4 s = reinterpret_cast<const f32x4*>(dx)[idx];
+    f32x4* out = reinterpret_cast<f32x4*>(dx) + ((size_t)(n * H + h) * W + w) * C4 + c;
+    f32x4 s = *out;
     for (int a = 0; a < nh; ++a)
         for (int b = 0; b < nw; ++b) {
             if (a == 0 && b == 0) continue;
             const int rh = hs[a], rw = ws[b];
-            const f32x4* src;
-            if (rh < pad) src = reinterpret_cast<const f32x4*>(top) + ((size_t)(n * pad + rh) * Wp + rw) * C4;
-            else if (rh >= pad + H) src = reinterpret_cast<const f32x4*>(bottom) + ((size_t)(n * pad + rh - pad - H) * Wp + rw) * C4;
-            else if (rw < pad) src = reinterpret_cast<const f32x4*>(left) + ((size_t)(n * H + rh - pad) * pad + rw) * C4;
-            else src = reinterpret_cast<const f32x4*>(right) + ((size_t)(n * H + rh - pad) * pad + rw - pad - W) * C4;
-            s += src[c];
+            size_t e;   // element offset inside one part's ring
+            if (rh < pad) e = ((size_t)(n * pad + rh) * Wp + rw) * C4;
+            else if (rh >= pad + H) e = off_bottom / 4 + ((size_t)(n * pad + rh - pad - H) * Wp + rw) * C4;
+            else if (rw < pad) e = off_left / 4 + ((size_t)(n * H + rh - pad) * pad + rw) * C4;
+            else e = off_right / 4 + ((size_t)(n * H + rh - pad) * pad + rw - pad - W) * C4;
+            for (int p = 0; p < parts; ++p) s += reinterpret_cast<const f32x4*>(ring + p * part_stride)[e + c];
         }
-    reinterpret_cast<f32x4*>(dx)[idx] = s;
+    *out = s;
 }
 
 // Data gradient of a stride-1 "same" reflect-padded convolution (2*pad == K-1, square filter) WITHOUT building the whole
@@ -949,14 +963,15 @@ struct SameDgrad {
     Gather g;
     Scatter o;
     StripSet ss;
-    size_t ring_elems[4], dst_elems;
-    int max_tiles;
+    size_t ring_elems[4], ring_total, dst_elems;
+    int max_tiles, parts;
 };
 
 static bool same_dgrad_geom(const float* dy, const float* w_dg, const float* w_dg_t, float* dx, float* ring, int B, int H, int W,
                             int Cin, int Cout, int KH, int KW, int pad, SameDgrad* f) {
     if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
     if (dwc_ilog2_exact(Cout) < 5 || (Cin & 3) || pad <= 0 || KH != KW || 2 * pad != KH - 1) return false;
+    if (H < 2 * pad + 2 || W < 2 * pad + 2) return false;    // the two border bands of an axis must not overlap
     const int Wp = W + 2 * pad;
     const int magic = kw_magic_for(KW, KH * KW + 64);
     if (magic < 0) return false;
@@ -995,15 +1010,20 @@ static bool same_dgrad_geom(const float* dy, const float* w_dg, const float* w_d
         st.tiles = ((st.g.M + 63) / 64) * st.tiles_n;
         if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
     }
+    f->ring_total = (size_t)(p - ring);
+    // every strip contracts over pad filter rows (columns): cut that range into parts of >= 8 slabs so that the launch
+    // has enough workgroups in flight to hide the load latency of these short K loops
+    const int range = pad * KW * spt;
+    f->parts = range >= 32 ? 4 : (range >= 24 ? 3 : (range >= 16 ? 2 : 1));
+    f->ss.kt_per_part = (range + f->parts - 1) / f->parts;
+    f->ss.part_stride = f->ring_total;
     return true;
 }
 
 size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
     if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f)) return 0;
-    size_t ring = 0;
-    for (int z = 0; z < 4; ++z) ring += f.ring_elems[z];
-    ring = (ring * sizeof(float) + 255) / 256 * 256;
+    const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
 
@@ -1011,20 +1031,17 @@ int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float*
                              int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
     SameDgrad f;
     if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
-    size_t ring = 0;
-    for (int z = 0; z < 4; ++z) ring += f.ring_elems[z];
-    const size_t ring_bytes = (ring * sizeof(float) + 255) / 256 * 256;
+    const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_gemm(f.g, w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes, ws_bytes - ring_bytes, st);
     if (rc != DWC_OK) return rc;
-    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 4), dim3(256), 0, st, f.ss);
+    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
-    const size_t total = (size_t)B * H * W * (Cin / 4);
-    const float* r0 = (const float*)ws;
-    hipLaunchKernelGGL(fold_ring_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dx, r0, r0 + f.ring_elems[0],
-                       r0 + f.ring_elems[0] + f.ring_elems[1], r0 + f.ring_elems[0] + f.ring_elems[1] + f.ring_elems[2], B, H, W,
-                       Cin / 4, pad);
+    const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
+    hipLaunchKernelGGL(fold_ring_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dx, (const float*)ws, f.ring_elems[0],
+                       f.ring_elems[0] + f.ring_elems[1], f.ring_elems[0] + f.ring_elems[1] + f.ring_elems[2], f.parts,
+                       f.ring_total, B, H, W, Cin / 4, pad);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

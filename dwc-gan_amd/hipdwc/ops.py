@@ -246,7 +246,7 @@ class _Conv2d(torch.autograd.Function):
                 scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                 "conv2d_bwd_data_image")
         elif ctx.needs_input_grad[0] and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
-                and (cop & (cop - 1)) == 0:
+                and (cop & (cop - 1)) == 0 and min(H, W) >= 2 * pad + 2:
             # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
             w_dg, w_dg_t = _prepped(w, "dgrad", cop, Cx, 1), _prepped(w, "dgrad_t", cop, Cx, 1)
             dx = empty_cl(B, Cx, H, W, dev)

@@ -58,9 +58,8 @@ class StyleEncoder(nn.Module):
         b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
         out = ops.linear(f, w, b)
         k, c = self.num_class, self.c_dim
-        mus = [out[:, i * c:(i + 1) * c] for i in range(k)]
-        lvs = [out[:, (k + i) * c:(k + i + 1) * c] for i in range(k)]
-        return mus, lvs
+        heads = out[:, :2 * k * c].reshape(out.shape[0], 2 * k, c).unbind(1)   # one autograd node instead of 2k slices
+        return list(heads[:k]), list(heads[k:])
 
 
 def _packed_index(lens_sorted, t_max, bsz, device):
@@ -155,9 +154,8 @@ class TxtEncoder(nn.Module):
         b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
         out = torch.nn.functional.linear(feat, w, b)
         k, c = self.num_class, self.style_dim // self.num_class
-        mus = [out[:, i * c:(i + 1) * c] for i in range(k)]
-        lvs = [out[:, (k + i) * c:(k + i + 1) * c] for i in range(k)]
-        return mus, lvs
+        heads = out.reshape(bsz, 2 * k, c).unbind(1)
+        return list(heads[:k]), list(heads[k:])
 
 
 class AdaINGen_v2(nn.Module):
@@ -212,13 +210,22 @@ class AdaINGen_v2(nn.Module):
     def assign_adain_params(self, adain_params, model):
         """Hand each AdaIN layer, in module order, its slice of the MLP output: first C columns ->
         bias (shift), next C -> weight (scale), both flattened to B*C (reference networks_v2.py:78-87)."""
+        layers = [m for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d"]
+        widths = {m.num_features for m in layers}
+        if len(widths) == 1 and adain_params.shape[1] >= 2 * len(layers) * layers[0].num_features:
+            # equal widths (the shipped decoder): ONE transposing copy [B, L*2, C] -> [L*2, B*C] whose rows are the
+            # flattened per-layer vectors, handed out by unbind (one autograd node instead of 2L slices + 2L clones)
+            c, n = layers[0].num_features, 2 * len(layers)
+            rows = adain_params[:, :n * c].reshape(adain_params.shape[0], n, c).transpose(0, 1).reshape(n, -1).unbind(0)
+            for i, m in enumerate(layers):
+                m.bias, m.weight = rows[2 * i], rows[2 * i + 1]
+            return
         col = 0
-        for m in model.modules():
-            if m.__class__.__name__ == "AdaptiveInstanceNorm2d":
-                c = m.num_features
-                m.bias = adain_params[:, col:col + c].contiguous().view(-1)
-                m.weight = adain_params[:, col + c:col + 2 * c].contiguous().view(-1)
-                col += 2 * c
+        for m in layers:
+            c = m.num_features
+            m.bias = adain_params[:, col:col + c].contiguous().view(-1)
+            m.weight = adain_params[:, col + c:col + 2 * c].contiguous().view(-1)
+            col += 2 * c
 
     def get_num_adain_params(self, model):
         return sum(2 * m.num_features for m in model.modules() if m.__class__.__name__ == "AdaptiveInstanceNorm2d")
