@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-gpu-batch", type=int, default=PER_GPU_BATCH,
                     help="development knob; the contract workload (and the default) is 16")
+    ap.add_argument("--vgg-w", type=float, default=0.0,
+                    help="development knob: perceptual-loss weight (the reference's shipped default is 0.1) with a RANDOMLY "
+                         "initialised VGG16 (the trained weights cannot be fetched here); the contract workload is 0")
     args = ap.parse_args()
 
     per_gpu_batch = args.per_gpu_batch
@@ -91,6 +94,14 @@ def main():
 
     from solver import Solver
     cfg = synth.make_config(image_size=IMAGE_SIZE)           # shipped config, vgg_w = 0 (weights not obtainable offline)
+    if args.vgg_w > 0:
+        import tempfile
+        from networks.networks import Vgg16
+        vgg_dir = tempfile.mkdtemp(prefix="dwc_vgg_%d_" % rank)
+        os.makedirs(os.path.join(vgg_dir, "models"))
+        torch.manual_seed(777)
+        torch.save(Vgg16().state_dict(), os.path.join(vgg_dir, "models", "vgg16.weight"))
+        cfg["vgg_w"], cfg["vgg_model_path"] = args.vgg_w, vgg_dir
     torch.manual_seed(1234)                                  # same seed on every rank: identical initial weights
     import io
     import contextlib
@@ -175,7 +186,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CelebA-shaped 128x128, per-GPU batch 16, fp32, full iteration "
-                                   "(dis_update + gen_update + EMA + LR step), vgg_w=0",
+                                   "(dis_update + gen_update + EMA + LR step), vgg_w=%g" % args.vgg_w,
                        "image_size": IMAGE_SIZE, "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world,
                        "parallelism": "dp%d" % world},
             "whole_step_tflops": round(ALGO_GFLOP_PER_IMAGE * value / 1e3, 2),

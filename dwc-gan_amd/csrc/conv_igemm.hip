@@ -838,6 +838,49 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// Zero-padded convolutions (the frozen VGG16 of the perceptual loss, reference networks.py:639-688: nn.Conv2d(padding=1)):
+// the forward kernel with the zero rule instead of the reflect rule, and as data gradient the zero-padded correlation
+// with the flipped filter on the H x W grid (the adjoint of zero padding is a crop: nothing to fold).
+int dwc_conv2d_fwd_zeropad(const float* x, const float* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
+    f.g.reflect = 0;
+    return launch_gemm(f.g, w_prepared, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+static bool zeropad_dgrad_geom(const float* dy, float* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                               FwdGeom* f) {
+    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
+    if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3) || KH != KW || 2 * pad != KH - 1) return false;
+    Gather& g = f->g;
+    g.tap_t = 0;
+    g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
+    g.OH = H; g.OW = W; g.KH = KH; g.KW = KW;
+    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
+    if (g.kw_magic < 0) return false;
+    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 0;
+    g.M = B * H * W; g.K = KH * KW * Cout;
+    g.logOW = dwc_ilog2_exact(W); g.logOHW = dwc_ilog2_exact(H * W);
+    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
+    f->o.dst = dx; f->o.N = Cin; f->o.OHf = H; f->o.OWf = W; f->o.os = 1;
+    f->dst_elems = (size_t)g.M * Cin;
+    return true;
+}
+
+size_t dwc_conv2d_bwd_data_zeropad_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
+    FwdGeom f;
+    if (!zeropad_dgrad_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f)) return 0;
+    return gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
+}
+
+int dwc_conv2d_bwd_data_zeropad(const float* dy, const float* w_dgrad, float* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!zeropad_dgrad_geom(dy, dx, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
+    return launch_gemm(f.g, w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
 // forward / weight gradient with per-axis stride and reflect pad (no scratch on the forward: never split)
 int dwc_conv2d_fwd_ex(const float* x, const float* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin,
                       int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream) {

@@ -180,6 +180,65 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
     }
 }
 
+// ---- 2x2 max pooling (VGG16, reference networks.py:666,671,677) --------------------------------------
+// Ties go to the first element in window scan order, as torch's max_pool2d does (after a ReLU all-zero windows tie).
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+                                                           size_t total4) {
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;
+        size_t r = i / cq;
+        const int ox = r % Wo;
+        r /= Wo;
+        const int oy = r % Ho;
+        const size_t n = r / Ho;
+        const size_t b = (n * H + 2 * oy) * W + 2 * ox;
+        const f32x4 v0 = xs[b * cq + c], v1 = xs[(b + 1) * cq + c], v2 = xs[(b + W) * cq + c], v3 = xs[(b + W + 1) * cq + c];
+        f32x4 m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
+        reinterpret_cast<f32x4*>(y)[i] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int H, int W, int cq, size_t total4) {
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
+    f32x4* out = reinterpret_cast<f32x4*>(dx);
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % cq;               // one thread per pooled element: it owns its whole 2x2 window of dx
+        size_t r = i / cq;
+        const int ox = r % Wo;
+        r /= Wo;
+        const int oy = r % Ho;
+        const size_t n = r / Ho;
+        const size_t b = (n * H + 2 * oy) * W + 2 * ox;
+        const size_t at[4] = {b * cq + c, (b + 1) * cq + c, (b + W) * cq + c, (b + W + 1) * cq + c};
+        f32x4 v[4], g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = xs[at[j]];
+            g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4 d = ds[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int best = 0;
+#pragma unroll
+            for (int j = 1; j < 4; ++j)
+                if (v[j][k] > v[best][k]) best = j;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == best) g[j][k] = d[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[at[j]] = g[j];
+    }
+}
+
 // ---- image boundary ----------------------------------------------------------------------------
 __global__ void pack_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pixel index over B*HW
@@ -379,6 +438,23 @@ int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, voi
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C / 4,
+                       total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

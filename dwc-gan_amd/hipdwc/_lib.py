@@ -29,6 +29,11 @@ SIGNATURES = {
     "dwc_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_bwd_data_image_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_conv2d_bwd_data_image": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_bwd_data_zeropad_ws_bytes": (c_sz, [c_int] * 8),
+    "dwc_conv2d_bwd_data_zeropad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_maxpool2_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_maxpool2_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_fwd_ex": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 12 + [c_fp]),

@@ -118,3 +118,26 @@ def moving_average(model, model_copy, beta=0.999):
     else:
         for s, d in zip(src, dst):
             d.copy_(torch.lerp(s, d, beta))
+
+
+def load_vgg16(model_dir):
+    """Reference utils.py:180-193 without the download: loads <model_dir>/vgg16.weight (the state_dict the reference
+    caches there after converting the Torch7 file).  There is no network on the training boxes this targets, so a
+    missing file is an error, not a fetch."""
+    import os
+    from networks.networks import Vgg16
+    path = os.path.join(model_dir, "vgg16.weight")
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s not found: place the reference's converted VGG16 state_dict there "
+                                "(reference utils.py:186-190 produces it), or run with vgg_w: 0" % path)
+    vgg = Vgg16()
+    vgg.load_state_dict(torch.load(path, map_location="cpu"))
+    return vgg
+
+
+def vgg_preprocess(batch):
+    """Reference utils.py:207-217: RGB -> BGR, [-1, 1] -> [0, 255], subtract the ImageNet BGR means."""
+    r, g, b = torch.chunk(batch[:, :3], 3, dim=1)
+    out = (torch.cat((b, g, r), dim=1) + 1) * 255 * 0.5
+    mean = torch.tensor([103.939, 116.779, 123.680], dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
+    return out - mean

@@ -365,6 +365,97 @@ def conv2d_heads(x, w4, b4):
     return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads"])
 
 
+class _Conv2dZeroPad(torch.autograd.Function):
+    """relu?(conv(zero_pad(x)) + b) with FROZEN weights (the VGG16 of the perceptual loss, reference
+    networks.py:639-688): forward and data gradient only."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, pad, act):
+        _require_device(x)
+        if w.requires_grad or (b is not None and b.requires_grad):
+            raise NotImplementedError("zero-padded convolutions are built for frozen weights (no weight gradient)")
+        lib = _lib.load()
+        x = cl(x)
+        B, Cx, H, W = x.shape
+        Cout, Cin, KH, KW = w.shape
+        if Cin > Cx:
+            raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
+        cop = _pad4(Cout)
+        w_prep = _prepped(w, "fwd", cop, Cx, 1)
+        bias = None
+        if b is not None:
+            bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
+        y = empty_cl(B, cop, H, W, x.device)
+        st = _stream()
+        nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, 1, pad)
+        wsp = workspace(nws, x.device).data_ptr() if nws else None
+        flops = 2.0 * B * H * W * Cout * Cin * KH * KW
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_zeropad(
+            x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, 1, pad, act, wsp, nws, st),
+            detail="fwd-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_fwd_zeropad")
+        ctx.save_for_backward(w, y if act != 0 else None)
+        ctx.geom = (B, H, W, Cx, cop, KH, KW, pad, act, Cin, Cout)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        w, y = ctx.saved_tensors
+        B, H, W, Cx, cop, KH, KW, pad, act, Cin, Cout = ctx.geom
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        dy = cl(dy)
+        dev, st, rows = dy.device, _stream(), B * H * W
+        g = dy
+        if act != 0:
+            g = empty_cl(B, cop, H, W, dev)
+            ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, cop), dev)
+            _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), None, rows, cop, act, ws.data_ptr(),
+                                            ws.numel(), st), "act_bwd_bias")
+        w_dg = _prepped(w, "dgrad", cop, Cx, 1)
+        dx = empty_cl(B, Cx, H, W, dev)
+        nws = lib.dwc_conv2d_bwd_data_zeropad_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
+        wsp = workspace(nws, dev).data_ptr() if nws else None
+        flops = 2.0 * rows * Cout * Cin * KH * KW
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_zeropad(
+            g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, wsp, nws, st),
+            detail="dgrad-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_bwd_data_zeropad")
+        return dx, None, None, None, None
+
+
+def conv2d_zeropad(x, w, b, pad, act="none"):
+    """Zero-padded stride-1 convolution + bias + activation with frozen weights."""
+    y = _Conv2dZeroPad.apply(x, w, b, int(pad), ACT[act])
+    return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_device(x)
+        lib = _lib.load()
+        x = cl(x)
+        B, C, H, W = x.shape
+        y = empty_cl(B, C, H // 2, W // 2, x.device)
+        _lib.check(lib.dwc_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        B, C, H, W = x.shape
+        dx = empty_cl(B, C, H, W, x.device)
+        _lib.check(lib.dwc_maxpool2_bwd(x.data_ptr(), cl(dy).data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "maxpool2_bwd")
+        return dx
+
+
+def max_pool2(x):
+    """F.max_pool2d(x, kernel_size=2, stride=2) (even H, W; C % 4 == 0)."""
+    return _MaxPool2.apply(x)
+
+
 def linear(x, w, b, act="none"):
     """nn.Linear (+ReLU) as a 1x1 convolution over a 1x1 image (reference networks.py:587-634).
     Input width must be a power of two >= 4."""

@@ -334,3 +334,27 @@ class MsImageDis(nn.Module):
     def calc_gen_loss(self, input_fake, target_cls, weight_gan=1.0, weight_cls=1.0):
         """G-side adversarial objective (reference networks.py:148-170)."""
         return self.gen_loss_terms(self.forward(input_fake), target_cls, weight_gan, weight_cls)
+
+
+class Vgg16(nn.Module):
+    """The frozen VGG16 trunk of the perceptual loss (reference networks.py:639-688): thirteen zero-padded 3x3
+    convolutions + ReLU, 2x2 max pooling after blocks 1-3, output relu5_3.  Same attribute names and state_dict keys
+    (conv1_1.weight ... conv5_3.bias); the nn.Conv2d objects are parameter containers."""
+
+    CFG = ((1, 3, 64, 2), (2, 64, 128, 2), (3, 128, 256, 3), (4, 256, 512, 3), (5, 512, 512, 3))
+
+    def __init__(self):
+        super().__init__()
+        for blk, cin, cout, n in self.CFG:
+            for i in range(n):
+                setattr(self, "conv%d_%d" % (blk, i + 1), nn.Conv2d(cin if i == 0 else cout, cout, kernel_size=3, stride=1, padding=1))
+
+    def forward(self, X):
+        h = ops.pack_image(X) if X.shape[1] < 4 else X
+        for blk, _, _, n in self.CFG:
+            for i in range(n):
+                conv = getattr(self, "conv%d_%d" % (blk, i + 1))
+                h = ops.conv2d_zeropad(h, conv.weight, conv.bias, 1, "relu")
+            if blk <= 3:
+                h = ops.max_pool2(h)
+        return h

@@ -91,10 +91,13 @@ class Solver(nn.Module):
         self.dis.apply(weights_init("gaussian"))       # ... then D again (reference solver.py:73-74)
         self.criterionL1 = torch.nn.L1Loss()
 
-        if configs.get("vgg_w", 0) > 0:
-            raise NotImplementedError(
-                "vgg_w > 0 needs the VGG16 perceptual network (reference solver.py:79-83), which is outside the "
-                "hot path built here (SURVEY.md section 8(f)); run with vgg_w: 0")
+        if configs.get("vgg_w", 0) > 0:                 # reference solver.py:79-83
+            from hipdwc.host import load_vgg16
+            self.vgg = load_vgg16(configs["vgg_model_path"] + "/models")
+            self.vgg = self.vgg.to(device) if device is not None else self.vgg
+            self.vgg.eval()
+            for param in self.vgg.parameters():
+                param.requires_grad = False
 
     # ---- bookkeeping -----------------------------------------------------------------------
     def print_network(self, model, name):
@@ -138,6 +141,14 @@ class Solver(nn.Module):
         if x.dim() == 4:
             return ops.l1_mean(x, y)
         return torch.mean(torch.abs(x - y))
+
+    def compute_vgg_loss(self, vgg, img, target):
+        """mean((IN(vgg(img)) - IN(vgg(target)))^2) on relu5_3 (reference solver.py:242-247).  Images may be NCHW
+        3-channel or the internal NHWC4 form (plane 3 ignored)."""
+        from hipdwc.host import vgg_preprocess
+        img_fea = vgg(vgg_preprocess(img))
+        target_fea = vgg(vgg_preprocess(target))
+        return torch.mean((ops.instance_norm(img_fea) - ops.instance_norm(target_fea)) ** 2)
 
     def criterion_l1(self, a, z):
         a = torch.cat(a, dim=1) if isinstance(a, (list, tuple)) else a
@@ -245,6 +256,8 @@ class Solver(nn.Module):
                 self.loss_kl_x = gmm_earth_mover_distance_sp(style_real, c_src)
                 self.loss_kl_trg = gmm_earth_mover_distance_sp(style_txt, c_trg)
             self.loss_gen_vgg = 0
+            if cyc and cfg["vgg_w"] > 0:                 # reference solver.py:221-223
+                self.loss_gen_vgg = self.compute_vgg_loss(self.vgg, x4, x_cycle)
 
             self.loss_gen_total = self.loss_gen_adv + \
                 cfg["recon_x_w"] * self.loss_gen_recon_x + \

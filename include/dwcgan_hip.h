@@ -157,6 +157,21 @@ int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, voi
 int dwc_pack_nchw_to_nhwc4(const float* x_nchw, float* y_nhwc4, int B, int C, int H, int W, void* stream);
 int dwc_unpack_nhwc4_to_nchw(const float* x_nhwc4, float* y_nchw, int B, int C, int H, int W, void* stream);
 
+/* ---- VGG16 perceptual loss (reference networks.py:639-688 Vgg16, solver.py:242-247 compute_vgg_loss): frozen 3x3
+ *      convolutions with ZERO padding (nn.Conv2d(padding=1)) + ReLU and 2x2 max pooling.  The weights are frozen, so only
+ *      the forward and the data gradient exist; instance norm of the features is dwc_instnorm_*. ---- */
+int dwc_conv2d_fwd_zeropad(const float* x, const float* w_prepared, const float* bias, float* y,
+                           int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                           int act, void* ws, size_t ws_bytes, void* stream);
+/* dx:[B,H,W,Cin] from dy:[B,H,W,Cout] (stride 1, 2*pad == K-1); w_dgrad as for dwc_conv2d_bwd_data. */
+size_t dwc_conv2d_bwd_data_zeropad_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
+int dwc_conv2d_bwd_data_zeropad(const float* dy, const float* w_dgrad, float* dx,
+                                int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                                void* ws, size_t ws_bytes, void* stream);
+/* F.max_pool2d(x, 2, 2) on NHWC (reference networks.py:666,671,677); ties to the first element in scan order. */
+int dwc_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int dwc_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+
 /* ---- attention blend (reference solver.py:148,161,170,179-180,192,330-331):
  *      out[...,0:3] = img*att + real*(1-att) on NHWC4 images (att = channel 3 of `heads`) ------ */
 int dwc_blend_fwd(const float* heads, const float* real, float* out, int npix, void* stream);

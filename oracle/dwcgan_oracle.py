@@ -364,6 +364,36 @@ def l1_mean(a, b):
 # --------------------------------------------------------------------------------------
 # optimiser bookkeeping restated
 # --------------------------------------------------------------------------------------
+# ---- VGG16 perceptual loss (reference networks.py:639-688, solver.py:242-247, utils.py:207-217) -----------------------
+VGG_CFG = ((1, 2), (2, 2), (3, 3), (4, 3), (5, 3))       # (block, number of 3x3 convs); 2x2 max pool after blocks 1-3
+
+
+def vgg_preprocess(batch):
+    """RGB -> BGR, [-1, 1] -> [0, 255], subtract the ImageNet BGR means (reference utils.py:207-217)."""
+    r, g, b = torch.chunk(batch, 3, dim=1)
+    out = (torch.cat((b, g, r), dim=1) + 1) * 255 * 0.5
+    return out - torch.tensor([103.939, 116.779, 123.680], dtype=out.dtype).view(1, 3, 1, 1)
+
+
+def vgg16_relu5_3(sd, x):
+    """sd: state_dict with conv{b}_{i}.weight/.bias (reference networks.py:642-659); zero padding 1, ReLU after every
+    conv, max pooling after blocks 1-3 (reference networks.py:661-686)."""
+    h = x
+    for blk, n in VGG_CFG:
+        for i in range(n):
+            h = F.relu(F.conv2d(h, sd["conv%d_%d.weight" % (blk, i + 1)], sd["conv%d_%d.bias" % (blk, i + 1)], padding=1))
+        if blk <= 3:
+            h = F.max_pool2d(h, kernel_size=2, stride=2)
+    return h
+
+
+def vgg_loss(sd, img, target):
+    """reference solver.py:242-247 with nn.InstanceNorm2d(512, affine=False) (solver.py:56)."""
+    a = F.instance_norm(vgg16_relu5_3(sd, vgg_preprocess(img)), eps=1e-5)
+    b = F.instance_norm(vgg16_relu5_3(sd, vgg_preprocess(target)), eps=1e-5)
+    return torch.mean((a - b) ** 2)
+
+
 class AdamState:
     """torch.optim.Adam as the reference configures it (reference solver.py:62-68): coupled L2
     weight decay added to the gradient, bias-corrected moments, eps outside the sqrt.
@@ -399,8 +429,9 @@ class OracleSolver:
     state_dicts (buffers such as the AdaIN running stats are accepted and ignored).
     """
 
-    def __init__(self, cfg, gen_params, dis_params, noise=None, as_written=False):
+    def __init__(self, cfg, gen_params, dis_params, noise=None, as_written=False, vgg_params=None):
         self.cfg = cfg
+        self.vgg = vgg_params          # frozen Vgg16 state_dict; needed when cfg["vgg_w"] > 0 (reference solver.py:79-83)
         self.noise = noise or GlobalCpuNoise()
         self.as_written = as_written   # True: back-propagate everything like .backward() does
         keep = lambda k: "running_" not in k
@@ -509,7 +540,9 @@ class OracleSolver:
         else:
             L["loss_kl_x"] = gmm_em_sp(s_real, c_src)
             L["loss_kl_trg"] = gmm_em_sp(s_txt, c_trg)
-        L["loss_gen_vgg"] = 0.0                               # vgg_w = 0 on every parity config
+        L["loss_gen_vgg"] = 0.0
+        if cfg["recon_x_cyc_w"] > 0 and cfg["vgg_w"] > 0:       # reference solver.py:221-223
+            L["loss_gen_vgg"] = vgg_loss(self.vgg, x_real, x_cyc)
         total = L["loss_gen_adv"] + \
             cfg["recon_x_w"] * L["loss_gen_recon_x"] + \
             cfg["recon_c_w"] * L["loss_gen_recon_c_real"] + \

@@ -9,6 +9,7 @@ synthetic inputs, and their numeric outputs recorded.
     python tests/golden/make_golden.py ops tiny init      # seconds
     python tests/golden/make_golden.py traj64             # ~5 min
     python tests/golden/make_golden.py traj128            # ~50 min (S=128, B=16, 100 steps)
+    python tests/golden/make_golden.py vgg                # seconds (perceptual loss, seeded random VGG16)
 
 The reference's ``utils.py`` imports torchvision/torchfile at module top
 (reference utils.py:23-29) although the training step never uses them; both are
@@ -312,6 +313,37 @@ def gen_traj(ref_solver, S, B, steps, lstm_dropout, tag, threads=None):
                            "threads": torch.get_num_threads(), "rows": rows}, f)
 
 
+def gen_vgg(ref_solver, ref_nets):
+    """compute_vgg_loss of the reference (solver.py:242-247) on a seeded, randomly initialised Vgg16 (the trained
+    weights cannot be fetched here): loss, gradient w.r.t. the target image, relu5_3 features of the first image.
+    The 59 MB of weights are not stored: both sides rebuild them from the seed; per-tensor checksums confirm it."""
+    torch.manual_seed(777)
+    vgg = ref_nets.Vgg16()
+    vgg.eval()
+    for prm in vgg.parameters():
+        prm.requires_grad = False
+    cfg = synth.make_config(image_size=64)
+    trainer = build_ref_solver(ref_solver, cfg)           # only for its compute_vgg_loss method / instancenorm
+    g = torch.Generator().manual_seed(778)
+    out = {}
+    for S, B in ((32, 2), (64, 1)):
+        img = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+        target = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).requires_grad_(True)
+        loss = trainer.compute_vgg_loss(vgg, img, target)
+        loss.backward()
+        with torch.no_grad():
+            fea = vgg(ref_solver.vgg_preprocess(img, torch.device("cpu")))
+        tag = "s%d" % S
+        out[tag + "_img"], out[tag + "_target"] = t2n(img), t2n(target)
+        out[tag + "_loss"] = np.float64(loss.item())
+        out[tag + "_dtarget"] = t2n(target.grad)
+        out[tag + "_fea"] = t2n(fea)
+    np.savez_compressed(os.path.join(HERE, "vgg_loss.npz"), **out)
+    with open(os.path.join(HERE, "vgg_init_checksums.json"), "w") as f:
+        json.dump({"seed": 777, "torch": torch.__version__, "tensors": {k: checksum(v) for k, v in vgg.state_dict().items()}}, f)
+    print("vgg_loss.npz written:", {k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "tiny", "init"]
     ref_solver, ref_nets, ref_v2, ref_gmm, ref_tools = import_reference()
@@ -321,6 +353,8 @@ if __name__ == "__main__":
         gen_tiny(ref_solver)
     if "init" in what:
         gen_init_checksums(ref_solver)
+    if "vgg" in what:
+        gen_vgg(ref_solver, ref_nets)
     if "traj64" in what:
         gen_traj(ref_solver, 64, 4, 100, None, "s64_b4_default")
         gen_traj(ref_solver, 64, 4, 100, 0.0, "s64_b4_nolstmdrop")

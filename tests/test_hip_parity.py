@@ -504,3 +504,90 @@ def test_tiny_dis_gradients_vs_reference(tiny, golden_dir):
             close(g, T(ref[k]), rel=2e-3, msg=k)
     finally:
         host.set_noise(host.DeviceNoise())
+
+
+# ---- VGG16 perceptual loss (reference networks.py:639-688, solver.py:242-247) ----------
+@pytest.mark.parametrize("B,C,H", [(2, 64, 16), (1, 8, 6), (3, 4, 10)])
+def test_max_pool2_and_zeropad_conv(B, C, H):
+    g = torch.Generator().manual_seed(B + C + H)
+    x = torch.randn(B, C, H, H, generator=g)
+    x[:, :, :2, :2] = 0.0                                  # a tied (all-zero) window: gradient goes to its first element
+    w, b = torch.randn(16, C, 3, 3, generator=g) * 0.2, torch.randn(16, generator=g) * 0.1
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(xr, w, b, padding=1)), 2, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd = dev(x, True)
+    yd = ops.max_pool2(ops.conv2d_zeropad(xd, dev(w), dev(b), 1, "relu"))
+    close(yd, yr, msg="y")
+    (yd * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, rel=5e-5, msg="dx")
+    p = torch.randn(B, C, H, H, generator=g)
+    pr = p.clone().requires_grad_(True)
+    qr = torch.nn.functional.max_pool2d(pr, 2, 2)
+    gq = torch.randn(qr.shape, generator=g)
+    (qr * gq).sum().backward()
+    pd = dev(p, True)
+    qd = ops.max_pool2(pd)
+    assert torch.equal(qd.cpu(), qr.detach())
+    (qd * gq.to(DEV)).sum().backward()
+    assert torch.equal(pd.grad.cpu(), pr.grad)
+
+
+@pytest.mark.parametrize("tag", ["s32", "s64"])
+def test_vgg_perceptual_loss_vs_reference(golden_dir, tag):
+    """Solver.compute_vgg_loss on the seeded random Vgg16 against the values recorded from the reference."""
+    from networks.networks import Vgg16
+    from solver import Solver
+    z = np.load(os.path.join(golden_dir, "vgg_loss.npz"))
+    torch.manual_seed(777)
+    vgg = Vgg16().to(DEV).eval()
+    for prm in vgg.parameters():
+        prm.requires_grad = False
+    img, target = dev(torch.from_numpy(z[tag + "_img"])), dev(torch.from_numpy(z[tag + "_target"]), True)
+    with torch.no_grad():
+        from hipdwc.host import vgg_preprocess
+        fea = vgg(vgg_preprocess(img))
+    close(fea, torch.from_numpy(z[tag + "_fea"]), rel=2e-5, msg="relu5_3")
+    loss = Solver.compute_vgg_loss(None, vgg, img, target)
+    assert float(loss.detach()) == pytest.approx(float(z[tag + "_loss"]), rel=2e-3)
+    loss.backward()
+    close(target.grad, torch.from_numpy(z[tag + "_dtarget"]), rel=5e-3, atol=1e-9, msg="d loss / d target")
+
+
+def test_iteration_with_vgg_loss_vs_oracle(tmp_path):
+    """vgg_w > 0 (the shipped config's default): Solver loads <vgg_model_path>/models/vgg16.weight like the reference
+    (utils.py:180-193, minus the download) and adds the perceptual term; one tiny-configuration iteration against
+    the oracle, loss scalars and a generator gradient."""
+    from networks.networks import Vgg16
+    from solver import Solver
+    torch.manual_seed(777)
+    vgg_sd = Vgg16().state_dict()
+    os.makedirs(tmp_path / "models")
+    torch.save(vgg_sd, tmp_path / "models" / "vgg16.weight")
+    cfg = synth.make_config(image_size=32, tiny=True, lstm_dropout=0.0)
+    cfg["vgg_w"], cfg["vgg_model_path"] = 0.1, str(tmp_path)
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(4321)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        s.copy_nets()
+        rng = torch.get_rng_state()
+        batch = synth.make_batch(3, 32, seed=5)
+        oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in s.gen.state_dict().items()},
+                                  {k: v.cpu() for k, v in s.dis.state_dict().items()}, vgg_params=vgg_sd)
+        oracle.copy_nets()
+        oracle.iteration(batch, 0)
+        torch.set_rng_state(rng)
+        db = {k: v.to(DEV) for k, v in batch.items()}
+        a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
+        s.dis_update(*a)
+        s.gen_update(*a)
+        assert oracle.losses["loss_gen_vgg"] > 0
+        for k, want in oracle.losses.items():
+            got = float(torch.as_tensor(getattr(s, k)).detach())
+            assert abs(got - want) <= (2e-3 if k == "loss_gen_vgg" else 2e-4) * max(1.0, abs(want)), (k, got, want)
+        name = "dec.model.2.conv.weight"
+        close(dict(s.gen.named_parameters())[name].grad, oracle.last_gen_grads[name], rel=1e-2, msg=name)
+    finally:
+        host.set_noise(host.DeviceNoise())

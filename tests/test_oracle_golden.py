@@ -202,3 +202,36 @@ def test_tiny_dis_grads(tiny, golden_dir):
     assert abs(solver.losses["loss_dis_all"] - float(ref["loss_dis"])) < 1e-4
     for k, g in solver.last_dis_grads.items():
         close_scaled(g, T(ref[k]), 1e-3, msg=k)
+
+
+# ---- VGG16 perceptual loss ----------------------------------------------------------
+def _seeded_vgg_state():
+    """The product's Vgg16 built under the fixture's seed: same constructor order as the reference's, so the same
+    weights (the 59 MB are never stored)."""
+    from networks.networks import Vgg16
+    torch.manual_seed(777)
+    return Vgg16().state_dict()
+
+
+def test_vgg_seeded_init_matches_reference(golden_dir):
+    with open(os.path.join(golden_dir, "vgg_init_checksums.json")) as f:
+        gold = json.load(f)["tensors"]
+    sd = _seeded_vgg_state()
+    assert list(sd.keys()) == list(gold.keys())
+    for k, v in sd.items():
+        d = v.double()
+        assert [float(d.sum()), float((d * d).sum())] == pytest.approx(gold[k][:2], rel=1e-12), k
+
+
+@pytest.mark.parametrize("tag", ["s32", "s64"])
+def test_vgg_loss_restatement(golden_dir, tag):
+    """oracle.vgg_loss against the reference's compute_vgg_loss (solver.py:242-247): features, loss, image gradient."""
+    z = np.load(os.path.join(golden_dir, "vgg_loss.npz"))
+    sd = _seeded_vgg_state()
+    img, target = T(z[tag + "_img"]), T(z[tag + "_target"]).requires_grad_(True)
+    fea = orc.vgg16_relu5_3(sd, orc.vgg_preprocess(img))
+    close_scaled(fea, T(z[tag + "_fea"]), 1e-5, msg="relu5_3")
+    loss = orc.vgg_loss(sd, img, target)
+    assert float(loss) == pytest.approx(float(z[tag + "_loss"]), rel=1e-4)
+    loss.backward()
+    close_scaled(target.grad, T(z[tag + "_dtarget"]), 1e-3, atol=1e-9, msg="d loss / d target")
