@@ -170,7 +170,7 @@ class _Conv2d(torch.autograd.Function):
     """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act):
+    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
@@ -178,6 +178,7 @@ class _Conv2d(torch.autograd.Function):
         Cout, Cin, KH, KW = w.shape
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
+        ctx.bias_grad = bias_grad
         cop = _pad4(Cout)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
@@ -212,6 +213,10 @@ class _Conv2d(torch.autograd.Function):
         need_db = has_b and ctx.needs_input_grad[2]
         g = dy
         db = None
+        if need_db and not ctx.bias_grad:
+            # the output goes straight into an instance norm: a per-channel constant is removed by its mean
+            # subtraction, so this gradient is identically zero (the reference computes rounding noise here)
+            db, need_db = torch.zeros(Cout, dtype=torch.float32, device=dev), False
         if act != 0 or need_db:
             db_full = torch.empty(cop, dtype=torch.float32, device=dev) if need_db else None
             g_out = empty_cl(B, cop, Ho, Wo, dev) if act != 0 else None
@@ -272,19 +277,21 @@ class _Conv2d(torch.autograd.Function):
                 scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_bwd_data")
             if pad > 0:
                 _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, w, b, stride, pad, act="none"):
+def conv2d(x, w, b, stride, pad, act="none", bias_grad=True):
     """Reflect-padded convolution + bias + activation.  Returns Cout channels (a channel
-    slice of the 4-aligned buffer when Cout is not a multiple of 4)."""
-    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act])
+    slice of the 4-aligned buffer when Cout is not a multiple of 4).  ``bias_grad=False``: the caller feeds the
+    result to an instance norm, whose mean subtraction makes the bias gradient identically zero -- it is returned
+    as zeros instead of being reduced from dY."""
+    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad))
     return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
 
 
 def conv2d_padded(x, w, b, stride, pad, act="none"):
     """As conv2d, but returns the 4-aligned channel buffer itself."""
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act])
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], True)
 
 
 class _HeadsConvWide(torch.autograd.Function):
@@ -362,7 +369,7 @@ def conv2d_heads(x, w4, b4):
     """tanh/sigmoid image heads: [B,C,H,W] features, [4,C,7,7] weights -> NHWC4 image [B,4,H,W]."""
     if x.shape[3] % 8 == 0 and w4.shape[2] == w4.shape[3] == 7:
         return _HeadsConvWide.apply(x, w4, b4)
-    return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads"])
+    return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads"], True)
 
 
 class _Conv2dZeroPad(torch.autograd.Function):

@@ -111,7 +111,8 @@ class Conv2dBlock(nn.Module):
         if self.norm is None:
             y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, self.act_kind)
             return y if residual is None else y + residual
-        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, "none")
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, "none",
+                       bias_grad=self.norm_kind == "ln")      # IN / AdaIN subtract the per-(n,c) mean: d/d bias == 0
         relu = self.act_kind == "relu"
         if self.norm_kind == "ln":
             y = self.norm(y, relu=relu)
