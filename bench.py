@@ -34,7 +34,7 @@ DOMINANT = "conv_gemm_kernel"          # the implicit-GEMM conv kernel (all tile
 # HBM-side bytes per launch of that kernel from the PMC passes committed as profiles/r01_pmc_hbm_traffic.json
 # (rocprofv3 --pmc FETCH_SIZE and, separately, WRITE_SIZE, same command; FETCH_SIZE doubled per the gfx950 note
 # in MI355X_MICROARCH.md).  A profile-time constant: bench.py cannot read PMCs itself.
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 259838976
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 274721196
 
 
 def run_iteration(trainer, batch, cfg, it):

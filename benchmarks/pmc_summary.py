@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per launch from two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+TCC has 4 counter slots, they cost 3 + 2).  Produces profiles/rNN_pmc_hbm_traffic.json.
+
+    cd /tmp && export TMPDIR=/tmp && cd $REPO
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+    python benchmarks/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_hbm_traffic.json
+
+Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
+FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(directory, counter):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *counter_collection.csv under %s" % directory)
+    acc = {}
+    for path in files:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+                ent = acc.setdefault(short, [0.0, 0])
+                ent[0] += float(row["Counter_Value"])
+                ent[1] += 1
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, out = sys.argv[1:4]
+    fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    keep = ("conv_gemm_kernel", "conv_gemm_strips_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "in_stats_partial",
+            "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
+            "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd")
+    res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 "
+                      "--warmup 1 --no-cpu-baseline",
+           "note": "units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
+                   "separate passes; summarised by benchmarks/pmc_summary.py",
+           "kernels": {}}
+    for k in keep:
+        if k not in fetch or k not in write:
+            continue
+        f_avg, w_avg = fetch[k][0] / fetch[k][1], write[k][0] / write[k][1]
+        res["kernels"][k] = {"FETCH_SIZE_KiB_avg_per_launch": round(f_avg, 1), "launches": fetch[k][1],
+                             "WRITE_SIZE_KiB_avg_per_launch": round(w_avg, 1),
+                             "hbm_bytes_per_launch_corrected": int((2 * f_avg + w_avg) * 1024)}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res["kernels"].get("conv_gemm_kernel"), indent=1))
+
+
+if __name__ == "__main__":
+    main()
