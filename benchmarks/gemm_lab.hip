@@ -241,6 +241,7 @@ int main(int argc, char** argv) {
     run_lab_v1(p);
     run_lab_v2(p);
     run_lab_v3(p);
+    run_lab_v4(p);
     return 0;
 }
 
