@@ -136,6 +136,13 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     if ent.get(key, (None, None))[0] == w._version:
         return ent[key][1]
     lib = _lib.load()
+    if kind == "heads_wide":
+        # the 4-channel heads as 8 pixels x 4 channels: bank [p*4 + co][ci][KH][KW+7], copy p shifted right by p taps
+        bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, 7 - p)) for p in range(8)]).reshape(
+            32, w.shape[1], w.shape[2], w.shape[3] + 7)
+        out = _prepped(bank, "fwd", 32, cin_pad, 1)
+        ent[key] = (w._version, out)
+        return out
     if kind == "dgrad_image":
         # bank of 8 shifted copies of the flipped, transposed filter: [p*4 + ci][co][KH][KW+7] (dwc_conv2d_bwd_data_image);
         # cout_pad = gathered (dY) channels, cin_pad = 4 image planes
@@ -309,9 +316,7 @@ class _HeadsConvWide(torch.autograd.Function):
         co, ci, KH, KW = w4.shape
         assert co == 4 and ci == C and W % 8 == 0
         pad = KH // 2
-        wd = w4.detach()
-        wide = torch.stack([torch.nn.functional.pad(wd, (p, 7 - p)) for p in range(8)]).reshape(32, C, KH, KW + 7)
-        w_prep = _prepped(wide, "fwd", 32, C, 1)
+        w_prep = _prepped(w4, "heads_wide", 32, C, 1)
         bias = b4.detach().repeat(8).contiguous()
         y = empty_cl(B, 4, H, W, x.device)
         st = _stream()

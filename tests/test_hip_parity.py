@@ -120,6 +120,7 @@ def test_conv_no_bias_and_cout_not_multiple_of_4():
     (7, 3, 12, 16, [7, 4, 1]),                        # tiny configuration, one sample of length 1
     (40, 16, 364, 300, None),                         # the shipped text encoder, layer 0
     (12, 20, 600, 300, None),                         # layer 1 input width, two 16-row tiles
+    (6, 70, 12, 20, None),                            # more than 64 sequences (row chunks), H not a multiple of 16
 ])
 def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens):
     """One bidirectional layer on padded input + lengths against torch's nn.LSTM on the PackedSequence (what the
