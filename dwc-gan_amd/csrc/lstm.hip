@@ -80,6 +80,24 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(const float* __restrict__ x
     const size_t dTB = (size_t)d * T * B;
     const bool has_prev = tp >= 0 && tp < T;
     const int unit = u0 + r;
+    // operands of the cell update, fetched BEFORE the matrix phase so that their latency hides behind it
+    float xpv[MT][4], cpv[MT];
+    bool act[MT], mine[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+        mine[k] = b < B && u < H;
+        act[k] = mine[k] && t < lens[min(b, B - 1)];
+        cpv[k] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xpv[k][n] = 0.f;
+        if (act[k]) {
+            const size_t row = dTB + (size_t)t * B + b;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xpv[k][n] = xproj[row * 4 * H + (size_t)n * H + u];
+            if (has_prev) cpv[k] = c[(dTB + (size_t)tp * B + b) * H + u];
+        }
+    }
     f32x4 acc[4][MT];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -99,23 +117,21 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(const float* __restrict__ x
 #pragma unroll
             for (int i = 0; i < 4; ++i) ex[wave][n][m * 16 + 4 * j + i][r] = acc[n][m][i];
     __syncthreads();
-    for (int p = threadIdx.x; p < MT * 256; p += 256) {
-        const int bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
-        if (b >= B || u >= H) continue;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        if (!mine[k]) continue;
+        const int p = threadIdx.x + 256 * k, bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
         const size_t row = dTB + (size_t)t * B + b;
-        const bool active = t < lens[b];
         float hv = 0.f, cv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
-        if (active) {
-            const float* xp = xproj + row * 4 * H + u;
-            const float cp = has_prev ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
+        if (act[k]) {
             float pre[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) pre[n] = xp[(size_t)n * H] + ((ex[0][n][bl][ul] + ex[1][n][bl][ul]) + (ex[2][n][bl][ul] + ex[3][n][bl][ul]));
+            for (int n = 0; n < 4; ++n) pre[n] = xpv[k][n] + ((ex[0][n][bl][ul] + ex[1][n][bl][ul]) + (ex[2][n][bl][ul] + ex[3][n][bl][ul]));
             gi = sigmoidf_(pre[0]);
             gf = sigmoidf_(pre[1]);
             gg = tanhf(pre[2]);
             go = sigmoidf_(pre[3]);
-            cv = gf * cp + gi * gg;
+            cv = gf * cpv[k] + gi * gg;
             hv = go * tanhf(cv);
         }
         out[row * H + u] = hv;
@@ -143,6 +159,30 @@ __global__ __launch_bounds__(256) void lstm_step_bwd(const float* __restrict__ d
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
     const size_t dTB = (size_t)d * T * B;
     const int unit = u0 + r;
+    // operands of the cell gradient, fetched BEFORE the matrix phase so that their latency hides behind it
+    float gv[MT][4], cvv[MT], cpv[MT], dhv[MT], dcv[MT];
+    bool act[MT], mine[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+        mine[k] = b < B && u < H;
+        const int len = lens[min(b, B - 1)];
+        act[k] = mine[k] && t < len;
+        cvv[k] = cpv[k] = dhv[k] = dcv[k] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) gv[k][n] = 0.f;
+        if (act[k]) {
+            const size_t row = dTB + (size_t)t * B + b;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) gv[k][n] = gates[row * 4 * H + (size_t)n * H + u];
+            cvv[k] = c[row * H + u];
+            const bool has_prev = d == 0 ? tp >= 0 : tp < len;   // reverse: the state before the first step is zero
+            if (has_prev) cpv[k] = c[(dTB + (size_t)tp * B + b) * H + u];
+            dcv[k] = dc_carry[((size_t)d * B + b) * H + u];
+            if (d_out) dhv[k] = d_out[row * H + u];
+            if (d_c) dcv[k] += d_c[row * H + u];
+        }
+    }
     // dh_rec[b][u] = sum_n dgates[tn][b][n] * W_hh[n][u]: contraction over 4H, split over the four waves
     f32x4 acc[1][MT];
 #pragma unroll
@@ -158,33 +198,25 @@ __global__ __launch_bounds__(256) void lstm_step_bwd(const float* __restrict__ d
 #pragma unroll
         for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[0][m][i];
     __syncthreads();
-    for (int p = threadIdx.x; p < MT * 256; p += 256) {
-        const int bl = p >> 4, b = b0 + bl, u = u0 + (p & 15);
-        if (b >= B || u >= H) continue;
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        if (!mine[k]) continue;
+        const int p = threadIdx.x + 256 * k, bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
         const size_t row = dTB + (size_t)t * B + b;
-        const int len = lens[b];
         float* dg = dgates + row * 4 * H + u;
-        if (t >= len) {                                      // inactive: nothing flows
+        if (!act[k]) {                                       // inactive: nothing flows
             dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
             continue;
         }
-        const size_t sb = ((size_t)d * B + b) * H + u;
-        float dh = ex[0][bl][p & 15] + ex[1][bl][p & 15] + ex[2][bl][p & 15] + ex[3][bl][p & 15];
-        float dc = dc_carry[sb];
-        if (d_out) dh += d_out[row * H + u];
-        if (d_c) dc += d_c[row * H + u];
-        const float* gs = gates + row * 4 * H + u;
-        const float gi = gs[0], gf = gs[H], gg = gs[2 * H], go = gs[3 * H];
-        const float cv = c[row * H + u];
-        const bool has_prev = d == 0 ? tp >= 0 : tp < len;   // reverse: the state before the first step is zero
-        const float cp = has_prev ? c[(dTB + (size_t)tp * B + b) * H + u] : 0.f;
-        const float th = tanhf(cv);
-        dc += dh * go * (1.f - th * th);
+        const float dh = dhv[k] + ((ex[0][bl][ul] + ex[1][bl][ul]) + (ex[2][bl][ul] + ex[3][bl][ul]));
+        const float gi = gv[k][0], gf = gv[k][1], gg = gv[k][2], go = gv[k][3];
+        const float th = tanhf(cvv[k]);
+        const float dc = dcv[k] + dh * go * (1.f - th * th);
         dg[0] = dc * gg * gi * (1.f - gi);
-        dg[H] = dc * cp * gf * (1.f - gf);
+        dg[H] = dc * cpv[k] * gf * (1.f - gf);
         dg[2 * H] = dc * gi * (1.f - gg * gg);
         dg[3 * H] = dh * th * go * (1.f - go);
-        dc_carry[sb] = dc * gf;
+        dc_carry[((size_t)d * B + b) * H + u] = dc * gf;
     }
 }
 
