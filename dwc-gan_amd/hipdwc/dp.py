@@ -7,7 +7,7 @@ global-batch gradient.  There is exactly one exchange per optimiser step: an all
 that optimiser's gradients (D: 13.99 M floats = 55.9 MB, G: 20.36 M = 81.4 MB at 128x128),
 packed into flat fp32 buckets so that RCCL sees a few large messages (xGMI is point-to-point:
 per-link bandwidth, not message rate, is the limit).  ~1 ms on the wire against a step of
-~200 ms, so the exchange is issued right after backward without further overlap machinery.
+~100 ms, so the exchange is issued right after backward without further overlap machinery.
 
 The one piece that does not shard is the text encoder's batch-mixing ``view`` (reference
 networks_v2.py:249): an N-rank run equals N independent local batches, not one global batch.
@@ -60,11 +60,12 @@ class GradAllReduce:
         for work, flat, bucket in handles:
             work.wait()
             flat.mul_(inv)
-            off = 0
+            views, off = [], 0
             for g in bucket:
                 n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
+                views.append(flat[off:off + n].view_as(g))
                 off += n
+            torch._foreach_copy_(bucket, views)          # one multi-tensor launch instead of one copy per gradient
 
 
 def broadcast_module(module, src=0, group=None):
