@@ -313,6 +313,146 @@ __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
                                            blockIdx.y * ss.part_stride, false, 0, 0, blockIdx.x, s.tiles);
 }
 
+// gridDim.z independent products of one geometry: source, weights and destination advance by a fixed stride per
+// class (the 16 transform-domain products of a Winograd convolution).
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gemm_batched_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
+                                                                size_t src_class_stride, Scatter o, size_t dst_class_stride,
+                                                                int tiles_n, int nk) {
+    DWC_PROBE();
+    const int cls = blockIdx.z;
+    g.src += (size_t)cls * src_class_stride;
+    o.dst += (size_t)cls * dst_class_stride;
+    conv_gemm_body<BM, BN, WM, WN, TM, TN>(g, wmat + (size_t)cls * w_class_stride, o, nullptr, DWC_ACT_NONE, tiles_n, 0, nk, 0, false,
+                                           0, 0, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (the ResBlocks: 44 % of the GEMM time): 2.25x fewer
+// multiply-adds.  y = A^T [ (G g G^T) (.) (B^T d B) ] A per 4x4 input tile / 2x2 output tile, summed over channels, i.e.
+// 16 products M_e[tile][co] = V_e[tile][ci] . U_e[ci][co] on the GEMM body above, between an input transform (which
+// applies the reflect or zero boundary rule while gathering) and an output transform (+bias, +activation).
+//   V, M: [16][T][C] with T = B*(H/2)*(W/2) tiles, channels contiguous (what the GEMM stages as K / writes as N)
+//   U: [16][N][K] (K contiguous), from wino_filter_kernel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
+                                                          int for_dgrad) {
+    // forward: row = co, k = ci, filter g = W[co][ci]; data gradient: row = ci, k = co, g = W[co][ci] rotated by 180 degrees
+    const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * K) return;
+    const int k = idx % K, row = idx / K;
+    const int co = for_dgrad ? k : row, ci = for_dgrad ? row : k;
+    const float* gp = w + ((size_t)co * Cin + ci) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = for_dgrad ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
+    float t[4][3];                                     // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const size_t plane = (size_t)rows * K;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                      // (G g) G^T
+        U[(size_t)(a * 4 + 0) * plane + idx] = t[a][0];
+        U[(size_t)(a * 4 + 1) * plane + idx] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(size_t)(a * 4 + 2) * plane + idx] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(size_t)(a * 4 + 3) * plane + idx] = t[a][2];
+    }
+}
+
+// one thread per (tile, 4 channels): V = B^T d B of the 4x4 patch at rows 2*ty-1.., cols 2*tx-1..
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
+                                                         int cq, int reflect, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % cq;
+    size_t tl = idx / cq;
+    const int TW = W >> 1, TH = H >> 1;
+    const int tx = tl % TW;
+    const int ty = (tl / TW) % TH;
+    const int n = tl / ((size_t)TW * TH);
+    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (size_t)n * H * W * cq + c;
+    f32x4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        int h = 2 * ty - 1 + a;
+        const bool hin = h >= 0 && h < H;
+        h = reflect ? reflect_idx(h, H) : min(max(h, 0), H - 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            int w = 2 * tx - 1 + b;
+            const bool in = hin && w >= 0 && w < W;
+            w = reflect ? reflect_idx(w, W) : min(max(w, 0), W - 1);
+            const f32x4 v = xs[((size_t)h * W + w) * cq];
+            d[a][b] = (reflect || in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 t[4][4];                                     // B^T d
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[0][b] = d[0][b] - d[2][b];
+        t[1][b] = d[1][b] + d[2][b];
+        t[2][b] = d[2][b] - d[1][b];
+        t[3][b] = d[1][b] - d[3][b];
+    }
+    const size_t plane4 = total;                       // f32x4 elements per transform plane: T * cq
+    f32x4* out = reinterpret_cast<f32x4*>(V) + idx;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                      // (B^T d) B
+        out[(size_t)(a * 4 + 0) * plane4] = t[a][0] - t[a][2];
+        out[(size_t)(a * 4 + 1) * plane4] = t[a][1] + t[a][2];
+        out[(size_t)(a * 4 + 2) * plane4] = t[a][2] - t[a][1];
+        out[(size_t)(a * 4 + 3) * plane4] = t[a][1] - t[a][3];
+    }
+}
+
+// one thread per (tile, 4 channels): Y = A^T M A (+bias, +activation) -> the tile's 2x2 output pixels
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int B, int H, int W, int cq, int act, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % cq;
+    size_t tl = idx / cq;
+    const int TW = W >> 1, TH = H >> 1;
+    const int tx = tl % TW;
+    const int ty = (tl / TW) % TH;
+    const int n = tl / ((size_t)TW * TH);
+    const f32x4* in = reinterpret_cast<const f32x4*>(Mt) + idx;
+    f32x4 m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m[a][b] = in[(size_t)(a * 4 + b) * total];
+    f32x4 t[2][4];                                     // A^T m
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[0][b] = m[0][b] + m[1][b] + m[2][b];
+        t[1][b] = m[1][b] - m[2][b] - m[3][b];
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = reinterpret_cast<const f32x4*>(bias)[c];
+    f32x4* ys = reinterpret_cast<f32x4*>(y) + (size_t)n * H * W * cq + c;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        f32x4 o0 = t[a][0] + t[a][1] + t[a][2] + bv;
+        f32x4 o1 = t[a][1] - t[a][2] - t[a][3] + bv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o0[k] = dwc_act_apply(o0[k], act, c * 4 + k);
+            o1[k] = dwc_act_apply(o1[k], act, c * 4 + k);
+        }
+        ys[((size_t)(2 * ty + a) * W + 2 * tx) * cq] = o0;
+        ys[((size_t)(2 * ty + a) * W + 2 * tx + 1) * cq] = o1;
+    }
+}
+
 // dst[i] = act(sum_s part[s][i] + bias[i % N]), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst,
                                                             const float* __restrict__ bias, size_t total4, size_t stride4, int splits,
@@ -838,6 +978,68 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// ---- Winograd F(2x2,3x3) entry points ----------------------------------------------------------------------------
+static bool wino_ok(int B, int H, int W, int Cin, int Cout) {
+    return B > 0 && H >= 4 && W >= 4 && !(H & 1) && !(W & 1) && dwc_ilog2_exact(Cin) >= 5 && Cout >= 32 && !(Cout & 3);
+}
+
+size_t dwc_wino_filter_elems(int Cout, int Cin) { return (size_t)16 * Cout * Cin; }
+
+int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, void* stream) {
+    if (Cout <= 0 || Cin <= 0) return DWC_EINVAL;
+    const size_t total = (size_t)Cout * Cin;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin,
+                       for_dgrad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!wino_ok(B, H, W, Cin, Cout)) return 0;
+    const size_t T = (size_t)B * (H / 2) * (W / 2);
+    return 16 * T * ((size_t)Cin + Cout) * sizeof(float);
+}
+
+// y = act(conv3x3(pad1(x)) + bias), stride 1; pad rule reflect (reflect != 0) or zero.  U from dwc_wino_prepare_filter
+// (for the data gradient: prepared with for_dgrad = 1, x := dY, Cin := channels of dY, Cout := channels of dx, zero rule).
+int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act,
+                    int reflect, void* ws, size_t ws_bytes, void* stream) {
+    if (!wino_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
+    if (!ws || ws_bytes < dwc_conv2d_wino_ws_bytes(B, H, W, Cin, Cout)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = B * (H / 2) * (W / 2);
+    float* V = (float*)ws;
+    float* Mt = V + (size_t)16 * T * Cin;
+    const size_t tin = (size_t)T * (Cin / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, reflect, tin);
+    DWC_LAUNCH_CHECK();
+    // 16 products [T x Cin] . [Cin x Cout] as 1x1 "convolutions" over T one-pixel images
+    Gather g;
+    g.tap_t = 0;
+    g.src = V; g.SH = 1; g.SW = 1; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
+    g.OH = 1; g.OW = 1; g.logOW = 0; g.logOHW = 0; g.KH = 1; g.KW = 1; g.kw_magic = 65536;
+    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = g.off_w = 0; g.reflect = 1; g.M = T; g.K = Cin;
+    Scatter o;
+    o.dst = Mt; o.N = Cout; o.OHf = 1; o.OWf = 1; o.os = 1;
+    const Plan p = plan_gemm(T, Cout, Cin, 16);
+    const int nk = (Cin + BK - 1) / BK;
+    const size_t ws_w = (size_t)Cout * Cin, ws_s = (size_t)T * Cin, ws_d = (size_t)T * Cout;
+#define WINO_LAUNCH(BM, BN, WM, WN, TM, TN)                                                                                       \
+    hipLaunchKernelGGL((conv_gemm_batched_kernel<BM, BN, WM, WN, TM, TN>),                                                        \
+                       dim3(((T + BM - 1) / BM) * ((Cout + BN - 1) / BN), 1, 16), dim3(256), 0, st, g, U, ws_w, ws_s, o, ws_d,    \
+                       (Cout + BN - 1) / BN, nk)
+    if (p.bm == 128 && p.bn == 128) WINO_LAUNCH(128, 128, 2, 2, 2, 2);
+    else if (p.bm == 128 && p.bn == 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1);
+    else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1);
+    else WINO_LAUNCH(128, 32, 4, 1, 1, 1);
+#undef WINO_LAUNCH
+    DWC_LAUNCH_CHECK();
+    const size_t tout = (size_t)T * (Cout / 4);
+    hipLaunchKernelGGL(wino_output_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, Mt, bias, y, B, H, W, Cout / 4, act, tout);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 // Zero-padded convolutions (the frozen VGG16 of the perceptual loss, reference networks.py:639-688: nn.Conv2d(padding=1)):
 // the forward kernel with the zero rule instead of the reflect rule, and as data gradient the zero-padded correlation
 // with the flipped filter on the H x W grid (the adjoint of zero padding is a crop: nothing to fold).
@@ -1070,15 +1272,32 @@ size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout,
     return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
 
+static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only);
+
 int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    return same_dgrad_run(dy, w_dgrad, w_dgrad_t, dx, B, H, W, Cin, Cout, KH, KW, pad, ws, ws_bytes, stream, false);
+}
+
+// Only the border ring: dx must already hold the interior (e.g. from dwc_conv2d_wino with the zero rule).
+int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    return same_dgrad_run(dy, w_dgrad, w_dgrad_t, dx, B, H, W, Cin, Cout, KH, KW, pad, ws, ws_bytes, stream, true);
+}
+
+static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W, int Cin,
+                          int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
     if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm(f.g, w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes, ws_bytes - ring_bytes, st);
-    if (rc != DWC_OK) return rc;
+    if (!ring_only) {
+        int rc = launch_gemm(f.g, w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes,
+                             ws_bytes - ring_bytes, st);
+        if (rc != DWC_OK) return rc;
+    }
     hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);

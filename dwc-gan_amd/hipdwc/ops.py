@@ -5,6 +5,7 @@ Tensors keep the reference's logical NCHW shapes but live channels-last in memor
 function here requires device tensors; there is no CPU path (use the oracle for that,
 from tests only).
 """
+import os
 import weakref
 
 import torch
@@ -136,6 +137,18 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     if ent.get(key, (None, None))[0] == w._version:
         return ent[key][1]
     lib = _lib.load()
+    if kind in ("wino_fwd", "wino_dgrad"):
+        # transform-domain filter bank [16][N][K] (dwc_wino_prepare_filter); channel paddings as for the plain layouts
+        co, ci, kh, kw = w.shape
+        wz = w.detach()
+        if co != cout_pad or ci != cin_pad:
+            wz = torch.zeros((cout_pad, cin_pad, 3, 3), dtype=torch.float32, device=w.device)
+            wz[:co, :ci] = w.detach()
+        out = torch.empty(lib.dwc_wino_filter_elems(cout_pad, cin_pad), dtype=torch.float32, device=w.device)
+        _lib.check(lib.dwc_wino_prepare_filter(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad,
+                                               int(kind == "wino_dgrad"), _stream()), "wino_prepare_filter")
+        ent[key] = (w._version, out)
+        return out
     if kind == "heads_wide":
         # the 4-channel heads as 8 pixels x 4 channels: bank [p*4 + co][ci][KH][KW+7], copy p shifted right by p taps
         bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, 7 - p)) for p in range(8)]).reshape(
@@ -173,6 +186,15 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
 # --------------------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------------------
+WINOGRAD = os.environ.get("DWC_NO_WINOGRAD", "0") != "1"      # development knob: DWC_NO_WINOGRAD=1 runs 3x3 convs directly
+
+
+def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
+    """Stride-1 3x3 pad-1 convolutions with enough channels run as Winograd F(2x2,3x3) (dwc_conv2d_wino)."""
+    return (WINOGRAD and KH == 3 and KW == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 and H >= 4 and W >= 4
+            and c_gather >= 64 and (c_gather & (c_gather - 1)) == 0 and c_out >= 64)
+
+
 class _Conv2d(torch.autograd.Function):
     """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4."""
 
@@ -189,7 +211,8 @@ class _Conv2d(torch.autograd.Function):
         cop = _pad4(Cout)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        w_hwio = _prepped(w, "fwd", cop, Cx, stride)
+        use_wino = _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
+        w_hwio = None if use_wino else _prepped(w, "fwd", cop, Cx, stride)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -197,11 +220,18 @@ class _Conv2d(torch.autograd.Function):
         y = empty_cl(B, cop, Ho, Wo, x.device)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
         st = _stream()
-        nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
-        wsp = workspace(nws, x.device).data_ptr() if nws else None
-        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
-            x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
-            st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
+        if use_wino:
+            U = _prepped(w, "wino_fwd", cop, Cx, 1)
+            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop), x.device)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
+                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, ws.data_ptr(), ws.numel(), st),
+                detail="fwd-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino")
+        else:
+            nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
+            wsp = workspace(nws, x.device).data_ptr() if nws else None
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
+                x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
+                st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
@@ -264,11 +294,25 @@ class _Conv2d(torch.autograd.Function):
             dx = empty_cl(B, Cx, H, W, dev)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = lib.dwc_conv2d_bwd_data_same_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
-            ws = workspace(nws, dev)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_same(
-                g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
-                ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
-                "conv2d_bwd_data_same")
+            if _wino_ok(H, W, KH, KW, stride, pad, cop, Cx):
+                # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
+                U = _prepped(w, "wino_dgrad", cop, Cx, 1)
+                nwino = lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx)
+                ws = workspace(nwino + nws, dev)
+
+                def run():
+                    rc = lib.dwc_conv2d_wino(g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0,
+                                             ws.data_ptr(), nwino, st)
+                    return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
+                                                              W, Cx, cop, KH, KW, pad, ws.data_ptr() + nwino, nws, st)
+                _lib.check(_timed("conv_gemm_kernel", flops, run, scope_name=ctx.bscope,
+                                  detail="dgrad-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino dgrad")
+            else:
+                ws = workspace(nws, dev)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_same(
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
+                    ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                    "conv2d_bwd_data_same")
         elif ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride)
             dx = empty_cl(B, Cx, H, W, dev)

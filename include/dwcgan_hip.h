@@ -89,6 +89,21 @@ size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout,
 int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
                              int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                              void* ws, size_t ws_bytes, void* stream);
+/* Only the ring part of dwc_conv2d_bwd_data_same: dx already holds the interior (dwc_conv2d_wino with the zero rule). */
+int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
+                             int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
+                             void* ws, size_t ws_bytes, void* stream);
+/* Winograd F(2x2,3x3) for stride-1 3x3 convolutions with pad 1 (the ResBlock convolutions, reference networks.py:514-515):
+ * 2.25x fewer multiply-adds than the direct product.  U:[16][N][K] from dwc_wino_prepare_filter (for_dgrad = 0: N = Cout,
+ * K = Cin; for_dgrad = 1: the 180-degree rotated, transposed filter, N = Cin, K = Cout).  dwc_conv2d_wino computes
+ * y = act(conv3x3(pad1(x)) + bias) with the reflect rule (reflect != 0) or the zero rule; the data gradient's interior is
+ * the same call on dY with the for_dgrad filter and the zero rule.  H, W even; Cin a power of two >= 32; Cout % 4 == 0.
+ * Scratch: the two transform-domain tensors, 16 * B*H*W/4 * (Cin + Cout) floats. */
+size_t dwc_wino_filter_elems(int Cout, int Cin);
+int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, void* stream);
+size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
+                    int act, int reflect, void* ws, size_t ws_bytes, void* stream);
 /* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
  * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).
  * 8 adjacent pixels x 4 channels are produced as 32 GEMM columns.  w_wide: dwc_weight_prepare_fwd layout of the bank

@@ -41,7 +41,8 @@ CONV_SHAPES = [
     (1, 4, 64, 21, 7, 1, 3, "none"),        # same, odd size: padded width 27 -> pitch 32
     (3, 4, 32, 16, 5, 1, 2, "lrelu"),       # same, 5x5 / 32 gathered channels
     (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
-    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv, BN=128 path, 2 N tiles
+    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv (Winograd F(2x2,3x3) forward and data-gradient interior)
+    (3, 64, 128, 12, 3, 1, 1, "relu"),      # Winograd, rectangular channel counts, non power-of-two size
     (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
     (2, 128, 64, 24, 5, 1, 2, "none"),      # BN=64 path, non power-of-two spatial size
     (2, 64, 4, 32, 7, 1, 3, "heads"),       # fused tanh/sigmoid heads, BN=32 path
