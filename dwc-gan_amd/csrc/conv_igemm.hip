@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* __restrict__ dy, int N, float* __restrict__ slab,
-                                                         int m_chunk) {
+                                                         int m_chunk, int splits_per_class = 0, size_t src_class_stride = 0,
+                                                         size_t dy_class_stride = 0) {
     static_assert(WM * WN == 4 && WM * TM * 32 == 128 && WN * TN * 32 == BN, "tile shape");
     DWC_PROBE();
     constexpr int A_TILE = 32 * 128, B_TILE = 32 * BN;
@@ -486,7 +487,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int k0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
-    const int m_begin = blockIdx.z * m_chunk;
+    int split = blockIdx.z;
+    if (splits_per_class > 0) {       // batched form (Winograd): blockIdx.z = class * splits_per_class + split
+        const int cls = blockIdx.z / splits_per_class;
+        split = blockIdx.z - cls * splits_per_class;
+        g.src += (size_t)cls * src_class_stride;
+        dy += (size_t)cls * dy_class_stride;
+    }
+    const int m_begin = split * m_chunk;
     const int m_end = min(g.M, m_begin + m_chunk);
 
     // A^T tile: thread owns one 4-wide k group (fixed tap / channel) and rows (t>>5)+8i.
@@ -818,10 +826,10 @@ bool conv_args_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int st
 // rounds * (slabs per workgroup + prologue/epilogue) where a round is one full set of resident workgroups: the
 // split count is chosen to fill 1..4 rounds EXACTLY rather than to reach a fixed number of workgroups (29 ranges x
 // 36 tiles = 1044 workgroups is two rounds plus a third for the last 20).
-void wgrad_plan(int M, int K, int N, int* splits, int* chunk) {
+void wgrad_plan(int M, int K, int N, int* splits, int* chunk, int classes = 1) {
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     const long resident = bn == 128 ? 2 : (bn == 64 ? 3 : 4);       // workgroups per CU by LDS footprint
-    const long tiles = (long)((K + 127) / 128) * ((N + bn - 1) / bn);
+    const long tiles = (long)((K + 127) / 128) * ((N + bn - 1) / bn) * classes;
     const long slots = NUM_CU * resident;
     const long slabs = (M + 31) / 32;
     long best_cost = -1, best_c = slabs;
@@ -978,6 +986,72 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// Z = A dY A^T: the 2x2 output-gradient tile lifted to the 4x4 transform domain.  One thread per (tile, 4 channels).
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Z, int B, int H, int W, int cq,
+                                                      size_t total) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = idx % cq;
+    size_t tl = idx / cq;
+    const int TW = W >> 1, TH = H >> 1;
+    const int tx = tl % TW;
+    const int ty = (tl / TW) % TH;
+    const int n = tl / ((size_t)TW * TH);
+    const f32x4* ds = reinterpret_cast<const f32x4*>(dy) + (size_t)n * H * W * cq + c;
+    f32x4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) d[a][b] = ds[((size_t)(2 * ty + a) * W + 2 * tx + b) * cq];
+    f32x4 t[4][2];                                     // A d,  A = [[1,0],[1,1],[1,-1],[0,-1]]
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        t[0][b] = d[0][b];
+        t[1][b] = d[0][b] + d[1][b];
+        t[2][b] = d[0][b] - d[1][b];
+        t[3][b] = -d[1][b];
+    }
+    f32x4* out = reinterpret_cast<f32x4*>(Z) + idx;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {                      // (A d) A^T
+        out[(size_t)(a * 4 + 0) * total] = t[a][0];
+        out[(size_t)(a * 4 + 1) * total] = t[a][0] + t[a][1];
+        out[(size_t)(a * 4 + 2) * total] = t[a][0] - t[a][1];
+        out[(size_t)(a * 4 + 3) * total] = -t[a][1];
+    }
+}
+
+// slab[(class*splits + s)][ci][co] summed over s (fixed order) = dU_class[ci][co];  dg = G^T dU G -> dw[co][ci][3][3]
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cin, int Cout,
+                                         int cin_real, int cout_real) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t plane = (size_t)Cin * Cout;
+    if (idx >= plane) return;
+    const int co = idx % Cout, ci = idx / Cout;
+    if (co >= cout_real || ci >= cin_real) return;
+    float u[4][4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slab[((size_t)e * splits + z) * plane + idx];
+        u[e >> 2][e & 3] = s;
+    }
+    float t[3][4];                                     // G^T u,  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+        t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+        t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+    float* o = dw + ((size_t)co * cin_real + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                      // (G^T u) G
+        o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
+        o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+    }
+}
+
 // ---- Winograd F(2x2,3x3) entry points ----------------------------------------------------------------------------
 static bool wino_ok(int B, int H, int W, int Cin, int Cout) {
     return B > 0 && H >= 4 && W >= 4 && !(H & 1) && !(W & 1) && dwc_ilog2_exact(Cin) >= 5 && Cout >= 32 && !(Cout & 3);
@@ -1036,6 +1110,63 @@ int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y,
     DWC_LAUNCH_CHECK();
     const size_t tout = (size_t)T * (Cout / 4);
     hipLaunchKernelGGL(wino_output_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, Mt, bias, y, B, H, W, Cout / 4, act, tout);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+static void wino_wgrad_sizes(int B, int H, int W, int Cin, int Cout, size_t* v, size_t* z, size_t* slabs, int* splits, int* chunk) {
+    const size_t T = (size_t)B * (H / 2) * (W / 2);
+    *v = 16 * T * Cin;
+    *z = 16 * T * Cout;
+    wgrad_plan((int)T, Cin, Cout, splits, chunk, 16);
+    *slabs = (size_t)16 * *splits * Cin * Cout;
+}
+
+size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!wino_ok(B, H, W, Cin, Cout)) return 0;
+    size_t v, z, sl;
+    int splits, chunk;
+    wino_wgrad_sizes(B, H, W, Cin, Cout, &v, &z, &sl, &splits, &chunk);
+    return (v + z + sl) * sizeof(float);
+}
+
+// dw (OIHW, [cout_real][cin_real][3][3]) of a reflect-padded stride-1 3x3 convolution from x:[B,H,W,Cin], dy:[B,H,W,Cout]:
+// dU_e = V_e^T Z_e over the tiles (16 products on the weight-gradient GEMM), then dg = G^T dU G.
+int dwc_conv2d_wino_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                               int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
+    if (!wino_ok(B, H, W, Cin, Cout) || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
+    size_t nv, nz, nsl;
+    int splits, chunk;
+    wino_wgrad_sizes(B, H, W, Cin, Cout, &nv, &nz, &nsl, &splits, &chunk);
+    if (!ws || ws_bytes < (nv + nz + nsl) * sizeof(float)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = B * (H / 2) * (W / 2);
+    float* V = (float*)ws;
+    float* Z = V + nv;
+    float* slab = Z + nz;
+    const size_t tin = (size_t)T * (Cin / 4), tout = (size_t)T * (Cout / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, 1, tin);
+    DWC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino_dy_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, dy, Z, B, H, W, Cout / 4, tout);
+    DWC_LAUNCH_CHECK();
+    Gather g;
+    g.tap_t = 0;
+    g.src = V; g.SH = 1; g.SW = 1; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
+    g.OH = 1; g.OW = 1; g.logOW = 0; g.logOHW = 0; g.KH = 1; g.KW = 1; g.kw_magic = 65536;
+    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = g.off_w = 0; g.reflect = 1; g.M = T; g.K = Cin;
+    const int tk = (Cin + 127) / 128;
+    const size_t sv = (size_t)T * Cin, sz = (size_t)T * Cout;
+    if (Cout > 64) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, 16 * splits), dim3(256), 0, st, g, Z,
+                           Cout, slab, chunk, splits, sv, sz);
+    } else {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1>), dim3(tk, 1, 16 * splits), dim3(256), 0, st, g, Z, Cout, slab, chunk,
+                           splits, sv, sz);
+    }
+    DWC_LAUNCH_CHECK();
+    const size_t plane = (size_t)Cin * Cout;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((plane + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
+                       cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

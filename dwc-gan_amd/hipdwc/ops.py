@@ -271,10 +271,16 @@ class _Conv2d(torch.autograd.Function):
             nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             detail = "wgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-            ws = workspace(nws, dev)
-            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
-                x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
-                ws.numel(), st), scope_name=ctx.bscope, detail=detail), "conv2d_bwd_weight")
+            if _wino_ok(H, W, KH, KW, stride, pad, Cx, cop):
+                ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop), dev)
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="wgrad-wino" + detail[5:]), "conv2d_wino_bwd_weight")
+            else:
+                ws = workspace(nws, dev)
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
+                    ws.numel(), st), scope_name=ctx.bscope, detail=detail), "conv2d_bwd_weight")
         if ctx.needs_input_grad[0] and Cx == 4 and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
                 and (cop & (cop - 1)) == 0:
             # gradient w.r.t. an NHWC4 image (7x7 stems): 8 pixels x 4 planes per GEMM row, see dwc_conv2d_bwd_data_image
