@@ -1077,13 +1077,14 @@ size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout) {
 // y = act(conv3x3(pad1(x)) + bias), stride 1; pad rule reflect (reflect != 0) or zero.  U from dwc_wino_prepare_filter
 // (for the data gradient: prepared with for_dgrad = 1, x := dY, Cin := channels of dY, Cout := channels of dx, zero rule).
 int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act,
-                    int reflect, void* ws, size_t ws_bytes, void* stream) {
+                    int reflect, float* v_keep, void* ws, size_t ws_bytes, void* stream) {
     if (!wino_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
     if (!ws || ws_bytes < dwc_conv2d_wino_ws_bytes(B, H, W, Cin, Cout)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int T = B * (H / 2) * (W / 2);
-    float* V = (float*)ws;
-    float* Mt = V + (size_t)16 * T * Cin;
+    // v_keep: caller-owned [16][T][Cin] buffer that receives the transformed input (kept for the weight gradient)
+    float* V = v_keep ? v_keep : (float*)ws;
+    float* Mt = (float*)ws + (size_t)16 * T * Cin;
     const size_t tin = (size_t)T * (Cin / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, reflect, tin);
     DWC_LAUNCH_CHECK();
@@ -1132,8 +1133,8 @@ size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cou
 
 // dw (OIHW, [cout_real][cin_real][3][3]) of a reflect-padded stride-1 3x3 convolution from x:[B,H,W,Cin], dy:[B,H,W,Cout]:
 // dU_e = V_e^T Z_e over the tiles (16 products on the weight-gradient GEMM), then dg = G^T dU G.
-int dwc_conv2d_wino_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
-                               int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
+int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw_oihw, int B, int H, int W, int Cin,
+                               int Cout, int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
     if (!wino_ok(B, H, W, Cin, Cout) || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
     size_t nv, nz, nsl;
     int splits, chunk;
@@ -1145,8 +1146,13 @@ int dwc_conv2d_wino_bwd_weight(const float* x, const float* dy, float* dw_oihw, 
     float* Z = V + nv;
     float* slab = Z + nz;
     const size_t tin = (size_t)T * (Cin / 4), tout = (size_t)T * (Cout / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, 1, tin);
-    DWC_LAUNCH_CHECK();
+    if (v_saved) {                 // the forward kept B^T x B (dwc_conv2d_wino's v_keep): no second transform
+        V = const_cast<float*>(v_saved);
+    } else {
+        if (!x) return DWC_EINVAL;
+        hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, 1, tin);
+        DWC_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(wino_dy_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, dy, Z, B, H, W, Cout / 4, tout);
     DWC_LAUNCH_CHECK();
     Gather g;

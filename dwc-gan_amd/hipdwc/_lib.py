@@ -31,9 +31,9 @@ SIGNATURES = {
     "dwc_wino_filter_elems": (c_sz, [c_int] * 2),
     "dwc_wino_prepare_filter": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_wino_ws_bytes": (c_sz, [c_int] * 5),
-    "dwc_conv2d_wino": (c_int, [c_fp] * 4 + [c_int] * 7 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_wino": (c_int, [c_fp] * 4 + [c_int] * 7 + [c_fp, c_fp, c_sz, c_fp]),
     "dwc_conv2d_wino_bwd_weight_ws_bytes": (c_sz, [c_int] * 5),
-    "dwc_conv2d_wino_bwd_weight": (c_int, [c_fp] * 3 + [c_int] * 7 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_wino_bwd_weight": (c_int, [c_fp] * 4 + [c_int] * 7 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_bwd_data_image_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_conv2d_bwd_data_image": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),

@@ -223,16 +223,18 @@ class _Conv2d(torch.autograd.Function):
         if use_wino:
             U = _prepped(w, "wino_fwd", cop, Cx, 1)
             ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop), x.device)
+            # the transformed input is what the weight gradient contracts with: keep it instead of transforming x again
+            v_keep = torch.empty(4 * B * H * W * Cx, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
-                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, ws.data_ptr(), ws.numel(), st),
-                detail="fwd-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino")
+                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, _p(v_keep), ws.data_ptr(), ws.numel(),
+                st), detail="fwd-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino")
         else:
             nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
             wsp = workspace(nws, x.device).data_ptr() if nws else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
                 x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
                 st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
-        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.save_for_backward(x, w, y if act != 0 else None, v_keep if use_wino else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
         return y
@@ -240,7 +242,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, y = ctx.saved_tensors
+        x, w, y, v_keep = ctx.saved_tensors
         B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, has_b = ctx.geom
         dy = cl(dy)
         Ho, Wo = dy.shape[2], dy.shape[3]
@@ -274,7 +276,7 @@ class _Conv2d(torch.autograd.Function):
             if _wino_ok(H, W, KH, KW, stride, pad, Cx, cop):
                 ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
-                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, ws.data_ptr(), ws.numel(), st),
+                    x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, ws.data_ptr(), ws.numel(), st),
                     scope_name=ctx.bscope, detail="wgrad-wino" + detail[5:]), "conv2d_wino_bwd_weight")
             else:
                 ws = workspace(nws, dev)
@@ -307,7 +309,7 @@ class _Conv2d(torch.autograd.Function):
                 ws = workspace(nwino + nws, dev)
 
                 def run():
-                    rc = lib.dwc_conv2d_wino(g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0,
+                    rc = lib.dwc_conv2d_wino(g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, None,
                                              ws.data_ptr(), nwino, st)
                     return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
                                                               W, Cx, cop, KH, KW, pad, ws.data_ptr() + nwino, nws, st)

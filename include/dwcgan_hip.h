@@ -102,13 +102,16 @@ int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float*
 size_t dwc_wino_filter_elems(int Cout, int Cin);
 int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, void* stream);
 size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
+/* v_keep (may be NULL): caller-owned [16][B*H*W/4][Cin] buffer that receives the transformed input instead of the
+ * scratch, so that dwc_conv2d_wino_bwd_weight can reuse it (v_saved) instead of transforming x again. */
 int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                    int act, int reflect, void* ws, size_t ws_bytes, void* stream);
+                    int act, int reflect, float* v_keep, void* ws, size_t ws_bytes, void* stream);
 /* Weight gradient of the same convolutions in the transform domain: dU_e = V_e^T Z_e over the tiles (V = B^T x B with the
  * reflect rule, Z = A dY A^T), then dg = G^T dU G, written in OIHW [cout_real][cin_real][3][3]. */
 size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout);
-int dwc_conv2d_wino_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
-                               int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
+int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw_oihw,
+                               int B, int H, int W, int Cin, int Cout, int cin_real, int cout_real,
+                               void* ws, size_t ws_bytes, void* stream);
 /* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
  * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).
  * 8 adjacent pixels x 4 channels are produced as 32 GEMM columns.  w_wide: dwc_weight_prepare_fwd layout of the bank
