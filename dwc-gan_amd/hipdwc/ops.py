@@ -67,24 +67,27 @@ class KernelTimer:
     def __init__(self):
         self.spans = []   # (kernel tag, algorithmic flops, start event, end event)
         self.details = []  # problem shape of each span (benchmarks/step_breakdown.py)
+        self.executed = []  # multiply-add flops the matrix cores actually issued (< algorithmic for Winograd launches)
 
-    def run(self, tag, flops, fn, detail=""):
+    def run(self, tag, flops, fn, detail="", exec_flops=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn()
         b.record()
         self.spans.append((tag, flops, a, b))
         self.details.append(detail)
+        self.executed.append(flops if exec_flops is None else exec_flops)
         return rc
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for tag, flops, a, b in self.spans:
-            ent = out.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for (tag, flops, a, b), ex in zip(self.spans, self.executed):
+            ent = out.setdefault(tag, {"launches": 0, "ms": 0.0, "flops": 0.0, "exec_flops": 0.0})
             ent["launches"] += 1
             ent["ms"] += a.elapsed_time(b)
             ent["flops"] += flops
+            ent["exec_flops"] += ex
         return out
 
 
@@ -107,11 +110,11 @@ class scope:
         SCOPE = self.prev
 
 
-def _timed(tag, flops, fn, scope_name=None, detail=""):
+def _timed(tag, flops, fn, scope_name=None, detail="", exec_flops=None):
     if TIMER is None:
         return fn()
     s = SCOPE if scope_name is None else scope_name
-    return TIMER.run((s + "/" + tag) if s else tag, flops, fn, detail)
+    return TIMER.run((s + "/" + tag) if s else tag, flops, fn, detail, exec_flops)
 
 
 def _pad4(n):
@@ -227,7 +230,8 @@ class _Conv2d(torch.autograd.Function):
             v_keep = torch.empty(4 * B * H * W * Cx, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, _p(v_keep), ws.data_ptr(), ws.numel(),
-                st), detail="fwd-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino")
+                st), detail="fwd-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=flops / 2.25),
+                "conv2d_wino")
         else:
             nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
             wsp = workspace(nws, x.device).data_ptr() if nws else None
@@ -277,7 +281,7 @@ class _Conv2d(torch.autograd.Function):
                 ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
                     x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, ws.data_ptr(), ws.numel(), st),
-                    scope_name=ctx.bscope, detail="wgrad-wino" + detail[5:]), "conv2d_wino_bwd_weight")
+                    scope_name=ctx.bscope, detail="wgrad-wino" + detail[5:], exec_flops=flops / 2.25), "conv2d_wino_bwd_weight")
             else:
                 ws = workspace(nws, dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
@@ -313,7 +317,7 @@ class _Conv2d(torch.autograd.Function):
                                              ws.data_ptr(), nwino, st)
                     return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
                                                               W, Cx, cop, KH, KW, pad, ws.data_ptr() + nwino, nws, st)
-                _lib.check(_timed("conv_gemm_kernel", flops, run, scope_name=ctx.bscope,
+                _lib.check(_timed("conv_gemm_kernel", flops, run, scope_name=ctx.bscope, exec_flops=flops / 2.25,
                                   detail="dgrad-wino B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_wino dgrad")
             else:
                 ws = workspace(nws, dev)
