@@ -449,18 +449,25 @@ class _Conv2dZeroPad(torch.autograd.Function):
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
         cop = _pad4(Cout)
-        w_prep = _prepped(w, "fwd", cop, Cx, 1)
+        w_prep = None if _wino_ok(H, W, KH, KW, 1, pad, Cx, cop) else _prepped(w, "fwd", cop, Cx, 1)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
         y = empty_cl(B, cop, H, W, x.device)
         st = _stream()
-        nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, 1, pad)
-        wsp = workspace(nws, x.device).data_ptr() if nws else None
         flops = 2.0 * B * H * W * Cout * Cin * KH * KW
-        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_zeropad(
-            x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, 1, pad, act, wsp, nws, st),
-            detail="fwd-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_fwd_zeropad")
+        if _wino_ok(H, W, KH, KW, 1, pad, Cx, cop):
+            U = _prepped(w, "wino_fwd", cop, Cx, 1)
+            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop), x.device)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
+                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 0, None, ws.data_ptr(), ws.numel(), st),
+                detail="fwd-zeropad-wino B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH), exec_flops=flops / 2.25), "conv2d_wino")
+        else:
+            nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, 1, pad)
+            wsp = workspace(nws, x.device).data_ptr() if nws else None
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_zeropad(
+                x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, 1, pad, act, wsp, nws, st),
+                detail="fwd-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_fwd_zeropad")
         ctx.save_for_backward(w, y if act != 0 else None)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, pad, act, Cin, Cout)
         return y
@@ -480,11 +487,18 @@ class _Conv2dZeroPad(torch.autograd.Function):
             ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, cop), dev)
             _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), None, rows, cop, act, ws.data_ptr(),
                                             ws.numel(), st), "act_bwd_bias")
-        w_dg = _prepped(w, "dgrad", cop, Cx, 1)
         dx = empty_cl(B, Cx, H, W, dev)
+        flops = 2.0 * rows * Cout * Cin * KH * KW
+        if _wino_ok(H, W, KH, KW, 1, pad, cop, Cx):          # the adjoint of zero padding is a crop: no ring at all
+            U = _prepped(w, "wino_dgrad", cop, Cx, 1)
+            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx), dev)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
+                g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, None, ws.data_ptr(), ws.numel(), st),
+                detail="dgrad-zeropad-wino B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH), exec_flops=flops / 2.25), "conv2d_wino")
+            return dx, None, None, None, None
+        w_dg = _prepped(w, "dgrad", cop, Cx, 1)
         nws = lib.dwc_conv2d_bwd_data_zeropad_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
         wsp = workspace(nws, dev).data_ptr() if nws else None
-        flops = 2.0 * rows * Cout * Cin * KH * KW
         _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_zeropad(
             g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, wsp, nws, st),
             detail="dgrad-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_bwd_data_zeropad")
