@@ -73,12 +73,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-gpu-batch", type=int, default=PER_GPU_BATCH,
                     help="development knob; the contract workload (and the default) is 16")
+    ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
+                    help="development knob: Winograd output tile of the 3x3 convolutions (default 2 = F(2x2,3x3); 4 = F(4x4,3x3), "
+                         "faster but ~10x the rounding error, see hipdwc/ops.py; 0 = direct)")
     ap.add_argument("--vgg-w", type=float, default=0.0,
                     help="development knob: perceptual-loss weight (the reference's shipped default is 0.1) with a RANDOMLY "
                          "initialised VGG16 (the trained weights cannot be fetched here); the contract workload is 0")
     args = ap.parse_args()
 
     per_gpu_batch = args.per_gpu_batch
+    if args.winograd is not None:
+        ops.WINOGRAD_TILE = args.winograd
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -192,7 +197,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CelebA-shaped 128x128, per-GPU batch 16, fp32, full iteration "
-                                   "(dis_update + gen_update + EMA + LR step), vgg_w=%g" % args.vgg_w,
+                                   "(dis_update + gen_update + EMA + LR step), vgg_w=%g, 3x3 convs as Winograd tile %d" % (
+                                       args.vgg_w, ops.WINOGRAD_TILE),
                        "image_size": IMAGE_SIZE, "per_gpu_batch": per_gpu_batch, "global_batch": per_gpu_batch * world,
                        "parallelism": "dp%d" % world},
             "whole_step_tflops": round(ALGO_GFLOP_PER_IMAGE * value / 1e3, 2),

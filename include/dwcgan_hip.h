@@ -93,24 +93,26 @@ int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float*
 int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
                              int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                              void* ws, size_t ws_bytes, void* stream);
-/* Winograd F(2x2,3x3) for stride-1 3x3 convolutions with pad 1 (the ResBlock convolutions, reference networks.py:514-515):
- * 2.25x fewer multiply-adds than the direct product.  U:[16][N][K] from dwc_wino_prepare_filter (for_dgrad = 0: N = Cout,
- * K = Cin; for_dgrad = 1: the 180-degree rotated, transposed filter, N = Cin, K = Cout).  dwc_conv2d_wino computes
- * y = act(conv3x3(pad1(x)) + bias) with the reflect rule (reflect != 0) or the zero rule; the data gradient's interior is
- * the same call on dY with the for_dgrad filter and the zero rule.  H, W even; Cin a power of two >= 32; Cout % 4 == 0.
- * Scratch: the two transform-domain tensors, 16 * B*H*W/4 * (Cin + Cout) floats. */
-size_t dwc_wino_filter_elems(int Cout, int Cin);
-int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, void* stream);
-size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout);
-/* v_keep (may be NULL): caller-owned [16][B*H*W/4][Cin] buffer that receives the transformed input instead of the
- * scratch, so that dwc_conv2d_wino_bwd_weight can reuse it (v_saved) instead of transforming x again. */
+/* Winograd for stride-1 3x3 convolutions with pad 1 (the ResBlock convolutions, reference networks.py:514-515).
+ * tile = 2: F(2x2,3x3), 16 transform-domain products, 2.25x fewer multiply-adds than the direct product;
+ * tile = 4: F(4x4,3x3), 36 products, 4x fewer (about one decimal digit less accurate).  H, W multiples of tile.
+ * U:[classes][N][K] from dwc_wino_prepare_filter (for_dgrad = 0: N = Cout, K = Cin; for_dgrad = 1: the 180-degree rotated,
+ * transposed filter, N = Cin, K = Cout).  dwc_conv2d_wino computes y = act(conv3x3(pad1(x)) + bias) with the reflect rule
+ * (reflect != 0) or the zero rule; the data gradient's interior is the same call on dY with the for_dgrad filter and the
+ * zero rule.  Cin a power of two >= 32; Cout % 4 == 0.  Scratch: the two transform-domain tensors,
+ * classes * B*H*W/tile^2 * (Cin + Cout) floats.
+ * v_keep (may be NULL): caller-owned [classes][B*H*W/tile^2][Cin] buffer that receives the transformed input instead of
+ * the scratch, so that dwc_conv2d_wino_bwd_weight can reuse it (v_saved) instead of transforming x again. */
+size_t dwc_wino_filter_elems(int Cout, int Cin, int tile);
+int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, int tile, void* stream);
+size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile);
 int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                    int act, int reflect, float* v_keep, void* ws, size_t ws_bytes, void* stream);
+                    int act, int reflect, int tile, float* v_keep, void* ws, size_t ws_bytes, void* stream);
 /* Weight gradient of the same convolutions in the transform domain: dU_e = V_e^T Z_e over the tiles (V = B^T x B with the
  * reflect rule, Z = A dY A^T), then dg = G^T dU G, written in OIHW [cout_real][cin_real][3][3]. */
-size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout);
+size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile);
 int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw_oihw,
-                               int B, int H, int W, int Cin, int Cout, int cin_real, int cout_real,
+                               int B, int H, int W, int Cin, int Cout, int cin_real, int cout_real, int tile,
                                void* ws, size_t ws_bytes, void* stream);
 /* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
  * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).

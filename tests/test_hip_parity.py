@@ -43,6 +43,7 @@ CONV_SHAPES = [
     (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
     (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv (Winograd F(2x2,3x3) forward and data-gradient interior)
     (3, 64, 128, 12, 3, 1, 1, "relu"),      # Winograd, rectangular channel counts, non power-of-two size
+    (2, 64, 64, 10, 3, 1, 1, "none"),       # size not a multiple of 4: F(2x2,3x3)
     (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
     (2, 128, 64, 24, 5, 1, 2, "none"),      # BN=64 path, non power-of-two spatial size
     (2, 64, 4, 32, 7, 1, 3, "heads"),       # fused tanh/sigmoid heads, BN=32 path
@@ -54,6 +55,18 @@ CONV_SHAPES = [
     (2, 8, 16, 12, 3, 1, 1, "sigmoid"),     # small channel counts (tiny config)
     (1, 16, 32, 6, 4, 2, 1, "tanh"),
 ]
+
+
+@pytest.fixture(params=[2, 4], ids=["wino2", "wino4"])
+def winograd_tile(request, monkeypatch):
+    monkeypatch.setattr(ops, "WINOGRAD_TILE", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[4] == 3 and s[1] >= 64], ids=lambda s: "x".join(str(v) for v in s))
+def test_conv3x3_winograd_tiles(shape, winograd_tile):
+    """The stride-1 3x3 layers under both Winograd tiles (F(2x2,3x3) default, F(4x4,3x3) opt-in), same tolerances."""
+    test_conv_forward_backward(shape)
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
