@@ -236,6 +236,7 @@ int main(int argc, char** argv) {
     run_v0<128, 128, 2, 2, 2, 2, NO_GLOBAL | NO_BARRIER | NO_LDS_READ>("v0 128x128 MFMA only", p);
     run_v0<128, 128, 2, 2, 2, 2, NO_LDS_READ>("v0 128x128 global+barrier, no LDS read", p);
     run_v0<128, 64, 2, 2, 2, 1, 0>("v0 128x64 baseline", p);
+    run_v0<256, 64, 4, 1, 2, 2, 0>("v0 256x64 baseline (waves 4x1, 64x64 each)", p);
     run_v0<128, 64, 2, 2, 2, 1, NO_GLOBAL | NO_BARRIER>("v0 128x64 no global, no barrier", p);
     run_v0<128, 64, 2, 2, 2, 1, NO_GLOBAL | NO_BARRIER | NO_LDS_READ>("v0 128x64 MFMA only", p);
     run_lab_v1(p);
