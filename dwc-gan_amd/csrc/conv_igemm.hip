@@ -1021,21 +1021,31 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     }
 }
 
-// slab[(class*splits + s)][ci][co] summed over s (fixed order) = dU_class[ci][co];  dg = G^T dU G -> dw[co][ci][3][3]
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cin, int Cout,
-                                         int cin_real, int cout_real) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// slab[(class*splits + s)][ci][co] summed over s (fixed order) = dU_class[ci][co];  dg = G^T dU G -> dw[co][ci][3][3].
+// 256 threads = 64 consecutive (ci,co) pairs x 4 class groups: each thread sums the split slabs of 4 of the 16 classes
+// (coalesced 256-byte rows), the 16 sums of a pair meet in LDS, one thread per pair applies the inverse filter transform.
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
+                                                                int Cin, int Cout, int cin_real, int cout_real) {
+    __shared__ float us[16][65];
     const size_t plane = (size_t)Cin * Cout;
-    if (idx >= plane) return;
+    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const size_t idx = (size_t)blockIdx.x * 64 + lane;
+    if (idx < plane) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = cg + 4 * k;
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += slab[((size_t)e * splits + z) * plane + idx];
+            us[e][lane] = s;
+        }
+    }
+    __syncthreads();
+    if (cg != 0 || idx >= plane) return;
     const int co = idx % Cout, ci = idx / Cout;
     if (co >= cout_real || ci >= cin_real) return;
     float u[4][4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slab[((size_t)e * splits + z) * plane + idx];
-        u[e >> 2][e & 3] = s;
-    }
+    for (int e = 0; e < 16; ++e) u[e >> 2][e & 3] = us[e][lane];
     float t[3][4];                                     // G^T u,  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -1406,7 +1416,7 @@ int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float
     DWC_LAUNCH_CHECK();
     const size_t plane = (size_t)Cin * Cout;
     if (tile == 2)
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((plane + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((plane + 63) / 64), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
                            cin_real, cout_real);
     else
         hipLaunchKernelGGL(wino4_wgrad_reduce_kernel, dim3((plane + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
