@@ -78,6 +78,8 @@ class Solver(nn.Module):
         self.lr_policy = configs["lr_policy"]
         self.grad_sync = None      # set to hipdwc.dp.GradAllReduce for multi-GPU data parallel
         self._ema = None
+        self._gen_steps = 0            # bumped whenever G's parameters change: validity of the cached content code
+        self._content_cache = None
 
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
         # torch.optim.Adam subclasses (same param_groups / state_dict / scheduler interface) whose step()
@@ -179,7 +181,14 @@ class Solver(nn.Module):
         x4 = ops.pack_image(x_real)
         B = x4.shape[0]
         with torch.no_grad():
-            content, style_real, _ = self.gen.encode(x4)
+            style_real, _ = self.gen.enc_style(x4)              # draw: mapping dropout (same order as gen.encode)
+        # The content code of x_real is a deterministic function of x_real and G, and G does not change between this step
+        # and the generator step that follows: computed ONCE, on the tape, and handed to gen_update (the reference
+        # encodes x_real again there, solver.py:155, with identical values).
+        content_taped = self.gen.enc_content(x4)
+        self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
+        with torch.no_grad():
+            content = content_taped.detach()
             style_real = torch.cat(style_real, dim=1)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
@@ -209,7 +218,12 @@ class Solver(nn.Module):
             # they run here as ONE 3B-sample pass each (larger GEMMs, a third of the launches); the
             # random draws are still made in the reference's order, the masks just get applied later.
             B = x4.shape[0]
-            content_real, style_real, logvar = gen.encode(x4)                    # draw: mapping dropout
+            style_real, logvar = gen.enc_style(x4)                               # draw: mapping dropout
+            cache, self._content_cache = self._content_cache, None
+            if cache is not None and cache[0] is x_real and cache[1] == x_real._version and cache[2] == self._gen_steps:
+                content_real = cache[3]                                          # taped in dis_update on the same batch and G
+            else:
+                content_real = gen.enc_content(x4)
             s_real = torch.cat(style_real, dim=1)
             mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
             style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)   # draws of the text encoder
@@ -276,6 +290,7 @@ class Solver(nn.Module):
         if self.grad_sync is not None:      # data parallel: average G's gradients over the ranks
             self.grad_sync(self.gen_opt.param_groups[0]["params"])
         self.gen_opt.step()
+        self._gen_steps += 1
 
     # ---- visualisation path (reference solver.py:249-289), batched instead of per image ---------
     @torch.no_grad()
@@ -315,6 +330,7 @@ class Solver(nn.Module):
     def resume(self, checkpoint_dir, configs):
         name = self._latest(checkpoint_dir, "gen")
         self.gen.load_state_dict(torch.load(name, map_location="cpu")["a"])
+        self._gen_steps, self._content_cache = self._gen_steps + 1, None
         iterations = int(name[-15:-7]) if "avg" in name else int(name[-11:-3])
         name = self._latest(checkpoint_dir, "dis")
         self.dis.load_state_dict(torch.load(name, map_location="cpu")["b"])
@@ -335,6 +351,7 @@ class Solver(nn.Module):
         sg = self.gen.state_dict()
         sg.update({k: v for k, v in gen_dict.items() if k in sg and "embed_tokens" not in k})
         self.gen.load_state_dict(sg)
+        self._gen_steps, self._content_cache = self._gen_steps + 1, None
         print("Initial model loaded...")
 
     def save(self, snapshot_dir, iterations):
