@@ -939,6 +939,163 @@ bool bwd_geom(const float* dy, float* dxp, int B, int H, int W, int Cin, int Cou
 
 }  // namespace
 
+// F(2x2,3x3) with the output transform FUSED into the GEMM: a workgroup owns BM tiles x BN output channels and walks all
+// 16 transform-domain products for them as ONE flattened K loop of 16 * Cin/32 slabs (no per-product prologue/epilogue,
+// no transform-domain output tensor in HBM).  At the end of product e = (xi, nu) its accumulator M_e is folded into the
+// four output pixels of the tile, Y[a][b] += A^T[a][xi] * A^T[b][nu] * M_e (coefficients 0, +-1), and cleared; the
+// epilogue adds the bias, applies the activation and scatters the 2x2 pixels.
+//   V:[16][T][Cin] (wino_input_kernel), U:[16][N][Cin], y:[B][H][W][N]
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict__ V, const float* __restrict__ U,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int T, int Cin,
+                                                         int N, int H, int W, int act, int tiles_n) {
+    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    DWC_PROBE();
+    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+    constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
+    float* sA = smem;
+    float* sB = smem + 2 * A_TILE;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb >= 16) {
+            const int q = nb >> 3, r = nb & 7, x = bid & 7, yy = bid >> 3;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
+        }
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int arow = t >> 3;
+    const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 4;
+    const float* a_ptr[A_PASSES];
+    const float* b_ptr[B_PASSES];
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) a_ptr[i] = V + (size_t)min(m0 + arow + 32 * i, T - 1) * Cin + acol;
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = U + (size_t)min(n0 + arow + 32 * p, N - 1) * Cin + acol;
+    const int nk = Cin / BK;                                  // slabs per product (Cin is a power of two >= 32)
+    const int total = 16 * nk;
+    const size_t v_class = (size_t)T * Cin, u_class = (size_t)N * Cin;
+    auto stage_slab = [&](int s, int buf) {                  // s = e * nk + kt
+        const int e = s / nk, kt = s - e * nk;
+        const size_t ao = (size_t)e * v_class + kt * BK, bo = (size_t)e * u_class + kt * BK;
+        float* la = sA + buf * A_TILE + wave * (8 * BK);
+        float* lb = sB + buf * B_TILE + wave * (8 * BK);
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + ao),
+                                             (__attribute__((address_space(3))) void*)(la + i * 32 * BK), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[p] + bo),
+                                             (__attribute__((address_space(3))) void*)(lb + p * 32 * BK), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN], Y[4][TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) Y[o][i][j][r] = 0.f;
+            }
+    const int fsw = (l31 >> 1) & 7;
+    int frag_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag_off[q] = ((2 * q + hi) ^ fsw) * 4;
+    const int a_row = (wm * TM * 32 + l31) * BK;
+    const int b_row = (wn * TN * 32 + l31) * BK;
+    f32x4 fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int set, int buf, int q) {
+        const float* a = sA + buf * A_TILE + a_row + frag_off[q];
+        const float* b = sB + buf * B_TILE + b_row + frag_off[q];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * BK);
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][j], fb[set][n][j], acc[i][n], 0, 0, 0);
+    };
+    stage_slab(0, 0);
+    lds_dma_barrier();
+    int buf = 0, kt = 0, e = 0;
+    load_frags(0, 0, 0);
+    for (int s = 0; s < total; ++s) {
+        const bool more = s + 1 < total;
+        if (more) stage_slab(s + 1, buf ^ 1);
+        load_frags(1, buf, 1);
+        mfma_group(0);
+        load_frags(0, buf, 2);
+        mfma_group(1);
+        load_frags(1, buf, 3);
+        mfma_group(0);
+        lds_dma_barrier();
+        if (more) load_frags(0, buf ^ 1, 0);
+        mfma_group(1);
+        buf ^= 1;
+        if (++kt == nk) {                                    // product e = (xi, nu) complete: fold into the 2x2 outputs
+            kt = 0;
+            const int xi = e >> 2, nu = e & 3;
+            // A^T = [[1,1,1,0],[0,1,-1,-1]]
+            const float ca0 = xi < 3 ? 1.f : 0.f, ca1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
+            const float cb0 = nu < 3 ? 1.f : 0.f, cb1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
+            const float c00 = ca0 * cb0, c01 = ca0 * cb1, c10 = ca1 * cb0, c11 = ca1 * cb1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float m = acc[i][n][r];
+                        Y[0][i][n][r] += c00 * m;
+                        Y[1][i][n][r] += c01 * m;
+                        Y[2][i][n][r] += c10 * m;
+                        Y[3][i][n][r] += c11 * m;
+                        acc[i][n][r] = 0.f;
+                    }
+            ++e;
+        }
+    }
+    const int TW = W >> 1, TH = H >> 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int m = m0 + row;
+            if (m >= T) continue;
+            const int tx = m % TW;
+            const int ty = (m / TW) % TH;
+            const int nimg = m / (TW * TH);
+            float* base = y + (((size_t)nimg * H + 2 * ty) * W + 2 * tx) * N;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = n0 + (wn * TN + n) * 32 + l31;
+                if (col >= N) continue;
+                const float bv = bias ? bias[col] : 0.f;
+                base[col] = dwc_act_apply(Y[0][i][n][r] + bv, act, col);
+                base[(size_t)N + col] = dwc_act_apply(Y[1][i][n][r] + bv, act, col);
+                base[(size_t)W * N + col] = dwc_act_apply(Y[2][i][n][r] + bv, act, col);
+                base[(size_t)(W + 1) * N + col] = dwc_act_apply(Y[3][i][n][r] + bv, act, col);
+            }
+        }
+    }
+}
+
 extern "C" {
 
 int dwc_version(void) { return 2; }
@@ -1314,6 +1471,18 @@ int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y,
         hipLaunchKernelGGL(wino4_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin, reflect, tin);
     }
     DWC_LAUNCH_CHECK();
+    static const bool unfused = getenv("DWC_WINO_UNFUSED") != nullptr;      // development knob: separate GEMM + output transform
+    // Fused GEMM + output transform (one workgroup walks all 16 products of its 64 tiles x 64 channels): 14 % faster than the
+    // separate kernels when it yields at least two workgroups per CU; with fewer (batch 16: one per CU) the 16x smaller grid
+    // loses to the separate launches.
+    const long fused_wgs = (long)((T + 63) / 64) * ((Cout + 63) / 64);
+    if (tile == 2 && !unfused && fused_wgs >= 2 * NUM_CU) {
+        const int tn = (Cout + 63) / 64;
+        hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T, Cin,
+                           Cout, H, W, act, tn);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     // the products [T x Cin] . [Cin x Cout] as 1x1 "convolutions" over T one-pixel images, one class each
     Gather g;
     g.tap_t = 0;
