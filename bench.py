@@ -31,11 +31,11 @@ PER_GPU_BATCH = 16
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 ALGO_GFLOP_PER_IMAGE = 569.6           # BASELINE.md section 4 / SURVEY.md 8(d): necessary fwd+bwd conv+linear work
 DOMINANT = "conv_gemm_kernel"          # the forward / data-gradient GEMM family: one span = one conv call = conv_gemm_kernel, or for a 3x3
-                                       # layer wino_input + conv_gemm_batched_kernel + wino_output (+ ring strips and fold for a data gradient)
+                                       # layer wino_input + wino_fused_kernel (or conv_gemm_batched_kernel + wino_output) (+ ring strips and fold for a data gradient)
 # HBM-side bytes per launch of that kernel from the PMC passes committed as profiles/r01_pmc_hbm_traffic.json
 # (rocprofv3 --pmc FETCH_SIZE and, separately, WRITE_SIZE, same command; FETCH_SIZE doubled per the gfx950 note
 # in MI355X_MICROARCH.md).  A profile-time constant: bench.py cannot read PMCs itself.
-DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 476527250
+DOMINANT_TRAFFIC_BYTES_PER_LAUNCH = 421611563
 
 
 def run_iteration(trainer, batch, cfg, it):

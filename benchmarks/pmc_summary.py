@@ -38,7 +38,7 @@ def per_kernel(directory, counter):
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
-    keep = ("conv_gemm_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel", "wino_input_kernel", "wino_output_kernel",
+    keep = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel", "wino_input_kernel", "wino_output_kernel",
             "wino_dy_kernel", "wino_wgrad_reduce_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "in_stats_partial",
             "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
             "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd")
@@ -56,8 +56,8 @@ def main():
                              "hbm_bytes_per_launch_corrected": int((2 * f_avg + w_avg) * 1024)}
     # the forward / data-gradient GEMM family as bench.py's roofline spans see it: one span = one conv call, which for a
     # 3x3 layer is input transform + batched GEMM + output transform (+ ring strips and fold for a data gradient)
-    family = ("conv_gemm_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel", "wino_input_kernel",
-              "wino_output_kernel", "fold_ring_kernel")
+    family = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel",
+              "wino_input_kernel", "wino_output_kernel", "fold_ring_kernel")
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     spans_per_step = int(sys.argv[5]) if len(sys.argv) > 5 else 236
     total = sum((2 * fetch[k][0] + write[k][0]) * 1024 for k in family if k in fetch and k in write)
