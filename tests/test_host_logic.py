@@ -143,3 +143,38 @@ def test_no_cpu_fallback():
     blk = nets.Conv2dBlock(4, 8, 3, 1, 1, norm="in", activation="relu", pad_type="reflect")
     with pytest.raises(RuntimeError, match="no CPU"):
         blk(x)
+
+
+def test_checkpoint_save_resume_roundtrip(tmp_path):
+    """reference solver.py:359-413: file names and keys ({'a': gen}, {'b': dis}, *_avg copies, optimizer.pt), the
+    iteration parsed back from the name, schedulers advanced to it."""
+    from solver import Solver
+    cfg = synth.make_config(image_size=32, tiny=True)
+    cfg["step_size"], cfg["gamma"] = 3, 0.5
+    torch.manual_seed(5)
+    a = Solver(cfg, torch.device("cpu"), None)
+    a.copy_nets()
+    with torch.no_grad():
+        for p in a.gen_copy.parameters():
+            p.mul_(0.5)
+    a.save(str(tmp_path), 6)
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["dis_00000007.pt", "dis_00000007_avg.pt", "gen_00000007.pt", "gen_00000007_avg.pt", "optimizer.pt"]
+    assert set(torch.load(tmp_path / "gen_00000007.pt").keys()) == {"a"} and set(torch.load(tmp_path / "dis_00000007.pt").keys()) == {"b"}
+    torch.manual_seed(99)
+    b = Solver(cfg, torch.device("cpu"), None)
+    it = b.resume(str(tmp_path), cfg)
+    assert it == 7
+    # the newest file whose name contains 'gen' is the averaged copy, exactly as in the reference (sorted()[-1])
+    src = a.gen_copy.state_dict()
+    for k, v in b.gen.state_dict().items():
+        assert torch.equal(v, src[k]), k
+    # the reference rebuilds the schedulers with last_epoch=iterations AND steps them `iterations` times under torch != 0.4.1
+    # (solver.py:374-379): the learning rate after resume is that recipe's, reproduced here on a dummy optimiser
+    dummy = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=cfg["lr"])
+    dummy.param_groups[0]["initial_lr"] = cfg["lr"]
+    sch = torch.optim.lr_scheduler.StepLR(dummy, step_size=3, gamma=0.5, last_epoch=7)
+    for _ in range(7):
+        sch.step()
+    assert b.gen_opt.param_groups[0]["lr"] == pytest.approx(dummy.param_groups[0]["lr"])
+    assert b.dis_opt.param_groups[0]["lr"] == pytest.approx(dummy.param_groups[0]["lr"])
