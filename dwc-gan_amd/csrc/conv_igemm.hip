@@ -20,38 +20,12 @@
 // allows it (one wave per SIMD cannot hide its own LDS/barrier latency), and products with few
 // output tiles but a long K (the discriminator tails, M = B*16 rows) are split along K into
 // partial images that a small epilogue kernel sums (+bias, +activation) in a fixed order.
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include "dwc_common.h"
+#include "conv_geom.h"
 
 namespace {
 
 constexpr int BK = 32;
 
-struct Gather {        // how GEMM row m / column k address the source tensor
-    const float* src;  // [B][SH][SW][SC]
-    int SH, SW, SC, logSC;
-    int OH, OW;        // pixel grid enumerated by m (per image)
-    int logOW, logOHW; // log2 of OW and OH*OW when both are powers of two, else -1
-    int KH, KW, kw_magic;
-    int mul_h, mul_w, kstep, off_h, off_w;  // src_h = oh*mul_h + kh*kstep + off_h (same for w)
-    int reflect;       // 1: reflect at the border, 0: zero outside
-    int M, K;
-    int tap_t;         // 1: taps enumerated (kw, kh) instead of (kh, kw) — weights prepared from the transposed filter
-};
-
-struct Scatter {       // where GEMM row m lands in the destination tensor
-    float* dst;        // [B][OHf][OWf][N]
-    int N;
-    int OHf, OWf, os;  // dst pixel = (oh*os + oph, ow*os + opw)
-};
-
-__device__ __forceinline__ int reflect_idx(int i, int n) {
-    i = i < 0 ? -i : i;
-    return i >= n ? 2 * (n - 1) - i : i;
-}
 
 // ------------------------------------------------------------------------------------------
 // Forward / data-gradient GEMM.  Staging is DIRECT global->LDS (global_load_lds_dwordx4): no
@@ -162,7 +136,7 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
                 h = min(max(h, 0), g.SH - 1);
                 w = min(max(w, 0), g.SW - 1);
             }
-            const float* p = g.src + ((a_img[i] + h * g.SW + w) << g.logSC) + ci;
+            const float* p = (const float*)g.src + ((a_img[i] + h * g.SW + w) << g.logSC) + ci;
             a_src[i] = inb ? p : g_zero_page;   // (no channel offset is ever added to the zero page, see stage_slab)
         }
     };
@@ -252,7 +226,7 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
         }
     }
 
-    float* dst = o.dst + part_offset;
+    float* dst = (float*)o.dst + part_offset;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -291,25 +265,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* _
                                            cls & 1, blockIdx.x, gridDim.x);
 }
 
-// Up to four small products with their own geometry, K range and weight matrix in ONE launch (blockIdx.z picks the
-// strip): the border ring of a data gradient, see dwc_conv2d_bwd_data_same.
-struct Strip {
-    Gather g;
-    Scatter o;
-    const float* w;
-    int kt0, kt1, tiles, tiles_n;
-};
-struct StripSet {
-    Strip s[4];
-    int kt_per_part;        // the K range of every strip is cut into gridDim.y parts (summed by fold_ring_kernel)
-    size_t part_stride;     // elements between the ring buffers of consecutive parts
-};
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
     const Strip& s = ss.s[blockIdx.z];
     if ((int)blockIdx.x >= s.tiles) return;
     const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
+    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, (const float*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
                                            blockIdx.y * ss.part_stride, false, 0, 0, blockIdx.x, s.tiles);
 }
 
@@ -321,8 +282,8 @@ __global__ __launch_bounds__(256) void conv_gemm_batched_kernel(Gather g, const 
                                                                 int tiles_n, int nk) {
     DWC_PROBE();
     const int cls = blockIdx.z;
-    g.src += (size_t)cls * src_class_stride;
-    o.dst += (size_t)cls * dst_class_stride;
+    g.src = (const float*)g.src + (size_t)cls * src_class_stride;
+    o.dst = (float*)o.dst + (size_t)cls * dst_class_stride;
     conv_gemm_body<BM, BN, WM, WN, TM, TN>(g, wmat + (size_t)cls * w_class_stride, o, nullptr, DWC_ACT_NONE, tiles_n, 0, nk, 0, false,
                                            0, 0, blockIdx.x, gridDim.x);
 }
@@ -491,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
     if (splits_per_class > 0) {       // batched form (Winograd): blockIdx.z = class * splits_per_class + split
         const int cls = blockIdx.z / splits_per_class;
         split = blockIdx.z - cls * splits_per_class;
-        g.src += (size_t)cls * src_class_stride;
+        g.src = (const float*)g.src + (size_t)cls * src_class_stride;
         dy += (size_t)cls * dy_class_stride;
     }
     const int m_begin = split * m_chunk;
@@ -539,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
             }
             const int h = reflect_idx(oh * g.mul_h + dh, g.SH);
             const int w = reflect_idx(ow * g.mul_w + dw, g.SW);
-            const float* s = g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci;
+            const float* s = (const float*)g.src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                              (__attribute__((address_space(3))) void*)(la + i * 8 * 128), 16, 0, 0);
         }
@@ -702,77 +663,7 @@ __global__ void weight_prepare_dgrad_kernel(const float* __restrict__ w, float* 
     out[idx] = ok ? w[((size_t)co * Cin + ci) * KH * KW + kh * KW + kw] : 0.f;
 }
 
-int kw_magic_for(int KW, int max_tap) {
-    const int magic = (65536 + KW - 1) / KW;
-    for (int tp = 0; tp <= max_tap; ++tp)
-        if (((tp * magic) >> 16) != tp / KW) return -1;
-    return magic;
-}
 
-// ---- tile / split selection ------------------------------------------------------------------
-constexpr int NUM_CU = 256;
-struct Plan {
-    int bm, bn, splits, kt_per_split;
-};
-
-// Cost model (relative time of the busiest CU).  A CU holds up to `resident` workgroups of a
-// tile shape (LDS / VGPR limits of the direct-to-LDS kernel); it receives n = ceil(blocks/256)
-// of them and works through them `resident` at a time.  A full group runs at the tile's measured
-// MFMA-rate factor f (relative to 128x128 at 2 WG/CU, r01 kernel_bench: 130 / 108 / ~95 TFLOP/s);
-// a trailing partial group runs at reduced efficiency because fewer waves per SIMD are left to
-// cover barrier / LDS latency (one WG alone: 0.62).  This is what makes 768 tiles of 128x128
-// (1.5 groups) lose to 1536 tiles of 128x64 (exactly 2 groups) for the 3B-batched 3x3 convs.
-Plan plan_gemm(int M, int N, int K, int classes) {
-    struct Cand { int bm, bn, resident; float f; };
-    static const Cand all[] = {{128, 128, 2, 1.0f}, {128, 64, 3, 0.85f}, {64, 64, 5, 0.72f}, {128, 32, 4, 0.5f}};
-    const int nk = (K + BK - 1) / BK;
-    Plan best = {128, 32, 1, nk};
-    float best_cost = 3.0e38f;
-    auto valid = [N](const Cand& c) {
-        if (N <= 32) return c.bn == 32;
-        if (N <= 64) return c.bn == 64;
-        return c.bn != 32;
-    };
-    // development knob: DWC_GEMM_TILE=128x128|128x64|64x64 pins the tile where it is valid for this N
-    const char* force = getenv("DWC_GEMM_TILE");
-    const Cand* pinned = nullptr;
-    if (force)
-        for (const Cand& c : all) {
-            char tag[16];
-            snprintf(tag, sizeof tag, "%dx%d", c.bm, c.bn);
-            if (valid(c) && strcmp(tag, force) == 0) pinned = &c;
-        }
-    for (const Cand& c : all) {
-        if (!valid(c) || (pinned && pinned != &c)) continue;
-        const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
-        const long n = (blocks + NUM_CU - 1) / NUM_CU;
-        const long full = n / c.resident, rem = n % c.resident;
-        const float tile = (float)c.bm * c.bn / c.f;
-        float cost = (float)full * c.resident * tile;
-        if (rem) cost += (float)rem * tile / (rem == 1 ? 0.62f : 0.9f);
-        if (cost < best_cost) {
-            best_cost = cost;
-            best = {c.bm, c.bn, 1, nk};
-        }
-    }
-    // split-K: too few output tiles to fill the chip but a long contraction
-    const long blocks = (long)((M + best.bm - 1) / best.bm) * ((N + best.bn - 1) / best.bn) * classes;
-    if (blocks < NUM_CU / 2 && nk >= 8) {
-        int s = (int)((2 * NUM_CU + blocks - 1) / blocks);
-        if (s > nk / 4) s = nk / 4;
-        if (s > 32) s = 32;
-        if (s >= 2) {
-            best.kt_per_split = (nk + s - 1) / s;
-            best.splits = (nk + best.kt_per_split - 1) / best.kt_per_split;
-        }
-    }
-    return best;
-}
-
-size_t gemm_ws_bytes(int M, int N, int K, int classes, size_t dst_elems) {
-    const Plan p = plan_gemm(M, N, K, classes);
-    return p.splits > 1 ? (size_t)p.splits * dst_elems * sizeof(float) : 0;
-}
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 void launch_variant(const Gather& g, const float* w, size_t wcs, int classes, const Scatter& o, const float* bias, int act,
@@ -785,7 +676,7 @@ void launch_variant(const Gather& g, const float* w, size_t wcs, int classes, co
 int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int classes, Scatter o, const float* bias, int act,
                 size_t dst_elems, void* ws, size_t ws_bytes, hipStream_t st) {
     Plan p = plan_gemm(g.M, o.N, g.K, classes);
-    float* final_dst = o.dst;
+    float* final_dst = (float*)o.dst;
     size_t part_stride = 0;
     if (p.splits > 1) {
         if (!ws || ws_bytes < (size_t)p.splits * dst_elems * sizeof(float)) {
@@ -812,130 +703,6 @@ int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int clas
     return DWC_OK;
 }
 
-bool conv_args_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return false;
-    if (dwc_ilog2_exact(Cin) < 2 || (Cout & 3) || Cout <= 0) return false;
-    if (stride != 1 && stride != 2) return false;
-    if (pad < 0 || pad >= H || pad >= W) return false;  // reflect needs pad < size
-    if (H + 2 * pad < KH || W + 2 * pad < KW) return false;
-    return true;
-}
-
-// Split of the pixel contraction of the weight gradient into `splits` ranges of `chunk` rows (a multiple of the
-// 32-row slab).  Every workgroup of a launch does the same amount of work, so the launch takes
-// rounds * (slabs per workgroup + prologue/epilogue) where a round is one full set of resident workgroups: the
-// split count is chosen to fill 1..4 rounds EXACTLY rather than to reach a fixed number of workgroups (29 ranges x
-// 36 tiles = 1044 workgroups is two rounds plus a third for the last 20).
-void wgrad_plan(int M, int K, int N, int* splits, int* chunk, int classes = 1) {
-    const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-    const long resident = bn == 128 ? 2 : (bn == 64 ? 3 : 4);       // workgroups per CU by LDS footprint
-    const long tiles = (long)((K + 127) / 128) * ((N + bn - 1) / bn) * classes;
-    const long slots = NUM_CU * resident;
-    const long slabs = (M + 31) / 32;
-    long best_cost = -1, best_c = slabs;
-    for (long r = 1; r <= 4; ++r) {
-        long s = r * slots / tiles;
-        if (s < 1) s = 1;
-        if (s > slabs / 8) s = slabs / 8 > 0 ? slabs / 8 : 1;       // at least 8 slabs per workgroup
-        const long c = (slabs + s - 1) / s;
-        const long s_eff = (slabs + c - 1) / c;
-        const long rounds = (tiles * s_eff + slots - 1) / slots;
-        const long cost = rounds * (c + 3);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best_c = c;
-        }
-    }
-    *chunk = (int)best_c * 32;
-    *splits = (int)((slabs + best_c - 1) / best_c);
-}
-
-struct FwdGeom {
-    Gather g;
-    Scatter o;
-    size_t dst_elems;
-};
-
-// general forward geometry: separate strides / reflect pads per axis (the plain entry points pass
-// the same value twice; the "wide" 8-pixels-per-row form of the image heads uses stride_w = 8)
-bool fwd_geom_ex(const float* x, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw, int ph,
-                 int pw, FwdGeom* f) {
-    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || sh < 1 || sw < 1) return false;
-    if (dwc_ilog2_exact(Cin) < 2 || (Cout & 3) || Cout <= 0) return false;
-    if (ph < 0 || pw < 0 || ph >= H || pw >= W || H + 2 * ph < KH || W + 2 * pw < KW) return false;
-    const int Ho = (H + 2 * ph - KH) / sh + 1, Wo = (W + 2 * pw - KW) / sw + 1;
-    // the furthest gathered index must stay inside the single reflection: i <= 2*(n-1)
-    if ((Ho - 1) * sh - ph + KH - 1 > 2 * (H - 1) || (Wo - 1) * sw - pw + KW - 1 > 2 * (W - 1)) return false;
-    Gather& g = f->g;
-    g.tap_t = 0;
-    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
-    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-    if (g.kw_magic < 0) return false;
-    g.mul_h = sh; g.mul_w = sw; g.kstep = 1; g.off_h = -ph; g.off_w = -pw; g.reflect = 1;
-    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
-    g.logOW = dwc_ilog2_exact(Wo); g.logOHW = dwc_ilog2_exact(Ho * Wo);
-    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
-    f->o.dst = y; f->o.N = Cout; f->o.OHf = Ho; f->o.OWf = Wo; f->o.os = 1;
-    f->dst_elems = (size_t)g.M * Cout;
-    return true;
-}
-
-bool fwd_geom(const float* x, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, FwdGeom* f) {
-    if (!conv_args_ok(B, H, W, Cin, Cout, KH, KW, stride, pad)) return false;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    Gather& g = f->g;
-    g.tap_t = 0;
-    g.src = x; g.SH = H; g.SW = W; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = Ho; g.OW = Wo; g.KH = KH; g.KW = KW;
-    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-    if (g.kw_magic < 0) return false;
-    g.mul_h = g.mul_w = stride; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 1;
-    g.M = B * Ho * Wo; g.K = KH * KW * Cin;
-    g.logOW = dwc_ilog2_exact(Wo); g.logOHW = dwc_ilog2_exact(Ho * Wo);
-    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
-    f->o.dst = y; f->o.N = Cout; f->o.OHf = Ho; f->o.OWf = Wo; f->o.os = 1;
-    f->dst_elems = (size_t)g.M * Cout;
-    return true;
-}
-
-struct BwdGeom {
-    Gather g;
-    Scatter o;
-    size_t dst_elems, wcs;
-    int classes;
-};
-
-bool bwd_geom(const float* dy, float* dxp, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
-              BwdGeom* f) {
-    // here the gathered tensor is dy (Cout channels) and the produced one is dx (Cin channels)
-    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, stride, pad)) return false;
-    if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3)) return false;
-    if (stride == 2 && !(KH == 4 && KW == 4 && pad == 1 && !(H & 1) && !(W & 1))) return false;
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
-    Gather& g = f->g;
-    g.tap_t = 0;
-    g.src = dy; g.SH = Ho; g.SW = Wo; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
-    g.reflect = 0; g.logOW = g.logOHW = -1;
-    f->o.dst = dxp; f->o.N = Cin; f->o.OHf = Hp; f->o.OWf = Wp;
-    f->dst_elems = (size_t)B * Hp * Wp * Cin;
-    if (stride == 1) {
-        g.OH = Hp; g.OW = Wp; g.KH = KH; g.KW = KW;
-        g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-        if (g.kw_magic < 0) return false;
-        g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1);
-        g.M = B * Hp * Wp; g.K = KH * KW * Cout;
-        f->o.os = 1; f->classes = 1; f->wcs = 0;
-    } else {
-        g.OH = Hp / 2; g.OW = Wp / 2; g.KH = 2; g.KW = 2;
-        g.kw_magic = kw_magic_for(2, 64);
-        g.mul_h = g.mul_w = 1; g.kstep = -1; g.off_h = 0; g.off_w = 0;
-        g.M = B * (Hp / 2) * (Wp / 2); g.K = 4 * Cout;
-        f->o.os = 2; f->classes = 4; f->wcs = (size_t)Cin * ((4 * Cout + BK - 1) / BK * BK);
-    }
-    return true;
-}
 
 }  // namespace
 
@@ -1605,24 +1372,6 @@ int dwc_conv2d_fwd_zeropad(const float* x, const float* w_prepared, const float*
     return launch_gemm(f.g, w_prepared, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
-static bool zeropad_dgrad_geom(const float* dy, float* dx, int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
-                               FwdGeom* f) {
-    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
-    if (dwc_ilog2_exact(Cout) < 2 || (Cin & 3) || KH != KW || 2 * pad != KH - 1) return false;
-    Gather& g = f->g;
-    g.tap_t = 0;
-    g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
-    g.OH = H; g.OW = W; g.KH = KH; g.KW = KW;
-    g.kw_magic = kw_magic_for(KW, KH * KW + 64);
-    if (g.kw_magic < 0) return false;
-    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = -pad; g.off_w = -pad; g.reflect = 0;
-    g.M = B * H * W; g.K = KH * KW * Cout;
-    g.logOW = dwc_ilog2_exact(W); g.logOHW = dwc_ilog2_exact(H * W);
-    if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
-    f->o.dst = dx; f->o.N = Cin; f->o.OHf = H; f->o.OWf = W; f->o.os = 1;
-    f->dst_elems = (size_t)g.M * Cin;
-    return true;
-}
 
 size_t dwc_conv2d_bwd_data_zeropad_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     FwdGeom f;
@@ -1752,72 +1501,6 @@ __global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict
     *out = s;
 }
 
-// Data gradient of a stride-1 "same" reflect-padded convolution (2*pad == K-1, square filter) WITHOUT building the whole
-// padded gradient image: the interior is a zero-padded correlation of dY with the flipped filter over the H x W grid
-// (power-of-two geometry, no wasted rows), written straight into dx; the border ring of the padded image -- the only
-// part the reflect adjoint needs besides -- is four thin strips, each restricted to the filter rows (columns) that can
-// reach real dY pixels, computed by one extra launch and folded onto dx.  Ring work is pad*(KH+KW)/(KH*KW) of the
-// 2*pad*(H+W+2*pad)/(H*W) a full padded image would add: 4 % instead of 13 % for 3x3 on 32x32.
-struct SameDgrad {
-    Gather g;
-    Scatter o;
-    StripSet ss;
-    size_t ring_elems[4], ring_total, dst_elems;
-    int max_tiles, parts;
-};
-
-static bool same_dgrad_geom(const float* dy, const float* w_dg, const float* w_dg_t, float* dx, float* ring, int B, int H, int W,
-                            int Cin, int Cout, int KH, int KW, int pad, SameDgrad* f) {
-    if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
-    if (dwc_ilog2_exact(Cout) < 5 || (Cin & 3) || pad <= 0 || KH != KW || 2 * pad != KH - 1) return false;
-    if (H < 2 * pad + 2 || W < 2 * pad + 2) return false;    // the two border bands of an axis must not overlap
-    const int Wp = W + 2 * pad;
-    const int magic = kw_magic_for(KW, KH * KW + 64);
-    if (magic < 0) return false;
-    auto base = [&](Gather& g, int OH, int OW, int off_h, int off_w, int tap_t) {
-        g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
-        g.OH = OH; g.OW = OW; g.KH = KH; g.KW = KW; g.kw_magic = magic;
-        g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = off_h; g.off_w = off_w; g.reflect = 0;
-        g.M = B * OH * OW; g.K = KH * KW * Cout; g.tap_t = tap_t;
-        g.logOW = dwc_ilog2_exact(OW); g.logOHW = dwc_ilog2_exact(OH * OW);
-        if (g.logOW < 0 || g.logOHW < 0) g.logOW = g.logOHW = -1;
-    };
-    // interior: padded coordinate (i+pad, j+pad) -> source offset -(K-1)+pad = -pad
-    base(f->g, H, W, -pad, -pad, 0);
-    f->o.dst = dx; f->o.N = Cin; f->o.OHf = H; f->o.OWf = W; f->o.os = 1;
-    f->dst_elems = (size_t)B * H * W * Cin;
-    // ring strips (padded coordinates): top rows [0,pad), bottom rows [pad+H, Hp), left/right columns of the rows between
-    const int spt = Cout / BK;                               // K-slabs per filter tap (Cout is a power of two >= 32)
-    const int geo[4][4] = {{pad, Wp, -(KH - 1), -(KW - 1)},
-                           {pad, Wp, -(KH - 1) + pad + H, -(KW - 1)},
-                           {H, pad, -(KH - 1) + pad, -(KW - 1)},
-                           {H, pad, -(KH - 1) + pad, -(KW - 1) + pad + W}};
-    float* p = ring;
-    f->max_tiles = 0;
-    for (int z = 0; z < 4; ++z) {
-        Strip& st = f->ss.s[z];
-        base(st.g, geo[z][0], geo[z][1], geo[z][2], geo[z][3], z >= 2);
-        st.o.dst = p; st.o.N = Cin; st.o.OHf = geo[z][0]; st.o.OWf = geo[z][1]; st.o.os = 1;
-        f->ring_elems[z] = (size_t)st.g.M * Cin;
-        p += f->ring_elems[z];
-        st.w = z < 2 ? w_dg : w_dg_t;
-        // strips 0 / 2 sit before the image: only the LAST pad filter rows (columns) reach real pixels; 1 / 3 the first
-        const int first = (z & 1) ? 0 : KH - pad;
-        st.kt0 = first * KW * spt;
-        st.kt1 = ((z & 1) ? pad : KH) * KW * spt;
-        st.tiles_n = (Cin + 63) / 64;
-        st.tiles = ((st.g.M + 63) / 64) * st.tiles_n;
-        if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
-    }
-    f->ring_total = (size_t)(p - ring);
-    // every strip contracts over pad filter rows (columns): cut that range into parts of >= 8 slabs so that the launch
-    // has enough workgroups in flight to hide the load latency of these short K loops
-    const int range = pad * KW * spt;
-    f->parts = range >= 32 ? 4 : (range >= 24 ? 3 : (range >= 16 ? 2 : 1));
-    f->ss.kt_per_part = (range + f->parts - 1) / f->parts;
-    f->ss.part_stride = f->ring_total;
-    return true;
-}
 
 size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
@@ -1862,27 +1545,6 @@ static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_
     return DWC_OK;
 }
 
-// Data gradient w.r.t. an NHWC4 IMAGE (stem convolutions, Cin = 4): N = 4 would fill 1/8 of a 32-wide MFMA tile, so
-// 8 horizontally adjacent pixels x 4 channels are produced as 32 columns of a KH x (KW+7), stride-(1,8) filter bank
-// (copy p = the flipped filter shifted right by p taps) applied to dY with the zero rule; the padded gradient image
-// lands in `ws` with a row pitch of ceil((W+2*pad)/8)*8 pixels and is folded onto dx (reflect-pad adjoint).
-static bool image_dgrad_geom(const float* dy, float* dxp, int B, int H, int W, int Cout, int KH, int KW, int pad, FwdGeom* f) {
-    if (B <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || pad <= 0 || 2 * pad != KH - 1 || 2 * pad != KW - 1) return false;
-    if (dwc_ilog2_exact(Cout) < 5 || pad >= H || pad >= W) return false;
-    const int Hp = H + 2 * pad, Wg = (W + 2 * pad + 7) / 8;
-    Gather& g = f->g;
-    g.tap_t = 0;
-    g.src = dy; g.SH = H; g.SW = W; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
-    g.OH = Hp; g.OW = Wg; g.KH = KH; g.KW = KW + 7;
-    g.kw_magic = kw_magic_for(KW + 7, KH * (KW + 7) + 64);
-    if (g.kw_magic < 0) return false;
-    g.mul_h = 1; g.mul_w = 8; g.kstep = 1; g.off_h = -(KH - 1); g.off_w = -(KW - 1); g.reflect = 0;
-    g.M = B * Hp * Wg; g.K = KH * (KW + 7) * Cout;
-    g.logOW = g.logOHW = -1;
-    f->o.dst = dxp; f->o.N = 32; f->o.OHf = Hp; f->o.OWf = Wg; f->o.os = 1;
-    f->dst_elems = (size_t)g.M * 32;
-    return true;
-}
 
 size_t dwc_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad) {
     FwdGeom f;

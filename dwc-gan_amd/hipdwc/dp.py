@@ -71,8 +71,11 @@ class GradAllReduce:
 def broadcast_module(module, src=0, group=None):
     """Make every rank start from rank ``src``'s parameters and buffers."""
     with torch.no_grad():
-        for t in list(module.parameters()) + list(module.buffers()):
+        tensors = list(module.parameters()) + list(module.buffers())
+        for t in tensors:
             dist.broadcast(t.data, src=src, group=group)
+        # written through .data: bump the version counters so caches keyed on them (hipdwc.ops._prepped) notice
+        torch.autograd.graph.increment_version(tensors)
 
 
 def shard_batch(batch, rank, world):

@@ -90,8 +90,11 @@ def weights_init(init_type="gaussian"):
         name = type(m).__name__
         if (name.startswith("Conv") or name.startswith("Linear")) and hasattr(m, "weight"):
             fill(m.weight.data)
+            touched = [m.weight]
             if getattr(m, "bias", None) is not None:
                 nn.init.constant_(m.bias.data, 0.0)
+                touched.append(m.bias)
+            torch.autograd.graph.increment_version(touched)     # .data writes: keep version-keyed caches honest
     return visit
 
 
@@ -115,6 +118,7 @@ def moving_average(model, model_copy, beta=0.999):
     if src and src[0].is_cuda:
         # dst + (1-beta)*(src-dst) in torch.lerp's high-weight form, one fused multi-tensor call
         torch._foreach_lerp_(dst, src, 1.0 - beta)
+        torch.autograd.graph.increment_version(list(model_copy.parameters()))   # .data writes do not bump it
     else:
         for s, d in zip(src, dst):
             d.copy_(torch.lerp(s, d, beta))

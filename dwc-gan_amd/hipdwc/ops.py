@@ -127,17 +127,26 @@ def _pad4(n):
 _WCACHE = {}   # id(tensor) -> (weakref to it, {layout key: (version, prepared tensor)})
 
 
-def _prepped(w, kind, cout_pad, cin_pad, stride):
+def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None):
     """Re-laid-out copy of an OIHW weight; recomputed only when the parameter changed
-    (optimizer steps bump ``_version``)."""
-    slot = _WCACHE.get(id(w))
-    if slot is None or slot[0]() is not w:
-        wid = id(w)
-        slot = (weakref.ref(w, lambda _r, wid=wid: _WCACHE.pop(wid, None)), {})
+    (optimizer steps bump ``_version``).  ``owner``: the parameter(s) ``w`` was derived from when ``w`` itself is a
+    fresh tensor on every call (a reshaped Linear weight, the concatenated image heads): the cache then lives on the
+    owner(s) and is keyed on their versions, so the derived tensor does not defeat it."""
+    owners = (w,) if owner is None else (tuple(owner) if isinstance(owner, (tuple, list)) else (owner,))
+    anchor = owners[0]
+    slot = _WCACHE.get(id(anchor))
+    if slot is None or slot[0]() is not anchor:
+        wid = id(anchor)
+        slot = (weakref.ref(anchor, lambda _r, wid=wid: _WCACHE.pop(wid, None)), {})
         _WCACHE[wid] = slot
     ent = slot[1]
-    key = (kind, cout_pad, cin_pad, stride)
-    if ent.get(key, (None, None))[0] == w._version:
+    key = (kind, cout_pad, cin_pad, stride, tuple(w.shape))
+    # validity = (version counter, storage address) of every owner: writers that go through ``.data``
+    # (dist.broadcast(t.data), load_state_dict on a rebound tensor, Module.to()) do not always bump the version but most
+    # of them move or re-bind the storage; the in-tree ``.data`` writers bump the version explicitly
+    # (dp.broadcast_module, host.moving_average, host.weights_init)
+    stamp = tuple((o._version, o.data_ptr()) for o in owners)
+    if ent.get(key, (None, None))[0] == stamp:
         return ent[key][1]
     lib = _lib.load()
     if kind in ("wino_fwd", "wino_dgrad"):
@@ -150,14 +159,14 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
         out = torch.empty(lib.dwc_wino_filter_elems(cout_pad, cin_pad, stride), dtype=torch.float32, device=w.device)
         _lib.check(lib.dwc_wino_prepare_filter(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad,
                                                int(kind == "wino_dgrad"), stride, _stream()), "wino_prepare_filter")
-        ent[key] = (w._version, out)
+        ent[key] = (stamp, out)
         return out
     if kind == "heads_wide":
         # the 4-channel heads as 8 pixels x 4 channels: bank [p*4 + co][ci][KH][KW+7], copy p shifted right by p taps
         bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, 7 - p)) for p in range(8)]).reshape(
             32, w.shape[1], w.shape[2], w.shape[3] + 7)
         out = _prepped(bank, "fwd", 32, cin_pad, 1)
-        ent[key] = (w._version, out)
+        ent[key] = (stamp, out)
         return out
     if kind == "dgrad_image":
         # bank of 8 shifted copies of the flipped, transposed filter: [p*4 + ci][co][KH][KW+7] (dwc_conv2d_bwd_data_image);
@@ -167,7 +176,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
         wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
         bank = torch.stack([torch.nn.functional.pad(wf, (p, 7 - p)) for p in range(8)]).reshape(8 * cin_pad, cout_pad, kh, kw + 7)
         out = _prepped(bank, "fwd", 8 * cin_pad, cout_pad, 1)
-        ent[key] = (w._version, out)
+        ent[key] = (stamp, out)
         return out
     cout, cin, kh, kw = w.shape
     wc = w.detach().contiguous()
@@ -182,7 +191,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride):
     else:
         _lib.check(lib.dwc_weight_prepare_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
                                                 cin_pad, _stream()), "weight_prepare_dgrad")
-    ent[key] = (w._version, out)
+    ent[key] = (stamp, out)
     return out
 
 
