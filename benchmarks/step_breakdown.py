@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Per-problem-shape breakdown of the GEMM launches of ONE training iteration (development aid).
 
-    python benchmarks/step_breakdown.py [per_gpu_batch]
+    python benchmarks/step_breakdown.py [per_gpu_batch] [c1|c2]
 
-Runs a few warm-up iterations of the bench workload (128x128, fp32), then one iteration with HIP
+Runs a few warm-up iterations of the bench workload (128x128; c1 fp32, c2 bf16), then one iteration with HIP
 events around every conv C-ABI call, and prints time / launches / TFLOP/s per (kind, shape),
 largest first.  Tells which layer shapes hold the GEMM roofline fraction down.
 """
@@ -24,7 +24,11 @@ PEAK_TF = 157.3
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    global PEAK_TF
+    conf = sys.argv[2] if len(sys.argv) > 2 else "c1"
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else bench.CONFIGS[conf]["per_gpu_batch"]
+    ops.set_precision(bench.CONFIGS[conf]["precision"])
+    PEAK_TF = bench.MFMA_PEAK_TFLOPS[bench.CONFIGS[conf]["precision"]]
     dev = torch.device("cuda:0")
     from solver import Solver
     cfg = synth.make_config(image_size=128)

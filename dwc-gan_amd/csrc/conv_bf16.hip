@@ -1,0 +1,839 @@
+// bf16-activation implicit-GEMM convolution on the bf16 matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16):
+// BASELINE configs[2] ("128x128 batch=128, bf16 activations + MFMA im2col conv path").
+//
+// Same formulation as conv_igemm.hip (reference networks.py:579-585: reflect pad + conv + bias + activation, and its
+// autograd; geometry shared through conv_geom.h), with
+//   * activations, prepared weights and gradients of activations in bf16 (NHWC, 16-byte chunks = 8 channels),
+//   * fp32 accumulation in the MFMA, fp32 bias / activation epilogue, ONE rounding to bf16 at the store,
+//   * fp32 master weights (re-laid-out and rounded once per optimiser step by dwc_bf16_weight_prepare_*), fp32 weight
+//     gradients (split partial sums in fp32, reduced in a fixed order), fp32 split-K / ring partials.
+// A K-slab is 64 elements = 128 bytes per tile row, i.e. the LDS image, the direct global->LDS staging and the XOR
+// swizzle are byte-for-byte those of the fp32 kernel; one ds_read_b128 is one 32x32x16 operand fragment.
+// The product is taken transposed (D = W_tile . X_tile^T): a lane then owns one output PIXEL and its 16 accumulator
+// registers run over channels in groups of 4, so partials leave as 16-byte fp32 stores and final tiles are packed
+// to bf16, staged through LDS and written as whole 16-byte chunks of a pixel's channel row.
+// The weight gradient contracts over pixels, which is the slow axis of both operands: its LDS tiles stay row-major
+// ([pixel][channel], coalesced from HBM) and the MFMA operands are fetched with the transposing LDS read
+// ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes, delivered channel-major).
+#include "conv_geom.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;          // elements per K-slab (128 bytes per tile row)
+constexpr int MIN_LOG_C = 3;    // a 16-byte staging chunk is 8 channels
+
+__device__ __attribute__((aligned(16))) bf16 g_zero_page_h[128];
+
+__device__ __forceinline__ void lds_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / data-gradient GEMM body.  F32OUT: the destination is fp32 (split-K partials, ring strips).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT>
+__device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restrict__ wmat, const Scatter& o,
+                                            const float* __restrict__ bias, int act, int tiles_n, int kt0, int kt1_in,
+                                            size_t part_offset, bool partial, int oph, int opw, int bid, int nb) {
+    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+    constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
+    constexpr int LDC = BN + 8;                       // epilogue staging pitch (elements)
+    static_assert(BM * LDC <= 2 * (A_TILE + B_TILE), "epilogue staging fits the operand buffers");
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (A_TILE + B_TILE)];
+    bf16* sA = smem;
+    bf16* sB = smem + 2 * A_TILE;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    if (nb >= 16) {     // XCD-aware remap: the 32 CUs of one XCD walk neighbouring tiles
+        const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int arow = t >> 3;                               // tile row this lane stages (+32 per pass)
+    const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 8;  // LOGICAL k offset fetched into physical chunk t&7
+    int a_bh[A_PASSES], a_bw[A_PASSES], a_img[A_PASSES];
+    const int ohw = g.OH * g.OW;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+        const int mm = min(m0 + arow + 32 * i, g.M - 1);
+        const int n = mm / ohw;
+        const int rem = mm - n * ohw;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        a_bh[i] = oh * g.mul_h + g.off_h;
+        a_bw[i] = ow * g.mul_w + g.off_w;
+        a_img[i] = n * g.SH * g.SW;
+    }
+    const int Kp = (g.K + BK - 1) / BK * BK;
+    const bf16* b_ptr[B_PASSES];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = wmat + (size_t)min(n0 + arow + 32 * p, o.N - 1) * Kp + acol;
+
+    const int nk_all = Kp / BK;
+    const int kt1 = min(nk_all, kt1_in);
+    const int n_taps = g.KH * g.KW;
+    const bf16* src = (const bf16*)g.src;
+
+    int cur_tap = -1;
+    const bf16* a_src[A_PASSES];     // per-row source of the current tap (zero page when out of bounds)
+    const bool tap_uniform = g.SC >= BK;
+    auto row_sources = [&](int tap, int ci) {
+        int kh = (tap * g.kw_magic) >> 16;
+        int kw = tap - kh * g.KW;
+        if (g.tap_t) {
+            const int x = kh;
+            kh = kw;
+            kw = x;
+        }
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            int h = a_bh[i] + kh * g.kstep;
+            int w = a_bw[i] + kw * g.kstep;
+            bool inb = true;
+            if (g.reflect) {
+                h = reflect_idx(h, g.SH);
+                w = reflect_idx(w, g.SW);
+            } else {
+                inb = h >= 0 && h < g.SH && w >= 0 && w < g.SW;
+                h = min(max(h, 0), g.SH - 1);
+                w = min(max(w, 0), g.SW - 1);
+            }
+            const bf16* p = src + ((a_img[i] + h * g.SW + w) << g.logSC) + ci;
+            a_src[i] = inb ? p : g_zero_page_h;
+        }
+    };
+    auto stage_slab = [&](int kt, int buf) {
+        int coff;
+        if (tap_uniform) {
+            const int kg0 = kt * BK;
+            const int tap = min(kg0 >> g.logSC, n_taps - 1);
+            if (tap != cur_tap) {
+                row_sources(tap, acol);
+                cur_tap = tap;
+            }
+            coff = kg0 & (g.SC - 1);
+        } else {
+            const int kg = kt * BK + acol;
+            row_sources(min(kg >> g.logSC, n_taps - 1), kg & (g.SC - 1));
+            coff = 0;
+        }
+        bf16* la = sA + buf * A_TILE + wave * (8 * BK);
+        bf16* lb = sB + buf * B_TILE + wave * (8 * BK);
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const bf16* s = a_src[i];
+            if (s != g_zero_page_h) s += coff;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(la + i * 32 * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[p] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)(lb + p * 32 * BK), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: logical chunk 2q+hi of row r sits in physical chunk (2q+hi) ^ ((r>>1)&7)
+    const int fsw = (l31 >> 1) & 7;
+    int frag_off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag_off[q] = ((2 * q + hi) ^ fsw) * 8;
+    const int a_row = (wm * TM * 32 + l31) * BK;
+    const int b_row = (wn * TN * 32 + l31) * BK;
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int set, int buf, int q) {
+        const bf16* a = sA + buf * A_TILE + a_row + frag_off[q];
+        const bf16* b = sB + buf * B_TILE + b_row + frag_off[q];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(a + i * 32 * BK);
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const bf16x8*>(b + n * 32 * BK);
+    };
+    // D[channel][pixel] = W_tile . X_tile^T: the weight fragment is the A operand, the activation fragment the B operand
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][n], fa[set][i], acc[i][n], 0, 0, 0);
+    };
+
+    if (kt0 < kt1) {
+        stage_slab(kt0, 0);
+        lds_dma_barrier();
+        int buf = 0;
+        load_frags(0, 0, 0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = kt + 1 < kt1;
+            if (more) stage_slab(kt + 1, buf ^ 1);       // other buffer: fully read before the last barrier
+            load_frags(1, buf, 1);
+            mfma_group(0);
+            load_frags(0, buf, 2);
+            mfma_group(1);
+            load_frags(1, buf, 3);
+            mfma_group(0);
+            lds_dma_barrier();                            // direct loads landed (vmcnt), this buffer fully read
+            if (more) load_frags(0, buf ^ 1, 0);
+            mfma_group(1);
+            buf ^= 1;
+        }
+    }
+
+    // accumulator layout: lane l31 = pixel row of tile i, register r = channel (r&3) + 8*(r>>2) + 4*hi of tile n
+    if constexpr (F32OUT) {
+        float* dst = (float*)o.dst + part_offset;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + l31;
+            if (m >= g.M) continue;
+            const int n_img = m / ohw;
+            const int rem = m - n_img * ohw;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                    if (col >= o.N) continue;
+                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                    if (!partial) {
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], act, col + k);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + prow * o.N + col) = v;
+                }
+        }
+    } else {
+        __syncthreads();                                  // every wave is done with the operand tiles
+        bf16* sC = smem;                                  // [BM][LDC]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 32 + l31;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                    const int col = n0 + cl;
+                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                    if (col < o.N) {
+                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], act, col + k);
+                    }
+                    *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4(v[0], v[1], v[2], v[3]);
+                }
+        }
+        __syncthreads();
+        bf16* dst = (bf16*)o.dst;
+        constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
+        const bool wide = (o.N & 7) == 0;                 // rows are 16-byte aligned
+        for (int idx = t; idx < BM * CPR; idx += 256) {
+            const int row = idx / CPR, ch = idx - row * CPR;
+            const int m = m0 + row, col = n0 + ch * 8;
+            if (m >= g.M || col >= o.N) continue;
+            const int n_img = m / ohw;
+            const int rem = m - n_img * ohw;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+            bf16* d = dst + prow * o.N + col;
+            const bf16* s = sC + row * LDC + ch * 8;
+            if (wide && col + 8 <= o.N) {
+                *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(s);
+            } else {
+                *reinterpret_cast<bf16x4*>(d) = *reinterpret_cast<const bf16x4*>(s);
+                if (col + 8 <= o.N) *reinterpret_cast<bf16x4*>(d + 4) = *reinterpret_cast<const bf16x4*>(s + 4);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT>
+__global__ __launch_bounds__(256) void gemm_kernel_h(Gather g, const bf16* __restrict__ wmat, size_t w_class_stride, Scatter o,
+                                                     const float* __restrict__ bias, int act, int tiles_n, int kt_per_split,
+                                                     size_t part_stride) {
+    const int cls = blockIdx.z, split = blockIdx.y;
+    gemm_body_h<BM, BN, WM, WN, TM, TN, F32OUT>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
+                                                (split + 1) * kt_per_split, (size_t)split * part_stride, part_stride != 0,
+                                                cls >> 1, cls & 1, blockIdx.x, gridDim.x);
+}
+
+// the border ring of a stride-1 data gradient: up to four small products in one launch, fp32 strips (see conv_igemm.hip)
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_strips_kernel_h(StripSet ss) {
+    const Strip& s = ss.s[blockIdx.z];
+    if ((int)blockIdx.x >= s.tiles) return;
+    const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
+    gemm_body_h<BM, BN, WM, WN, TM, TN, true>(s.g, (const bf16*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0,
+                                              min(s.kt1, kt0 + ss.kt_per_part), blockIdx.y * ss.part_stride, true, 0, 0,
+                                              blockIdx.x, s.tiles);
+}
+
+// dst[i] = act(sum_s part[s][i] + bias[i % N]) rounded to bf16, fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel_h(const float* __restrict__ part, bf16* __restrict__ dst,
+                                                              const float* __restrict__ bias, size_t total4, size_t stride4,
+                                                              int splits, int N, int act) {
+    const int nq = N >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 s = reinterpret_cast<const f32x4*>(part)[i];
+        for (int z = 1; z < splits; ++z) s += reinterpret_cast<const f32x4*>(part)[(size_t)z * stride4 + i];
+        const int c4 = i % nq;
+        if (bias) s += reinterpret_cast<const f32x4*>(bias)[c4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] = dwc_act_apply(s[k], act, c4 * 4 + k);
+        reinterpret_cast<bf16x4*>(dst)[i] = pack4(s[0], s[1], s[2], s[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: dW[k][n] = sum_m A[m][k] * dY[m][n], tile 128(k) x BN(n), pixels in slabs of 64, split over pixel
+// ranges into fp32 slabs.  LDS tiles are row-major [pixel][channel]; 16-byte chunk c of pixel row m is stored at chunk
+// slot c ^ sw(m) so that the four pixel rows of a transposing read fall on different banks:
+//   256-byte rows (128 channels): sw = 4*(m&3);  128-byte rows (64): sw = 4*((m>>1)&1);  64-byte rows (32): none.
+// ------------------------------------------------------------------------------------------
+template <int CPRW>
+__device__ __forceinline__ int tr_swizzle(int m) {
+    return CPRW == 16 ? 4 * (m & 3) : (CPRW == 8 ? 4 * ((m >> 1) & 1) : 0);
+}
+
+template <int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __restrict__ dy, int N, float* __restrict__ slab,
+                                                      int m_chunk) {
+    static_assert(WM * WN == 4 && WM * TM * 32 == 128 && WN * TN * 32 == BN, "tile shape");
+    constexpr int MS = 64;                               // pixels per slab
+    constexpr int A_TILE = MS * 128, B_TILE = MS * BN;   // elements
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (A_TILE + B_TILE)];
+    bf16* sA = smem;               // [buf][m][128 k]
+    bf16* sB = smem + 2 * A_TILE;  // [buf][m][BN]
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int k0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int m_begin = split * m_chunk;
+    const int m_end = min(g.M, m_begin + m_chunk);
+    const bf16* src = (const bf16*)g.src;
+
+    // A staging: thread = (row ar [+16 per pass], chunk slot t&15); it fetches LOGICAL chunk slot ^ sw(row), whose tap and
+    // channel are fixed for the thread (16*pass keeps row & 3).  k >= K (tile tail) is clamped to a valid tap: never stored.
+    const int ar = t >> 4;
+    const int a_lc = (t & 15) ^ tr_swizzle<16>(ar);
+    const int kg = k0 + a_lc * 8;
+    const int tap = min(kg >> g.logSC, g.KH * g.KW - 1);
+    const int ci = kg & (g.SC - 1);
+    const int kh = (tap * g.kw_magic) >> 16;
+    const int kw = tap - kh * g.KW;
+    const int dh = kh * g.kstep + g.off_h, dw = kw * g.kstep + g.off_w;
+    constexpr int CB = BN / 8;                           // chunks per dY tile row
+    constexpr int B_RPP = 256 / CB;                      // rows per pass
+    constexpr int B_PASSES = MS / B_RPP;
+    const int br = t / CB;
+    const int b_lc = (t % CB) ^ tr_swizzle<CB>(br);
+    const int bcol_c = min(n0 + b_lc * 8, N - 8 >= 0 ? N - 8 : 0);      // columns past N are never stored: clamp instead of masking
+    const int ohw = g.OH * g.OW;
+
+    auto stage_slab = [&](int mb, int buf) {
+        bf16* la = sA + buf * A_TILE + wave * 512;
+        bf16* lb = sB + buf * B_TILE + wave * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = min(mb + ar + 16 * i, g.M - 1);
+            int n, oh, ow;
+            if (g.logOW >= 0) {
+                n = m >> g.logOHW;
+                const int rem = m & (ohw - 1);
+                oh = rem >> g.logOW;
+                ow = rem & (g.OW - 1);
+            } else {
+                n = m / ohw;
+                const int rem = m - n * ohw;
+                oh = rem / g.OW;
+                ow = rem - oh * g.OW;
+            }
+            const int h = reflect_idx(oh * g.mul_h + dh, g.SH);
+            const int w = reflect_idx(ow * g.mul_w + dw, g.SW);
+            const bf16* s = src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(la + i * 16 * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < B_PASSES; ++p) {
+            const int m = mb + br + p * B_RPP;
+            const bf16* s = m < m_end ? dy + (size_t)m * N + bcol_c : g_zero_page_h;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)(lb + p * B_RPP * BN), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing reads: 16-lane group gq = lane>>4 covers columns 16*(gq&1).. of a 32-wide tile and pixels 8*(gq>>1)..;
+    // lane 4q+p of the group addresses pixel row q, columns 4p..4p+3; it receives column (lane&15), pixels 0..3 of the block.
+    const int li = lane & 15, gam = (lane >> 4) & 1, hi = lane >> 5;
+    const int tq = li >> 2, tp = li & 3;
+    int a_off[TM], b_off[TN];          // element offsets inside one slab tile for m-step 0, first half (pixel row 8*hi + tq)
+    {
+        const int m_loc = 8 * hi + tq;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int kl = (wm * TM + i) * 32 + 16 * gam + 4 * tp;
+            a_off[i] = m_loc * 128 + (((kl >> 3) ^ tr_swizzle<16>(m_loc)) << 3) + (kl & 7);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int nl = (wn * TN + n) * 32 + 16 * gam + 4 * tp;
+            b_off[n] = m_loc * BN + (((nl >> 3) ^ tr_swizzle<CB>(m_loc)) << 3) + (nl & 7);
+        }
+    }
+    // rows advance by 4 (second half) and 16 (next m-step): both keep (m & 3); for 128-byte rows the swizzle uses bit 1 of
+    // m, unchanged by +4 and +16 as well
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto load_ops = [&](int set, int buf, int ms) {
+        const bf16* a = sA + buf * A_TILE + ms * 16 * 128;
+        const bf16* b = sB + buf * B_TILE + ms * 16 * BN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a + a_off[i]));
+            const bf16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a + a_off[i] + 4 * 128));
+            fa[set][i] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + b_off[n]));
+            const bf16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + b_off[n] + 4 * BN));
+            fb[set][n] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    auto mfma_ops = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][n], acc[i][n], 0, 0, 0);
+    };
+    if (m_begin < m_end) {
+        stage_slab(m_begin, 0);
+        lds_dma_barrier();
+        int buf = 0;
+        load_ops(0, 0, 0);
+        for (int mb = m_begin; mb < m_end; mb += MS) {
+            const bool more = mb + MS < m_end;
+            if (more) stage_slab(mb + MS, buf ^ 1);
+            load_ops(1, buf, 1);
+            mfma_ops(0);
+            load_ops(0, buf, 2);
+            mfma_ops(1);
+            load_ops(1, buf, 3);
+            mfma_ops(0);
+            lds_dma_barrier();
+            if (more) load_ops(0, buf ^ 1, 0);
+            mfma_ops(1);
+            buf ^= 1;
+        }
+    }
+    float* out = slab + (size_t)blockIdx.z * g.K * N;
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = k0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (k >= g.K) continue;
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = n0 + (wn * TN + n) * 32 + l31;
+                if (col < N) out[(size_t)k * N + col] = acc[i][n][r];
+            }
+        }
+}
+
+// slab[s][(kh,kw,ci)][co] summed over s -> dw[co][ci][kh][kw] (state_dict layout, fp32), real channels only
+__global__ void wgrad_reduce_kernel_h(const float* __restrict__ slab, float* __restrict__ dw, int splits, int K, int N, int Cin,
+                                      int KHW, int cin_real, int cout_real) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)K * N) return;
+    const int co = idx % N;
+    const int k = idx / N;
+    const int ci = k % Cin, tap = k / Cin;
+    if (co >= cout_real || ci >= cin_real) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * K * N + idx];
+    dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
+}
+
+// reflect-pad adjoint on bf16 images (fp32 accumulation)
+__global__ void fold_reflect_kernel_h(const bf16* __restrict__ gp, bf16* __restrict__ dx, int B, int H, int W, int C4, int pad,
+                                      int Wp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C4;
+    if (idx >= total) return;
+    const int c = idx % C4;
+    size_t r = idx / C4;
+    const int w = r % W;
+    r /= W;
+    const int h = r % H;
+    const int n = r / H;
+    const int Hp = H + 2 * pad;
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const bf16x4* g4 = reinterpret_cast<const bf16x4*>(gp);
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            const bf16x4 v = g4[((size_t)(n * Hp + hs[a]) * Wp + ws[b]) * C4 + c];
+            s += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+    reinterpret_cast<bf16x4*>(dx)[idx] = pack4(s[0], s[1], s[2], s[3]);
+}
+
+// dx (bf16, holds the interior) += the fp32 border ring folded back by the reflect rule (see fold_ring_kernel, conv_igemm.hip)
+__global__ void fold_ring_kernel_h(bf16* __restrict__ dx, const float* __restrict__ ring, size_t off_bottom, size_t off_left,
+                                   size_t off_right, int parts, size_t part_stride, int B, int H, int W, int C4, int pad) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int band = 2 * pad * (W + H);
+    const size_t total = (size_t)B * band * C4;
+    if (idx >= total) return;
+    const int c = idx % C4;
+    size_t r = idx / C4;
+    const int q = r % band;
+    const int n = r / band;
+    int h, w;
+    if (q < 2 * pad * W) {
+        const int br = q / W;
+        w = q - br * W;
+        h = br < pad ? 1 + br : H - 1 - pad + (br - pad);
+    } else {
+        const int q2 = q - 2 * pad * W, bc = q2 / H;
+        h = q2 - bc * H;
+        w = bc < pad ? 1 + bc : W - 1 - pad + (bc - pad);
+        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;
+    }
+    if (h < 0 || h >= H || w < 0 || w >= W) return;
+    const int Wp = W + 2 * pad;
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    bf16x4* out = reinterpret_cast<bf16x4*>(dx) + ((size_t)(n * H + h) * W + w) * C4 + c;
+    const bf16x4 cur = *out;
+    f32x4 s = {(float)cur[0], (float)cur[1], (float)cur[2], (float)cur[3]};
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            if (a == 0 && b == 0) continue;
+            const int rh = hs[a], rw = ws[b];
+            size_t e;
+            if (rh < pad) e = ((size_t)(n * pad + rh) * Wp + rw) * C4;
+            else if (rh >= pad + H) e = off_bottom / 4 + ((size_t)(n * pad + rh - pad - H) * Wp + rw) * C4;
+            else if (rw < pad) e = off_left / 4 + ((size_t)(n * H + rh - pad) * pad + rw) * C4;
+            else e = off_right / 4 + ((size_t)(n * H + rh - pad) * pad + rw - pad - W) * C4;
+            for (int p = 0; p < parts; ++p) s += reinterpret_cast<const f32x4*>(ring + p * part_stride)[e + c];
+        }
+    *out = pack4(s[0], s[1], s[2], s[3]);
+}
+
+// fp32 OIHW master weights -> bf16 [N][Kp] streaming layouts (see conv_igemm.hip: same orderings, Kp a multiple of 64)
+__global__ void weight_prepare_fwd_kernel_h(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int KHW,
+                                            int cout_pad, int cin_pad, int Kp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)cout_pad * Kp) return;
+    const int k = idx % Kp, co = idx / Kp;
+    const int ci = k % cin_pad, tap = k / cin_pad;
+    float v = 0.f;
+    if (co < Cout && ci < Cin && tap < KHW) v = w[((size_t)co * Cin + ci) * KHW + tap];
+    out[idx] = (bf16)v;
+}
+
+__global__ void weight_prepare_dgrad_kernel_h(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                              int stride, int cout_pad, int cin_pad, int Kp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_class = (size_t)cin_pad * Kp;
+    const int classes = stride == 1 ? 1 : 4;
+    if (idx >= per_class * classes) return;
+    const int cls = idx / per_class;
+    const size_t r = idx % per_class;
+    const int k = r % Kp, ci = r / Kp;
+    const int co = k % cout_pad, tapo = k / cout_pad;
+    int kh, kw;
+    bool ok = co < Cout && ci < Cin;
+    if (stride == 1) {
+        ok = ok && tapo < KH * KW;
+        kh = KH - 1 - tapo / KW;
+        kw = KW - 1 - tapo % KW;
+    } else {
+        ok = ok && tapo < 4;
+        kh = (cls >> 1) + 2 * (tapo >> 1);
+        kw = (cls & 1) + 2 * (tapo & 1);
+    }
+    out[idx] = (bf16)(ok ? w[((size_t)co * Cin + ci) * KH * KW + kh * KW + kw] : 0.f);
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+void launch_variant_h(const Gather& g, const bf16* w, size_t wcs, int classes, const Scatter& o, const float* bias, int act,
+                      const Plan& p, size_t part_stride, bool f32out, hipStream_t st) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (o.N + BN - 1) / BN;
+    if (f32out)
+        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, true>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0,
+                           st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+    else
+        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, false>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0,
+                           st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+}
+
+int launch_gemm_h(const Gather& g, const bf16* w, size_t w_class_stride, int classes, Scatter o, const float* bias, int act,
+                  size_t dst_elems, void* ws, size_t ws_bytes, hipStream_t st) {
+    Plan p = plan_gemm(g.M, o.N, g.K, classes, BK);
+    bf16* final_dst = (bf16*)o.dst;
+    size_t part_stride = 0;
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < (size_t)p.splits * dst_elems * sizeof(float)) {
+            p.splits = 1;
+            p.kt_per_split = (g.K + BK - 1) / BK;
+        } else {
+            o.dst = ws;
+            part_stride = dst_elems;
+        }
+    }
+    const bool f32out = p.splits > 1;
+    if (p.bm == 128 && p.bn == 128) launch_variant_h<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else if (p.bm == 128 && p.bn == 64) launch_variant_h<128, 64, 2, 2, 2, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else if (p.bm == 64 && p.bn == 64) launch_variant_h<64, 64, 2, 2, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else launch_variant_h<128, 32, 4, 1, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    DWC_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        const size_t total4 = dst_elems / 4;
+        size_t blocks = (total4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel_h, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, final_dst, bias, total4,
+                           total4, p.splits, o.N, act);
+        DWC_LAUNCH_CHECK();
+    }
+    return DWC_OK;
+}
+
+int wgrad_launch_h(const FwdGeom& f, const bf16* dy, float* dw_oihw, int Cin, int Cout, int KHW, int cin_real, int cout_real,
+                   void* ws, size_t ws_bytes, hipStream_t st) {
+    const Gather& g = f.g;
+    if (Cout < 8) return DWC_EINVAL;
+    int splits, chunk;
+    wgrad_plan(g.M, g.K, Cout, &splits, &chunk, 1, 64);
+    if (!ws || ws_bytes < (size_t)splits * g.K * Cout * sizeof(float)) return DWC_EWORKSPACE;
+    float* slab = (float*)ws;
+    const int tk = (g.K + 127) / 128;
+    if (Cout > 64) {
+        hipLaunchKernelGGL((wgrad_kernel_h<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy, Cout, slab,
+                           chunk);
+    } else if (Cout > 32) {
+        hipLaunchKernelGGL((wgrad_kernel_h<64, 2, 2, 2, 1>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    } else {
+        hipLaunchKernelGGL((wgrad_kernel_h<32, 4, 1, 1, 1>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    }
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)g.K * Cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel_h, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
+                       cin_real, cout_real);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dwc_bf16_weight_prepared_elems(int Cout, int Cin, int KH, int KW, int stride, int cout_pad, int cin_pad, int for_dgrad) {
+    if (!for_dgrad) return (size_t)cout_pad * ((KH * KW * cin_pad + BK - 1) / BK * BK);
+    if (stride == 1) return (size_t)cin_pad * ((KH * KW * cout_pad + BK - 1) / BK * BK);
+    return (size_t)4 * cin_pad * ((4 * cout_pad + BK - 1) / BK * BK);
+}
+
+int dwc_bf16_weight_prepare_fwd(const float* w, void* out, int Cout, int Cin, int KH, int KW, int cout_pad, int cin_pad,
+                                void* stream) {
+    if (cout_pad < Cout || cin_pad < Cin) return DWC_EINVAL;
+    const int Kp = (KH * KW * cin_pad + BK - 1) / BK * BK;
+    const size_t total = (size_t)cout_pad * Kp;
+    hipLaunchKernelGGL(weight_prepare_fwd_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out, Cout,
+                       Cin, KH * KW, cout_pad, cin_pad, Kp);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_bf16_weight_prepare_dgrad(const float* w, void* out, int Cout, int Cin, int KH, int KW, int stride, int cout_pad,
+                                  int cin_pad, void* stream) {
+    if (cout_pad < Cout || cin_pad < Cin) return DWC_EINVAL;
+    if (stride == 2 && !(KH == 4 && KW == 4)) return DWC_EINVAL;
+    if (stride != 1 && stride != 2) return DWC_EINVAL;
+    const int Kp = ((stride == 1 ? KH * KW : 4) * cout_pad + BK - 1) / BK * BK;
+    const size_t total = (size_t)(stride == 1 ? 1 : 4) * cin_pad * Kp;
+    hipLaunchKernelGGL(weight_prepare_dgrad_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (bf16*)out,
+                       Cout, Cin, KH, KW, stride, cout_pad, cin_pad, Kp);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_bf16_conv2d_fwd_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    FwdGeom f;
+    if (!fwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, MIN_LOG_C)) return 0;
+    return gemm_ws_bytes(f.g.M, Cout, f.g.K, 1, f.dst_elems, BK);
+}
+
+int dwc_bf16_conv2d_fwd(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                        int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if ((Cout & 7) || !fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, MIN_LOG_C)) return DWC_EINVAL;
+    return launch_gemm_h(f.g, (const bf16*)w_prepared, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int dwc_bf16_conv2d_fwd_ex(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream) {
+    FwdGeom f;
+    if ((Cout & 7) || !fwd_geom_ex(x, y, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f, MIN_LOG_C)) return DWC_EINVAL;
+    return launch_gemm_h(f.g, (const bf16*)w_prepared, 0, 1, f.o, bias, act, f.dst_elems, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t dwc_bf16_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    BwdGeom f;
+    if (!bwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, BK, MIN_LOG_C)) return 0;
+    return gemm_ws_bytes(f.g.M, Cin, f.g.K, f.classes, f.dst_elems, BK);
+}
+
+int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int B, int H, int W, int Cin, int Cout, int KH,
+                             int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    BwdGeom f;
+    if ((Cin & 7) || !bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, BK, MIN_LOG_C)) return DWC_EINVAL;
+    return launch_gemm_h(f.g, (const bf16*)w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes,
+                         (hipStream_t)stream);
+}
+
+int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || pad < 0 || pad >= H || pad >= W) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_reflect_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxp,
+                       (bf16*)dx, B, H, W, C / 4, pad, W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
+    SameDgrad f;
+    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return 0;
+    const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
+    return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems, BK);
+}
+
+int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    SameDgrad f;
+    if ((Cin & 7) || !same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return DWC_EINVAL;
+    const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
+    if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_gemm_h(f.g, (const bf16*)w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes,
+                           ws_bytes - ring_bytes, st);
+    if (rc != DWC_OK) return rc;
+    hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
+    hipLaunchKernelGGL(fold_ring_kernel_h, dim3((total + 255) / 256), dim3(256), 0, st, (bf16*)dx, (const float*)ws, f.ring_elems[0],
+                       f.ring_elems[0] + f.ring_elems[1], f.ring_elems[0] + f.ring_elems[1] + f.ring_elems[2], f.parts,
+                       f.ring_total, B, H, W, Cin / 4, pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+// gradient w.r.t. an NHWC8 image through a stem convolution: 4 pixels x 8 planes per GEMM row (see dwc_conv2d_bwd_data_image)
+size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad) {
+    FwdGeom f;
+    if (!image_dgrad_geom(nullptr, nullptr, B, H, W, Cout, KH, KW, pad, &f, 4)) return 0;
+    return f.dst_elems * sizeof(bf16);
+}
+
+int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
+                                   int pad, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!image_dgrad_geom(dy, ws, B, H, W, Cout, KH, KW, pad, &f, 4)) return DWC_EINVAL;
+    if (!ws || ws_bytes < f.dst_elems * sizeof(bf16)) return DWC_EWORKSPACE;
+    const int rc = launch_gemm_h(f.g, (const bf16*)w_wide, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, nullptr, 0,
+                                 (hipStream_t)stream);
+    if (rc != DWC_OK) return rc;
+    const size_t total = (size_t)B * H * W * 2;       // 8 planes = 2 groups of 4 per pixel
+    hipLaunchKernelGGL(fold_reflect_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)ws,
+                       (bf16*)dx, B, H, W, 2, pad, f.g.OW * 4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_bf16_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    int splits, chunk;
+    wgrad_plan(B * Ho * Wo, KH * KW * Cin, Cout, &splits, &chunk, 1, 64);
+    return (size_t)splits * KH * KW * Cin * Cout * sizeof(float);
+}
+
+int dwc_bf16_conv2d_bwd_weight(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
+                               int KW, int stride, int pad, int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom(x, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, MIN_LOG_C)) return DWC_EINVAL;
+    if (cin_real > Cin || cout_real > Cout || (Cout & 7)) return DWC_EINVAL;
+    return wgrad_launch_h(f, (const bf16*)dy, dw_oihw, Cin, Cout, KH * KW, cin_real, cout_real, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t dwc_bf16_conv2d_bwd_weight_ex_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w,
+                                              int pad_h, int pad_w) {
+    FwdGeom f;
+    if (!fwd_geom_ex(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f, MIN_LOG_C)) return 0;
+    int splits, chunk;
+    wgrad_plan(f.g.M, f.g.K, Cout, &splits, &chunk, 1, 64);
+    return (size_t)splits * f.g.K * Cout * sizeof(float);
+}
+
+int dwc_bf16_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride_h, int stride_w, int pad_h, int pad_w, int cin_real, int cout_real, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!fwd_geom_ex(x, nullptr, B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w, &f, MIN_LOG_C)) return DWC_EINVAL;
+    if (cin_real > Cin || cout_real > Cout || (Cout & 7)) return DWC_EINVAL;
+    return wgrad_launch_h(f, (const bf16*)dy, dw_oihw, Cin, Cout, KH * KW, cin_real, cout_real, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

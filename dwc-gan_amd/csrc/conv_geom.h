@@ -136,12 +136,12 @@ bool conv_args_ok(int B, int H, int W, int Cin, int Cout, int KH, int KW, int st
 // rounds * (slabs per workgroup + prologue/epilogue) where a round is one full set of resident workgroups: the
 // split count is chosen to fill 1..4 rounds EXACTLY rather than to reach a fixed number of workgroups (29 ranges x
 // 36 tiles = 1044 workgroups is two rounds plus a third for the last 20).
-void wgrad_plan(int M, int K, int N, int* splits, int* chunk, int classes = 1) {
+void wgrad_plan(int M, int K, int N, int* splits, int* chunk, int classes = 1, int slab_rows = 32) {
     const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
     const long resident = bn == 128 ? 2 : (bn == 64 ? 3 : 4);       // workgroups per CU by LDS footprint
     const long tiles = (long)((K + 127) / 128) * ((N + bn - 1) / bn) * classes;
     const long slots = NUM_CU * resident;
-    const long slabs = (M + 31) / 32;
+    const long slabs = (M + slab_rows - 1) / slab_rows;
     long best_cost = -1, best_c = slabs;
     for (long r = 1; r <= 4; ++r) {
         long s = r * slots / tiles;
@@ -156,7 +156,7 @@ void wgrad_plan(int M, int K, int N, int* splits, int* chunk, int classes = 1) {
             best_c = c;
         }
     }
-    *chunk = (int)best_c * 32;
+    *chunk = (int)best_c * slab_rows;
     *splits = (int)((slabs + best_c - 1) / best_c);
 }
 

@@ -6,6 +6,25 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 dwc_bf16;
+typedef __bf16 dwc_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 dwc_bf16x8 __attribute__((ext_vector_type(8)));
+
+// Element-type generic group-of-4 accessors (index in units of 4 elements): fp32 tensors move 16 bytes, bf16 tensors
+// 8 bytes per access; all arithmetic stays fp32 and a value is rounded to bf16 once, at its store.
+#ifdef __HIPCC__
+__device__ __forceinline__ f32x4 ld4(const float* p, size_t i4) { return reinterpret_cast<const f32x4*>(p)[i4]; }
+__device__ __forceinline__ f32x4 ld4(const dwc_bf16* p, size_t i4) {
+    const dwc_bf16x4 v = reinterpret_cast<const dwc_bf16x4*>(p)[i4];
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void st4(float* p, size_t i4, f32x4 v) { reinterpret_cast<f32x4*>(p)[i4] = v; }
+__device__ __forceinline__ void st4(dwc_bf16* p, size_t i4, f32x4 v) {
+    dwc_bf16x4 r;
+    r[0] = (dwc_bf16)v[0]; r[1] = (dwc_bf16)v[1]; r[2] = (dwc_bf16)v[2]; r[3] = (dwc_bf16)v[3];
+    reinterpret_cast<dwc_bf16x4*>(p)[i4] = r;
+}
+#endif
 
 #define DWC_LAUNCH_CHECK()                                   \
     do {                                                     \
@@ -42,6 +61,7 @@ __device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
         case DWC_ACT_TANH: return tanhf(v);
         case DWC_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case DWC_ACT_HEADS: return ((ch & 3) == 3) ? 1.f / (1.f + expf(-v)) : tanhf(v);
+        case DWC_ACT_HEADS8: return ((ch & 7) == 3) ? 1.f / (1.f + expf(-v)) : ((ch & 7) < 3 ? tanhf(v) : 0.f);
         default: return v;
     }
 }
@@ -54,6 +74,7 @@ __device__ __forceinline__ float dwc_act_grad(float y, int act, int ch) {
         case DWC_ACT_TANH: return 1.f - y * y;
         case DWC_ACT_SIGMOID: return y * (1.f - y);
         case DWC_ACT_HEADS: return ((ch & 3) == 3) ? y * (1.f - y) : 1.f - y * y;
+        case DWC_ACT_HEADS8: return ((ch & 7) == 3) ? y * (1.f - y) : ((ch & 7) < 3 ? 1.f - y * y : 0.f);
         default: return 1.f;
     }
 }

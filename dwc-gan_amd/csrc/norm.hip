@@ -38,21 +38,22 @@ RowSplit plan_rows(int B, int HW) {
 // instance norm
 // ---------------------------------------------------------------------------------------
 // partial[(n*chunks+chunk)*C + c] = sum (x-pivot), second plane = sum (x-pivot)^2
-__global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int rows_per_chunk, size_t plane) {
     __shared__ f32x4 sm[2][256];
     const int cq = C >> 2;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (size_t)n * HW * cq;
-    const f32x4 piv = xs[col];
+    const T* xs = x + (size_t)n * HW * C;
+    const f32x4 piv = ld4(xs, col);
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(HW, r0 + rows_per_chunk);
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     if (rg < groups)
         for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 v = xs[(size_t)r * cq + col] - piv;
+            const f32x4 v = ld4(xs, (size_t)r * cq + col) - piv;
             s1 += v;
             s2 += v * v;
         }
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256) void in_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void in_stats_final(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
+template <typename T>
+__global__ void in_stats_final(const T* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
                                float* __restrict__ rstd, int B, int HW, int C, int chunks, size_t plane, float eps) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
@@ -83,14 +85,15 @@ __global__ void in_stats_final(const float* __restrict__ x, const float* __restr
     const float inv = 1.f / (float)HW;
     const float d = s1 * inv;
     const float var = fmaxf(s2 * inv - d * d, 0.f);
-    mean[idx] = x[(size_t)n * HW * C + c] + d;
+    mean[idx] = (float)x[(size_t)n * HW * C + c] + d;
     rstd[idx] = 1.f / sqrtf(var + eps);
 }
 
-__global__ __launch_bounds__(256) void in_apply(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, const float* __restrict__ residual,
-                                                float* __restrict__ y, int HW, int C, size_t total4, int relu) {
+                                                const float* __restrict__ beta, const T* __restrict__ residual,
+                                                T* __restrict__ y, int HW, int C, size_t total4, int relu) {
     const int cq = C >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = i % cq;
@@ -98,13 +101,13 @@ __global__ __launch_bounds__(256) void in_apply(const float* __restrict__ x, con
         const size_t s = n * cq + c4;
         f32x4 sc = reinterpret_cast<const f32x4*>(rstd)[s];
         if (gamma) sc *= reinterpret_cast<const f32x4*>(gamma)[s];
-        f32x4 v = (reinterpret_cast<const f32x4*>(x)[i] - reinterpret_cast<const f32x4*>(mean)[s]) * sc;
+        f32x4 v = (ld4(x, i) - reinterpret_cast<const f32x4*>(mean)[s]) * sc;
         if (beta) v += reinterpret_cast<const f32x4*>(beta)[s];
         if (relu) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
-        if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
-        reinterpret_cast<f32x4*>(y)[i] = v;
+        if (residual) v += ld4(residual, i);
+        st4(y, i, v);
     }
 }
 
@@ -119,7 +122,8 @@ __device__ __forceinline__ f32x4 relu_mask(f32x4 dy, f32x4 pre, int relu) {
     return dy;
 }
 
-__global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part, int HW, int C, int rows_per_chunk, size_t plane,
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ 
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const size_t base = (size_t)n * HW * cq;
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + base;
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy) + base;
+    const T* xs = x + base * 4;
+    const T* ds = dy + base * 4;
     const size_t s = (size_t)n * cq + col;
     const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[s];
     const f32x4 rs = reinterpret_cast<const f32x4*>(rstd)[s];
@@ -143,8 +147,8 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const float* __restrict__ 
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     if (rg < groups)
         for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 xh = (xs[(size_t)r * cq + col] - mu) * rs;
-            const f32x4 g = relu_mask(ds[(size_t)r * cq + col], xh * ga + be, relu);
+            const f32x4 xh = (ld4(xs, (size_t)r * cq + col) - mu) * rs;
+            const f32x4 g = relu_mask(ld4(ds, (size_t)r * cq + col), xh * ga + be, relu);
             s1 += g;
             s2 += g * xh;
         }
@@ -179,10 +183,11 @@ __global__ void in_bwd_final(const float* __restrict__ part, float* __restrict__
     if (dbeta) dbeta[idx] = s1;
 }
 
-__global__ __launch_bounds__(256) void in_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    const float* __restrict__ sums, float* __restrict__ dx, int HW, int C, int BC,
+                                                    const float* __restrict__ sums, T* __restrict__ dx, int HW, int C, int BC,
                                                     size_t total4, int relu) {
     const int cq = C >> 2;
     const float inv_hw = 1.f / (float)HW;
@@ -197,27 +202,28 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const float* __restrict__ dy
         if (beta) be = reinterpret_cast<const f32x4*>(beta)[s];
         const f32x4 s1 = reinterpret_cast<const f32x4*>(sums)[s];
         const f32x4 s2 = reinterpret_cast<const f32x4*>(sums + BC)[s];
-        const f32x4 xh = (reinterpret_cast<const f32x4*>(x)[i] - mu) * rs;
-        const f32x4 g = relu_mask(reinterpret_cast<const f32x4*>(dy)[i], xh * ga + be, relu);
-        reinterpret_cast<f32x4*>(dx)[i] = ga * rs * (g - s1 * inv_hw - xh * (s2 * inv_hw));
+        const f32x4 xh = (ld4(x, i) - mu) * rs;
+        const f32x4 g = relu_mask(ld4(dy, i), xh * ga + be, relu);
+        st4(dx, i, ga * rs * (g - s1 * inv_hw - xh * (s2 * inv_hw)));
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // MUNIT layer norm (statistics per sample over C*HW)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_stats_partial(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int rows_per_chunk) {
     __shared__ float sm[4];
     const int cq = C >> 2;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (size_t)n * HW * cq;
-    const float piv = x[(size_t)n * HW * C];
+    const T* xs = x + (size_t)n * HW * C;
+    const float piv = (float)x[(size_t)n * HW * C];
     const size_t e0 = (size_t)chunk * rows_per_chunk * cq;
     const size_t e1 = min((size_t)HW * cq, e0 + (size_t)rows_per_chunk * cq);
     float s1 = 0.f, s2 = 0.f;
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const f32x4 v = xs[e] - piv;
+        const f32x4 v = ld4(xs, e) - piv;
         s1 += (v[0] + v[1]) + (v[2] + v[3]);
         s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(256) void ln_stats_partial(const float* __restrict_
     }
 }
 
-__global__ void ln_stats_final(const float* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
+template <typename T>
+__global__ void ln_stats_final(const T* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
                                float* __restrict__ inv, int B, int HW, int C, int chunks, float eps) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= B) return;
@@ -242,13 +249,14 @@ __global__ void ln_stats_final(const float* __restrict__ x, const float* __restr
     const double d = s1 / N;
     double var = (s2 - s1 * d) / (N - 1.0);  // unbiased (torch.std default), reference networks.py:745
     if (var < 0) var = 0;
-    mean[n] = (float)((double)x[(size_t)n * HW * C] + d);
+    mean[n] = (float)((double)(float)x[(size_t)n * HW * C] + d);
     inv[n] = (float)(1.0 / (sqrt(var) + (double)eps));
 }
 
-__global__ __launch_bounds__(256) void ln_apply(const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ inv, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float* __restrict__ y, int HW, int C, size_t total4,
+                                                const float* __restrict__ beta, T* __restrict__ y, int HW, int C, size_t total4,
                                                 int relu) {
     const int cq = C >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
@@ -257,17 +265,18 @@ __global__ __launch_bounds__(256) void ln_apply(const float* __restrict__ x, con
         const float mu = mean[n], iv = inv[n];
         const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
         const f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 v = (reinterpret_cast<const f32x4*>(x)[i] - mu) * iv * ga + be;
+        f32x4 v = (ld4(x, i) - mu) * iv * ga + be;
         if (relu) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         }
-        reinterpret_cast<f32x4*>(y)[i] = v;
+        st4(y, i, v);
     }
 }
 
 // per block: sample sums (sum g, sum g*(x-mu)) with g = dy_eff*gamma, and per-channel
 // partials of dgamma (dy_eff*xhat) and dbeta (dy_eff)
-__global__ __launch_bounds__(256) void ln_bwd_partial(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_partial(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ inv,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part_s, float* __restrict__ part_c, int HW, int C,
@@ -279,8 +288,8 @@ __global__ __launch_bounds__(256) void ln_bwd_partial(const float* __restrict__ 
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const size_t base = (size_t)n * HW * cq;
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + base;
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy) + base;
+    const T* xs = x + base * 4;
+    const T* ds = dy + base * 4;
     const float mu = mean[n], iv = inv[n];
     const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[col];
     const f32x4 be = reinterpret_cast<const f32x4*>(beta)[col];
@@ -290,9 +299,9 @@ __global__ __launch_bounds__(256) void ln_bwd_partial(const float* __restrict__ 
     float t1 = 0.f, t2 = 0.f;
     if (rg < groups)
         for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 xc = xs[(size_t)r * cq + col] - mu;
+            const f32x4 xc = ld4(xs, (size_t)r * cq + col) - mu;
             const f32x4 xh = xc * iv;
-            const f32x4 d = relu_mask(ds[(size_t)r * cq + col], xh * ga + be, relu);
+            const f32x4 d = relu_mask(ld4(ds, (size_t)r * cq + col), xh * ga + be, relu);
             dg += d * xh;
             db += d;
             const f32x4 g = d * ga;
@@ -372,10 +381,11 @@ __global__ __launch_bounds__(1024) void ln_bwd_final(const float* __restrict__ p
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ mean, const float* __restrict__ inv,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                    const float* __restrict__ sums, float* __restrict__ dx, int HW, int C,
+                                                    const float* __restrict__ sums, T* __restrict__ dx, int HW, int C,
                                                     size_t total4, float eps, int relu) {
     const int cq = C >> 2;
     const float N = (float)HW * (float)C;
@@ -389,9 +399,9 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const float* __restrict__ dy
         const float k2 = sigma > 0.f ? iv * iv * sums[n * 2 + 1] / ((N - 1.f) * sigma) : 0.f;
         const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
         const f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
-        const f32x4 xc = reinterpret_cast<const f32x4*>(x)[i] - mu;
-        const f32x4 d = relu_mask(reinterpret_cast<const f32x4*>(dy)[i], xc * iv * ga + be, relu);
-        reinterpret_cast<f32x4*>(dx)[i] = (d * ga - mean_g) * iv - xc * k2;
+        const f32x4 xc = ld4(x, i) - mu;
+        const f32x4 d = relu_mask(ld4(dy, i), xc * iv * ga + be, relu);
+        st4(dx, i, (d * ga - mean_g) * iv - xc * k2);
     }
 }
 
@@ -409,99 +419,153 @@ int grid_for(size_t total4) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-size_t dwc_instnorm_ws_bytes(int B, int HW, int C) {
+size_t instnorm_ws_bytes(int B, int HW, int C) {
     const RowSplit rs = plan_rows(B, HW);
     return ((size_t)2 * B * rs.chunks * C + (size_t)2 * B * C) * sizeof(float);
 }
 
-int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+template <typename T>
+int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y, float* mean,
                      float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
     if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
+    if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
-    hipLaunchKernelGGL(in_stats_partial, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
+    hipLaunchKernelGGL(in_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
     DWC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_stats_final, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
+    hipLaunchKernelGGL(in_stats_final<T>, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
                        plane, eps);
     DWC_LAUNCH_CHECK();
     const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(in_apply, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
+    hipLaunchKernelGGL(in_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
                        total4, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+template <typename T>
+int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
                      size_t ws_bytes, void* stream) {
     if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
+    if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
     float* sums = part + 2 * plane;
-    hipLaunchKernelGGL(in_bwd_partial, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
+    hipLaunchKernelGGL(in_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
                        rs.rows_per_chunk, plane, relu);
     DWC_LAUNCH_CHECK();
     hipLaunchKernelGGL(in_bwd_final, dim3((B * C + 255) / 256), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks,
                        plane);
     DWC_LAUNCH_CHECK();
     const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(in_bwd_apply, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
+    hipLaunchKernelGGL(in_bwd_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
                        B * C, total4, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-size_t dwc_layernorm_ws_bytes(int B, int HW, int C) {
+size_t layernorm_ws_bytes(int B, int HW, int C) {
     const RowSplit rs = plan_rows(B, HW);
     return ((size_t)B * rs.chunks * 2 + (size_t)B * rs.chunks * 2 * C + (size_t)2 * B + 16) * sizeof(float);
 }
 
-int dwc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
+template <typename T>
+int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* inv, int B, int HW,
                       int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
     if (!norm_shape_ok(B, HW, C) || (size_t)HW * C < 2) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
+    if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(ln_stats_partial, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk);
+    hipLaunchKernelGGL(ln_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk);
     DWC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_stats_final, dim3((B + 63) / 64), dim3(64), 0, st, x, part, mean, inv, B, HW, C, rs.chunks, eps);
+    hipLaunchKernelGGL(ln_stats_final<T>, dim3((B + 63) / 64), dim3(64), 0, st, x, part, mean, inv, B, HW, C, rs.chunks, eps);
     DWC_LAUNCH_CHECK();
     const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(ln_apply, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, total4, relu);
+    hipLaunchKernelGGL(ln_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, total4, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* inv, const float* gamma,
-                      const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+template <typename T>
+int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv, const float* gamma,
+                    const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
                       void* ws, size_t ws_bytes, void* stream) {
     if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
+    if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
     float* part_s = (float*)ws;
     float* part_c = part_s + (size_t)B * rs.chunks * 2;
     float* sums = part_c + (size_t)B * rs.chunks * 2 * C;
-    hipLaunchKernelGGL(ln_bwd_partial, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, part_s, part_c, HW,
+    hipLaunchKernelGGL(ln_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, part_s, part_c, HW,
                        C, rs.rows_per_chunk, relu);
     DWC_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_bwd_final, dim3(B + (C + 63) / 64), dim3(1024), 0, st, part_s, part_c, sums, dgamma, dbeta, B, C,
                        rs.chunks);
     DWC_LAUNCH_CHECK();
     const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(ln_bwd_apply, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,
+    hipLaunchKernelGGL(ln_bwd_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,
                        total4, eps, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dwc_instnorm_ws_bytes(int B, int HW, int C) { return instnorm_ws_bytes(B, HW, C); }
+size_t dwc_layernorm_ws_bytes(int B, int HW, int C) { return layernorm_ws_bytes(B, HW, C); }
+
+int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, stream);
+}
+int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+                     size_t ws_bytes, void* stream) {
+    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, stream);
+}
+int dwc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
+                      int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_fwd_t<float>(x, gamma, beta, y, mean, inv, B, HW, C, eps, relu, ws, ws_bytes, stream);
+}
+int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* inv, const float* gamma,
+                      const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_bwd_t<float>(dy, x, mean, inv, gamma, beta, dx, dgamma, dbeta, B, HW, C, eps, relu, ws, ws_bytes, stream);
+}
+
+/* bf16 activations (x, residual, y, dy, dx); statistics, gamma/beta and their gradients stay fp32 */
+int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_fwd_t<dwc_bf16>((const dwc_bf16*)x, gamma, beta, (const dwc_bf16*)residual, (dwc_bf16*)y, mean, rstd, B, HW, C,
+                                    eps, relu, ws, ws_bytes, stream);
+}
+int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+                          size_t ws_bytes, void* stream) {
+    return instnorm_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (const dwc_bf16*)x, mean, rstd, gamma, beta, (dwc_bf16*)dx, dgamma, dbeta,
+                                    B, HW, C, relu, ws, ws_bytes, stream);
+}
+int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
+                           int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_fwd_t<dwc_bf16>((const dwc_bf16*)x, gamma, beta, (dwc_bf16*)y, mean, inv, B, HW, C, eps, relu, ws, ws_bytes,
+                                     stream);
+}
+int dwc_bf16_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* inv, const float* gamma,
+                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+                           void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (const dwc_bf16*)x, mean, inv, gamma, beta, (dwc_bf16*)dx, dgamma, dbeta,
+                                     B, HW, C, eps, relu, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

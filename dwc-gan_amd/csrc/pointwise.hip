@@ -18,8 +18,9 @@ int grid_for(size_t items, int cap = 4096) {
 }
 
 // ---- activation backward + bias gradient ------------------------------------------------
-__global__ __launch_bounds__(256) void act_bwd_partial(const float* __restrict__ dy, const float* __restrict__ y,
-                                                       float* __restrict__ g, float* __restrict__ part, int rows, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy, const T* __restrict__ y,
+                                                       T* __restrict__ g, float* __restrict__ part, int rows, int C,
                                                        int rows_per_chunk, int act) {
     __shared__ f32x4 sm[256];
     const int cq = C >> 2;
@@ -31,13 +32,13 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const float* __restrict__
     f32x4 s = {0, 0, 0, 0};
     for (int r = r0 + rg; r < r1; r += groups) {
         const size_t i = (size_t)r * cq + col;
-        f32x4 d = reinterpret_cast<const f32x4*>(dy)[i];
+        f32x4 d = ld4(dy, i);
         if (act != DWC_ACT_NONE) {
-            const f32x4 yy = reinterpret_cast<const f32x4*>(y)[i];
+            const f32x4 yy = ld4(y, i);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] *= dwc_act_grad(yy[k], act, k);
+            for (int k = 0; k < 4; ++k) d[k] *= dwc_act_grad(yy[k], act, col * 4 + k);
         }
-        if (g) reinterpret_cast<f32x4*>(g)[i] = d;
+        if (g) st4(g, i, d);
         s += d;
     }
     if (!part) return;
@@ -74,6 +75,12 @@ void act_plan(int rows, int* chunks, int* rpc) {
     *chunks = (rows + *rpc - 1) / *rpc;
 }
 
+size_t act_bwd_ws(int rows, int C) {
+    int chunks, rpc;
+    act_plan(rows, &chunks, &rpc);
+    return (size_t)chunks * C * sizeof(float);
+}
+
 // ---- bilinear x2 (align_corners=False), torch's tap rule ------------------------------------
 __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float& l0, float& l1) {
     float src = ((float)o + 0.5f) * 0.5f - 0.5f;
@@ -84,9 +91,10 @@ __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float
     l0 = 1.f - l1;
 }
 
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq,
                                                              size_t total4) {
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    const T* xs = x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;
         size_t r = i / cq;
@@ -99,16 +107,17 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
         up_taps(oy, H, y0, y1, ly0, ly1);
         up_taps(ox, W, x0, x1, lx0, lx1);
         const size_t b = n * H * W;
-        const f32x4 p00 = xs[(b + (size_t)y0 * W + x0) * cq + c], p01 = xs[(b + (size_t)y0 * W + x1) * cq + c];
-        const f32x4 p10 = xs[(b + (size_t)y1 * W + x0) * cq + c], p11 = xs[(b + (size_t)y1 * W + x1) * cq + c];
-        reinterpret_cast<f32x4*>(y)[i] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+        const f32x4 p00 = ld4(xs, (b + (size_t)y0 * W + x0) * cq + c), p01 = ld4(xs, (b + (size_t)y0 * W + x1) * cq + c);
+        const f32x4 p10 = ld4(xs, (b + (size_t)y1 * W + x0) * cq + c), p11 = ld4(xs, (b + (size_t)y1 * W + x1) * cq + c);
+        st4(y, i, ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11));
     }
 }
 
 // adjoint, gather form: every input pixel collects from the <=4x4 output pixels that read it
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int cq,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int cq,
                                                              size_t total4) {
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
+    const T* ds = dy;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;
         size_t r = i / cq;
@@ -142,16 +151,17 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
             f32x4 row = {0, 0, 0, 0};
 #pragma unroll
             for (int b = 0; b < 5; ++b)
-                if (wx[b] != 0.f) row += wx[b] * ds[(base + (size_t)(oy0 + a) * (2 * W) + (ox0 + b)) * cq + c];
+                if (wx[b] != 0.f) row += wx[b] * ld4(ds, (base + (size_t)(oy0 + a) * (2 * W) + (ox0 + b)) * cq + c);
             s += wy[a] * row;
         }
-        reinterpret_cast<f32x4*>(dx)[i] = s;
+        st4(dx, i, s);
     }
 }
 
-__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq,
                                                            size_t total4) {
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
+    const T* xs = x;
     const int Ho = H / 2, Wo = W / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;
@@ -161,13 +171,14 @@ __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restri
         const int oy = r % Ho;
         const size_t n = r / Ho;
         const size_t b = (n * H + 2 * oy) * W + 2 * ox;
-        reinterpret_cast<f32x4*>(y)[i] = ((xs[b * cq + c] + xs[(b + 1) * cq + c]) + (xs[(b + W) * cq + c] + xs[(b + W + 1) * cq + c])) * 0.25f;
+        st4(y, i, ((ld4(xs, b * cq + c) + ld4(xs, (b + 1) * cq + c)) + (ld4(xs, (b + W) * cq + c) + ld4(xs, (b + W + 1) * cq + c))) * 0.25f);
     }
 }
 
-__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int cq,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int cq,
                                                            size_t total4) {
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
+    const T* ds = dy;
     const int Ho = H / 2, Wo = W / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restri
         r /= W;
         const int iy = r % H;
         const size_t n = r / H;
-        reinterpret_cast<f32x4*>(dx)[i] = ds[((n * Ho + iy / 2) * Wo + ix / 2) * cq + c] * 0.25f;
+        st4(dx, i, ld4(ds, ((n * Ho + iy / 2) * Wo + ix / 2) * cq + c) * 0.25f);
     }
 }
 
@@ -257,6 +268,61 @@ __global__ void unpack_nhwc4_kernel(const float* __restrict__ x, float* __restri
     for (int c = 0; c < C; ++c) y[(n * C + c) * HW + p] = v[c];
 }
 
+// NCHW(<=3) fp32 -> NHWC8 bf16 (planes C..7 zero) and back: the bf16 path's image layout (16 bytes per pixel)
+__global__ void pack_nhwc8_kernel(const float* __restrict__ x, dwc_bf16* __restrict__ y, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / HW, p = i % HW;
+    dwc_bf16x8 v;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = (dwc_bf16)0.f;
+    for (int c = 0; c < C; ++c) v[c] = (dwc_bf16)x[(n * C + c) * HW + p];
+    reinterpret_cast<dwc_bf16x8*>(y)[i] = v;
+}
+
+__global__ void unpack_nhwc8_kernel(const dwc_bf16* __restrict__ x, float* __restrict__ y, int C, int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t n = i / HW, p = i % HW;
+    const dwc_bf16x8 v = reinterpret_cast<const dwc_bf16x8*>(x)[i];
+    for (int c = 0; c < C; ++c) y[(n * C + c) * HW + p] = (float)v[c];
+}
+
+__global__ void blend8_fwd_kernel(const dwc_bf16* __restrict__ heads, const dwc_bf16* __restrict__ real, dwc_bf16* __restrict__ out,
+                                  size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const dwc_bf16x8 h = reinterpret_cast<const dwc_bf16x8*>(heads)[i];
+    const dwc_bf16x8 r = reinterpret_cast<const dwc_bf16x8*>(real)[i];
+    const float a = (float)h[3], na = 1.f - a;
+    dwc_bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (dwc_bf16)0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (dwc_bf16)((float)h[c] * a + (float)r[c] * na);
+    reinterpret_cast<dwc_bf16x8*>(out)[i] = o;
+}
+
+__global__ void blend8_bwd_kernel(const dwc_bf16* __restrict__ dout, const dwc_bf16* __restrict__ heads,
+                                  const dwc_bf16* __restrict__ real, dwc_bf16* __restrict__ dheads, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const dwc_bf16x8 d = reinterpret_cast<const dwc_bf16x8*>(dout)[i];
+    const dwc_bf16x8 h = reinterpret_cast<const dwc_bf16x8*>(heads)[i];
+    const dwc_bf16x8 r = reinterpret_cast<const dwc_bf16x8*>(real)[i];
+    dwc_bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (dwc_bf16)0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = (dwc_bf16)((float)d[c] * (float)h[3]);
+        s += (float)d[c] * (float)h[c] - (float)d[c] * (float)r[c];
+    }
+    o[3] = (dwc_bf16)s;
+    reinterpret_cast<dwc_bf16x8*>(dheads)[i] = o;
+}
+
 // ---- attention blend -----------------------------------------------------------------------------
 __global__ void blend_fwd_kernel(const float* __restrict__ heads, const float* __restrict__ real, float* __restrict__ out, size_t npix) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -288,16 +354,18 @@ __global__ void blend_bwd_kernel(const float* __restrict__ dout, const float* __
 }
 
 // ---- mean |a-b| ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void l1_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ part,
                                                          size_t n4, size_t n, int skip4) {
     __shared__ float sm[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 d = reinterpret_cast<const f32x4*>(a)[i] - reinterpret_cast<const f32x4*>(b)[i];
+        const f32x4 d = ld4(a, i) - ld4(b, i);
+        if (skip4 == 8 && (i & 1)) continue;               // planes 4..7 of an 8-plane image
         s += (fabsf(d[0]) + fabsf(d[1])) + (fabsf(d[2]) + (skip4 ? 0.f : fabsf(d[3])));
     }
     if (blockIdx.x == 0)
-        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += fabsf(a[i] - b[i]);
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += fabsf((float)a[i] - (float)b[i]);
     s = dwc_block_sum_256(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -310,15 +378,16 @@ __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__
     if (threadIdx.x == 0) out[0] = s * inv_n;
 }
 
-__global__ void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dout, float* __restrict__ da,
-                              float* __restrict__ db, size_t n, float inv_n, int skip4) {
+template <typename T>
+__global__ void l1_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ dout, T* __restrict__ da,
+                              T* __restrict__ db, size_t n, float inv_n, int skip4) {
     const float sc = dout[0] * inv_n;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float d = a[i] - b[i];
+        const float d = (float)a[i] - (float)b[i];
         float g = d > 0.f ? sc : (d < 0.f ? -sc : 0.f);
-        if (skip4 && (i & 3) == 3) g = 0.f;
-        if (da) da[i] = g;
-        if (db) db[i] = -g;
+        if (skip4 && (i & (skip4 - 1)) >= 3) g = 0.f;
+        if (da) da[i] = (T)g;
+        if (db) db[i] = (T)(-g);
     }
 }
 
@@ -388,17 +457,21 @@ size_t dwc_act_bwd_bias_ws_bytes(int rows, int C) {
     return (size_t)chunks * C * sizeof(float);
 }
 
-int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
-                     void* stream) {
+}  // extern "C"
+
+namespace {
+
+template <typename T>
+int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes, void* stream) {
     if (rows <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
     const int cq = C >> 2;
     if (cq < 256 ? (256 % cq) != 0 : (cq % 256) != 0) return DWC_EINVAL;
     if (act != DWC_ACT_NONE && !y) return DWC_EINVAL;
-    if (db && (!ws || ws_bytes < dwc_act_bwd_bias_ws_bytes(rows, C))) return DWC_EWORKSPACE;
+    if (db && (!ws || ws_bytes < act_bwd_ws(rows, C))) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int chunks, rpc;
     act_plan(rows, &chunks, &rpc);
-    hipLaunchKernelGGL(act_bwd_partial, dim3(chunks, (cq + 255) / 256), dim3(256), 0, st, dy, y, g, db ? (float*)ws : nullptr,
+    hipLaunchKernelGGL(act_bwd_partial<T>, dim3(chunks, (cq + 255) / 256), dim3(256), 0, st, dy, y, g, db ? (float*)ws : nullptr,
                        rows, C, rpc, act);
     DWC_LAUNCH_CHECK();
     if (db) {
@@ -408,38 +481,71 @@ int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int r
     return DWC_OK;
 }
 
-int dwc_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+template <typename T>
+int upsample2x_fwd_t(const T* x, T* y, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4,
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4,
                        total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+template <typename T>
+int upsample2x_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4,
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4,
                        total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+template <typename T>
+int avgpool2_fwd_t(const T* x, T* y, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel<T>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+template <typename T>
+int avgpool2_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4, total4);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel<T>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4, total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
+                     void* stream) {
+    return act_bwd_bias_t<float>(dy, y, g, db, rows, C, act, ws, ws_bytes, stream);
+}
+int dwc_bf16_act_bwd_bias(const void* dy, const void* y, void* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
+                          void* stream) {
+    return act_bwd_bias_t<dwc_bf16>((const dwc_bf16*)dy, (const dwc_bf16*)y, (dwc_bf16*)g, db, rows, C, act, ws, ws_bytes, stream);
+}
+int dwc_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) { return upsample2x_fwd_t<float>(x, y, B, H, W, C, stream); }
+int dwc_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) { return upsample2x_bwd_t<float>(dy, dx, B, H, W, C, stream); }
+int dwc_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) { return avgpool2_fwd_t<float>(x, y, B, H, W, C, stream); }
+int dwc_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) { return avgpool2_bwd_t<float>(dy, dx, B, H, W, C, stream); }
+int dwc_bf16_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    return upsample2x_fwd_t<dwc_bf16>((const dwc_bf16*)x, (dwc_bf16*)y, B, H, W, C, stream);
+}
+int dwc_bf16_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    return upsample2x_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (dwc_bf16*)dx, B, H, W, C, stream);
+}
+int dwc_bf16_avgpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    return avgpool2_fwd_t<dwc_bf16>((const dwc_bf16*)x, (dwc_bf16*)y, B, H, W, C, stream);
+}
+int dwc_bf16_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    return avgpool2_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (dwc_bf16*)dx, B, H, W, C, stream);
 }
 
 int dwc_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
@@ -492,26 +598,79 @@ int dwc_blend_bwd(const float* dout, const float* heads, const float* real, floa
 
 size_t dwc_l1_ws_bytes(size_t n) { return (size_t)grid_for(n / 4 + 1, 1024) * sizeof(float); }
 
-int dwc_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes,
-                    void* stream) {
-    if (n == 0 || (skip4 && (n & 3))) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_l1_ws_bytes(n)) return DWC_EWORKSPACE;
+}  // extern "C"
+
+namespace {
+
+// skip4: 0 = mean over every element; 4 / 8 = the tensors are NHWC4 / NHWC8 images, mean over planes 0..2 only
+template <typename T>
+int l1_mean_fwd_t(const T* a, const T* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes, void* stream) {
+    if (skip4 == 1) skip4 = 4;
+    if (n == 0 || (skip4 != 0 && skip4 != 4 && skip4 != 8) || (skip4 && (n % skip4))) return DWC_EINVAL;
+    if (!ws || ws_bytes < (size_t)grid_for(n / 4 + 1, 1024) * sizeof(float)) return DWC_EWORKSPACE;
     const int blocks = grid_for(n / 4 + 1, 1024);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, st, a, b, (float*)ws, n / 4, n, skip4);
+    hipLaunchKernelGGL(l1_partial_kernel<T>, dim3(blocks), dim3(256), 0, st, a, b, (float*)ws, n / 4, n, skip4);
     DWC_LAUNCH_CHECK();
-    const double count = skip4 ? (double)n * 0.75 : (double)n;
+    const double count = skip4 ? (double)n * 3.0 / skip4 : (double)n;
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, blocks, (float)(1.0 / count));
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
-int dwc_l1_mean_bwd(const float* a, const float* b, const float* dout, float* da, float* db, size_t n, int skip4,
-                    void* stream) {
-    if (n == 0 || (skip4 && (n & 3))) return DWC_EINVAL;
-    const double count = skip4 ? (double)n * 0.75 : (double)n;
-    hipLaunchKernelGGL(l1_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, dout, da, db, n,
+template <typename T>
+int l1_mean_bwd_t(const T* a, const T* b, const float* dout, T* da, T* db, size_t n, int skip4, void* stream) {
+    if (skip4 == 1) skip4 = 4;
+    if (n == 0 || (skip4 != 0 && skip4 != 4 && skip4 != 8) || (skip4 && (n % skip4))) return DWC_EINVAL;
+    const double count = skip4 ? (double)n * 3.0 / skip4 : (double)n;
+    hipLaunchKernelGGL(l1_bwd_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, dout, da, db, n,
                        (float)(1.0 / count), skip4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_l1_mean_fwd(const float* a, const float* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes, void* stream) {
+    return l1_mean_fwd_t<float>(a, b, out, n, skip4, ws, ws_bytes, stream);
+}
+int dwc_l1_mean_bwd(const float* a, const float* b, const float* dout, float* da, float* db, size_t n, int skip4, void* stream) {
+    return l1_mean_bwd_t<float>(a, b, dout, da, db, n, skip4, stream);
+}
+int dwc_bf16_l1_mean_fwd(const void* a, const void* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes, void* stream) {
+    return l1_mean_fwd_t<dwc_bf16>((const dwc_bf16*)a, (const dwc_bf16*)b, out, n, skip4, ws, ws_bytes, stream);
+}
+int dwc_bf16_l1_mean_bwd(const void* a, const void* b, const float* dout, void* da, void* db, size_t n, int skip4, void* stream) {
+    return l1_mean_bwd_t<dwc_bf16>((const dwc_bf16*)a, (const dwc_bf16*)b, dout, (dwc_bf16*)da, (dwc_bf16*)db, n, skip4, stream);
+}
+
+int dwc_pack_nchw_to_nhwc8_bf16(const float* x, void* y, int B, int C, int H, int W, void* stream) {
+    if (C < 1 || C > 8 || B <= 0 || H <= 0 || W <= 0) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(pack_nhwc8_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (dwc_bf16*)y, C, H * W, total);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+int dwc_unpack_nhwc8_bf16_to_nchw(const void* x, float* y, int B, int C, int H, int W, void* stream) {
+    if (C < 1 || C > 8 || B <= 0 || H <= 0 || W <= 0) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(unpack_nhwc8_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const dwc_bf16*)x, y, C, H * W, total);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+int dwc_bf16_blend_fwd(const void* heads, const void* real, void* out, int npix, void* stream) {
+    if (npix <= 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(blend8_fwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const dwc_bf16*)heads,
+                       (const dwc_bf16*)real, (dwc_bf16*)out, (size_t)npix);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+int dwc_bf16_blend_bwd(const void* dout, const void* heads, const void* real, void* dheads, int npix, void* stream) {
+    if (npix <= 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(blend8_bwd_kernel, dim3((npix + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const dwc_bf16*)dout,
+                       (const dwc_bf16*)heads, (const dwc_bf16*)real, (dwc_bf16*)dheads, (size_t)npix);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

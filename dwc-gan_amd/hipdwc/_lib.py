@@ -71,6 +71,39 @@ SIGNATURES = {
     "dwc_ema_lerp": (c_int, [c_fp, c_fp, c_sz, c_f, c_fp]),
     "dwc_adam_multi": (c_int, [c_fp, c_fp, c_fp, c_int] + [ctypes.c_double] * 4 + [c_fp]),
     "dwc_ema_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_f, c_fp]),
+    # ---- bf16-activation path (same argument lists as the fp32 entry points of the same name) ----
+    "dwc_bf16_weight_prepared_elems": (c_sz, [c_int] * 8),
+    "dwc_bf16_weight_prepare_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_weight_prepare_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_conv2d_fwd_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_bf16_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_fwd_ex": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 12 + [c_fp]),
+    "dwc_bf16_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_bf16_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
+    "dwc_bf16_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_data_image_ws_bytes": (c_sz, [c_int] * 7),
+    "dwc_bf16_conv2d_bwd_data_image": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),
+    "dwc_bf16_conv2d_bwd_weight": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 11 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_weight_ex_ws_bytes": (c_sz, [c_int] * 11),
+    "dwc_bf16_conv2d_bwd_weight_ex": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 13 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_upsample2x_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_upsample2x_bwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_avgpool2_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_avgpool2_bwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_pack_nchw_to_nhwc8_bf16": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_unpack_nhwc8_bf16_to_nchw": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_blend_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_bf16_blend_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_bf16_l1_mean_fwd": (c_int, [c_fp, c_fp, c_fp, c_sz, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",

@@ -6,8 +6,16 @@ BatchNorm) and every loss is a batch mean, so equal shards + gradient AVERAGING 
 global-batch gradient.  There is exactly one exchange per optimiser step: an all-reduce of
 that optimiser's gradients (D: 13.99 M floats = 55.9 MB, G: 20.36 M = 81.4 MB at 128x128),
 packed into flat fp32 buckets so that RCCL sees a few large messages (xGMI is point-to-point:
-per-link bandwidth, not message rate, is the limit).  ~1 ms on the wire against a step of
-~100 ms, so the exchange is issued right after backward without further overlap machinery.
+per-link bandwidth, not message rate, is the limit).
+
+Two forms:
+  * ``OverlappedGradReducer`` (what ``bench.py`` and the trainer use for world > 1): the gradients of a network ARE views
+    of persistent flat fp32 buckets laid out in reverse parameter order (the order backward produces them), so there is
+    no packing pass and no copy back; a post-accumulate-grad hook counts each bucket down and launches its all-reduce
+    the moment its last gradient has been written, i.e. while the rest of backward still runs.  The
+    layout is fixed at construction from the full parameter list, so it agrees across ranks by construction.
+  * ``GradAllReduce``: the simple form (pack after backward, reduce, unpack) kept for callers that hand over an arbitrary
+    parameter list.
 
 The one piece that does not shard is the text encoder's batch-mixing ``view`` (reference
 networks_v2.py:249): an N-rank run equals N independent local batches, not one global batch.
@@ -66,6 +74,97 @@ class GradAllReduce:
                 views.append(flat[off:off + n].view_as(g))
                 off += n
             torch._foreach_copy_(bucket, views)          # one multi-tensor launch instead of one copy per gradient
+
+
+class OverlappedGradReducer:
+    """Gradient averaging overlapped with backward for ONE optimiser's parameters.
+
+    ``prepare(skip=())`` replaces ``optimizer.zero_grad()``: zero-fills the flat buckets (one memset each) and points every
+    parameter's ``.grad`` at its view, so autograd accumulates in place.  ``skip``: parameters known to receive no gradient
+    on this step (the attention head while attention is switched off, reference solver.py:109-111) -- they are not waited
+    for.  During backward a hook per parameter counts its bucket down; a bucket whose count reaches zero is all-reduced
+    asynchronously at once.  ``finish()`` (after backward) launches whatever is left, waits, and sets ``.grad = None`` on
+    every parameter that received no gradient so that Adam skips it exactly as in a single-process run
+    (SURVEY.md section 7 quirk viii: no weight decay / momentum for gradient-less parameters).  Averaging uses
+    ReduceOp.AVG where the backend has it (RCCL) and SUM followed by one scale per bucket otherwise (gloo)."""
+
+    def __init__(self, params, group=None, bucket_bytes=64 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, cap = self.params[0].device, max(1, bucket_bytes // 4)
+        self.avg = dist.get_backend(group) == "nccl"
+        # reverse parameter order: the last layers' gradients are produced first
+        layout, cur, n = [], [], 0
+        for p in reversed(self.params):
+            if cur and n + p.numel() > cap:
+                layout.append(cur)
+                cur, n = [], 0
+            cur.append(p)
+            n += p.numel()
+        layout.append(cur)
+        self.buckets = []          # dicts: flat buffer, params, views
+        self.where = {}            # id(param) -> bucket index
+        for bi, plist in enumerate(layout):
+            flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in plist:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+                self.where[id(p)] = bi
+            self.buckets.append({"flat": flat, "params": plist, "views": views, "pending": 0, "work": None})
+        self.touched = set()
+        self.active = False
+        self.launched_early = 0    # buckets whose all-reduce started from inside backward (overlap evidence)
+        self.calls = 0
+        self.bytes = 0
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _launch(self, b):
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        b["work"] = dist.all_reduce(b["flat"], op=op, group=self.group, async_op=True)
+        self.calls += 1
+        self.bytes += b["flat"].numel() * 4
+
+    def _hook(self, p):
+        if not self.active or id(p) in self.touched:
+            return
+        self.touched.add(id(p))
+        b = self.buckets[self.where[id(p)]]
+        b["pending"] -= 1
+        if b["pending"] == 0 and b["work"] is None and self.world > 1:
+            self._launch(b)
+            self.launched_early += 1
+
+    @torch.no_grad()
+    def prepare(self, skip=()):
+        skip_ids = {id(p) for p in skip}
+        self.touched.clear()
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["work"] = None
+            b["pending"] = sum(1 for p in b["params"] if id(p) not in skip_ids)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v
+        self.active = True
+
+    @torch.no_grad()
+    def finish(self):
+        self.active = False
+        if self.world > 1:
+            for b in self.buckets:
+                if b["work"] is None:
+                    self._launch(b)
+            for b in self.buckets:
+                b["work"].wait()
+                if not self.avg:
+                    b["flat"].mul_(1.0 / self.world)
+        for p in self.params:
+            if id(p) not in self.touched:
+                p.grad = None          # no gradient this step: Adam must skip it (same set on every rank)
 
 
 def broadcast_module(module, src=0, group=None):

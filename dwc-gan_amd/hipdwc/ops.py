@@ -12,7 +12,37 @@ import torch
 
 from . import _lib
 
-ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "heads": 5}
+ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "heads": 5, "heads8": 6}
+
+# Activation precision of the conv/norm stack.  "fp32" (default; BASELINE configs[1], the parity configuration): fp32 NHWC
+# activations, images as NHWC4.  "bf16" (BASELINE configs[2]): `pack_image` produces bf16 NHWC8 images and every op
+# downstream keeps bf16 activations / activation gradients on the bf16 MFMA kernels (dwc_bf16_* entry points); master
+# weights, weight gradients, biases, norm statistics, AdaIN/LN parameters and all loss reductions stay fp32.
+# Ops dispatch on the dtype of the tensor they are given, so fp32 side branches (the style MLP, the text encoder) coexist.
+PRECISION = "fp32"
+BF16 = torch.bfloat16
+
+
+def set_precision(name):
+    """Select "fp32" or "bf16" activations for images packed from now on."""
+    global PRECISION
+    if name not in ("fp32", "bf16"):
+        raise ValueError("precision must be 'fp32' or 'bf16'")
+    PRECISION = name
+
+
+def act_dtype():
+    return BF16 if PRECISION == "bf16" else torch.float32
+
+
+def image_planes(dtype=None):
+    """Channel planes of an internal image buffer: NHWC4 (fp32) or NHWC8 (bf16; one 16-byte chunk per pixel either way)."""
+    return 8 if (act_dtype() if dtype is None else dtype) == BF16 else 4
+
+
+def _fn(lib, name, t):
+    """C-ABI entry point `dwc_<name>` for fp32 tensors, `dwc_bf16_<name>` for bf16 ones."""
+    return getattr(lib, ("dwc_bf16_" if t.dtype == BF16 else "dwc_") + name)
 
 
 # --------------------------------------------------------------------------------------
@@ -43,16 +73,16 @@ def workspace(nbytes, device):
 
 
 def cl(x):
-    """channels-last contiguous fp32 view/copy of a 4-D tensor."""
-    if x.dtype != torch.float32:
-        raise TypeError("fp32 only")
+    """channels-last contiguous view/copy of a 4-D fp32 or bf16 tensor."""
+    if x.dtype not in (torch.float32, BF16):
+        raise TypeError("fp32 or bf16 only")
     if x.dim() != 4:
         raise ValueError("expected a 4-D NCHW-shaped tensor")
     return x.contiguous(memory_format=torch.channels_last)
 
 
-def empty_cl(b, c, h, w, device):
-    return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+def empty_cl(b, c, h, w, device, dtype=torch.float32):
+    return torch.empty((b, c, h, w), dtype=dtype, device=device, memory_format=torch.channels_last)
 
 
 def _p(t):
@@ -121,13 +151,18 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _padc(n, dtype):
+    """Channel count rounded up to one 16-byte chunk's worth of the next multiple the kernels need (4 fp32 / 8 bf16)."""
+    return (n + 7) // 8 * 8 if dtype == BF16 else (n + 3) // 4 * 4
+
+
 # --------------------------------------------------------------------------------------
 # weight layouts, cached per parameter version
 # --------------------------------------------------------------------------------------
 _WCACHE = {}   # id(tensor) -> (weakref to it, {layout key: (version, prepared tensor)})
 
 
-def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None):
+def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
     """Re-laid-out copy of an OIHW weight; recomputed only when the parameter changed
     (optimizer steps bump ``_version``).  ``owner``: the parameter(s) ``w`` was derived from when ``w`` itself is a
     fresh tensor on every call (a reshaped Linear weight, the concatenated image heads): the cache then lives on the
@@ -140,7 +175,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None):
         slot = (weakref.ref(anchor, lambda _r, wid=wid: _WCACHE.pop(wid, None)), {})
         _WCACHE[wid] = slot
     ent = slot[1]
-    key = (kind, cout_pad, cin_pad, stride, tuple(w.shape))
+    key = (kind, cout_pad, cin_pad, stride, tuple(w.shape), bool(half))
     # validity = (version counter, storage address) of every owner: writers that go through ``.data``
     # (dist.broadcast(t.data), load_state_dict on a rebound tensor, Module.to()) do not always bump the version but most
     # of them move or re-bind the storage; the in-tree ``.data`` writers bump the version explicitly
@@ -162,20 +197,24 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None):
         ent[key] = (stamp, out)
         return out
     if kind == "heads_wide":
-        # the 4-channel heads as 8 pixels x 4 channels: bank [p*4 + co][ci][KH][KW+7], copy p shifted right by p taps
-        bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, 7 - p)) for p in range(8)]).reshape(
-            32, w.shape[1], w.shape[2], w.shape[3] + 7)
-        out = _prepped(bank, "fwd", 32, cin_pad, 1)
+        # the P-plane heads (P = w.shape[0]: 4, or 8 on the bf16 path) as px = 32/P pixels x P planes:
+        # bank [p*P + co][ci][KH][KW+px-1], copy p shifted right by p taps
+        px = 32 // w.shape[0]
+        bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, px - 1 - p)) for p in range(px)]).reshape(
+            32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
+        out = _prepped(bank, "fwd", 32, cin_pad, 1, half=half)
         ent[key] = (stamp, out)
         return out
     if kind == "dgrad_image":
-        # bank of 8 shifted copies of the flipped, transposed filter: [p*4 + ci][co][KH][KW+7] (dwc_conv2d_bwd_data_image);
-        # cout_pad = gathered (dY) channels, cin_pad = 4 image planes
+        # bank of px shifted copies of the flipped, transposed filter: [p*P + ci][co][KH][KW+px-1] (dwc_conv2d_bwd_data_image);
+        # cout_pad = gathered (dY) channels, cin_pad = P image planes (4 fp32 / 8 bf16), px = 32 / P
         co, ci, kh, kw = w.shape
+        px = 32 // cin_pad
         wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
         wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
-        bank = torch.stack([torch.nn.functional.pad(wf, (p, 7 - p)) for p in range(8)]).reshape(8 * cin_pad, cout_pad, kh, kw + 7)
-        out = _prepped(bank, "fwd", 8 * cin_pad, cout_pad, 1)
+        bank = torch.stack([torch.nn.functional.pad(wf, (p, px - 1 - p)) for p in range(px)]).reshape(
+            px * cin_pad, cout_pad, kh, kw + px - 1)
+        out = _prepped(bank, "fwd", px * cin_pad, cout_pad, 1, half=half)
         ent[key] = (stamp, out)
         return out
     cout, cin, kh, kw = w.shape
@@ -183,14 +222,15 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None):
     if kind == "dgrad_t":           # dgrad layout of the filter with its two spatial axes swapped (taps enumerated kw-major)
         wc = w.detach().transpose(2, 3).contiguous()
         kind = "dgrad"
-    n = lib.dwc_weight_prepared_elems(cout, cin, kh, kw, stride, cout_pad, cin_pad, int(kind == "dgrad"))
-    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    pre = "dwc_bf16_" if half else "dwc_"
+    n = getattr(lib, pre + "weight_prepared_elems")(cout, cin, kh, kw, stride, cout_pad, cin_pad, int(kind == "dgrad"))
+    out = torch.empty(n, dtype=BF16 if half else torch.float32, device=w.device)
     if kind == "fwd":
-        _lib.check(lib.dwc_weight_prepare_fwd(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
-                                              _stream()), "weight_prepare_fwd")
+        _lib.check(getattr(lib, pre + "weight_prepare_fwd")(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
+                                                            _stream()), "weight_prepare_fwd")
     else:
-        _lib.check(lib.dwc_weight_prepare_dgrad(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride, cout_pad,
-                                                cin_pad, _stream()), "weight_prepare_dgrad")
+        _lib.check(getattr(lib, pre + "weight_prepare_dgrad")(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride,
+                                                              cout_pad, cin_pad, _stream()), "weight_prepare_dgrad")
     ent[key] = (stamp, out)
     return out
 
@@ -222,33 +262,37 @@ def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
 
 
 class _Conv2d(torch.autograd.Function):
-    """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4."""
+    """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4 (fp32) / 8 (bf16); its dtype is x's.
+    ``owner``: the parameter(s) ``w`` is derived from when ``w`` is a fresh tensor on every call (prepared-weight cache)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True):
+    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True, owner=None):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
+        half = x.dtype == BF16
         B, Cx, H, W = x.shape
         Cout, Cin, KH, KW = w.shape
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
         ctx.bias_grad = bias_grad
-        cop = _pad4(Cout)
+        ctx.owner = owner
+        cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        use_wino = _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
-        w_hwio = None if use_wino else _prepped(w, "fwd", cop, Cx, stride)
+        use_wino = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
+        w_hwio = None if use_wino else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
             bias = bias.contiguous()
-        y = empty_cl(B, cop, Ho, Wo, x.device)
+        y = empty_cl(B, cop, Ho, Wo, x.device, x.dtype)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
         st = _stream()
+        v_keep = None
         if use_wino:
             wt = use_wino
-            U = _prepped(w, "wino_fwd", cop, Cx, wt)
+            U = _prepped(w, "wino_fwd", cop, Cx, wt, owner)
             ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop, wt), x.device)
             # the transformed input is what the weight gradient contracts with: keep it instead of transforming x again
             v_keep = torch.empty((wt + 2) ** 2 * B * (H // wt) * (W // wt) * Cx, dtype=torch.float32,
@@ -258,9 +302,9 @@ class _Conv2d(torch.autograd.Function):
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
         else:
-            nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
+            nws = _fn(lib, "conv2d_fwd_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
             wsp = workspace(nws, x.device).data_ptr() if nws else None
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd", x)(
                 x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
                 st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None, v_keep if use_wino else None)
@@ -273,6 +317,9 @@ class _Conv2d(torch.autograd.Function):
         lib = _lib.load()
         x, w, y, v_keep = ctx.saved_tensors
         B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, has_b = ctx.geom
+        owner = ctx.owner
+        dt = x.dtype
+        half = dt == BF16
         dy = cl(dy)
         Ho, Wo = dy.shape[2], dy.shape[3]
         rows = B * Ho * Wo
@@ -287,22 +334,22 @@ class _Conv2d(torch.autograd.Function):
             db, need_db = torch.zeros(Cout, dtype=torch.float32, device=dev), False
         if act != 0 or need_db:
             db_full = torch.empty(cop, dtype=torch.float32, device=dev) if need_db else None
-            g_out = empty_cl(B, cop, Ho, Wo, dev) if act != 0 else None
+            g_out = empty_cl(B, cop, Ho, Wo, dev, dt) if act != 0 else None
             nws = lib.dwc_act_bwd_bias_ws_bytes(rows, cop)
             ws = workspace(nws, dev)
-            _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
-                                            ws.numel(), st), "act_bwd_bias")
+            _lib.check(_fn(lib, "act_bwd_bias", x)(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
+                                                   ws.numel(), st), "act_bwd_bias")
             if g_out is not None:
                 g = g_out
             if need_db:
                 db = db_full[:Cout]
         dx = dw = None
+        pow2 = (cop & (cop - 1)) == 0
         if ctx.needs_input_grad[1]:
             dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
-            nws = lib.dwc_conv2d_bwd_weight_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             detail = "wgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-            wt = _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
+            wt = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
             if wt:
                 ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop, wt), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
@@ -310,33 +357,35 @@ class _Conv2d(torch.autograd.Function):
                     ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-wino%d" % wt + detail[5:],
                     exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino_bwd_weight")
             else:
+                nws = _fn(lib, "conv2d_bwd_weight_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, stride, pad)
                 ws = workspace(nws, dev)
-                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: _fn(lib, "conv2d_bwd_weight", x)(
                     x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, Cin, Cout, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail=detail), "conv2d_bwd_weight")
-        if ctx.needs_input_grad[0] and Cx == 4 and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
-                and (cop & (cop - 1)) == 0:
-            # gradient w.r.t. an NHWC4 image (7x7 stems): 8 pixels x 4 planes per GEMM row, see dwc_conv2d_bwd_data_image
-            w_img = _prepped(w, "dgrad_image", cop, 4, 1)
-            dx = empty_cl(B, 4, H, W, dev)
+        same = stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 and pow2
+        if ctx.needs_input_grad[0] and Cx == image_planes(dt) and same:
+            # gradient w.r.t. an NHWC4 / NHWC8 image (7x7 stems): 32/Cx pixels x Cx planes per GEMM row,
+            # see dwc_conv2d_bwd_data_image
+            w_img = _prepped(w, "dgrad_image", cop, Cx, 1, owner, half)
+            dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
-            nws = lib.dwc_conv2d_bwd_data_image_ws_bytes(B, H, W, cop, KH, KW, pad)
+            nws = _fn(lib, "conv2d_bwd_data_image_ws_bytes", x)(B, H, W, cop, KH, KW, pad)
             ws = workspace(nws, dev)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_image(
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_image", x)(
                 g.data_ptr(), w_img.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
                 scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                 "conv2d_bwd_data_image")
-        elif ctx.needs_input_grad[0] and stride == 1 and pad > 0 and 2 * pad == KH - 1 and KH == KW and cop >= 32 \
-                and (cop & (cop - 1)) == 0 and min(H, W) >= 2 * pad + 2:
+        elif ctx.needs_input_grad[0] and same and min(H, W) >= 2 * pad + 2 and (not half or cop >= 64):
             # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
-            w_dg, w_dg_t = _prepped(w, "dgrad", cop, Cx, 1), _prepped(w, "dgrad_t", cop, Cx, 1)
-            dx = empty_cl(B, Cx, H, W, dev)
+            w_dg = _prepped(w, "dgrad", cop, Cx, 1, owner, half)
+            w_dg_t = _prepped(w, "dgrad_t", cop, Cx, 1, owner, half)
+            dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
-            nws = lib.dwc_conv2d_bwd_data_same_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
-            wt = _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
+            nws = _fn(lib, "conv2d_bwd_data_same_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, pad)
+            wt = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
             if wt:
                 # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
-                U = _prepped(w, "wino_dgrad", cop, Cx, wt)
+                U = _prepped(w, "wino_dgrad", cop, Cx, wt, owner)
                 nwino = lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt)
                 ws = workspace(nwino + nws, dev)
 
@@ -350,66 +399,71 @@ class _Conv2d(torch.autograd.Function):
                            "conv2d_wino dgrad")
             else:
                 ws = workspace(nws, dev)
-                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_same(
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_same", x)(
                     g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_same")
         elif ctx.needs_input_grad[0]:
-            w_dg = _prepped(w, "dgrad", cop, Cx, stride)
-            dx = empty_cl(B, Cx, H, W, dev)
+            w_dg = _prepped(w, "dgrad", cop, Cx, stride, owner, half)
+            dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             # scratch arena: [gradient of the padded image (folded back below)] [split-K partials]
-            pad_bytes = 0 if pad == 0 else (B * (H + 2 * pad) * (W + 2 * pad) * Cx * 4 + 255) // 256 * 256
-            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, Cx, cop, KH, KW, stride, pad)
+            esz = 2 if half else 4
+            pad_bytes = 0 if pad == 0 else (B * (H + 2 * pad) * (W + 2 * pad) * Cx * esz + 255) // 256 * 256
+            nws = _fn(lib, "conv2d_bwd_data_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, stride, pad)
             base = workspace(pad_bytes + nws, dev).data_ptr() if pad_bytes + nws else 0
             target = dx.data_ptr() if pad == 0 else base
             wsp = base + pad_bytes if nws else None
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data", x)(
                 g.data_ptr(), w_dg.data_ptr(), target, B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st),
                 scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_bwd_data")
             if pad > 0:
-                _lib.check(lib.dwc_reflect_pad_adjoint(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
-        return dx, dw, db, None, None, None, None
+                _lib.check(_fn(lib, "reflect_pad_adjoint", x)(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, b, stride, pad, act="none", bias_grad=True):
+def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None):
     """Reflect-padded convolution + bias + activation.  Returns Cout channels (a channel
     slice of the 4-aligned buffer when Cout is not a multiple of 4).  ``bias_grad=False``: the caller feeds the
     result to an instance norm, whose mean subtraction makes the bias gradient identically zero -- it is returned
     as zeros instead of being reduced from dY."""
-    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad))
+    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner)
     return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
 
 
 def conv2d_padded(x, w, b, stride, pad, act="none"):
     """As conv2d, but returns the 4-aligned channel buffer itself."""
-    return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], True)
+    return _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], True, None)
 
 
 class _HeadsConvWide(torch.autograd.Function):
-    """The fused 4-channel image heads (tanh x3 + sigmoid) as a "wide" convolution: 8 horizontally
-    adjacent output pixels x 4 channels = 32 output channels of a KHx(KW+7), stride-(1,8) filter
-    bank whose p-th copy is the real filter shifted right by p taps.  The product then fills a
-    32-wide MFMA tile (2x zero work instead of 8x).  The [B,H,W/8,32] result IS the NHWC4 image."""
+    """The fused image heads (tanh x3 + sigmoid, P = 4 planes; 8 with four zero planes on the bf16 path) as a "wide"
+    convolution: px = 32/P horizontally adjacent output pixels x P planes = 32 output channels of a KHx(KW+px-1),
+    stride-(1,px) filter bank whose p-th copy is the real filter shifted right by p taps.  The product then fills a
+    32-wide MFMA tile (2x zero work instead of 8x).  The [B,H,W/px,32] result IS the NHWC-P image."""
 
     @staticmethod
-    def forward(ctx, x, w4, b4):
+    def forward(ctx, x, w4, b4, owner=None):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
+        half = x.dtype == BF16
         B, C, H, W = x.shape
-        co, ci, KH, KW = w4.shape
-        assert co == 4 and ci == C and W % 8 == 0
+        P, ci, KH, KW = w4.shape
+        px = 32 // P
+        assert P == image_planes(x.dtype) and ci == C and W % px == 0
         pad = KH // 2
-        w_prep = _prepped(w4, "heads_wide", 32, C, 1)
-        bias = b4.detach().repeat(8).contiguous()
-        y = empty_cl(B, 4, H, W, x.device)
+        w_prep = _prepped(w4, "heads_wide", 32, C, 1, owner, half)
+        bias = b4.detach().repeat(px).contiguous()
+        y = empty_cl(B, P, H, W, x.device, x.dtype)
         st = _stream()
         flops = 2.0 * B * H * W * 4 * C * KH * KW
-        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_ex(
-            x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad,
-            ACT["heads"], st)), "conv2d_fwd_ex")
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_ex", x)(
+            x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad,
+            ACT["heads8" if P == 8 else "heads"], st), detail="fwd-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)),
+            "conv2d_fwd_ex")
         ctx.save_for_backward(x, w4, y)
+        ctx.owner = owner
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
         return y
 
@@ -417,49 +471,54 @@ class _HeadsConvWide(torch.autograd.Function):
     def backward(ctx, dy):
         lib = _lib.load()
         x, w4, y = ctx.saved_tensors
+        half = x.dtype == BF16
         B, C, H, W = x.shape
-        _, _, KH, KW = w4.shape
+        P, _, KH, KW = w4.shape
+        px = 32 // P
         pad = KH // 2
         dev = x.device
         st = _stream()
         dy = cl(dy)
         rows = B * H * W
-        g = empty_cl(B, 4, H, W, dev)
-        db = torch.empty(4, dtype=torch.float32, device=dev)
-        ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, 4), dev)
-        _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), db.data_ptr(), rows, 4, ACT["heads"],
-                                        ws.data_ptr(), ws.numel(), st), "act_bwd_bias")
+        g = empty_cl(B, P, H, W, dev, x.dtype)
+        db = torch.empty(P, dtype=torch.float32, device=dev)
+        ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, P), dev)
+        _lib.check(_fn(lib, "act_bwd_bias", x)(dy.data_ptr(), y.data_ptr(), g.data_ptr(), db.data_ptr(), rows, P,
+                                               ACT["heads8" if P == 8 else "heads"], ws.data_ptr(), ws.numel(), st), "act_bwd_bias")
         dx = dw = None
         flops = 2.0 * rows * 4 * C * KH * KW
-        if ctx.needs_input_grad[0]:        # data gradient: the ordinary 4-channel formulation (N = C columns)
-            w_dg = _prepped(w4, "dgrad", 4, C, 1)
-            dx = empty_cl(B, C, H, W, dev)
-            pad_bytes = (B * (H + 2 * pad) * (W + 2 * pad) * C * 4 + 255) // 256 * 256
-            nws = lib.dwc_conv2d_bwd_data_ws_bytes(B, H, W, C, 4, KH, KW, 1, pad)
+        if ctx.needs_input_grad[0]:        # data gradient: the ordinary P-channel formulation (N = C columns)
+            w_dg = _prepped(w4, "dgrad", P, C, 1, ctx.owner, half)
+            dx = empty_cl(B, C, H, W, dev, x.dtype)
+            pad_bytes = (B * (H + 2 * pad) * (W + 2 * pad) * C * (2 if half else 4) + 255) // 256 * 256
+            nws = _fn(lib, "conv2d_bwd_data_ws_bytes", x)(B, H, W, C, P, KH, KW, 1, pad)
             base = workspace(pad_bytes + nws, dev).data_ptr()
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data(
-                g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, 4, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
-                st), scope_name=ctx.bscope), "conv2d_bwd_data")
-            _lib.check(lib.dwc_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data", x)(
+                g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, P, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
+                st), scope_name=ctx.bscope, detail="dgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_data")
+            _lib.check(_fn(lib, "reflect_pad_adjoint", x)(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
-            dwide = torch.empty((32, C, KH, KW + 7), dtype=torch.float32, device=dev)
-            nws = lib.dwc_conv2d_bwd_weight_ex_ws_bytes(B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad)
+            dwide = torch.empty((32, C, KH, KW + px - 1), dtype=torch.float32, device=dev)
+            nws = _fn(lib, "conv2d_bwd_weight_ex_ws_bytes", x)(B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad)
             ws = workspace(nws, dev)
-            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight_ex(
-                x.data_ptr(), g.data_ptr(), dwide.data_ptr(), B, H, W, C, 32, KH, KW + 7, 1, 8, pad, pad, C, 32, ws.data_ptr(),
-                ws.numel(), st), scope_name=ctx.bscope), "conv2d_bwd_weight_ex")
-            dv = dwide.view(8, 4, C, KH, KW + 7)
+            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: _fn(lib, "conv2d_bwd_weight_ex", x)(
+                x.data_ptr(), g.data_ptr(), dwide.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad, C, 32,
+                ws.data_ptr(), ws.numel(), st), scope_name=ctx.bscope,
+                detail="wgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_weight_ex")
+            dv = dwide.view(px, P, C, KH, KW + px - 1)
             dw = dv[0, :, :, :, 0:KW].clone()
-            for p in range(1, 8):
+            for p in range(1, px):
                 dw += dv[p, :, :, :, p:p + KW]
-        return dx, dw, (db if ctx.needs_input_grad[2] else None)
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
 
 
-def conv2d_heads(x, w4, b4):
-    """tanh/sigmoid image heads: [B,C,H,W] features, [4,C,7,7] weights -> NHWC4 image [B,4,H,W]."""
-    if x.shape[3] % 8 == 0 and w4.shape[2] == w4.shape[3] == 7:
-        return _HeadsConvWide.apply(x, w4, b4)
-    return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads"], True)
+def conv2d_heads(x, w4, b4, owner=None):
+    """tanh/sigmoid image heads: [B,C,H,W] features, [P,C,7,7] weights (P = 4 fp32, 8 bf16 with planes 4..7 zero) ->
+    NHWC-P image [B,P,H,W]."""
+    px = 32 // w4.shape[0]
+    if x.shape[3] % px == 0 and w4.shape[2] == w4.shape[3] == 7:
+        return _HeadsConvWide.apply(x, w4, b4, owner)
+    return _Conv2d.apply(x, w4, b4, 1, w4.shape[2] // 2, ACT["heads8" if w4.shape[0] == 8 else "heads"], True, owner)
 
 
 class _Conv2dZeroPad(torch.autograd.Function):
@@ -473,6 +532,8 @@ class _Conv2dZeroPad(torch.autograd.Function):
             raise NotImplementedError("zero-padded convolutions are built for frozen weights (no weight gradient)")
         lib = _lib.load()
         x = cl(x)
+        if x.dtype != torch.float32:
+            raise NotImplementedError("the zero-padded (VGG16) convolutions are built for the fp32 path")
         B, Cx, H, W = x.shape
         Cout, Cin, KH, KW = w.shape
         if Cin > Cx:
@@ -550,6 +611,8 @@ class _MaxPool2(torch.autograd.Function):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
+        if x.dtype != torch.float32:
+            raise NotImplementedError("max pooling (VGG16) is built for the fp32 path")
         B, C, H, W = x.shape
         y = empty_cl(B, C, H // 2, W // 2, x.device)
         _lib.check(lib.dwc_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "maxpool2_fwd")
@@ -571,10 +634,10 @@ def max_pool2(x):
     return _MaxPool2.apply(x)
 
 
-def linear(x, w, b, act="none"):
+def linear(x, w, b, act="none", owner=None):
     """nn.Linear (+ReLU) as a 1x1 convolution over a 1x1 image (reference networks.py:587-634).
     Input width must be a power of two >= 4."""
-    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), b, 1, 0, act)
+    y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), b, 1, 0, act, owner=owner or w)
     return y.reshape(x.shape[0], -1)
 
 
@@ -653,14 +716,14 @@ class _InstNorm(torch.autograd.Function):
         B, C, H, W = x.shape
         dev = x.device
         if gamma is not None:
-            gamma, beta = gamma.contiguous(), beta.contiguous()
+            gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
         if residual is not None:
-            residual = cl(residual)
-        y = empty_cl(B, C, H, W, dev)
+            residual = cl(residual.to(x.dtype))
+        y = empty_cl(B, C, H, W, dev, x.dtype)
         mean = torch.empty(B * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(lib.dwc_instnorm_fwd(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
+        _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
                    "instnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
@@ -675,13 +738,13 @@ class _InstNorm(torch.autograd.Function):
         dy = cl(dy)
         B, C, H, W = x.shape
         dev = x.device
-        dx = empty_cl(B, C, H, W, dev)
+        dx = empty_cl(B, C, H, W, dev, x.dtype)
         dgamma = dbeta = None
         if gamma is not None:
             dgamma = torch.empty(B * C, dtype=torch.float32, device=dev)
             dbeta = torch.empty(B * C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(lib.dwc_instnorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
+        _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                         dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
                                         ws.numel(), _stream()), "instnorm_bwd")
         return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
@@ -701,11 +764,11 @@ class _LayerNorm(torch.autograd.Function):
         B, C, H, W = x.shape
         dev = x.device
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
-        y = empty_cl(B, C, H, W, dev)
+        y = empty_cl(B, C, H, W, dev, x.dtype)
         mean = torch.empty(B, dtype=torch.float32, device=dev)
         inv = torch.empty(B, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(lib.dwc_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+        _lib.check(_fn(lib, "layernorm_fwd", x)(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                          inv.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
                    "layernorm_fwd")
         ctx.save_for_backward(x, mean, inv, g, b)
@@ -719,11 +782,11 @@ class _LayerNorm(torch.autograd.Function):
         dy = cl(dy)
         B, C, H, W = x.shape
         dev = x.device
-        dx = empty_cl(B, C, H, W, dev)
+        dx = empty_cl(B, C, H, W, dev, x.dtype)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(lib.dwc_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
+        _lib.check(_fn(lib, "layernorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
                                          b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
                                          ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), _stream()), "layernorm_bwd")
         return dx, dgamma, dbeta, None, None
@@ -745,11 +808,11 @@ class _Resample(torch.autograd.Function):
         B, C, H, W = x.shape
         ctx.shape, ctx.up = (B, C, H, W), up
         if up:
-            y = empty_cl(B, C, 2 * H, 2 * W, x.device)
-            _lib.check(lib.dwc_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "upsample2x_fwd")
+            y = empty_cl(B, C, 2 * H, 2 * W, x.device, x.dtype)
+            _lib.check(_fn(lib, "upsample2x_fwd", x)(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "upsample2x_fwd")
         else:
-            y = empty_cl(B, C, H // 2, W // 2, x.device)
-            _lib.check(lib.dwc_avgpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "avgpool2_fwd")
+            y = empty_cl(B, C, H // 2, W // 2, x.device, x.dtype)
+            _lib.check(_fn(lib, "avgpool2_fwd", x)(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "avgpool2_fwd")
         return y
 
     @staticmethod
@@ -757,11 +820,11 @@ class _Resample(torch.autograd.Function):
         lib = _lib.load()
         B, C, H, W = ctx.shape
         dy = cl(dy)
-        dx = empty_cl(B, C, H, W, dy.device)
+        dx = empty_cl(B, C, H, W, dy.device, dy.dtype)
         if ctx.up:
-            _lib.check(lib.dwc_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "upsample2x_bwd")
+            _lib.check(_fn(lib, "upsample2x_bwd", dy)(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "upsample2x_bwd")
         else:
-            _lib.check(lib.dwc_avgpool2_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "avgpool2_bwd")
+            _lib.check(_fn(lib, "avgpool2_bwd", dy)(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "avgpool2_bwd")
         return dx, None
 
 
@@ -777,17 +840,22 @@ def downsample_half(x):
 # image boundary / blend / L1
 # --------------------------------------------------------------------------------------
 class _Pack4(torch.autograd.Function):
-    """[B,3,H,W] (any strides) -> NHWC4 image [B,4,H,W] channels-last with a zero 4th plane."""
+    """[B,3,H,W] fp32 (any strides) -> internal image buffer, channels-last with zero padding planes:
+    NHWC4 fp32 [B,4,H,W], or NHWC8 bf16 [B,8,H,W] on the bf16 path."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, half):
         _require_device(x)
         lib = _lib.load()
-        x = x.contiguous()
+        x = x.float().contiguous()
         B, C, H, W = x.shape
-        ctx.shape = (B, C, H, W)
-        y = empty_cl(B, 4, H, W, x.device)
-        _lib.check(lib.dwc_pack_nchw_to_nhwc4(x.data_ptr(), y.data_ptr(), B, C, H, W, _stream()), "pack")
+        ctx.shape, ctx.half = (B, C, H, W), half
+        if half:
+            y = empty_cl(B, 8, H, W, x.device, BF16)
+            _lib.check(lib.dwc_pack_nchw_to_nhwc8_bf16(x.data_ptr(), y.data_ptr(), B, C, H, W, _stream()), "pack8")
+        else:
+            y = empty_cl(B, 4, H, W, x.device)
+            _lib.check(lib.dwc_pack_nchw_to_nhwc4(x.data_ptr(), y.data_ptr(), B, C, H, W, _stream()), "pack")
         return y
 
     @staticmethod
@@ -796,17 +864,26 @@ class _Pack4(torch.autograd.Function):
         B, C, H, W = ctx.shape
         dy = cl(dy)
         dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
-        _lib.check(lib.dwc_unpack_nhwc4_to_nchw(dy.data_ptr(), dx.data_ptr(), B, C, H, W, _stream()), "unpack")
-        return dx
+        if ctx.half:
+            _lib.check(lib.dwc_unpack_nhwc8_bf16_to_nchw(dy.data_ptr(), dx.data_ptr(), B, C, H, W, _stream()), "unpack8")
+        else:
+            _lib.check(lib.dwc_unpack_nhwc4_to_nchw(dy.data_ptr(), dx.data_ptr(), B, C, H, W, _stream()), "unpack")
+        return dx, None
+
+
+def is_image(x):
+    """True for an internal image buffer (NHWC4 fp32 / NHWC8 bf16, channels-last)."""
+    return x.dim() == 4 and x.dtype in (torch.float32, BF16) and x.shape[1] == image_planes(x.dtype) \
+        and x.is_contiguous(memory_format=torch.channels_last)
 
 
 def pack_image(x):
-    """Bring an image batch to the internal NHWC4 form (no-op when it already is)."""
-    if x.shape[1] == 4 and x.is_contiguous(memory_format=torch.channels_last):
+    """Bring an image batch to the internal form of the active precision (no-op when it already is one)."""
+    if x.dtype == act_dtype() and is_image(x):
         return x
-    if x.shape[1] > 4:
-        raise ValueError("image tensors have at most 4 channels")
-    return _Pack4.apply(x)
+    if x.shape[1] > 3:
+        raise ValueError("image tensors have at most 3 channels (or are already internal image buffers)")
+    return _Pack4.apply(x, PRECISION == "bf16")
 
 
 class _Blend(torch.autograd.Function):
@@ -818,8 +895,10 @@ class _Blend(torch.autograd.Function):
         lib = _lib.load()
         heads, real = cl(heads), cl(real)
         B, C, H, W = heads.shape
-        out = empty_cl(B, 4, H, W, heads.device)
-        _lib.check(lib.dwc_blend_fwd(heads.data_ptr(), real.data_ptr(), out.data_ptr(), B * H * W, _stream()), "blend_fwd")
+        if real.dtype != heads.dtype or real.shape != heads.shape or C != image_planes(heads.dtype):
+            raise ValueError("attention_blend needs two internal image buffers of one precision")
+        out = empty_cl(B, C, H, W, heads.device, heads.dtype)
+        _lib.check(_fn(lib, "blend_fwd", heads)(heads.data_ptr(), real.data_ptr(), out.data_ptr(), B * H * W, _stream()), "blend_fwd")
         ctx.save_for_backward(heads, real)
         return out
 
@@ -829,9 +908,9 @@ class _Blend(torch.autograd.Function):
         heads, real = ctx.saved_tensors
         dout = cl(dout)
         B, C, H, W = heads.shape
-        dh = empty_cl(B, 4, H, W, heads.device)
-        _lib.check(lib.dwc_blend_bwd(dout.data_ptr(), heads.data_ptr(), real.data_ptr(), dh.data_ptr(), B * H * W, _stream()),
-                   "blend_bwd")
+        dh = empty_cl(B, C, H, W, heads.device, heads.dtype)
+        _lib.check(_fn(lib, "blend_bwd", heads)(dout.data_ptr(), heads.data_ptr(), real.data_ptr(), dh.data_ptr(), B * H * W,
+                                                _stream()), "blend_bwd")
         return dh, None
 
 
@@ -846,6 +925,8 @@ class _L1Mean(torch.autograd.Function):
         lib = _lib.load()
         if a.shape != b.shape:
             raise ValueError("shape mismatch")
+        if a.dtype != b.dtype:
+            a, b = a.float(), b.float()
         if a.dim() == 4:
             a, b = cl(a), cl(b)
         else:
@@ -853,8 +934,8 @@ class _L1Mean(torch.autograd.Function):
         n = a.numel()
         out = torch.empty((), dtype=torch.float32, device=a.device)
         ws = workspace(lib.dwc_l1_ws_bytes(n), a.device)
-        _lib.check(lib.dwc_l1_mean_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, int(skip4), ws.data_ptr(), ws.numel(),
-                                       _stream()), "l1_mean_fwd")
+        _lib.check(_fn(lib, "l1_mean_fwd", a)(a.data_ptr(), b.data_ptr(), out.data_ptr(), n, int(skip4), ws.data_ptr(), ws.numel(),
+                                              _stream()), "l1_mean_fwd")
         ctx.save_for_backward(a, b)
         ctx.skip4 = int(skip4)
         return out
@@ -866,11 +947,12 @@ class _L1Mean(torch.autograd.Function):
         dout = dout.contiguous()
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
-        _lib.check(lib.dwc_l1_mean_bwd(a.data_ptr(), b.data_ptr(), dout.data_ptr(), _p(da), _p(db), a.numel(), ctx.skip4,
-                                       _stream()), "l1_mean_bwd")
+        _lib.check(_fn(lib, "l1_mean_bwd", a)(a.data_ptr(), b.data_ptr(), dout.float().data_ptr(), _p(da), _p(db), a.numel(),
+                                              ctx.skip4, _stream()), "l1_mean_bwd")
         return da, db, None
 
 
 def l1_mean(a, b, image=False):
-    """mean |a-b| (reference solver.py:113-114).  image=True: NHWC4 images, 4th plane ignored."""
-    return _L1Mean.apply(a, b, bool(image))
+    """mean |a-b| (reference solver.py:113-114).  image=True: internal image buffers (NHWC4 / NHWC8), mean over
+    planes 0..2 only."""
+    return _L1Mean.apply(a, b, a.shape[1] if image else 0)

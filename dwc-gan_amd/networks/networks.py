@@ -230,13 +230,19 @@ class Decoder(nn.Module):
         reference, whose optimiser skips gradient-less parameters (no weight decay / momentum)."""
         if self.output_dim != 3:
             raise NotImplementedError("fused heads assume a 3-channel image")
+        wc, bc = self.image_content.conv.weight, self.image_content.conv.bias
         wa, ba = self.image_attention.conv.weight, self.image_attention.conv.bias
+        owner = (wc, wa)                 # the prepared-weight cache lives on the two parameters, not on the concatenation
         if not attention_used:
             wa, ba = wa.detach(), ba.detach()
-        w = torch.cat([self.image_content.conv.weight, wa], 0)
-        b = torch.cat([self.image_content.conv.bias, ba], 0)
         with ops.scope("decode"):        # label for the profiler's decode-stack roofline figure
-            return ops.conv2d_heads(self.model(x), w, b)
+            feat = self.model(x)
+            ws, bs = [wc, wa], [bc, ba]
+            extra = ops.image_planes(feat.dtype) - 4         # bf16 images are NHWC8: four zero planes
+            if extra:
+                ws.append(wa.new_zeros((extra,) + tuple(wa.shape[1:])))
+                bs.append(ba.new_zeros(extra))
+            return ops.conv2d_heads(feat, torch.cat(ws, 0), torch.cat(bs, 0), owner=owner)
 
     def forward(self, x):
         heads = self.forward_nhwc4(x)
@@ -280,8 +286,8 @@ class MsImageDis(nn.Module):
         outputs = []
         for s in range(self.num_scales):
             h = self.cnns_feat[s](x)
-            src = ops.conv2d(h, self.cnns_src[s].weight, self.cnns_src[s].bias, 1, 0)
-            cls = ops.conv2d(h, self.cnns_cls[s].weight, None, 1, 0)
+            src = ops.conv2d(h, self.cnns_src[s].weight, self.cnns_src[s].bias, 1, 0).float()   # losses are fp32 reductions
+            cls = ops.conv2d(h, self.cnns_cls[s].weight, None, 1, 0).float()
             outputs.append([src, cls.reshape(cls.size(0), -1)])
             if not use_multiscales:
                 break

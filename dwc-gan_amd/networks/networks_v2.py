@@ -45,7 +45,7 @@ class StyleEncoder(nn.Module):
         h = ops.pack_image(x) if x.shape[1] < 4 else x
         for blk in list(self.model)[:-1]:
             h = blk(h)
-        f = h.mean(dim=(2, 3))                                   # global average pool over <=4x4 pixels
+        f = h.float().mean(dim=(2, 3))                           # global average pool over <=4x4 pixels (fp32 from here on)
         if self.use_map:
             f = ops.linear(f, self.mapping[0].weight, self.mapping[0].bias, "relu")
             if self.training and self.mapping[2].p > 0:

@@ -76,7 +76,8 @@ class Solver(nn.Module):
         self.d_reg_every, self.rnd_step = 16, 3
         self.init_ds_w = configs["ds_w"]
         self.lr_policy = configs["lr_policy"]
-        self.grad_sync = None      # set to hipdwc.dp.GradAllReduce for multi-GPU data parallel
+        self.grad_sync = None      # multi-GPU data parallel: hipdwc.dp.GradAllReduce (simple) or, via enable_data_parallel(),
+        self._reducers = None      # ... one hipdwc.dp.OverlappedGradReducer per optimiser (all-reduce overlapped with backward)
         self._ema = None
         self._gen_steps = 0            # bumped whenever G's parameters change: validity of the cached content code
         self._content_cache = None
@@ -94,12 +95,38 @@ class Solver(nn.Module):
         self.criterionL1 = torch.nn.L1Loss()
 
         if configs.get("vgg_w", 0) > 0:                 # reference solver.py:79-83
+            if ops.PRECISION != "fp32":
+                raise NotImplementedError("the VGG16 perceptual loss is built for the fp32 path (vgg_w must be 0 under bf16)")
             from hipdwc.host import load_vgg16
             self.vgg = load_vgg16(configs["vgg_model_path"] + "/models")
             self.vgg = self.vgg.to(device) if device is not None else self.vgg
             self.vgg.eval()
             for param in self.vgg.parameters():
                 param.requires_grad = False
+
+    # ---- data parallel -----------------------------------------------------------------------
+    def enable_data_parallel(self, group=None, bucket_bytes=64 << 20):
+        """One process per GPU (torch.distributed initialised by the caller, backend nccl = RCCL): gradients of D / G become
+        views of flat buckets that are all-reduced (averaged) as backward completes them (hipdwc.dp.OverlappedGradReducer)."""
+        from hipdwc import dp
+        self._reducers = {"dis": dp.OverlappedGradReducer(self.dis_opt.param_groups[0]["params"], group, bucket_bytes),
+                          "gen": dp.OverlappedGradReducer(self.gen_opt.param_groups[0]["params"], group, bucket_bytes)}
+        self.grad_sync = None
+
+    def _zero_grad(self, which):
+        if self._reducers is None:
+            (self.dis_opt if which == "dis" else self.gen_opt).zero_grad()
+            return
+        skip = ()
+        if which == "gen" and not self.use_attention:      # the attention head is taken off the tape (Decoder.forward_nhwc4)
+            skip = list(self.gen.dec.image_attention.parameters())
+        self._reducers[which].prepare(skip)
+
+    def _sync_grads(self, which):
+        if self._reducers is not None:
+            self._reducers[which].finish()
+        elif self.grad_sync is not None:      # simple form: pack, all-reduce, unpack after backward
+            self.grad_sync((self.dis_opt if which == "dis" else self.gen_opt).param_groups[0]["params"])
 
     # ---- bookkeeping -----------------------------------------------------------------------
     def print_network(self, model, name):
@@ -138,7 +165,7 @@ class Solver(nn.Module):
 
     # ---- small losses ------------------------------------------------------------------------
     def recon_criterion(self, x, y):
-        if x.dim() == 4 and x.shape[1] == 4 and y.shape[1] == 4:
+        if ops.is_image(x) and ops.is_image(y) and x.dtype == y.dtype:
             return ops.l1_mean(x, y, image=True)
         if x.dim() == 4:
             return ops.l1_mean(x, y)
@@ -170,14 +197,14 @@ class Solver(nn.Module):
         x4 = ops.pack_image(x_real)
         content, style_src, _ = self.gen.encode(x4)
         style_txt, _ = self.gen.encode_txt(torch.cat(style_src, dim=1), txt_src2trg, txt_lens)
-        return self._decode(content, torch.cat(style_txt, dim=1), x4)[:, :3]
+        return self._decode(content, torch.cat(style_txt, dim=1), x4)[:, :3].float()
 
     # ---- D step (reference solver.py:317-353) ---------------------------------------------------
     def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters):
         if configs["gp_w"] > 0.0 or configs["use_r1"]:
             raise NotImplementedError("gradient / R1 penalties need double backward through the HIP ops "
                                       "(off in the shipped config: gp_w 0, use_r1 False)")
-        self.dis_opt.zero_grad()
+        self._zero_grad("dis")
         x4 = ops.pack_image(x_real)
         B = x4.shape[0]
         with torch.no_grad():
@@ -203,13 +230,12 @@ class Solver(nn.Module):
             self.dis.dis_loss_terms(o_fake1, o_real, label_src, gw, cw)
         self.loss_dis_all = self.loss_dis
         self.loss_dis_all.backward()
-        if self.grad_sync is not None:      # data parallel: average D's gradients over the ranks
-            self.grad_sync(self.dis_opt.param_groups[0]["params"])
+        self._sync_grads("dis")             # data parallel: average D's gradients over the ranks
         self.dis_opt.step()
 
     # ---- G step (reference solver.py:151-240) ---------------------------------------------------
     def gen_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters):
-        self.gen_opt.zero_grad()
+        self._zero_grad("gen")
         gen, cfg = self.gen, configs
         x4 = ops.pack_image(x_real)
         with _frozen(self.dis):
@@ -287,8 +313,7 @@ class Solver(nn.Module):
                 cfg["vgg_w"] * self.loss_gen_vgg - \
                 self.init_ds_w * self.loss_ds
             self.loss_gen_total.backward()
-        if self.grad_sync is not None:      # data parallel: average G's gradients over the ranks
-            self.grad_sync(self.gen_opt.param_groups[0]["params"])
+        self._sync_grads("gen")             # data parallel: average G's gradients over the ranks
         self.gen_opt.step()
         self._gen_steps += 1
 
@@ -308,10 +333,10 @@ class Solver(nn.Module):
             z = dist_sampling_split(mus_txt, self.c_dim, self.stddev, self.device)
             z = self.style_replace(mus_real, mus_txt, style_real, z)
             h_trg = self.gen.decode_nhwc4(content, style_txt)
-            outs["rec"].append(self._decode(content, style_real, x4)[:, :3])
-            outs["trg"].append((ops.attention_blend(h_trg, x4) if self.use_attention else h_trg)[:, :3])
-            outs["sam"].append(self._decode(content, z, x4)[:, :3])
-            outs["att"].append(h_trg[:, 3:4].expand(-1, 3, -1, -1))
+            outs["rec"].append(self._decode(content, style_real, x4)[:, :3].float())
+            outs["trg"].append((ops.attention_blend(h_trg, x4) if self.use_attention else h_trg)[:, :3].float())
+            outs["sam"].append(self._decode(content, z, x4)[:, :3].float())
+            outs["att"].append(h_trg[:, 3:4].float().expand(-1, 3, -1, -1))
         res = [x_real, torch.cat(outs["rec"]), torch.cat(outs["trg"]), torch.cat(outs["sam"])]
         if self.use_attention:
             res.append((torch.cat(outs["att"]) - 0.5) / 0.5)

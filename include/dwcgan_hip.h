@@ -42,6 +42,7 @@ extern "C" {
 #define DWC_ACT_SIGMOID 4
 #define DWC_ACT_HEADS 5    /* channels 0..2 tanh, channel 3 sigmoid: image_content+image_attention
                               fused into one 4-channel conv (reference networks_v2.py:159-160) */
+#define DWC_ACT_HEADS8 6   /* the same heads on an 8-plane (NHWC8, bf16) image: planes 0..2 tanh, 3 sigmoid, 4..7 zero */
 
 int dwc_version(void);
 
@@ -263,6 +264,69 @@ int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_d
                    double weight_decay, void* stream);
 int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev,
                   const unsigned* chunk_start_dev, int n_chunks, float beta, void* stream);
+
+/* ==== bf16-activation path (BASELINE configs[2]: "bf16 activations + MFMA im2col conv path") ==============================
+ * The same call sites as above (reference networks.py:579-585, :514-515, networks_v2.py:153-156) with activations and
+ * their gradients stored as bf16 (NHWC, channel counts multiples of 8 = one 16-byte chunk; the 3-channel images travel as
+ * NHWC8 with planes 3..7 zero / plane 3 the attention map), v_mfma_f32_32x32x16_bf16 with fp32 accumulation, and fp32
+ * everywhere a sum is carried: master weights and their gradients, biases, IN/LN statistics, gamma/beta and their
+ * gradients, loss reductions, split-K / ring partial sums.  `void*` tensors are bf16; argument meaning, scratch rules and
+ * return codes are those of the fp32 entry point of the same name.  Prepared weights are bf16, K padded to 64. */
+size_t dwc_bf16_weight_prepared_elems(int Cout, int Cin, int KH, int KW, int stride, int cout_pad, int cin_pad, int for_dgrad);
+int dwc_bf16_weight_prepare_fwd(const float* w_oihw, void* w_prepared, int Cout, int Cin, int KH, int KW, int cout_pad,
+                                int cin_pad, void* stream);
+int dwc_bf16_weight_prepare_dgrad(const float* w_oihw, void* w_prepared, int Cout, int Cin, int KH, int KW, int stride,
+                                  int cout_pad, int cin_pad, void* stream);
+size_t dwc_bf16_conv2d_fwd_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dwc_bf16_conv2d_fwd(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_conv2d_fwd_ex(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream);
+size_t dwc_bf16_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int B, int H, int W, int Cin, int Cout, int KH,
+                             int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream);
+size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
+int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
+/* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
+size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
+int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
+                                   int pad, void* ws, size_t ws_bytes, void* stream);
+size_t dwc_bf16_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad);
+int dwc_bf16_conv2d_bwd_weight(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
+                               int KW, int stride, int pad, int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
+size_t dwc_bf16_conv2d_bwd_weight_ex_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h,
+                                              int stride_w, int pad_h, int pad_w);
+int dwc_bf16_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int KH,
+                                  int KW, int stride_h, int stride_w, int pad_h, int pad_w, int cin_real, int cout_real,
+                                  void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_act_bwd_bias(const void* dy, const void* y, void* g, float* db, int rows, int C, int act, void* ws,
+                          size_t ws_bytes, void* stream);
+int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+                          size_t ws_bytes, void* stream);
+int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
+                           int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* inv, const float* gamma,
+                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+                           void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_upsample2x_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int dwc_bf16_upsample2x_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+int dwc_bf16_avgpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int dwc_bf16_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+/* image boundary: NCHW fp32 (C <= 8) <-> NHWC8 bf16 */
+int dwc_pack_nchw_to_nhwc8_bf16(const float* x, void* y, int B, int C, int H, int W, void* stream);
+int dwc_unpack_nhwc8_bf16_to_nchw(const void* x, float* y, int B, int C, int H, int W, void* stream);
+/* attention blend on NHWC8 images (plane 3 of `heads` = attention) */
+int dwc_bf16_blend_fwd(const void* heads, const void* real, void* out, int npix, void* stream);
+int dwc_bf16_blend_bwd(const void* dout, const void* heads, const void* real, void* dheads, int npix, void* stream);
+/* mean |a-b| of bf16 tensors, fp32 result; skip4 = 8: NHWC8 images, planes 0..2 only (0: every element).
+ * (the fp32 dwc_l1_mean_* accept skip4 = 0, 1 or 4 (NHWC4 images), 8 likewise) */
+int dwc_bf16_l1_mean_fwd(const void* a, const void* b, float* out, size_t n, int skip4, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_l1_mean_bwd(const void* a, const void* b, const float* dout, void* da, void* db, size_t n, int skip4, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,305 @@
+"""GPU parity tests of the bf16-activation path (BASELINE configs[2]) through the C ABI (dwc_bf16_* entry points).
+
+Oracle: the same CPU restatement as the fp32 tests, fed the operands the kernels actually multiply — activations,
+upstream gradients and conv weights rounded to bf16 (exactly representable inputs), everything else fp32.  What then
+separates the two results is (a) the ONE rounding of every stored activation / activation gradient to bf16
+(relative 2^-9 = 2.0e-3 of the element) and (b) fp32 summation order.  Tolerances, on the tensor's own scale
+max|ref| like the fp32 tests:
+  * stored bf16 tensors (y, dx):                      6e-3   (2^-8 + margin)
+  * dx behind a fused activation:                     1.5e-2 (the activation derivative is taken from the bf16-rounded
+                                                             output and the product is rounded again before the GEMM)
+  * fp32 weight / bias gradients, no activation:      3e-4   (inputs exact, fp32 accumulation)
+  * fp32 weight / bias gradients behind an activation: 1e-2
+  * a whole training iteration: losses within 3e-2 relative of the fp32 oracle's (stated per test).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hipdwc import host, ops, synth          # noqa: E402
+from oracle import dwcgan_oracle as orc      # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rb(t):
+    """round to bf16, back to fp32"""
+    return t.to(BF).float()
+
+
+def close(a, b, rel, atol=1e-6, msg=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    lim = rel * b.abs().max().item() + atol
+    assert err <= lim, "%s: max err %.3e > %.3e" % (msg, err, lim)
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    ops.set_precision("bf16")
+    yield
+    ops.set_precision("fp32")
+
+
+def feat(x):
+    """fp32 NCHW tensor -> bf16 channels-last device tensor that requires grad"""
+    return x.to(DEV).to(BF).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+
+
+# (B, Cin, Cout, H, k, stride, pad, act); Cin == 3: an image (packed to NHWC8)
+CONV_SHAPES = [
+    (2, 3, 64, 32, 7, 1, 3, "relu"),        # stem on an NHWC8 image (dx through the 4-pixels-wide image dgrad)
+    (1, 3, 64, 21, 7, 1, 3, "none"),        # same, odd size
+    (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample (stride-2 data gradient: 4 parity classes + fold)
+    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv, direct 3x3 (no Winograd under bf16), ring dgrad
+    (3, 64, 128, 12, 3, 1, 1, "relu"),      # non power-of-two size
+    (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
+    (2, 128, 64, 24, 5, 1, 2, "none"),      # BN=64 path
+    (3, 3, 64, 16, 4, 2, 1, "lrelu"),       # D stem on an image
+    (3, 512, 512, 2, 4, 2, 1, "lrelu"),     # D tail on a 2x2 map (split-K, fp32 partials)
+    (3, 512, 8, 4, 4, 1, 0, "none"),        # cls head: 'valid' full-extent conv
+    (3, 512, 1, 4, 1, 1, 0, "none"),        # src head 1x1 (Cout 1 padded to 8)
+    (2, 8, 16, 12, 3, 1, 1, "sigmoid"),     # small channel counts (tiny config), generic padded-image dgrad
+    (1, 16, 32, 6, 4, 2, 1, "tanh"),
+    (4, 128, 256, 16, 4, 2, 1, "relu"),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_bf16_conv_forward_backward(shape):
+    B, ci, co, H, k, s, p, act = shape
+    g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)) + 11)
+    x = rb(torch.randn(B, ci, H, H, generator=g))
+    w = torch.randn(co, ci, k, k, generator=g) * (1.0 / (ci * k * k) ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = orc.conv_block(xr, rb(wr.detach()) + (wr - wr.detach()), br, s, p, act=act)      # value of rb(w), gradient w.r.t. w
+    gy = rb(torch.randn(yr.shape, generator=g))
+    (yr * gy).sum().backward()
+    image = ci == 3
+    if image:
+        x0 = x.to(DEV).requires_grad_(True)
+        xd = ops.pack_image(x0)
+        assert xd.dtype == BF and xd.shape[1] == 8
+    else:
+        x0 = xd = feat(x)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, bd, s, p, act)
+    assert yd.dtype == BF and yd.shape == yr.shape
+    close(yd, yr, 6e-3, msg="y")
+    (yd.float() * gy.to(DEV)).sum().backward()
+    plain = act == "none"
+    close(x0.grad, xr.grad, 6e-3 if plain else 1.5e-2, msg="dx")
+    close(wd.grad, wr.grad, 3e-4 if plain else 1e-2, msg="dw")
+    close(bd.grad, br.grad, 3e-4 if plain else 1e-2, msg="db")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 32), (1, 16, 9, 24), (2, 8, 6, 12), (1, 64, 12, 10)])
+def test_bf16_fused_image_heads(B, C, H, W):
+    """tanh x3 + sigmoid heads as one 8-plane conv; W % 4 == 0 takes the 'wide' 32-column formulation."""
+    g = torch.Generator().manual_seed(B + C + H + W)
+    x = rb(torch.randn(B, C, H, W, generator=g))
+    w = torch.randn(4, C, 7, 7, generator=g) * (1.0 / (C * 49) ** 0.5)
+    b = torch.randn(4, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    pre = orc.conv_block(xr, rb(wr.detach()) + (wr - wr.detach()), br, 1, 3)
+    yr = torch.cat([torch.tanh(pre[:, :3]), torch.sigmoid(pre[:, 3:4])], 1)
+    gy = rb(torch.randn(yr.shape, generator=g))
+    (yr * gy).sum().backward()
+    xd, wd, bd = feat(x), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    w8 = torch.cat([wd, wd.new_zeros(4, C, 7, 7)], 0)
+    b8 = torch.cat([bd, bd.new_zeros(4)], 0)
+    yd = ops.conv2d_heads(xd, w8, b8)
+    assert yd.shape == (B, 8, H, W) and yd.dtype == BF
+    assert float(yd[:, 4:].abs().max()) == 0.0
+    close(yd[:, :4], yr, 6e-3, msg="y")
+    gy8 = torch.cat([gy, torch.zeros(B, 4, H, W)], 1).to(DEV)
+    (yd.float() * gy8).sum().backward()
+    close(xd.grad, xr.grad, 1.5e-2, msg="dx")
+    close(wd.grad, wr.grad, 1e-2, msg="dw")
+    close(bd.grad, br.grad, 1e-2, msg="db")
+
+
+@pytest.mark.parametrize("B,C,H,adain,relu,res", [(2, 256, 16, True, True, False), (3, 64, 8, False, True, False),
+                                                   (2, 128, 12, True, False, True), (1, 8, 6, False, False, True)])
+def test_bf16_instance_norm(B, C, H, adain, relu, res):
+    g = torch.Generator().manual_seed(B * C + H)
+    x = rb(torch.randn(B, C, H, H, generator=g) * 2 + 0.5)
+    ga = torch.rand(B * C, generator=g) + 0.5 if adain else None
+    be = torch.randn(B * C, generator=g) if adain else None
+    r = rb(torch.randn(B, C, H, H, generator=g)) if res else None
+    xr = x.clone().requires_grad_(True)
+    gr = ga.clone().requires_grad_(True) if adain else None
+    br = be.clone().requires_grad_(True) if adain else None
+    rr = r.clone().requires_grad_(True) if res else None
+    yr = orc.adain(xr, gr, br) if adain else orc.instance_norm(xr)
+    if relu:
+        yr = torch.relu(yr)
+    if res:
+        yr = yr + rr
+    gy = rb(torch.randn(yr.shape, generator=g))
+    (yr * gy).sum().backward()
+    xd = feat(x)
+    gd = ga.to(DEV).requires_grad_(True) if adain else None
+    bd = be.to(DEV).requires_grad_(True) if adain else None
+    rd = feat(r) if res else None
+    yd = ops.instance_norm(xd, gd, bd, residual=rd, relu=relu)
+    assert yd.dtype == BF
+    close(yd, yr, 6e-3, msg="y")
+    (yd.float() * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, 8e-3, msg="dx")
+    if adain:
+        close(gd.grad, gr.grad, 2e-3, msg="dgamma")
+        close(bd.grad, br.grad, 2e-3, msg="dbeta")
+    if res:
+        close(rd.grad, rr.grad, 1e-6, msg="dres")
+
+
+@pytest.mark.parametrize("B,C,H,relu", [(2, 128, 16, True), (1, 64, 12, False), (3, 8, 6, True)])
+def test_bf16_layer_norm(B, C, H, relu):
+    g = torch.Generator().manual_seed(B * C + H + 1)
+    x = rb(torch.randn(B, C, H, H, generator=g) * 1.5 - 0.3)
+    ga, be = torch.rand(C, generator=g), torch.randn(C, generator=g) * 0.2
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    yr = orc.layer_norm_munit(xr, gr, br)
+    if relu:
+        yr = torch.relu(yr)
+    gy = rb(torch.randn(yr.shape, generator=g))
+    (yr * gy).sum().backward()
+    xd, gd, bd = feat(x), ga.to(DEV).requires_grad_(True), be.to(DEV).requires_grad_(True)
+    yd = ops.layer_norm_munit(xd, gd, bd, relu=relu)
+    close(yd, yr, 6e-3, msg="y")
+    (yd.float() * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, 8e-3, msg="dx")
+    close(gd.grad, gr.grad, 2e-3, msg="dgamma")
+    close(bd.grad, br.grad, 2e-3, msg="dbeta")
+
+
+def test_bf16_resample_blend_l1_pack():
+    g = torch.Generator().manual_seed(5)
+    x = rb(torch.randn(2, 64, 8, 12, generator=g))
+    xr = x.clone().requires_grad_(True)
+    up = orc.upsample_bilinear2x(xr)
+    gy = rb(torch.randn(up.shape, generator=g))
+    (up * gy).sum().backward()
+    xd = feat(x)
+    ud = ops.upsample2x(xd)
+    close(ud, up, 6e-3, msg="up")
+    (ud.float() * gy.to(DEV)).sum().backward()
+    close(xd.grad, xr.grad, 6e-3, msg="up dx")
+
+    xr2 = x.clone().requires_grad_(True)
+    dn = orc.downsample_half(xr2)
+    gy2 = rb(torch.randn(dn.shape, generator=g))
+    (dn * gy2).sum().backward()
+    xd2 = feat(x)
+    dd = ops.downsample_half(xd2)
+    close(dd, dn, 6e-3, msg="down")
+    (dd.float() * gy2.to(DEV)).sum().backward()
+    close(xd2.grad, xr2.grad, 6e-3, msg="down dx")
+
+    # image boundary: NCHW3 fp32 -> NHWC8 bf16, planes 3..7 zero
+    img = torch.rand(3, 3, 10, 14, generator=g) * 2 - 1
+    i8 = ops.pack_image(img.to(DEV))
+    assert i8.shape == (3, 8, 10, 14) and i8.dtype == BF and float(i8[:, 3:].abs().max()) == 0.0
+    close(i8[:, :3], rb(img), 0.0, atol=0.0, msg="pack")
+    assert ops.pack_image(i8) is i8
+
+    # blend + image L1 (planes 0..2 only)
+    heads = rb(torch.rand(3, 4, 10, 14, generator=g) * 0.9)
+    hr, real = heads.clone().requires_grad_(True), rb(img)
+    out = hr[:, :3] * hr[:, 3:4] + real * (1 - hr[:, 3:4])
+    lr_ = (out - real * 0.5).abs().mean()
+    lr_.backward()
+    h8 = torch.cat([heads, torch.zeros(3, 4, 10, 14)], 1)
+    hd = feat(h8)
+    od = ops.attention_blend(hd, i8)
+    close(od[:, :3], out, 6e-3, msg="blend")
+    assert float(od[:, 3:].abs().max()) == 0.0
+    tgt = ops.pack_image((real * 0.5).to(DEV))
+    ld = ops.l1_mean(od, tgt, image=True)
+    assert ld.dtype == torch.float32
+    assert abs(float(ld) - float(lr_)) <= 4e-3 * float(lr_)
+    ld.backward()
+    # d|o - t| is +-1/N per element: a bf16-rounded o that lands on the other side of t flips a sign, so the comparison is on
+    # the fraction of elements that agree, not on the maximum
+    gd, gr_ = hd.grad[:, :4].float().cpu(), hr.grad
+    bad = ((gd - gr_).abs() > 2e-2 * gr_.abs().max()).float().mean().item()
+    assert bad <= 0.02, "blend/l1 grad: %.3f of the elements differ" % bad
+
+    # feature L1
+    a, b = rb(torch.randn(2, 64, 8, 8, generator=g)), rb(torch.randn(2, 64, 8, 8, generator=g))
+    ar = a.clone().requires_grad_(True)
+    lr2 = (ar - b).abs().mean()
+    lr2.backward()
+    ad = feat(a)
+    ld2 = ops.l1_mean(ad, feat(b).detach())
+    assert abs(float(ld2) - float(lr2)) <= 1e-5 * float(lr2)
+    ld2.backward()
+    close(ad.grad, ar.grad, 6e-3, msg="l1 grad")
+
+
+def _run_iteration(cfg, B, S, seed, steps=1):
+    """HIP trainer (active precision) and the fp32 CPU oracle from the same weights / batch / random stream."""
+    from solver import Solver
+    dev = torch.device(DEV)
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(seed)
+        trainer = Solver(cfg, dev, None).to(dev)
+        trainer.copy_nets()
+        rng = torch.get_rng_state()
+        batch = synth.make_batch(B, S, seed=seed + 1)
+        oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in trainer.gen.state_dict().items()},
+                                  {k: v.cpu() for k, v in trainer.dis.state_dict().items()})
+        oracle.copy_nets()
+        o_losses = []
+        for it in range(steps):
+            oracle.iteration(batch, it)
+            o_losses.append(dict(oracle.losses))
+        torch.set_rng_state(rng)
+        db = {k: v.to(dev) for k, v in batch.items()}
+        h_losses = []
+        for it in range(steps):
+            a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, it)
+            trainer.dis_update(*a)
+            trainer.gen_update(*a)
+            trainer.smooth_moving()
+            trainer.update_learning_rate()
+            trainer.update_attention_status(it)
+            torch.cuda.synchronize()
+            h_losses.append({k: float(getattr(trainer, k)) for k in o_losses[it]})
+        return h_losses, o_losses, trainer
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
+LOSS_KEYS = ("loss_dis_all", "loss_gen_total", "loss_gen_adv", "loss_gen_recon_x", "loss_gen_recon_c_real", "loss_gen_recon_s_real",
+             "loss_gen_cycrecon_x", "loss_kl_x", "loss_kl_trg", "loss_ds")
+
+
+def test_bf16_tiny_iterations_vs_fp32_oracle():
+    """Two full iterations (attention on, then off) of the tiny configuration on the bf16 path against the fp32 oracle:
+    every loss scalar within 3e-2 relative (bf16 activations carry 8 significant bits; the losses are fp32 means)."""
+    cfg = synth.make_config(image_size=32, tiny=True, lstm_dropout=0.0)
+    h, o, trainer = _run_iteration(cfg, 3, 32, 1234, steps=2)
+    for it in range(2):
+        for k in LOSS_KEYS:
+            assert abs(h[it][k] - o[it][k]) <= 3e-2 * max(1.0, abs(o[it][k])), (it, k, h[it][k], o[it][k])
+    for p in trainer.gen.parameters():
+        assert p.dtype == torch.float32 and torch.isfinite(p).all()
+
+
+@pytest.mark.parametrize("S,B", [(64, 4), (128, 2)])
+def test_bf16_full_size_iteration_vs_fp32_oracle(S, B):
+    """The shipped configuration at full width on the bf16 path, one iteration against the fp32 oracle: the two headline
+    losses within 2e-2 relative, every other scalar within 3e-2 of max(1, |value|)."""
+    cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
+    h, o, _ = _run_iteration(cfg, B, S, 4321)
+    for k in ("loss_dis_all", "loss_gen_total"):
+        assert abs(h[0][k] - o[0][k]) <= 2e-2 * abs(o[0][k]), (k, h[0][k], o[0][k])
+    for k in LOSS_KEYS:
+        assert abs(h[0][k] - o[0][k]) <= 3e-2 * max(1.0, abs(o[0][k])), (k, h[0][k], o[0][k])

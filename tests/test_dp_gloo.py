@@ -76,7 +76,32 @@ def _worker(rank, world, port, q):
         gathered = [torch.zeros_like(w) for _ in range(world)]
         dist.all_gather(gathered, w)
         ok3 = all(torch.equal(gathered[0], t) for t in gathered)
-        q.put((rank, bool(ok1), float(err), bool(ok3), mine["fake"].shape[0]))
+        # (4) overlapped reducer: gradients are views of flat buckets, buckets are all-reduced from inside backward,
+        #     a parameter that is off the tape gets grad None (Adam skips it), result == full-batch gradient
+        torch.manual_seed(7)                              # same weights on both ranks
+        net = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+                                  torch.nn.Linear(32, 3))
+        unused = torch.nn.Parameter(torch.ones(5))       # like the attention head while attention is off
+        plist4 = list(net.parameters()) + [unused]
+        red = dp.OverlappedGradReducer(plist4, bucket_bytes=4 * 600)
+        xs = torch.randn(8, 6, generator=torch.Generator().manual_seed(3))
+        ys = torch.randn(8, 3, generator=torch.Generator().manual_seed(4))
+        ok4 = len(red.buckets) >= 3
+        for step in range(2):                             # twice: buffers are re-used, hooks fire again
+            red.prepare(skip=[unused])
+            sl = slice(rank * 4, rank * 4 + 4)
+            ((net(xs[sl]) - ys[sl]) ** 2).mean().backward()
+            early = red.launched_early
+            red.finish()
+            full_loss = ((net(xs) - ys) ** 2).mean()
+            gfull4 = torch.autograd.grad(full_loss, list(net.parameters()))
+            ok4 = ok4 and unused.grad is None and early >= 1
+            for p_, gf in zip(net.parameters(), gfull4):
+                ok4 = ok4 and p_.grad is not None and torch.allclose(p_.grad, gf, rtol=1e-5, atol=1e-6)
+                bk = red.buckets[red.where[id(p_)]]
+                idx = [i for i, q_ in enumerate(bk["params"]) if q_ is p_][0]
+                ok4 = ok4 and p_.grad.data_ptr() == bk["views"][idx].data_ptr()       # the gradient IS the bucket slice
+        q.put((rank, bool(ok1 and ok4), float(err), bool(ok3), mine["fake"].shape[0]))
         dist.destroy_process_group()
     except Exception as e:  # surface the failure in the parent
         q.put((rank, False, repr(e), False, -1))

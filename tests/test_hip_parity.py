@@ -464,13 +464,16 @@ def test_tiny_three_iterations_vs_reference(tiny):
         host.set_noise(host.DeviceNoise())
 
 
-@pytest.mark.parametrize("S,B", [(128, 2), (256, 1)])
+@pytest.mark.parametrize("S,B", [(128, 2), (256, 1), (128, 64), (256, 8)])
 def test_full_size_iteration_vs_oracle(S, B):
     """The shipped network sizes (dim 64, 4 ResBlocks, 5-layer 2-scale D) at 128x128 and at the 256x256 of
     BASELINE configs[4]: one full iteration, every loss scalar against the CPU oracle run from the same
     weights, batch and random stream.  Exercises the real layer shapes (128x128 tiles, split-K tails,
-    wide heads) that the tiny configuration cannot."""
+    wide heads) that the tiny configuration cannot.  (128, 64) and (256, 8) are the PER-GPU shapes of BASELINE
+    configs[3] (global batch 512 on 8 GPUs) and configs[4] (global batch 64 on 8 GPUs)."""
     from solver import Solver
+    if B >= 8:
+        torch.set_num_threads(min(32, os.cpu_count() or 1))       # the oracle leg: more threads than that are slower
     cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
     host.set_noise(host.HostNoise())
     try:
@@ -496,6 +499,57 @@ def test_full_size_iteration_vs_oracle(S, B):
                      "dec.model.2.conv.weight", "dec.image_content.conv.weight", "mlp.model.2.fc.weight"):
             g_hip = dict(s.gen.named_parameters())[name].grad
             close(g_hip, oracle.last_gen_grads[name], rel=1e-2, msg=name)   # whole-network gradient, 1-2 samples
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
+def test_em_distance_iteration_vs_oracle():
+    """dist_mode != 'kls': the generator objective with gmm_earth_mover_distance_sp (reference gmm.py:33-41, solver.py:210-213)
+    in place of the KL terms — unreachable under the shipped config, reachable through the API: two tiny iterations against
+    the oracle, all scalars, plus the gradient that only this branch produces (d loss_kl_x / d style-encoder heads)."""
+    from solver import Solver
+    cfg = synth.make_config(image_size=32, tiny=True, lstm_dropout=0.0)
+    cfg["dist_mode"] = "em"
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(99)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        s.copy_nets()
+        rng = torch.get_rng_state()
+        batch = synth.make_batch(3, 32, seed=12)
+        oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in s.gen.state_dict().items()},
+                                  {k: v.cpu() for k, v in s.dis.state_dict().items()})
+        oracle.copy_nets()
+        o_losses, o_grads = [], None
+        for it in range(2):
+            oracle.iteration(batch, it)
+            o_losses.append(dict(oracle.losses))
+            if it == 0:
+                o_grads = {k: v.clone() for k, v in oracle.last_gen_grads.items() if v is not None}
+        torch.set_rng_state(rng)
+        db = {k: v.to(DEV) for k, v in batch.items()}
+        for it in range(2):
+            a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, it)
+            s.dis_update(*a)
+            grabbed = {}
+            real_step = s.gen_opt.step
+
+            def grab(*aa, **kk):
+                grabbed.update({n: p.grad.detach().clone() for n, p in s.gen.named_parameters() if p.grad is not None})
+                return real_step(*aa, **kk)
+            s.gen_opt.step = grab
+            s.gen_update(*a)
+            s.gen_opt.step = real_step
+            s.smooth_moving()
+            s.update_learning_rate()
+            s.update_attention_status(it)
+            for k, want in o_losses[it].items():
+                got = float(torch.as_tensor(getattr(s, k)).detach())
+                assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), (it, k, got, want)
+            if it == 0:
+                for name in ("enc_style.fcs.0.weight", "enc_style.fcs.7.bias", "enc_txt.fcs.3.weight"):
+                    close(grabbed[name], o_grads[name], rel=5e-3, msg=name)
+        assert abs(o_losses[0]["loss_kl_x"]) > 1e-3          # the EM term is live
     finally:
         host.set_noise(host.DeviceNoise())
 
