@@ -26,8 +26,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 64;          // elements per K-slab (128 bytes per tile row)
 constexpr int MIN_LOG_C = 3;    // a 16-byte staging chunk is 8 channels
 
-__device__ __attribute__((aligned(16))) bf16 g_zero_page_h[128];
-
 __device__ __forceinline__ void lds_dma_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -42,18 +40,21 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient GEMM body.  F32OUT: the destination is fp32 (split-K partials, ring strips).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT, int STAGES = 2>
 __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restrict__ wmat, const Scatter& o,
                                             const float* __restrict__ bias, int act, int tiles_n, int kt0, int kt1_in,
                                             size_t part_offset, bool partial, int oph, int opw, int bid, int nb) {
-    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
+#if defined(__HIP_DEVICE_COMPILE__)      // the buffer-resource builtins exist for the device pass only
+    constexpr int NW = WM * WN;                       // waves per workgroup: 4 (256 threads) or 8 (512 threads, 256-row tiles)
+    constexpr int RP = 8 * NW;                        // tile rows staged per pass (one wave instruction = 8 rows x 128 bytes)
+    static_assert((NW == 4 || NW == 8) && WM * TM * 32 == BM && WN * TN * 32 == BN && BM % RP == 0 && BN % RP == 0, "tile shape");
+    constexpr int A_PASSES = BM / RP, B_PASSES = BN / RP;
     constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
     constexpr int LDC = BN + 8;                       // epilogue staging pitch (elements)
-    static_assert(BM * LDC <= 2 * (A_TILE + B_TILE), "epilogue staging fits the operand buffers");
-    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (A_TILE + B_TILE)];
+    constexpr int SMEM = STAGES * (A_TILE + B_TILE) > BM * LDC ? STAGES * (A_TILE + B_TILE) : BM * LDC;     // the epilogue staging re-uses it
+    __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];
     bf16* sA = smem;
-    bf16* sB = smem + 2 * A_TILE;
+    bf16* sB = smem + STAGES * A_TILE;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -67,13 +68,13 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
     const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int arow = t >> 3;                               // tile row this lane stages (+32 per pass)
+    const int arow = t >> 3;                               // tile row this lane stages (+RP per pass)
     const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 8;  // LOGICAL k offset fetched into physical chunk t&7
     int a_bh[A_PASSES], a_bw[A_PASSES], a_img[A_PASSES];
     const int ohw = g.OH * g.OW;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-        const int mm = min(m0 + arow + 32 * i, g.M - 1);
+        const int mm = min(m0 + arow + RP * i, g.M - 1);
         const int n = mm / ohw;
         const int rem = mm - n * ohw;
         const int oh = rem / g.OW, ow = rem - oh * g.OW;
@@ -82,19 +83,32 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
         a_img[i] = n * g.SH * g.SW;
     }
     const int Kp = (g.K + BK - 1) / BK * BK;
-    const bf16* b_ptr[B_PASSES];
+    // Staging through BUFFER loads into LDS (buffer_load_dwordx4 ... lds): a wave-uniform resource descriptor per operand,
+    // ONE 32-bit byte offset per lane and row that changes only when the slab crosses a filter tap, and the wave-uniform
+    // part of the address (channel offset inside the tap / K offset of the weight slab) in the scalar offset operand.  In
+    // the steady state a staging instruction therefore costs no vector ALU work at all, and a tap that falls outside the
+    // zero-padded image needs no zero page: its offset is pushed past the descriptor's size and the hardware returns zeros.
+    // (At bf16 MFMA rates the 64-bit pointer arithmetic, pointer compares and the zero-page literal load of the
+    // global_load_lds form cost more issue slots than the matrix instructions they feed: r02 PMC, 6.2 VALU per MFMA.)
+    const int n_img_total = g.M / ohw;
+    const unsigned src_bytes = (unsigned)n_img_total * g.SH * g.SW * g.SC * 2u;
+    const unsigned w_bytes = (unsigned)o.N * Kp * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(wmat), 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;                   // >= any descriptor size accepted by the entry points
+    unsigned b_off[B_PASSES];
 #pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = wmat + (size_t)min(n0 + arow + 32 * p, o.N - 1) * Kp + acol;
+    for (int p = 0; p < B_PASSES; ++p) b_off[p] = ((unsigned)min(n0 + arow + RP * p, o.N - 1) * Kp + acol) * 2u;
 
     const int nk_all = Kp / BK;
     const int kt1 = min(nk_all, kt1_in);
     const int n_taps = g.KH * g.KW;
-    const bf16* src = (const bf16*)g.src;
 
     int cur_tap = -1;
-    const bf16* a_src[A_PASSES];     // per-row source of the current tap (zero page when out of bounds)
+    unsigned a_off[A_PASSES];        // per-row byte offset of the current tap (OOB when the tap is outside a zero-padded image)
     const bool tap_uniform = g.SC >= BK;
-    auto row_sources = [&](int tap, int ci) {
+    const bool refl = g.reflect != 0;
+    auto row_offsets = [&](int tap, int ci) {
         int kh = (tap * g.kw_magic) >> 16;
         int kw = tap - kh * g.KW;
         if (g.tap_t) {
@@ -104,49 +118,41 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
         }
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            int h = a_bh[i] + kh * g.kstep;
-            int w = a_bw[i] + kw * g.kstep;
-            bool inb = true;
-            if (g.reflect) {
-                h = reflect_idx(h, g.SH);
-                w = reflect_idx(w, g.SW);
-            } else {
-                inb = h >= 0 && h < g.SH && w >= 0 && w < g.SW;
-                h = min(max(h, 0), g.SH - 1);
-                w = min(max(w, 0), g.SW - 1);
-            }
-            const bf16* p = src + ((a_img[i] + h * g.SW + w) << g.logSC) + ci;
-            a_src[i] = inb ? p : g_zero_page_h;
+            const int h = a_bh[i] + kh * g.kstep;
+            const int w = a_bw[i] + kw * g.kstep;
+            // the reflected index is in range for both rules (|offset| < size); the zero rule additionally masks
+            const bool inb = refl || ((unsigned)h < (unsigned)g.SH && (unsigned)w < (unsigned)g.SW);
+            const int hr = min(reflect_idx(h, g.SH), g.SH - 1), wr = min(reflect_idx(w, g.SW), g.SW - 1);
+            const unsigned off = ((unsigned)((a_img[i] + hr * g.SW + wr) << g.logSC) + (unsigned)ci) * 2u;
+            a_off[i] = inb ? off : OOB;
         }
     };
     auto stage_slab = [&](int kt, int buf) {
-        int coff;
+        int soff_a;
         if (tap_uniform) {
             const int kg0 = kt * BK;
             const int tap = min(kg0 >> g.logSC, n_taps - 1);
             if (tap != cur_tap) {
-                row_sources(tap, acol);
+                row_offsets(tap, acol);
                 cur_tap = tap;
             }
-            coff = kg0 & (g.SC - 1);
+            soff_a = __builtin_amdgcn_readfirstlane((kg0 & (g.SC - 1)) * 2);      // provably wave-uniform: a scalar offset operand
         } else {
             const int kg = kt * BK + acol;
-            row_sources(min(kg >> g.logSC, n_taps - 1), kg & (g.SC - 1));
-            coff = 0;
+            row_offsets(min(kg >> g.logSC, n_taps - 1), kg & (g.SC - 1));
+            soff_a = 0;
         }
         bf16* la = sA + buf * A_TILE + wave * (8 * BK);
         bf16* lb = sB + buf * B_TILE + wave * (8 * BK);
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i) {
-            const bf16* s = a_src[i];
-            if (s != g_zero_page_h) s += coff;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)(la + i * 32 * BK), 16, 0, 0);
-        }
+        for (int i = 0; i < A_PASSES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(la + i * RP * BK), 16,
+                                                     a_off[i], soff_a, 0, 0);
+        const int soff_b = kt * (BK * 2);
 #pragma unroll
         for (int p = 0; p < B_PASSES; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[p] + kt * BK),
-                                             (__attribute__((address_space(3))) void*)(lb + p * 32 * BK), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lb + p * RP * BK), 16,
+                                                     b_off[p], soff_b, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -182,24 +188,63 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
                 acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][n], fa[set][i], acc[i][n], 0, 0, 0);
     };
 
-    if (kt0 < kt1) {
-        stage_slab(kt0, 0);
-        lds_dma_barrier();
-        int buf = 0;
-        load_frags(0, 0, 0);
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const bool more = kt + 1 < kt1;
-            if (more) stage_slab(kt + 1, buf ^ 1);       // other buffer: fully read before the last barrier
-            load_frags(1, buf, 1);
-            mfma_group(0);
-            load_frags(0, buf, 2);
-            mfma_group(1);
-            load_frags(1, buf, 3);
-            mfma_group(0);
-            lds_dma_barrier();                            // direct loads landed (vmcnt), this buffer fully read
-            if (more) load_frags(0, buf ^ 1, 0);
-            mfma_group(1);
-            buf ^= 1;
+    if constexpr (STAGES == 2) {
+        if (kt0 < kt1) {
+            stage_slab(kt0, 0);
+            lds_dma_barrier();
+            int buf = 0;
+            load_frags(0, 0, 0);
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const bool more = kt + 1 < kt1;
+                if (more) stage_slab(kt + 1, buf ^ 1);       // other buffer: fully read before the last barrier
+                load_frags(1, buf, 1);
+                mfma_group(0);
+                load_frags(0, buf, 2);
+                mfma_group(1);
+                load_frags(1, buf, 3);
+                mfma_group(0);
+                lds_dma_barrier();                            // direct loads landed (vmcnt), this buffer fully read
+                if (more) load_frags(0, buf ^ 1, 0);
+                mfma_group(1);
+                buf ^= 1;
+            }
+        }
+    } else {
+        // Three-slab LDS ring: the direct loads of slab kt+2 are issued at the top of slab kt and stay in flight ACROSS the
+        // barrier that ends it -- each wave waits only for its loads of slab kt+1 (counted vmcnt: everything but the NDMA
+        // youngest), then a raw s_barrier publishes them.  A slab's loads thus have two compute phases to land in.
+        // WAR: slab kt+2 overwrites the buffer read during slab kt-1, whose reads every wave finished before the barrier
+        // that ended kt-1.
+        constexpr int NDMA = A_PASSES + B_PASSES;             // direct-load instructions per wave per slab
+        if (kt0 < kt1) {
+            stage_slab(kt0, 0);
+            if (kt0 + 1 < kt1) {
+                stage_slab(kt0 + 1, 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            int buf = 0;
+            load_frags(0, 0, 0);
+            for (int kt = kt0; kt < kt1; ++kt) {
+                const bool more = kt + 1 < kt1, more2 = kt + 2 < kt1;
+                const int nxt = buf == 2 ? 0 : buf + 1;
+                if (more2) stage_slab(kt + 2, nxt == 2 ? 0 : nxt + 1);
+                load_frags(1, buf, 1);
+                mfma_group(0);
+                load_frags(0, buf, 2);
+                mfma_group(1);
+                load_frags(1, buf, 3);
+                mfma_group(0);
+                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (more) load_frags(0, nxt, 0);
+                mfma_group(1);
+                buf = nxt;
+            }
         }
     }
 
@@ -254,7 +299,7 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
         bf16* dst = (bf16*)o.dst;
         constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
         const bool wide = (o.N & 7) == 0;                 // rows are 16-byte aligned
-        for (int idx = t; idx < BM * CPR; idx += 256) {
+        for (int idx = t; idx < BM * CPR; idx += 64 * NW) {
             const int row = idx / CPR, ch = idx - row * CPR;
             const int m = m0 + row, col = n0 + ch * 8;
             if (m >= g.M || col >= o.N) continue;
@@ -272,14 +317,15 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
             }
         }
     }
+#endif
 }
 
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT>
-__global__ __launch_bounds__(256) void gemm_kernel_h(Gather g, const bf16* __restrict__ wmat, size_t w_class_stride, Scatter o,
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT, int STAGES = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel_h(Gather g, const bf16* __restrict__ wmat, size_t w_class_stride, Scatter o,
                                                      const float* __restrict__ bias, int act, int tiles_n, int kt_per_split,
                                                      size_t part_stride) {
     const int cls = blockIdx.z, split = blockIdx.y;
-    gemm_body_h<BM, BN, WM, WN, TM, TN, F32OUT>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
+    gemm_body_h<BM, BN, WM, WN, TM, TN, F32OUT, STAGES>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
                                                 (split + 1) * kt_per_split, (size_t)split * part_stride, part_stride != 0,
                                                 cls >> 1, cls & 1, blockIdx.x, gridDim.x);
 }
@@ -325,6 +371,7 @@ __device__ __forceinline__ int tr_swizzle(int m) {
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __restrict__ dy, int N, float* __restrict__ slab,
                                                       int m_chunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
     static_assert(WM * WN == 4 && WM * TM * 32 == 128 && WN * TN * 32 == BN, "tile shape");
     constexpr int MS = 64;                               // pixels per slab
     constexpr int A_TILE = MS * 128, B_TILE = MS * BN;   // elements
@@ -338,7 +385,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
     const int split = blockIdx.z;
     const int m_begin = split * m_chunk;
     const int m_end = min(g.M, m_begin + m_chunk);
-    const bf16* src = (const bf16*)g.src;
 
     // A staging: thread = (row ar [+16 per pass], chunk slot t&15); it fetches LOGICAL chunk slot ^ sw(row), whose tap and
     // channel are fixed for the thread (16*pass keeps row & 3).  k >= K (tile tail) is clamped to a valid tap: never stored.
@@ -358,6 +404,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
     const int bcol_c = min(n0 + b_lc * 8, N - 8 >= 0 ? N - 8 : 0);      // columns past N are never stored: clamp instead of masking
     const int ohw = g.OH * g.OW;
 
+    // buffer loads into LDS (see gemm_body_h): the dY descriptor ends at this workgroup's last pixel row, so rows past the
+    // end of the pixel range read as zeros without a mask, and its slab offset travels in the scalar operand; the gathered
+    // x rows carry one 32-bit offset each.
+    const unsigned x_bytes = (unsigned)(g.M / ohw) * g.SH * g.SW * g.SC * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.src), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_dy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dy), 0, (unsigned)m_end * (unsigned)N * 2u, 0x00020000);
+    unsigned b_voff[B_PASSES];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p) b_voff[p] = ((unsigned)(br + p * B_RPP) * N + bcol_c) * 2u;
     auto stage_slab = [&](int mb, int buf) {
         bf16* la = sA + buf * A_TILE + wave * 512;
         bf16* lb = sB + buf * B_TILE + wave * 512;
@@ -378,17 +434,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
             }
             const int h = reflect_idx(oh * g.mul_h + dh, g.SH);
             const int w = reflect_idx(ow * g.mul_w + dw, g.SW);
-            const bf16* s = src + (((n * g.SH + h) * g.SW + w) << g.logSC) + ci;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)(la + i * 16 * 128), 16, 0, 0);
+            const unsigned off = ((unsigned)(((n * g.SH + h) * g.SW + w) << g.logSC) + (unsigned)ci) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(la + i * 16 * 128), 16, off, 0,
+                                                     0, 0);
         }
+        const int soff = __builtin_amdgcn_readfirstlane(mb * N * 2);
 #pragma unroll
-        for (int p = 0; p < B_PASSES; ++p) {
-            const int m = mb + br + p * B_RPP;
-            const bf16* s = m < m_end ? dy + (size_t)m * N + bcol_c : g_zero_page_h;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)(lb + p * B_RPP * BN), 16, 0, 0);
-        }
+        for (int p = 0; p < B_PASSES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (__attribute__((address_space(3))) void*)(lb + p * B_RPP * BN), 16,
+                                                     b_voff[p], soff, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -478,6 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
                 if (col < N) out[(size_t)k * N + col] = acc[i][n][r];
             }
         }
+#endif
 }
 
 // slab[s][(kh,kw,ci)][co] summed over s -> dw[co][ci][kh][kw] (state_dict layout, fp32), real channels only
@@ -609,21 +664,71 @@ __global__ void weight_prepare_dgrad_kernel_h(const float* __restrict__ w, bf16*
 }
 
 // ---- launchers -------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, int STAGES = 2>
 void launch_variant_h(const Gather& g, const bf16* w, size_t wcs, int classes, const Scatter& o, const float* bias, int act,
                       const Plan& p, size_t part_stride, bool f32out, hipStream_t st) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (o.N + BN - 1) / BN;
     if (f32out)
-        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, true>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0,
-                           st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, true, STAGES>), dim3(tiles_m * tiles_n, p.splits, classes),
+                           dim3(64 * WM * WN), 0, st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
     else
-        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, false>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0,
-                           st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+        hipLaunchKernelGGL((gemm_kernel_h<BM, BN, WM, WN, TM, TN, false, STAGES>), dim3(tiles_m * tiles_n, p.splits, classes),
+                           dim3(64 * WM * WN), 0, st, g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
+}
+
+// Tile choice for the bf16 kernels: the fp32 planner's candidates plus the 8-wave 256-row tiles (one workgroup per CU,
+// 128 KiB / 96 KiB of LDS).  At bf16 MFMA rates the 128x128 tile is bound by what a CU can pull out of L2 into LDS
+// (32 KB per 64-deep slab) and by LDS read bandwidth (one ds_read_b128 per MFMA with 64x64 wave tiles); a 256x256 tile
+// halves both per flop (128x64 wave tiles: 0.75 reads per MFMA), a 256x128 tile saves a quarter.  `f` = measured relative
+// rate at full residency (kernel_bench_bf16, r02), the cost model is plan_gemm's (rounds of resident workgroups).
+Plan plan_gemm_h(int M, int N, int K, int classes) {
+    struct Cand { int bm, bn, resident; float f; };
+    static const Cand all[] = {{256, 256, 1, 1.45f}, {256, 128, 1, 1.25f}, {128, 128, 2, 1.0f}, {128, 64, 3, 0.8f},
+                               {64, 64, 5, 0.55f}, {128, 32, 4, 0.35f}};
+    const int nk = (K + BK - 1) / BK;
+    Plan best = {128, 32, 1, nk};
+    float best_cost = 3.0e38f;
+    static const char* force = getenv("DWC_BF16_TILE");      // development knob: pin a tile, e.g. 128x128
+    for (const Cand& c : all) {
+        const bool ok = N <= 32 ? c.bn == 32 : (N <= 64 ? c.bn == 64 : (c.bn != 32 && (c.bn <= 128 || N > 128)));
+        if (!ok) continue;
+        if (force) {
+            char tag[16];
+            snprintf(tag, sizeof tag, "%dx%d", c.bm, c.bn);
+            if (strcmp(tag, force) != 0 && !(N <= 64)) continue;
+        }
+        const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
+        const long n = (blocks + NUM_CU - 1) / NUM_CU;
+        const long full = n / c.resident, rem = n % c.resident;
+        const float tile = (float)c.bm * c.bn / c.f;
+        float cost = (float)full * c.resident * tile;
+        if (rem) cost += (float)rem * tile / (rem == 1 && c.resident > 1 ? 0.62f : 0.9f);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = {c.bm, c.bn, 1, nk};
+        }
+    }
+    const long blocks = (long)((M + best.bm - 1) / best.bm) * ((N + best.bn - 1) / best.bn) * classes;
+    if (blocks < NUM_CU / 2 && nk >= 8) {
+        int s = (int)((2 * NUM_CU + blocks - 1) / blocks);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 32) s = 32;
+        if (s >= 2) {
+            best.kt_per_split = (nk + s - 1) / s;
+            best.splits = (nk + best.kt_per_split - 1) / best.kt_per_split;
+        }
+    }
+    return best;
+}
+
+size_t gemm_ws_bytes_h(int M, int N, int K, int classes, size_t dst_elems) {
+    const Plan p = plan_gemm_h(M, N, K, classes);
+    return p.splits > 1 ? (size_t)p.splits * dst_elems * sizeof(float) : 0;
 }
 
 int launch_gemm_h(const Gather& g, const bf16* w, size_t w_class_stride, int classes, Scatter o, const float* bias, int act,
                   size_t dst_elems, void* ws, size_t ws_bytes, hipStream_t st) {
-    Plan p = plan_gemm(g.M, o.N, g.K, classes, BK);
+    Plan p = plan_gemm_h(g.M, o.N, g.K, classes);
     bf16* final_dst = (bf16*)o.dst;
     size_t part_stride = 0;
     if (p.splits > 1) {
@@ -636,7 +741,11 @@ int launch_gemm_h(const Gather& g, const bf16* w, size_t w_class_stride, int cla
         }
     }
     const bool f32out = p.splits > 1;
-    if (p.bm == 128 && p.bn == 128) launch_variant_h<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    static const bool stages3 = getenv("DWC_BF16_STAGES3") != nullptr;      // development knob: 3-slab ring for the 128x128 tile too
+    if (p.bm == 256 && p.bn == 256) launch_variant_h<256, 256, 2, 4, 4, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else if (p.bm == 256 && p.bn == 128) launch_variant_h<256, 128, 4, 2, 2, 2, 3>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else if (p.bm == 128 && p.bn == 128 && stages3) launch_variant_h<128, 128, 2, 2, 2, 2, 3>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
+    else if (p.bm == 128 && p.bn == 128) launch_variant_h<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 128 && p.bn == 64) launch_variant_h<128, 64, 2, 2, 2, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 64 && p.bn == 64) launch_variant_h<64, 64, 2, 2, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else launch_variant_h<128, 32, 4, 1, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
@@ -714,7 +823,7 @@ int dwc_bf16_weight_prepare_dgrad(const float* w, void* out, int Cout, int Cin, 
 size_t dwc_bf16_conv2d_fwd_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     FwdGeom f;
     if (!fwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, MIN_LOG_C)) return 0;
-    return gemm_ws_bytes(f.g.M, Cout, f.g.K, 1, f.dst_elems, BK);
+    return gemm_ws_bytes_h(f.g.M, Cout, f.g.K, 1, f.dst_elems);
 }
 
 int dwc_bf16_conv2d_fwd(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
@@ -734,7 +843,7 @@ int dwc_bf16_conv2d_fwd_ex(const void* x, const void* w_prepared, const float* b
 size_t dwc_bf16_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     BwdGeom f;
     if (!bwd_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, BK, MIN_LOG_C)) return 0;
-    return gemm_ws_bytes(f.g.M, Cin, f.g.K, f.classes, f.dst_elems, BK);
+    return gemm_ws_bytes_h(f.g.M, Cin, f.g.K, f.classes, f.dst_elems);
 }
 
 int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int B, int H, int W, int Cin, int Cout, int KH,
@@ -758,7 +867,7 @@ size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int 
     SameDgrad f;
     if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return 0;
     const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
-    return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems, BK);
+    return ring + gemm_ws_bytes_h(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
 
 int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
