@@ -86,7 +86,7 @@ def cpu_baseline(gen_sd, dis_sd, cfg, image_size, batch, warmup, timed, thread_c
     if len(counts) > 1:
         small = synth.make_batch(max(1, batch // 4), image_size, seed=98)
         solver = make()
-        torch.set_num_threads(counts[-1])
+        torch.set_num_threads(counts[len(counts) // 2])
         solver.iteration(small, 0)                               # page everything in once
         for t in counts:
             torch.set_num_threads(t)
@@ -174,7 +174,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-warmup", type=int, default=3, help="CPU baseline: untimed iterations per thread count (BASELINE.md: >= 3)")
     ap.add_argument("--cpu-timed", type=int, default=5, help="CPU baseline: timed iterations per thread count (BASELINE.md: >= 5)")
-    ap.add_argument("--cpu-threads", default="16,32,64,128", help="CPU baseline: thread counts to sweep")
+    ap.add_argument("--cpu-threads", default="8,16,32,64",
+                    help="CPU baseline: thread counts to sweep (r02 probe on the 256-hardware-thread GPU box, images/s at batch 4: "
+                         "8: 1.10, 16: 1.40, 32: 0.80, 64: 0.33, 128: 0.11 -- this graph gets SLOWER beyond 16 threads)")
     ap.add_argument("--per-gpu-batch", type=int, default=None, help="development knob; overrides the config's per-GPU batch")
     ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
                     help="development knob: Winograd output tile of the fp32 3x3 convolutions (default 2 = F(2x2,3x3); 4 = "

@@ -352,7 +352,10 @@ class Solver(nn.Module):
                        if os.path.isfile(os.path.join(dirname, f)) and key in f and ".pt" in f)
         return files[-1] if files else None
 
-    def resume(self, checkpoint_dir, configs):
+    def resume(self, checkpoint_dir, configs, load_optimizer=False):
+        """Reference solver.py:359-376.  ``load_optimizer=True`` additionally restores Adam's moments and step counts from
+        ``optimizer.pt`` — the state ``save`` writes and the reference forgets to reload (its lines 370-372 are commented
+        out, so a resumed reference run restarts Adam from zero moments); off by default to keep the reference's behaviour."""
         name = self._latest(checkpoint_dir, "gen")
         self.gen.load_state_dict(torch.load(name, map_location="cpu")["a"])
         self._gen_steps, self._content_cache = self._gen_steps + 1, None
@@ -364,6 +367,16 @@ class Solver(nn.Module):
         for _ in range(iterations):
             self.gen_scheduler.step()
             self.dis_scheduler.step()
+        opt_path = os.path.join(checkpoint_dir, "optimizer.pt")
+        if load_optimizer:
+            if not os.path.exists(opt_path):
+                raise FileNotFoundError("load_optimizer=True but %s does not exist" % opt_path)
+            lr_g, lr_d = self.gen_opt.param_groups[0]["lr"], self.dis_opt.param_groups[0]["lr"]
+            state = torch.load(opt_path, map_location="cpu")
+            self.gen_opt.load_state_dict(state["gen"])
+            self.dis_opt.load_state_dict(state["dis"])
+            # the schedule position is the one derived from the iteration count above, not the saved group's
+            self.gen_opt.param_groups[0]["lr"], self.dis_opt.param_groups[0]["lr"] = lr_g, lr_d
         print("Resume from iteration %d" % iterations)
         return iterations
 

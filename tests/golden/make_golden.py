@@ -344,6 +344,71 @@ def gen_vgg(ref_solver, ref_nets):
     print("vgg_loss.npz written:", {k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in out.items()})
 
 
+def gen_sample(ref_solver):
+    """Solver.sample (reference solver.py:249-289) on the tiny configuration: the five output stacks, with attention on
+    (iteration-0 state) and off, from the seeded initial weights and a seeded CPU random stream."""
+    cfg = synth.make_config(image_size=32, tiny=True)
+    trainer = build_ref_solver(ref_solver, cfg)
+    batch = synth.make_batch(3, 32, seed=4321)
+    out = {}
+    for tag, att in (("att", True), ("noatt", False)):
+        trainer.use_attention = att
+        torch.manual_seed(555)
+        with torch.no_grad():
+            res = trainer.sample(batch["x_real"], batch["txt"], batch["txt_lens"])
+        out[tag + "/n"] = np.array(len(res))
+        for i, r in enumerate(res):
+            out["%s/%d" % (tag, i)] = t2n(r)
+    np.savez_compressed(os.path.join(HERE, "sample_tiny.npz"), **out)
+    print("sample_tiny.npz written:", {k: v.shape for k, v in out.items()})
+
+
+def gen_text(ref_solver):
+    """Input-pipeline fixtures (reference vocab.py, data_ios/celeba_text.py, data_ios/celeba_data.py:40-77):
+    the CelebA vocabulary in index order, sentences produced by the reference's labels2text for seeded label pairs
+    together with their ListsToTensor encoding, and the train/test split of a synthetic attribute file."""
+    import random
+    sys.path.insert(0, REF)
+    import vocab as ref_vocab
+    from data_ios import celeba_text as ref_text
+    v = ref_vocab.Vocab(dataset="CelebA")
+    random.seed(2024)
+    rng = np.random.RandomState(7)
+    sentences, pairs = [], []
+    for _ in range(400):
+        src, trg = (rng.rand(8) < 0.5).astype(np.int64), (rng.rand(8) < 0.5).astype(np.int64)
+        if rng.rand() < 0.15:
+            trg = src.copy()
+        sentences.append(ref_text.labels2text(src.copy(), trg.copy()))
+        pairs.append([src.tolist(), trg.tolist()])
+    toks, lens = ref_vocab.ListsToTensor([s.split() for s in sentences], v, mx_len=80)
+    # split: a synthetic list_attr file with 2500 entries and 40 attribute columns
+    names = ["A%02d" % i for i in range(32)] + ["Black_Hair", "Blond_Hair", "Brown_Hair", "Smiling", "Young", "Male",
+                                                "Eyeglasses", "No_Beard"]
+    r2 = np.random.RandomState(11)
+    lines = ["2500", " ".join(names)]
+    for i in range(2500):
+        vals = np.where(r2.rand(40) < 0.4, "1", "-1")
+        lines.append("%06d.jpg %s" % (i + 1, " ".join(vals)))
+    attr_txt = "\n".join(lines) + "\n"
+    import tempfile
+    from data_ios import celeba_data as ref_data
+    with tempfile.TemporaryDirectory() as d:
+        ap = os.path.join(d, "attr.txt")
+        with open(ap, "w") as f:
+            f.write(attr_txt)
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = ref_data.CelebA(d, ap, names[32:], None, "train")
+    with open(os.path.join(HERE, "text_pipeline.json"), "w") as f:
+        json.dump({"itos": v.itos, "pairs": pairs, "sentences": sentences, "tokens": toks.tolist(), "lens": lens.tolist(),
+                   "attr_seed": 11, "attr_names": names, "selected": names[32:],
+                   "test_head": ds.test_dataset[:50], "train_head": ds.train_dataset[:50],
+                   "n_test": len(ds.test_dataset), "n_train": len(ds.train_dataset),
+                   "train_tail": ds.train_dataset[-5:]}, f)
+    print("text_pipeline.json written:", len(sentences), "sentences, vocab", len(v.itos), "split", len(ds.test_dataset), len(ds.train_dataset))
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["ops", "tiny", "init"]
     ref_solver, ref_nets, ref_v2, ref_gmm, ref_tools = import_reference()
@@ -355,6 +420,10 @@ if __name__ == "__main__":
         gen_init_checksums(ref_solver)
     if "vgg" in what:
         gen_vgg(ref_solver, ref_nets)
+    if "sample" in what:
+        gen_sample(ref_solver)
+    if "text" in what:
+        gen_text(ref_solver)
     if "traj64" in what:
         gen_traj(ref_solver, 64, 4, 100, None, "s64_b4_default")
         gen_traj(ref_solver, 64, 4, 100, 0.0, "s64_b4_nolstmdrop")

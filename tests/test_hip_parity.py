@@ -662,6 +662,25 @@ def test_iteration_with_vgg_loss_vs_oracle(tmp_path):
         host.set_noise(host.DeviceNoise())
 
 
+@pytest.mark.parametrize("att", [True, False], ids=["attention", "no_attention"])
+def test_sample_vs_reference(tiny, golden_dir, att):
+    """Solver.sample (reference solver.py:249-289) against the stacks recorded from the reference on the tiny configuration:
+    reconstruction, text-driven translation, resampled-style translation and (attention on) the attention maps."""
+    ref = np.load(os.path.join(golden_dir, "sample_tiny.npz"))
+    tag = "att" if att else "noatt"
+    host.set_noise(host.HostNoise())
+    try:
+        s, cfg, batch = _tiny_solver(tiny)
+        s.use_attention = att
+        torch.manual_seed(555)
+        res = s.sample(batch["x_real"], batch["txt"], batch["txt_lens"])
+        assert len(res) == int(ref[tag + "/n"]) and s.training
+        for i, r in enumerate(res):
+            close(r, T(ref["%s/%d" % (tag, i)]), rel=2e-4, msg="%s output %d" % (tag, i))
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
 def test_sample_matches_manual_path():
     """Solver.sample (reference solver.py:249-289, the image grid train.py writes): per-image encode / text-encode /
     decode in eval mode.  Shapes, value ranges, train-mode restoration, and the reconstruction column against the same

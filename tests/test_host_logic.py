@@ -178,3 +178,34 @@ def test_checkpoint_save_resume_roundtrip(tmp_path):
         sch.step()
     assert b.gen_opt.param_groups[0]["lr"] == pytest.approx(dummy.param_groups[0]["lr"])
     assert b.dis_opt.param_groups[0]["lr"] == pytest.approx(dummy.param_groups[0]["lr"])
+
+
+def test_resume_can_reload_optimizer_state(tmp_path):
+    """save() writes optimizer.pt like the reference (solver.py:413); resume(load_optimizer=True) restores Adam's moments
+    and step counts from it (the reference leaves that reload commented out, solver.py:370-372), the default does not."""
+    from solver import Solver
+    cfg = synth.make_config(image_size=32, tiny=True)
+    torch.manual_seed(5)
+    a = Solver(cfg, torch.device("cpu"), None)
+    a.copy_nets()
+    g = torch.Generator().manual_seed(1)
+    for opt in (a.gen_opt, a.dis_opt):            # fabricate a non-trivial optimiser state (FusedAdam.step itself needs the GPU)
+        for p in opt.param_groups[0]["params"]:
+            opt.state[p] = {"step": torch.tensor(7.0), "exp_avg": torch.randn(p.shape, generator=g),
+                            "exp_avg_sq": torch.rand(p.shape, generator=g)}
+    a.save(str(tmp_path), 6)
+    b = Solver(cfg, torch.device("cpu"), None)
+    assert b.resume(str(tmp_path), cfg) == 7 and len(b.gen_opt.state) == 0
+    c = Solver(cfg, torch.device("cpu"), None)
+    assert c.resume(str(tmp_path), cfg, load_optimizer=True) == 7
+    for oa, oc in ((a.gen_opt, c.gen_opt), (a.dis_opt, c.dis_opt)):
+        pa, pc = oa.param_groups[0]["params"], oc.param_groups[0]["params"]
+        assert len(oc.state) == len(pa)
+        for x, y in zip(pa, pc):
+            assert float(oc.state[y]["step"]) == 7.0
+            assert torch.equal(oc.state[y]["exp_avg"], oa.state[x]["exp_avg"])
+            assert torch.equal(oc.state[y]["exp_avg_sq"], oa.state[x]["exp_avg_sq"])
+        assert oc.param_groups[0]["lr"] == pytest.approx(b.gen_opt.param_groups[0]["lr"])
+    with pytest.raises(FileNotFoundError):
+        os.remove(tmp_path / "optimizer.pt")
+        Solver(cfg, torch.device("cpu"), None).resume(str(tmp_path), cfg, load_optimizer=True)
