@@ -127,8 +127,12 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
             a_off[i] = inb ? off : OOB;
         }
     };
-    auto stage_slab = [&](int kt, int buf) {
-        int soff_a;
+    // staging of one slab = address preparation (vector ALU, only when the slab crosses a tap) + NDMA buffer-load
+    // instructions that can be issued in parts (interleaved with the MFMA groups of the slab being multiplied)
+    constexpr int NDMA = A_PASSES + B_PASSES;
+    int soff_a = 0, soff_b = 0;
+    bf16 *st_la = sA, *st_lb = sB;
+    auto prep_slab = [&](int kt, int buf) {
         if (tap_uniform) {
             const int kg0 = kt * BK;
             const int tap = min(kg0 >> g.logSC, n_taps - 1);
@@ -142,17 +146,26 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
             row_offsets(min(kg >> g.logSC, n_taps - 1), kg & (g.SC - 1));
             soff_a = 0;
         }
-        bf16* la = sA + buf * A_TILE + wave * (8 * BK);
-        bf16* lb = sB + buf * B_TILE + wave * (8 * BK);
+        soff_b = kt * (BK * 2);
+        st_la = sA + buf * A_TILE + wave * (8 * BK);
+        st_lb = sB + buf * B_TILE + wave * (8 * BK);
+    };
+    auto issue_dma = [&](int first, int last) {          // instructions [first, last) of the prepared slab; compile-time bounds
 #pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(la + i * RP * BK), 16,
-                                                     a_off[i], soff_a, 0, 0);
-        const int soff_b = kt * (BK * 2);
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lb + p * RP * BK), 16,
-                                                     b_off[p], soff_b, 0, 0);
+        for (int d = 0; d < NDMA; ++d) {
+            if (d < first || d >= last) continue;
+            if (d < A_PASSES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(st_la + d * RP * BK), 16,
+                                                         a_off[d < A_PASSES ? d : 0], soff_a, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b,
+                                                         (__attribute__((address_space(3))) void*)(st_lb + (d - A_PASSES) * RP * BK), 16,
+                                                         b_off[d >= A_PASSES ? d - A_PASSES : 0], soff_b, 0, 0);
+        }
+    };
+    auto stage_slab = [&](int kt, int buf) {
+        prep_slab(kt, buf);
+        issue_dma(0, NDMA);
     };
 
     f32x16 acc[TM][TN];
@@ -215,7 +228,7 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
         // youngest), then a raw s_barrier publishes them.  A slab's loads thus have two compute phases to land in.
         // WAR: slab kt+2 overwrites the buffer read during slab kt-1, whose reads every wave finished before the barrier
         // that ended kt-1.
-        constexpr int NDMA = A_PASSES + B_PASSES;             // direct-load instructions per wave per slab
+        constexpr int D1 = (NDMA + 3) / 4, D2 = (2 * NDMA + 3) / 4, D3 = (3 * NDMA + 3) / 4;   // issue in four parts
         if (kt0 < kt1) {
             stage_slab(kt0, 0);
             if (kt0 + 1 < kt1) {
@@ -230,13 +243,19 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
             for (int kt = kt0; kt < kt1; ++kt) {
                 const bool more = kt + 1 < kt1, more2 = kt + 2 < kt1;
                 const int nxt = buf == 2 ? 0 : buf + 1;
-                if (more2) stage_slab(kt + 2, nxt == 2 ? 0 : nxt + 1);
+                // the staging instructions of slab kt+2 are spread over this slab's MFMA groups: while the matrix pipe works
+                // through a group the wave issues the next two loads, instead of stalling the pipe behind a burst of them
+                if (more2) prep_slab(kt + 2, nxt == 2 ? 0 : nxt + 1);
                 load_frags(1, buf, 1);
+                if (more2) issue_dma(0, D1);
                 mfma_group(0);
                 load_frags(0, buf, 2);
+                if (more2) issue_dma(D1, D2);
                 mfma_group(1);
                 load_frags(1, buf, 3);
+                if (more2) issue_dma(D2, D3);
                 mfma_group(0);
+                if (more2) issue_dma(D3, NDMA);
                 if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -100,12 +100,40 @@ def test_hip_trajectory_s64_b4_default_100_steps():
     assert float(np.mean(rel_tail)) <= 0.06
 
 
+def _self_drift_envelope_128():
+    """|reference(6 threads) - reference(3 threads)| / |reference| on loss_gen_total, BASELINE configs[1] shape (128x128, batch 16):
+    the SAME reference program, only the reduction order inside the CPU library kernels differs."""
+    a, b = _rows("s128_b16_nolstmdrop")["rows"], _rows("s128_b16_nolstmdrop_threads3")["rows"]
+    n = min(len(a), len(b))
+    return np.array([abs(a[i]["loss_gen_total"] - b[i]["loss_gen_total"]) / abs(a[i]["loss_gen_total"]) for i in range(n)])
+
+
+def test_reference_self_drift_128_is_recorded():
+    env = _self_drift_envelope_128()
+    assert len(env) == 100
+    assert env[0] < 1e-6 and env[1] < 1e-6            # identical start
+    assert 0.03 < env.max() < 0.1                     # separates to several per cent (measured 0.062 at step ~45)
+    assert 0.005 < env[-20:].mean() < 0.03            # measured 0.011 over steps 80-99
+
+
 @pytest.mark.gpu
 def test_hip_trajectory_s128_b16_100_steps():
-    """BASELINE configs[1] shape (128x128, batch 16, fp32), LSTM inter-layer dropout off as in the fixture."""
+    """BASELINE configs[1] shape (128x128, batch 16, fp32), LSTM inter-layer dropout off as in the fixture.  The bounds are
+    DERIVED from the reference's drift from itself at this very shape (``_self_drift_envelope_128``: the same reference run
+    with 3 instead of 6 CPU threads): the largest deviation of the HIP run from the recorded reference may not exceed 2.5x the
+    largest self-deviation of the reference, and per 10-step window / over the last 20 steps its median / mean deviation may
+    not exceed 4x the reference's own (any two runs of this GAN differ by a factor of that order from window to window: the
+    64x64 fixtures show the same spread).  Steps 0-1, before chaos sets in, are held to the north star's 1e-3.  The per-step
+    error without the chaotic amplification is bounded separately and much tighter in tests/test_resync.py."""
+    env = _self_drift_envelope_128()
     out = _run_hip("s128_b16_nolstmdrop", 100)
     assert out[0][1] == pytest.approx(out[0][2], rel=5e-6) and out[0][3] == pytest.approx(out[0][4], rel=5e-6)
     assert abs(out[1][3] - out[1][4]) <= 1e-3 * max(1.0, abs(out[1][4]))
     rel = np.array([abs(g - gref) / abs(gref) for _, _, _, g, gref in out])
-    assert rel.max() <= 0.15, rel.max()
-    assert rel[-20:].mean() <= 0.06, rel[-20:].mean()
+    print("hip-vs-reference rel deviation of loss_gen_total: max %.4f (reference self-drift max %.4f), tail-20 mean %.4f (%.4f)" % (
+        rel.max(), env.max(), rel[-20:].mean(), env[-20:].mean()))
+    assert rel.max() <= 2.5 * env.max(), (rel.max(), env.max())
+    assert rel[-20:].mean() <= 4.0 * env[-20:].mean() + 2e-3, (rel[-20:].mean(), env[-20:].mean())
+    for w0 in range(10, 100, 10):
+        mine, ref = float(np.median(rel[w0:w0 + 10])), float(np.median(env[w0:w0 + 10]))
+        assert mine <= 4.0 * ref + 2e-3, (w0, mine, ref)
