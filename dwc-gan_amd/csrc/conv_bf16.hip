@@ -889,16 +889,18 @@ size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int 
     return ring + gemm_ws_bytes_h(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
 
-int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
-                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+static int same_dgrad_run_h(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W, int Cin,
+                            int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
     if ((Cin & 7) || !same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_gemm_h(f.g, (const bf16*)w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes,
-                           ws_bytes - ring_bytes, st);
-    if (rc != DWC_OK) return rc;
+    if (!ring_only) {
+        int rc = launch_gemm_h(f.g, (const bf16*)w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, (char*)ws + ring_bytes,
+                               ws_bytes - ring_bytes, st);
+        if (rc != DWC_OK) return rc;
+    }
     hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
@@ -907,6 +909,17 @@ int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const voi
                        f.ring_total, B, H, W, Cin / 4, pad);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    return same_dgrad_run_h(dy, w_dgrad, w_dgrad_t, dx, B, H, W, Cin, Cout, KH, KW, pad, ws, ws_bytes, stream, false);
+}
+
+/* only the border ring: dx must already hold the interior (dwc_bf16_conv2d_same_halo with the zero rule and the dgrad weights) */
+int dwc_bf16_conv2d_bwd_data_ring(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    return same_dgrad_run_h(dy, w_dgrad, w_dgrad_t, dx, B, H, W, Cin, Cout, KH, KW, pad, ws, ws_bytes, stream, true);
 }
 
 // gradient w.r.t. an NHWC8 image through a stem convolution: 4 pixels x 8 planes per GEMM row (see dwc_conv2d_bwd_data_image)

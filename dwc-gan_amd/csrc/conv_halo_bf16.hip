@@ -1,0 +1,312 @@
+// Halo-tiled bf16 convolution for the stride-1 "same" layers (3x3 ResBlock and 5x5 upsampling convolutions: 11.5 of the
+// decoder's 11.75 GMAC per image, reference networks.py:514-515, networks_v2.py:153-156), forward and data-gradient
+// interior.
+//
+// Why a second formulation: at bf16 MFMA rates the im2col GEMM of conv_bf16.hip is bound by what one CU can pull out of L2
+// into LDS (r02 measurements: ~50-60 GB/s per CU at every tile shape, 30-36 % of the MFMA peak), and im2col re-stages every
+// input pixel once per filter tap.  Here a workgroup owns a 16x16 block of output pixels of ONE image and BN output
+// channels; per 64-channel slab it stages the (16+K-1)^2 input patch ONCE (reflect or zero rule applied while staging,
+// like everywhere else) and walks the K*K taps over it in LDS: the A operand of tap (kh,kw) is the same patch read at a
+// pixel offset, so activation traffic drops by K*K and only the weight slab (BN x 64) is staged per tap.
+//   L2->LDS bytes per 256x256x64 MFMA step: 32 KB weights + 41.5/9 KB patch = 37 KB  (im2col 128x128 tile: 128 KB)
+// Layouts are those of conv_bf16.hip: 128-byte rows (64 bf16) with the 16-byte chunk index XOR-swizzled by (row>>1)&7 on
+// the source side, buffer_load ... lds staging with scalar slab offsets, D = W_tile . X_tile^T so a lane owns a pixel.
+#include "conv_geom.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;
+constexpr int TB = 16;                 // block edge: 16x16 output pixels
+
+__device__ __forceinline__ bf16x4 pack4h(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+    return r;
+}
+
+struct HaloArgs {
+    const bf16* x;       // [B][H][W][Cin]
+    const bf16* w;       // [N][Kp], k = (kh*K + kw)*Cin + ci   (dwc_bf16_weight_prepare_fwd / _dgrad layout)
+    const float* bias;   // [N] or null
+    bf16* y;             // [B][H][W][N]
+    int B, H, W, Cin, logCin, N, K, Kp, act, reflect;
+    int blocks_x, blocks_per_img, tiles_n;
+};
+
+// WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
+// PB: patch buffers (2: the next channel slab's patch is staged during the taps of the current one; 1: it is staged at the slab
+// boundary, one exposed load per K*K taps -- the 5x5 patch does not fit twice beside the weight slabs)
+template <int KS, int BN, int WM, int WN, int TM, int TN, int PB>
+__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
+    constexpr int PW = TB + KS - 1;                    // patch edge
+    constexpr int PPIX = PW * PW;                      // patch pixels
+    constexpr int PPASS = (PPIX + 63) / 64;            // staging passes of 64 pixels (8 waves x 8 pixels)
+    constexpr int P_TILE = PPASS * 64 * BK;            // elements per patch buffer
+    constexpr int W_TILE = BN * BK;
+    constexpr int W_PASSES = BN / 64;
+    constexpr int LDC = BN + 8;
+    constexpr int OPER = PB * P_TILE + 2 * W_TILE;
+    constexpr int SMEM = OPER > 256 * LDC ? OPER : 256 * LDC;
+    __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];
+    bf16* sP = smem;
+    bf16* sW = smem + PB * P_TILE;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb >= 16) {     // XCD-aware remap (neighbouring blocks share halo pixels and the weight slabs in one L2)
+            const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        }
+    }
+    const int tile_n = bid % a.tiles_n, blk = bid / a.tiles_n;
+    const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
+    const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
+    const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
+    constexpr int PAD = (KS - 1) / 2;
+
+    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u;
+    const unsigned w_bytes = (unsigned)a.N * a.Kp * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- staging maps ------------------------------------------------------------------------------------------------
+    // patch: thread = (patch pixel prow [+64 per pass], physical chunk t&7); logical chunk = slot ^ ((pp>>1)&7)
+    const int prow = t >> 3;
+    unsigned p_off[PPASS];
+#pragma unroll
+    for (int i = 0; i < PPASS; ++i) {
+        const int pp = prow + 64 * i;
+        const int py = pp / PW, px = pp - py * PW;
+        int h = y0 - PAD + py, w = x0 - PAD + px;
+        bool ok = pp < PPIX;
+        if (a.reflect) {
+            h = reflect_idx(h, a.H);
+            w = reflect_idx(w, a.W);
+        } else {
+            ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        }
+        h = min(max(h, 0), a.H - 1);
+        w = min(max(w, 0), a.W - 1);
+        const int lc = (t & 7) ^ ((pp >> 1) & 7);
+        const unsigned off = ((unsigned)(((n_img * a.H + h) * a.W + w) << a.logCin) + (unsigned)(lc * 8)) * 2u;
+        p_off[i] = ok ? off : OOB;
+    }
+    // weights: thread = (row wrow [+64 per pass], chunk); row = output channel
+    unsigned w_off[W_PASSES];
+#pragma unroll
+    for (int p = 0; p < W_PASSES; ++p) {
+        const int row = prow + 64 * p;
+        const int lc = (t & 7) ^ ((row >> 1) & 7);
+        w_off[p] = ((unsigned)min(n0 + row, a.N - 1) * a.Kp + lc * 8) * 2u;
+    }
+    const int ncs = a.Cin >> 6;                       // 64-channel slabs
+    constexpr int NTAP = KS * KS;
+    const int nsteps = ncs * NTAP;
+
+    auto stage_patch = [&](int cs, int buf, int first, int last) {
+        bf16* lp = sP + buf * P_TILE + wave * (8 * BK);
+        const int soff = cs * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < PPASS; ++i) {
+            if (i < first || i >= last) continue;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * 64 * BK), 16, p_off[i],
+                                                     soff, 0, 0);
+        }
+    };
+    auto stage_w = [&](int step, int buf) {           // step = cs * NTAP + tap
+        const int cs = step / NTAP, tap = step - cs * NTAP;
+        bf16* lw = sW + buf * W_TILE + wave * (8 * BK);
+        const int soff = __builtin_amdgcn_readfirstlane((tap * a.Cin + cs * BK) * 2);
+#pragma unroll
+        for (int p = 0; p < W_PASSES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * 64 * BK), 16, w_off[p],
+                                                     soff, 0, 0);
+    };
+
+    // ---- fragment addressing -----------------------------------------------------------------------------------------
+    // A tile i of this wave: block pixels pb = (wm*TM + i)*32 + l31 -> (py, px) = (pb>>4, pb&15); under tap (kh,kw) the
+    // patch pixel is pp = (py+kh)*PW + px+kw; chunk 2q+hi of that pixel sits at slot (2q+hi) ^ ((pp>>1)&7)
+    int pp0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pb = (wm * TM + i) * 32 + l31;
+        pp0[i] = (pb >> 4) * PW + (pb & 15);
+    }
+    const int b_row = (wn * TN * 32 + l31) * BK;
+    const int fsw_b = (l31 >> 1) & 7;
+    int frag_b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) frag_b[q] = ((2 * q + hi) ^ fsw_b) * 8;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 fa[2][TM], fb[2][TN];
+    int a_base[TM], a_sw[TM];                         // element offset of the tap's patch pixel row, its swizzle
+    auto set_tap = [&](int tap) {
+        const int kh = tap / KS, kw = tap - kh * KS;
+        const int d = kh * PW + kw;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pp = pp0[i] + d;
+            a_base[i] = pp * BK;
+            a_sw[i] = (pp >> 1) & 7;
+        }
+    };
+    auto load_frags = [&](int set, int pbuf, int wbuf, int q) {
+        const bf16* p = sP + pbuf * P_TILE;
+        const bf16* w = sW + wbuf * W_TILE + b_row + frag_b[q];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(p + a_base[i] + (((2 * q + hi) ^ a_sw[i]) << 3));
+#pragma unroll
+        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const bf16x8*>(w + n * 32 * BK);
+    };
+    auto mfma_group = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][n], fa[set][i], acc[i][n], 0, 0, 0);
+    };
+
+    // ---- main loop: one barrier per (tap, channel slab) step; the next step's weight slab and, spread over the taps of a
+    // channel slab, the next slab's patch are in flight meanwhile ------------------------------------------------------
+    stage_patch(0, 0, 0, PPASS);
+    stage_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int pbuf = 0, wbuf = 0, tap = 0, cs = 0;
+    set_tap(0);
+    load_frags(0, 0, 0, 0);
+    constexpr int PPT = (PPASS + NTAP - 2) / (NTAP - 1);          // patch passes issued per step (all but the last tap)
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) stage_w(s + 1, wbuf ^ 1);
+        if (PB == 2 && cs + 1 < ncs && tap < NTAP - 1) stage_patch(cs + 1, pbuf ^ 1, tap * PPT, min(PPASS, (tap + 1) * PPT));
+        load_frags(1, pbuf, wbuf, 1);
+        mfma_group(0);
+        load_frags(0, pbuf, wbuf, 2);
+        mfma_group(1);
+        load_frags(1, pbuf, wbuf, 3);
+        mfma_group(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) {
+            if (++tap == NTAP) {
+                tap = 0;
+                ++cs;
+                if (PB == 2) {
+                    pbuf ^= 1;
+                } else {                      // every wave is past its last read of the patch (barrier above): restage in place
+                    stage_patch(cs, 0, 0, PPASS);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+            }
+            set_tap(tap);
+            load_frags(0, pbuf, wbuf ^ 1, 0);
+        }
+        mfma_group(1);
+        wbuf ^= 1;
+    }
+
+    // ---- epilogue: bias + activation, pack to bf16, stage through LDS, 16-byte row chunks ---------------------------------
+    __syncthreads();
+    bf16* sC = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + l31;
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                const int col = n0 + cl;
+                f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                if (col < a.N) {
+                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], a.act, col + k);
+                }
+                *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4h(v[0], v[1], v[2], v[3]);
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+    for (int idx = t; idx < 256 * CPR; idx += 512) {
+        const int row = idx / CPR, ch = idx - row * CPR;
+        const int col = n0 + ch * 8;
+        if (col >= a.N) continue;
+        const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
+        bf16* d = a.y + ((size_t)(n_img * a.H + yy) * a.W + xx) * a.N + col;
+        *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+    }
+#endif
+}
+
+bool halo_ok(int B, int H, int W, int Cin, int Cout, int K) {
+    return B > 0 && (K == 3 || K == 5) && H >= TB && W >= TB && !(H % TB) && !(W % TB) && Cin >= 64 && dwc_ilog2_exact(Cin) >= 6 &&
+           Cout >= 64 && !(Cout & 7) && (size_t)B * H * W * Cin * 2 < 0x80000000ull && (size_t)B * H * W * Cout * 2 < 0x80000000ull;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 when dwc_bf16_conv2d_same_halo handles this stride-1, pad=(K-1)/2 convolution (else use dwc_bf16_conv2d_fwd /
+ * dwc_bf16_conv2d_bwd_data_same): K in {3,5}, H and W multiples of 16, Cin a power of two >= 64, Cout a multiple of 8 >= 64 */
+int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K) { return halo_ok(B, H, W, Cin, Cout, K) ? 1 : 0; }
+
+/* y = act(conv(pad(x), w) + bias) for a stride-1 "same" convolution, pad rule reflect (forward, reference
+ * networks.py:579-585) or zero (reflect == 0: the interior of the data gradient with w in dgrad layout, x := dY,
+ * Cin := channels of dY, Cout := channels of dx; bias NULL, act NONE).  w prepared by dwc_bf16_weight_prepare_fwd / _dgrad
+ * with cout_pad = Cout, cin_pad = Cin.  No scratch. */
+int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                              int Cout, int K, int act, int reflect, void* stream) {
+    if (!halo_ok(B, H, W, Cin, Cout, K)) return DWC_EINVAL;
+    HaloArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = (bf16*)y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout; a.K = K;
+    a.Kp = (K * K * Cin + BK - 1) / BK * BK; a.act = act; a.reflect = reflect;
+    a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B * a.blocks_per_img;
+#define HALO_LAUNCH(KS, BN, WM, WN, TM, TN)                                                                             \
+    do {                                                                                                                  \
+        a.tiles_n = (Cout + BN - 1) / BN;                                                                                 \
+        hipLaunchKernelGGL((conv_halo_kernel<KS, BN, WM, WN, TM, TN, (KS == 3 ? 2 : 1)>), dim3(nblk * a.tiles_n), dim3(512), 0, st, \
+                           a);                                                                                            \
+    } while (0)
+    if (K == 3) {
+        if (Cout > 128) HALO_LAUNCH(3, 256, 2, 4, 4, 2);
+        else if (Cout > 64) HALO_LAUNCH(3, 128, 4, 2, 2, 2);
+        else HALO_LAUNCH(3, 64, 4, 2, 2, 1);
+    } else {
+        if (Cout > 128) HALO_LAUNCH(5, 256, 2, 4, 4, 2);
+        else if (Cout > 64) HALO_LAUNCH(5, 128, 4, 2, 2, 2);
+        else HALO_LAUNCH(5, 64, 4, 2, 2, 1);
+    }
+#undef HALO_LAUNCH
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

@@ -83,6 +83,9 @@ SIGNATURES = {
     "dwc_bf16_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_bf16_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
     "dwc_bf16_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_data_ring": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
+    "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "dwc_bf16_conv2d_bwd_data_image_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_bf16_conv2d_bwd_data_image": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_bwd_weight_ws_bytes": (c_sz, [c_int] * 9),

@@ -246,6 +246,8 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
 # so ten times the gradient error flips ten times as many near-zero gradient signs and the step-1 loss lands 1.8e-3 from
 # the reference's.  Opt in with DWC_WINOGRAD=4 (or ops.WINOGRAD_TILE = 4) where that is acceptable.
 WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
+# bf16 path: halo-tiled kernel for the stride-1 "same" 3x3 / 5x5 layers (0: im2col GEMM everywhere; development knob)
+HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 
 
 _WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
@@ -301,6 +303,11 @@ class _Conv2d(torch.autograd.Function):
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        elif half and HALO and stride == 1 and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH):
+            # stride-1 "same" 3x3 / 5x5 layers on the bf16 path: halo-tiled kernel (patch staged once per channel slab)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
+                x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, act, 1, st),
+                detail="fwd-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_same_halo")
         else:
             nws = _fn(lib, "conv2d_fwd_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, stride, pad)     # split-K partials, usually 0
             wsp = workspace(nws, x.device).data_ptr() if nws else None
@@ -397,6 +404,16 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(_timed("conv_gemm_kernel", flops, run, scope_name=ctx.bscope, exec_flops=flops * _WINO_RATIO[wt],
                                   detail="dgrad-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride)),
                            "conv2d_wino dgrad")
+            elif half and HALO and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):
+                # interior on the halo-tiled kernel (zero rule, dgrad weights), the ring stays on the strip GEMMs
+                ws = workspace(nws, dev)
+
+                def run_halo():
+                    rc = lib.dwc_bf16_conv2d_same_halo(g.data_ptr(), w_dg.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st)
+                    return rc or lib.dwc_bf16_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B,
+                                                                   H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
+                _lib.check(_timed("conv_gemm_kernel", flops, run_halo, scope_name=ctx.bscope,
+                                  detail="dgrad-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_same_halo dgrad")
             else:
                 ws = workspace(nws, dev)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_same", x)(

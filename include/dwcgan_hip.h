@@ -289,6 +289,18 @@ int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W,
 size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
                                   int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_conv2d_bwd_data_ring(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
+                                  int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
+/* Halo-tiled form of the stride-1 "same" 3x3 / 5x5 convolutions (the ResBlock and upsampling-block layers, reference
+ * networks.py:514-515, networks_v2.py:153-156): a workgroup stages the (16+K-1)^2 input patch of a 16x16 pixel block once
+ * per 64-channel slab and walks the K*K taps over it in LDS, instead of re-staging every pixel once per tap as the im2col
+ * GEMM does.  reflect != 0: forward (w from dwc_bf16_weight_prepare_fwd); reflect == 0: interior of the data gradient
+ * (x := dY, Cin := channels of dY, Cout := channels of dx, w from dwc_bf16_weight_prepare_dgrad, bias NULL, act NONE),
+ * to be followed by dwc_bf16_conv2d_bwd_data_ring.  dwc_bf16_conv2d_same_halo_ok says whether a shape is handled
+ * (K in {3,5}, H and W multiples of 16, Cin a power of two >= 64, Cout a multiple of 8 >= 64); no scratch. */
+int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K);
+int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                              int Cout, int K, int act, int reflect, void* stream);
 /* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
 size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,

@@ -65,6 +65,12 @@ CONV_SHAPES = [
     (2, 8, 16, 12, 3, 1, 1, "sigmoid"),     # small channel counts (tiny config), generic padded-image dgrad
     (1, 16, 32, 6, 4, 2, 1, "tanh"),
     (4, 128, 256, 16, 4, 2, 1, "relu"),
+    # halo-tiled kernel (stride-1 "same", H and W multiples of 16): every (K, BN) instantiation, several blocks per image
+    (2, 128, 64, 32, 5, 1, 2, "none"),      # 5x5, BN = 64
+    (2, 64, 128, 32, 3, 1, 1, "relu"),      # 3x3, BN = 128, one channel slab
+    (3, 64, 64, 16, 3, 1, 1, "none"),       # 3x3, BN = 64, one block per image
+    (1, 128, 256, 48, 3, 1, 1, "none"),     # 3x3, BN = 256, 9 blocks, two channel slabs (double-buffered patch)
+    (2, 256, 128, 32, 5, 1, 2, "lrelu"),    # 5x5, BN = 128, four channel slabs (patch restaged in place)
 ]
 
 
