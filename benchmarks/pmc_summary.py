@@ -5,7 +5,8 @@ TCC has 4 counter slots, they cost 3 + 2).  Produces profiles/rNN_pmc_hbm_traffi
     cd /tmp && export TMPDIR=/tmp && cd $REPO
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
-    python benchmarks/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_hbm_traffic.json
+    python benchmarks/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_hbm_traffic_c1.json 3 225 c1 <commit>
+    (arguments: fetch dir, write dir, output, iterations profiled, conv spans per iteration, bench --config, commit profiled)
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact.
@@ -29,6 +30,12 @@ def per_kernel(directory, counter):
                     continue
                 name = row["Kernel_Name"]
                 short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+                if short.startswith("_ZN"):                   # templated kernels may come out mangled: _ZN12_GLOBAL__N_18in_applyI...
+                    import re
+                    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", short)
+                    if m:
+                        n0 = len(m.group(0))
+                        short = short[n0:n0 + int(m.group(1))]
                 ent = acc.setdefault(short, [0.0, 0])
                 ent[0] += float(row["Counter_Value"])
                 ent[1] += 1
@@ -40,6 +47,8 @@ def main():
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     keep = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel", "wino_input_kernel", "wino_output_kernel",
             "wino_dy_kernel", "wino_wgrad_reduce_kernel", "conv_wgrad_kernel", "wgrad_reduce_kernel", "in_stats_partial",
+            "gemm_kernel_h", "conv_halo_kernel", "gemm_strips_kernel_h", "wgrad_kernel_h", "wgrad_reduce_kernel_h", "fold_ring_kernel_h",
+            "fold_reflect_kernel_h", "splitk_reduce_kernel_h", "in_bwd_partial", "upsample2x_bwd_kernel", "ln_bwd_apply",
             "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
             "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd")
     res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 "
@@ -57,9 +66,14 @@ def main():
     # the forward / data-gradient GEMM family as bench.py's roofline spans see it: one span = one conv call, which for a
     # 3x3 layer is input transform + batched GEMM + output transform (+ ring strips and fold for a data gradient)
     family = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel",
-              "wino_input_kernel", "wino_output_kernel", "fold_ring_kernel")
+              "wino_input_kernel", "wino_output_kernel", "fold_ring_kernel",
+              # bf16 path (bench --config c2): im2col GEMM, halo-tiled kernel, ring strips + folds, split-K reduce
+              "gemm_kernel_h", "conv_halo_kernel", "gemm_strips_kernel_h", "fold_ring_kernel_h", "fold_reflect_kernel_h",
+              "splitk_reduce_kernel_h")
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     spans_per_step = int(sys.argv[5]) if len(sys.argv) > 5 else 236
+    res["config"] = sys.argv[6] if len(sys.argv) > 6 else "c1"
+    res["commit"] = sys.argv[7] if len(sys.argv) > 7 else "unknown"
     total = sum((2 * fetch[k][0] + write[k][0]) * 1024 for k in family if k in fetch and k in write)
     res["conv_gemm_family"] = {"kernels": list(family), "iterations_profiled": steps, "spans_per_iteration": spans_per_step,
                                "hbm_bytes_per_span_corrected": int(total / steps / spans_per_step)}
