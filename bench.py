@@ -208,10 +208,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dp = world == 1 and os.environ.get("DWC_FORCE_DP") == "1"      # development: drive the RCCL data-parallel path on ONE rank
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if force_dp:
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     from solver import Solver
     cfg = synth.make_config(image_size=image_size)           # shipped config, vgg_w = 0 (weights not obtainable offline)
@@ -231,7 +236,7 @@ def main():
     trainer.copy_nets()
     torch.cuda.manual_seed(1234 + rank)                      # per-rank style samples / dropout masks
     host.set_noise(host.DeviceNoise())
-    if world > 1:
+    if dist is not None:
         from hipdwc import dp
         dp.broadcast_module(trainer.gen)
         dp.broadcast_module(trainer.dis)
@@ -334,7 +339,11 @@ def main():
             "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if getattr(trainer, "_reducers", None):
+            out["data_parallel"] = {k: {"buckets": len(r.buckets), "bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in r.buckets],
+                                        "all_reduces": r.calls, "launched_from_inside_backward": r.launched_early}
+                                    for k, r in trainer._reducers.items()}
+        if world == 1 and not args.no_cpu_baseline and not force_dp:
             # always the fp32 parity workload (128x128, batch 16): the reference's own arithmetic on the host cores
             cpu_cfg = synth.make_config(image_size=128)
             if image_size != 128:                            # different architecture (D head sizes): fresh seeded weights

@@ -116,6 +116,7 @@ class OverlappedGradReducer:
                 self.where[id(p)] = bi
             self.buckets.append({"flat": flat, "params": plist, "views": views, "pending": 0, "work": None})
         self.touched = set()
+        self.force = False         # development: issue the collectives even in a one-rank group (exercises the RCCL path)
         self.active = False
         self.launched_early = 0    # buckets whose all-reduce started from inside backward (overlap evidence)
         self.calls = 0
@@ -135,7 +136,7 @@ class OverlappedGradReducer:
         self.touched.add(id(p))
         b = self.buckets[self.where[id(p)]]
         b["pending"] -= 1
-        if b["pending"] == 0 and b["work"] is None and self.world > 1:
+        if b["pending"] == 0 and b["work"] is None and (self.world > 1 or self.force):
             self._launch(b)
             self.launched_early += 1
 
@@ -154,7 +155,7 @@ class OverlappedGradReducer:
     @torch.no_grad()
     def finish(self):
         self.active = False
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for b in self.buckets:
                 if b["work"] is None:
                     self._launch(b)

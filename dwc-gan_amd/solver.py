@@ -112,6 +112,9 @@ class Solver(nn.Module):
         self._reducers = {"dis": dp.OverlappedGradReducer(self.dis_opt.param_groups[0]["params"], group, bucket_bytes),
                           "gen": dp.OverlappedGradReducer(self.gen_opt.param_groups[0]["params"], group, bucket_bytes)}
         self.grad_sync = None
+        if os.environ.get("DWC_FORCE_DP") == "1":
+            for r in self._reducers.values():
+                r.force = True
 
     def _zero_grad(self, which):
         if self._reducers is None:
