@@ -189,6 +189,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
 
+    # stdout carries exactly ONE line, the JSON record: anything native libraries print there (RCCL's version banner is
+    # written to the C stdout buffer and flushed at exit, i.e. AFTER the record) is diverted to stderr
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from hipdwc import host, ops, synth
 
@@ -353,7 +359,7 @@ def main():
                 init_gen, init_dis = ref.gen.state_dict(), ref.dis.state_dict()
             out["cpu_baseline"] = cpu_baseline(init_gen, init_dis, cpu_cfg, 128, 16, args.cpu_warmup, args.cpu_timed,
                                                [int(t) for t in args.cpu_threads.split(",") if t])
-        print(json.dumps(out), flush=True)
+        os.write(record_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,6 +15,8 @@
 // The weight gradient contracts over pixels, which is the slow axis of both operands: its LDS tiles stay row-major
 // ([pixel][channel], coalesced from HBM) and the MFMA operands are fetched with the transposing LDS read
 // ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes, delivered channel-major).
+#include <type_traits>
+
 #include "conv_geom.h"
 
 namespace {
@@ -268,52 +270,67 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
     }
 
     // accumulator layout: lane l31 = pixel row of tile i, register r = channel (r&3) + 8*(r>>2) + 4*hi of tile n
+    const float slope = dwc_act_slope(act);
     if constexpr (F32OUT) {
         float* dst = (float*)o.dst + part_offset;
+        auto store = [&](auto general) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + l31;
-            if (m >= g.M) continue;
-            const int n_img = m / ohw;
-            const int rem = m - n_img * ohw;
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + (wm * TM + i) * 32 + l31;
+                if (m >= g.M) continue;
+                const int n_img = m / ohw;
+                const int rem = m - n_img * ohw;
+                const int oh = rem / g.OW, ow = rem - oh * g.OW;
+                const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
 #pragma unroll
-            for (int n = 0; n < TN; ++n)
+                for (int n = 0; n < TN; ++n)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
-                    if (col >= o.N) continue;
-                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                    if (!partial) {
-                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                        if (col >= o.N) continue;
+                        f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                        if (!partial) {
+                            if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], act, col + k);
+                            for (int k = 0; k < 4; ++k) {
+                                if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], act, col + k);
+                                else v[k] = dwc_act_simple(v[k], slope);
+                            }
+                        }
+                        *reinterpret_cast<f32x4*>(dst + prow * o.N + col) = v;
                     }
-                    *reinterpret_cast<f32x4*>(dst + prow * o.N + col) = v;
-                }
-        }
+            }
+        };
+        if (dwc_act_is_simple(act)) store(std::false_type{});
+        else store(std::true_type{});
     } else {
         __syncthreads();                                  // every wave is done with the operand tiles
         bf16* sC = smem;                                  // [BM][LDC]
+        auto to_lds = [&](auto general) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 32 + l31;
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + l31;
 #pragma unroll
-            for (int n = 0; n < TN; ++n)
+                for (int n = 0; n < TN; ++n)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
-                    const int col = n0 + cl;
-                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                    if (col < o.N) {
-                        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                        const int col = n0 + cl;
+                        f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                        if (col < o.N) {
+                            if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], act, col + k);
+                            for (int k = 0; k < 4; ++k) {
+                                if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], act, col + k);
+                                else v[k] = dwc_act_simple(v[k], slope);
+                            }
+                        }
+                        *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4(v[0], v[1], v[2], v[3]);
                     }
-                    *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4(v[0], v[1], v[2], v[3]);
-                }
-        }
+            }
+        };
+        if (dwc_act_is_simple(act)) to_lds(std::false_type{});
+        else to_lds(std::true_type{});
         __syncthreads();
         bf16* dst = (bf16*)o.dst;
         constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row

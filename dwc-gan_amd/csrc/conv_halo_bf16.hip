@@ -11,6 +11,8 @@
 //   L2->LDS bytes per 256x256x64 MFMA step: 32 KB weights + 41.5/9 KB patch = 37 KB  (im2col 128x128 tile: 128 KB)
 // Layouts are those of conv_bf16.hip: 128-byte rows (64 bf16) with the 16-byte chunk index XOR-swizzled by (row>>1)&7 on
 // the source side, buffer_load ... lds staging with scalar slab offsets, D = W_tile . X_tile^T so a lane owns a pixel.
+#include <type_traits>
+
 #include "conv_geom.h"
 
 namespace {
@@ -40,7 +42,9 @@ struct HaloArgs {
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
 // PB: patch buffers (2: the next channel slab's patch is staged during the taps of the current one; 1: it is staged at the slab
 // boundary, one exposed load per K*K taps -- the 5x5 patch does not fit twice beside the weight slabs)
-template <int KS, int BN, int WM, int WN, int TM, int TN, int PB>
+// DBG (development, timing only -- results are wrong when set): 1 no MFMA, 2 no fragment reads in the loop, 4 no weight staging
+// in the loop, 8 no vmcnt wait, 16 no barrier
+template <int KS, int BN, int WM, int WN, int TM, int TN, int PB, int DBG = 0>
 __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
@@ -172,6 +176,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
         }
     };
     auto load_frags = [&](int set, int pbuf, int wbuf, int q) {
+        if ((DBG & 2) && set >= 0 && q != 0) return;
         const bf16* p = sP + pbuf * P_TILE;
         const bf16* w = sW + wbuf * W_TILE + b_row + frag_b[q];
 #pragma unroll
@@ -180,6 +185,13 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
         for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const bf16x8*>(w + n * 32 * BK);
     };
     auto mfma_group = [&](int set) {
+        if (DBG & 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[set][i]));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) asm volatile("" ::"v"(fb[set][n]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     constexpr int PPT = (PPASS + NTAP - 2) / (NTAP - 1);          // patch passes issued per step (all but the last tap)
     for (int s = 0; s < nsteps; ++s) {
         const bool more = s + 1 < nsteps;
-        if (more) stage_w(s + 1, wbuf ^ 1);
+        if (more && !(DBG & 4)) stage_w(s + 1, wbuf ^ 1);
         if (PB == 2 && cs + 1 < ncs && tap < NTAP - 1) stage_patch(cs + 1, pbuf ^ 1, tap * PPT, min(PPASS, (tap + 1) * PPT));
         load_frags(1, pbuf, wbuf, 1);
         mfma_group(0);
@@ -207,8 +219,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
         mfma_group(1);
         load_frags(1, pbuf, wbuf, 3);
         mfma_group(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(DBG & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(DBG & 16)) __syncthreads();
         if (more) {
             if (++tap == NTAP) {
                 tap = 0;
@@ -231,24 +243,32 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     // ---- epilogue: bias + activation, pack to bf16, stage through LDS, 16-byte row chunks ---------------------------------
     __syncthreads();
     bf16* sC = smem;
+    const float slope = dwc_act_slope(a.act);
+    auto to_lds = [&](auto general) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + l31;
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 32 + l31;
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
+            for (int n = 0; n < TN; ++n)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
-                const int col = n0 + cl;
-                f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                if (col < a.N) {
-                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                    const int col = n0 + cl;
+                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                    if (col < a.N) {
+                        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], a.act, col + k);
+                        for (int k = 0; k < 4; ++k) {
+                            if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
+                            else v[k] = dwc_act_simple(v[k], slope);
+                        }
+                    }
+                    *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4h(v[0], v[1], v[2], v[3]);
                 }
-                *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4h(v[0], v[1], v[2], v[3]);
-            }
-    }
+        }
+    };
+    if (dwc_act_is_simple(a.act)) to_lds(std::false_type{});
+    else to_lds(std::true_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;
     for (int idx = t; idx < 256 * CPR; idx += 512) {
@@ -295,6 +315,21 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         hipLaunchKernelGGL((conv_halo_kernel<KS, BN, WM, WN, TM, TN, (KS == 3 ? 2 : 1)>), dim3(nblk * a.tiles_n), dim3(512), 0, st, \
                            a);                                                                                            \
     } while (0)
+    static const int dbg = getenv("DWC_HALO_DBG") ? atoi(getenv("DWC_HALO_DBG")) : 0;     // development: timing ablations
+    if (dbg && K == 3 && Cout > 128) {
+        a.tiles_n = (Cout + 255) / 256;
+#define HALO_DBG(D)                                                                                                         \
+    case D:                                                                                                                  \
+        hipLaunchKernelGGL((conv_halo_kernel<3, 256, 2, 4, 4, 2, 2, D>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);        \
+        break;
+        switch (dbg) {
+            HALO_DBG(1) HALO_DBG(2) HALO_DBG(3) HALO_DBG(4) HALO_DBG(8) HALO_DBG(16) HALO_DBG(24) HALO_DBG(28) HALO_DBG(31)
+            default: return DWC_EINVAL;
+        }
+#undef HALO_DBG
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     if (K == 3) {
         if (Cout > 128) HALO_LAUNCH(3, 256, 2, 4, 4, 2);
         else if (Cout > 64) HALO_LAUNCH(3, 128, 4, 2, 2, 2);

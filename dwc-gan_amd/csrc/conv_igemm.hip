@@ -20,6 +20,8 @@
 // allows it (one wave per SIMD cannot hide its own LDS/barrier latency), and products with few
 // output tiles but a long K (the discriminator tails, M = B*16 rows) are split along K into
 // partial images that a small epilogue kernel sums (+bias, +activation) in a fixed order.
+#include <type_traits>
+
 #include "conv_geom.h"
 
 namespace {
@@ -227,31 +229,38 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
     }
 
     float* dst = (float*)o.dst + part_offset;
+    const float slope = dwc_act_slope(act);
+    // two loop nests (dwc_common.h, dwc_act_simple): the transcendental activations stay out of the common path's code
+    auto store = [&](auto general) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int m = m0 + row;
-            if (m >= g.M) continue;
-            const int n_img = m / ohw;
-            const int rem = m - n_img * ohw;
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = m0 + row;
+                if (m >= g.M) continue;
+                const int n_img = m / ohw;
+                const int rem = m - n_img * ohw;
+                const int oh = rem / g.OW, ow = rem - oh * g.OW;
+                const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
 #pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const int col = n0 + (wn * TN + n) * 32 + l31;
-                if (col < o.N) {
-                    float v = acc[i][n][r];
-                    if (!partial) {
-                        if (bias) v += bias[col];
-                        v = dwc_act_apply(v, act, col);
+                for (int n = 0; n < TN; ++n) {
+                    const int col = n0 + (wn * TN + n) * 32 + l31;
+                    if (col < o.N) {
+                        float v = acc[i][n][r];
+                        if (!partial) {
+                            if (bias) v += bias[col];
+                            if constexpr (decltype(general)::value) v = dwc_act_apply(v, act, col);
+                            else v = dwc_act_simple(v, slope);
+                        }
+                        dst[prow * o.N + col] = v;
                     }
-                    dst[prow * o.N + col] = v;
                 }
             }
         }
-    }
+    };
+    if (dwc_act_is_simple(act)) store(std::false_type{});
+    else store(std::true_type{});
 }
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
@@ -838,29 +847,38 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
         }
     }
     const int TW = W >> 1, TH = H >> 1;
+    const float slope = dwc_act_slope(act);
+    auto store = [&](auto general) {
+        auto fin = [&](float v, int col) {
+            if constexpr (decltype(general)::value) return dwc_act_apply(v, act, col);
+            else return dwc_act_simple(v, slope);
+        };
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int m = m0 + row;
-            if (m >= T) continue;
-            const int tx = m % TW;
-            const int ty = (m / TW) % TH;
-            const int nimg = m / (TW * TH);
-            float* base = y + (((size_t)nimg * H + 2 * ty) * W + 2 * tx) * N;
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = m0 + row;
+                if (m >= T) continue;
+                const int tx = m % TW;
+                const int ty = (m / TW) % TH;
+                const int nimg = m / (TW * TH);
+                float* base = y + (((size_t)nimg * H + 2 * ty) * W + 2 * tx) * N;
 #pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const int col = n0 + (wn * TN + n) * 32 + l31;
-                if (col >= N) continue;
-                const float bv = bias ? bias[col] : 0.f;
-                base[col] = dwc_act_apply(Y[0][i][n][r] + bv, act, col);
-                base[(size_t)N + col] = dwc_act_apply(Y[1][i][n][r] + bv, act, col);
-                base[(size_t)W * N + col] = dwc_act_apply(Y[2][i][n][r] + bv, act, col);
-                base[(size_t)(W + 1) * N + col] = dwc_act_apply(Y[3][i][n][r] + bv, act, col);
+                for (int n = 0; n < TN; ++n) {
+                    const int col = n0 + (wn * TN + n) * 32 + l31;
+                    if (col >= N) continue;
+                    const float bv = bias ? bias[col] : 0.f;
+                    base[col] = fin(Y[0][i][n][r] + bv, col);
+                    base[(size_t)N + col] = fin(Y[1][i][n][r] + bv, col);
+                    base[(size_t)W * N + col] = fin(Y[2][i][n][r] + bv, col);
+                    base[(size_t)(W + 1) * N + col] = fin(Y[3][i][n][r] + bv, col);
+                }
             }
         }
-    }
+    };
+    if (dwc_act_is_simple(act)) store(std::false_type{});
+    else store(std::true_type{});
 }
 
 extern "C" {

@@ -66,6 +66,15 @@ __device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
     }
 }
 
+// The activations without a transcendental (none / ReLU / LeakyReLU 0.1) as three ALU operations and no branch:
+// max(v,0) + slope*min(v,0) with slope 1 / 0 / 0.1 (exact for all three).  Epilogues take this form in one loop nest and
+// the general dwc_act_apply in a SEPARATE one: with the switch inside the fully unrolled per-element code every GEMM
+// kernel carried ~25 000 instructions of inlined tanhf/expf between its hot instructions (r02: a halo kernel with an EMPTY
+// main loop still took half the full kernel's time, instruction fetch of that epilogue).
+__device__ __forceinline__ bool dwc_act_is_simple(int act) { return act <= DWC_ACT_LRELU; }
+__device__ __forceinline__ float dwc_act_slope(int act) { return act == DWC_ACT_NONE ? 1.f : (act == DWC_ACT_RELU ? 0.f : 0.1f); }
+__device__ __forceinline__ float dwc_act_simple(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+
 // derivative expressed through the activation OUTPUT y
 __device__ __forceinline__ float dwc_act_grad(float y, int act, int ch) {
     switch (act) {

@@ -91,7 +91,9 @@ def main():
             w = 0.0
             for k, g in grads0[name].items():
                 ref = acc[name][k]
-                w = max(w, float((g - ref).abs().max() / (ref.abs().max() + 1e-12)))
+                if float(ref.abs().max()) < 1e-6:      # biases in front of an instance norm: exact zeros here, rounding noise there
+                    continue
+                w = max(w, float((g - ref).abs().max() / ref.abs().max()))
             return w
         res["dis_grad_rel_err"] = worst("dis")
         res["gen_grad_rel_err"] = worst("gen")
