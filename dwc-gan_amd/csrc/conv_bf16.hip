@@ -404,7 +404,7 @@ __device__ __forceinline__ int tr_swizzle(int m) {
     return CPRW == 16 ? 4 * (m & 3) : (CPRW == 8 ? 4 * ((m >> 1) & 1) : 0);
 }
 
-template <int BN, int WM, int WN, int TM, int TN>
+template <int BN, int WM, int WN, int TM, int TN, int DBG = 0>     // DBG: timing ablations (1 no MFMA, 2 no operand reads, 4 no staging)
 __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __restrict__ dy, int N, float* __restrict__ slab,
                                                       int m_chunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
     typedef __attribute__((address_space(3))) bf16x4* lds4;
     bf16x8 fa[2][TM], fb[2][TN];
     auto load_ops = [&](int set, int buf, int ms) {
+        if ((DBG & 2) && ms != 0) return;
         const bf16* a = sA + buf * A_TILE + ms * 16 * 128;
         const bf16* b = sB + buf * B_TILE + ms * 16 * BN;
 #pragma unroll
@@ -528,6 +529,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
         }
     };
     auto mfma_ops = [&](int set) {
+        if (DBG & 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[set][i]));
+#pragma unroll
+            for (int n = 0; n < TN; ++n) asm volatile("" ::"v"(fb[set][n]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
         load_ops(0, 0, 0);
         for (int mb = m_begin; mb < m_end; mb += MS) {
             const bool more = mb + MS < m_end;
-            if (more) stage_slab(mb + MS, buf ^ 1);
+            if (more && !(DBG & 4)) stage_slab(mb + MS, buf ^ 1);
             load_ops(1, buf, 1);
             mfma_ops(0);
             load_ops(0, buf, 2);
@@ -806,7 +814,12 @@ int wgrad_launch_h(const FwdGeom& f, const bf16* dy, float* dw_oihw, int Cin, in
     if (!ws || ws_bytes < (size_t)splits * g.K * Cout * sizeof(float)) return DWC_EWORKSPACE;
     float* slab = (float*)ws;
     const int tk = (g.K + 127) / 128;
-    if (Cout > 64) {
+    static const int dbg = getenv("DWC_WGRAD_DBG") ? atoi(getenv("DWC_WGRAD_DBG")) : 0;     // development: timing ablations
+    if (Cout > 64 && dbg) {
+#define WG_DBG(D) case D: hipLaunchKernelGGL((wgrad_kernel_h<128, 2, 2, 2, 2, D>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk); break;
+        switch (dbg) { WG_DBG(1) WG_DBG(2) WG_DBG(3) WG_DBG(4) WG_DBG(7) default: return DWC_EINVAL; }
+#undef WG_DBG
+    } else if (Cout > 64) {
         hipLaunchKernelGGL((wgrad_kernel_h<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy, Cout, slab,
                            chunk);
     } else if (Cout > 32) {

@@ -282,6 +282,215 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same layers, halo form.  dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dY[pixel][co]: the
+// im2col form (conv_bf16.hip) re-stages x once per tap (r02 ablation: staging is 40-45 % of that kernel's time).  Here a
+// workgroup owns CIW channels of x, BN channels of dY and a group of taps (all 9 of a 3x3; one filter COLUMN kw of a 5x5) and
+// walks over 8x16-pixel units: per unit the x patch and the dY block are staged once into LDS.  Wave w keeps the 32(ci) x
+// 32(co) accumulators of its (ci tile, co tile) for all TH x TW taps of the group.  Operand fragments come from LDS through
+// the transposing read (4 consecutive pixels x 16 channels) and LDS read bandwidth is what bounds this kernel, so the unit
+// is walked by PATCH row r: the TW fragments of x row r are read once and used for every kh (against dY row r - kh, kept in
+// a rolling register window of TH fragments): (TW + 1) fragment reads per TH*TW MFMAs instead of TH*TW + 1.
+// Pixel ranges are split over gridDim.y into fp32 slabs [split][tap*Cin + ci][co] that wgrad_halo_reduce sums in a fixed
+// order.
+// ------------------------------------------------------------------------------------------
+struct WgradHaloArgs {
+    const bf16* x;      // [B][H][W][Cin]
+    const bf16* dy;     // [B][H][W][N]
+    float* slab;        // [splits][K*K*Cin][N]
+    int B, H, W, Cin, logCin, N;
+    int units_x, units_per_img, total_units, units_per_split;
+    int n_tiles, tap_groups;
+};
+
+template <int KS, int BN, int DBG = 0>
+__global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BN == 128 || BN == 64, "dY tile width");
+    constexpr int TH = KS, TW = KS == 3 ? 3 : 1;        // taps of one workgroup: TH filter rows x TW filter columns
+    constexpr int CIW = BN == 128 ? 64 : 128;           // channels of x per workgroup (8 waves = CIW/32 x BN/32 tiles)
+    constexpr int UH = 8, UW = 16;                      // unit: 8 rows x 16 columns = 128 pixels, one MFMA k-step per row
+    constexpr int PW = UW + TW - 1, PH = UH + TH - 1, PPIX = PH * PW;
+    constexpr int PCH = CIW / 8;                        // 16-byte chunks per patch pixel
+    constexpr int P_RPP = 512 / PCH;                    // patch pixels per staging pass
+    constexpr int PPASS = (PPIX + P_RPP - 1) / P_RPP;
+    constexpr int P_TILE = PPASS * P_RPP * CIW;         // elements: [patch pixel][CIW channels]
+    constexpr int D_TILE = 128 * BN;                    // [pixel][BN channels]
+    constexpr int DCH = BN / 8;
+    constexpr int D_RPP = 512 / DCH;
+    constexpr int D_PASSES = 128 / D_RPP;
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int NT = TH * TW;
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (P_TILE + D_TILE)];
+    bf16* sP = smem;
+    bf16* sD = smem + 2 * P_TILE;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int id = blockIdx.x;
+    const int tgp = id % a.tap_groups;                  // 5x5: the filter column kw of this workgroup
+    id /= a.tap_groups;
+    const int tn = id % a.n_tiles, cs = id / a.n_tiles;
+    const int split = blockIdx.y;
+    const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
+    const int ci_tile = BN == 128 ? (wave >> 2) : (wave >> 1);
+    const int co_tile = BN == 128 ? (wave & 3) : (wave & 1);
+    const int kw0 = TW == 1 ? tgp : 0;                  // column shift applied when the patch is staged
+
+    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u, dy_bytes = (unsigned)a.B * a.H * a.W * a.N * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // 16-byte chunk swizzles (per LDS row) that make the 4-row x 32-byte blocks of the transposing read conflict free
+    auto p_swz = [](int pp) { return CIW == 64 ? 4 * ((pp >> 1) & 1) : 4 * (pp & 3); };
+    auto d_swz = [](int m) { return BN == 64 ? 4 * ((m >> 1) & 1) : 4 * (m & 3); };
+
+    auto stage_unit = [&](int u, int buf) {
+        const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
+        const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
+        const int y0 = uy * UH, x0 = ux * UW;
+        bf16* lp = sP + buf * P_TILE + wave * 512;
+        bf16* ld = sD + buf * D_TILE + wave * 512;
+#pragma unroll
+        for (int i = 0; i < PPASS; ++i) {
+            const int pp = t / PCH + P_RPP * i;
+            const int py = pp / PW, px = pp - py * PW;
+            const int h = min(reflect_idx(y0 - PAD + py, a.H), a.H - 1), w = min(reflect_idx(x0 - PAD + kw0 + px, a.W), a.W - 1);
+            const int lc = (t % PCH) ^ p_swz(pp);
+            const unsigned off = ((unsigned)(((n * a.H + h) * a.W + w) << a.logCin) + (unsigned)(cs * CIW + lc * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * P_RPP * CIW), 16,
+                                                     pp < PPIX ? off : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < D_PASSES; ++p) {
+            const int dr = t / DCH + D_RPP * p;
+            const int lc = (t % DCH) ^ d_swz(dr);
+            const unsigned pix = (unsigned)((n * a.H + y0 + (dr >> 4)) * a.W + x0 + (dr & 15));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (__attribute__((address_space(3))) void*)(ld + p * D_RPP * BN), 16,
+                                                     (pix * a.N + tn * BN + lc * 8) * 2u, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // transposing reads: lane 4q+p of a 16-lane group addresses pixel row q, channels 4p..4p+3 of a 4-pixel x 16-channel block
+    const int li = lane & 15, gam = (lane >> 4) & 1, hi = lane >> 5;
+    const int tq = li >> 2, tp = li & 3;
+    const int pxl = 8 * hi + tq;                         // pixel (column) inside the row's 16, first half (+4: second)
+    const int a_col = ci_tile * 32 + 16 * gam + 4 * tp;  // channel inside the CIW-channel patch
+    const int d_col = co_tile * 32 + 16 * gam + 4 * tp;  // channel inside the BN-wide dY tile
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    auto a_frag = [&](const bf16* p, int r, int kw) {
+        bf16x4 v[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pp = r * PW + pxl + 4 * half + kw;
+            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + pp * CIW + (((a_col >> 3) ^ p_swz(pp)) << 3) + (a_col & 7)));
+        }
+        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto d_frag = [&](const bf16* d, int ks) {
+        bf16x4 v[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m = ks * 16 + pxl + 4 * half;
+            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(d + m * BN + (((d_col >> 3) ^ d_swz(m)) << 3) + (d_col & 7)));
+        }
+        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    if (u0 < u1) {
+        stage_unit(u0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int u = u0; u < u1; ++u) {
+            if (u + 1 < u1 && !(DBG & 4)) stage_unit(u + 1, buf ^ 1);
+            const bf16* p = sP + buf * P_TILE;
+            const bf16* d = sD + buf * D_TILE;
+            bf16x8 fb[TH];                               // dY rows r, r-1, ... r-TH+1 (index = row % TH)
+#pragma unroll
+            for (int r = 0; r < PH; ++r) {
+                bf16x8 fa[TW];
+#pragma unroll
+                for (int kw = 0; kw < TW; ++kw) fa[kw] = a_frag(p, r, kw);
+                if (r < UH) fb[r % TH] = d_frag(d, r);
+#pragma unroll
+                for (int kh = 0; kh < TH; ++kh) {
+                    const int ks = r - kh;               // x row r is tap row kh of output row ks
+                    if (ks < 0 || ks >= UH) continue;
+#pragma unroll
+                    for (int kw = 0; kw < TW; ++kw)
+                        acc[kh * TW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kw], fb[ks % TH], acc[kh * TW + kw], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // slab[split][(tap*Cin + ci)][co]
+    const int l31 = lane & 31;
+    const int Ktot = KS * KS * a.Cin;
+    float* out = a.slab + (size_t)split * Ktot * a.N;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int tap = (j / TW) * KS + kw0 + (j % TW);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[j][r];
+        }
+    }
+#endif
+}
+
+// slab[s][(kh,kw,ci)][co] summed over s -> dw[co][ci][kh][kw] (state_dict layout, fp32), real channels only
+__global__ void wgrad_halo_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int K, int N, int Cin,
+                                         int KHW, int cin_real, int cout_real) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)K * N) return;
+    const int co = idx % N;
+    const int k = idx / N;
+    const int ci = k % Cin, tap = k / Cin;
+    if (co >= cout_real || ci >= cin_real) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * K * N + idx];
+    dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
+}
+
+// BN (channels of dY per workgroup) of a handled shape, 0 otherwise
+int wgrad_halo_bn(int B, int H, int W, int Cin, int Cout, int K) {
+    if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || dwc_ilog2_exact(Cin) < 6 ||
+        (size_t)B * H * W * Cin * 2 >= 0x80000000ull || (size_t)B * H * W * Cout * 2 >= 0x80000000ull)
+        return 0;
+    if (Cout >= 128 && !(Cout % 128)) return 128;
+    return (K == 5 && Cout >= 64 && !(Cout % 64) && !(Cin % 128)) ? 64 : 0;
+}
+
+void wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
+    const int ciw = bn == 128 ? 64 : 128;
+    const int roles = (Cin / ciw) * (Cout / bn) * (K == 3 ? 1 : K);
+    const int units = B * (H / 8) * (W / 16);
+    // pixel splits: fill the 256 CUs (one workgroup each: LDS) in whole rounds - 260 workgroups cost two rounds, 240 one -
+    // with at least 4 units per workgroup; among equally full launches the fewest splits (slab traffic)
+    const int cus = 256;
+    const int smax = units / 4 > 0 ? units / 4 : 1;
+    int s = 1;
+    double best = 0.0;
+    for (int c = 1; c <= smax && c * roles <= 2 * cus; ++c) {
+        const int wgs = c * roles, rounds = (wgs + cus - 1) / cus;
+        const double fill = (double)wgs / (rounds * cus) / (rounds > 1 ? 1.05 : 1.0);   // a second round also pays a second prologue
+        if (fill > best + 1e-9) best = fill, s = c;
+    }
+    *ups = (units + s - 1) / s;
+    *splits = (units + *ups - 1) / *ups;
+}
+
 bool halo_ok(int B, int H, int W, int Cin, int Cout, int K) {
     return B > 0 && (K == 3 || K == 5) && H >= TB && W >= TB && !(H % TB) && !(W % TB) && Cin >= 64 && dwc_ilog2_exact(Cin) >= 6 &&
            Cout >= 64 && !(Cout & 7) && (size_t)B * H * W * Cin * 2 < 0x80000000ull && (size_t)B * H * W * Cout * 2 < 0x80000000ull;
@@ -330,6 +539,16 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
+    static const int bn128 = getenv("DWC_HALO_BN128") ? atoi(getenv("DWC_HALO_BN128")) : 0;   // development: 1 -> PB 1, 2 -> PB 2
+    if (K == 3 && Cout > 128 && bn128) {
+        a.tiles_n = (Cout + 127) / 128;
+        if (bn128 == 1)
+            hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 2>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     if (K == 3) {
         if (Cout > 128) HALO_LAUNCH(3, 256, 2, 4, 4, 2);
         else if (Cout > 64) HALO_LAUNCH(3, 128, 4, 2, 2, 2);
@@ -340,6 +559,44 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         else HALO_LAUNCH(5, 64, 4, 2, 2, 1);
     }
 #undef HALO_LAUNCH
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_bf16_conv2d_wgrad_halo_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {
+    const int bn = wgrad_halo_bn(B, H, W, Cin, Cout, K);
+    if (!bn) return 0;
+    int splits, ups;
+    wgrad_halo_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    return (size_t)splits * K * K * Cin * Cout * sizeof(float);
+}
+
+/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution from x:[B,H,W,Cin] and
+ * dy:[B,H,W,Cout] (both bf16), halo form (see wgrad_halo_kernel); dwc_bf16_conv2d_wgrad_halo_ws_bytes == 0 means the shape
+ * is not handled (use dwc_bf16_conv2d_bwd_weight). */
+int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K,
+                               int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
+    const int bn = wgrad_halo_bn(B, H, W, Cin, Cout, K);
+    if (!bn || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
+    int splits, ups;
+    wgrad_halo_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    if (!ws || ws_bytes < (size_t)splits * K * K * Cin * Cout * sizeof(float)) return DWC_EWORKSPACE;
+    WgradHaloArgs a;
+    a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = (float*)ws;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout;
+    a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
+    a.n_tiles = Cout / bn; a.tap_groups = K == 3 ? 1 : K;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((Cin / (bn == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups, splits);
+    static const int dbg = getenv("DWC_WGRAD_HALO_DBG") ? atoi(getenv("DWC_WGRAD_HALO_DBG")) : 0;   // dev ablation (3x3)
+    if (K == 3 && dbg == 4) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 4>), grid, dim3(512), 0, st, a);
+    else if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64>), grid, dim3(512), 0, st, a);
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)K * K * Cin * Cout;
+    hipLaunchKernelGGL(wgrad_halo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw_oihw, splits,
+                       K * K * Cin, Cout, Cin, K * K, cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

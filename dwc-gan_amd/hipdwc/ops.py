@@ -248,6 +248,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
 WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 # bf16 path: halo-tiled kernel for the stride-1 "same" 3x3 / 5x5 layers (0: im2col GEMM everywhere; development knob)
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
+WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 
 
 _WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
@@ -363,6 +364,12 @@ class _Conv2d(torch.autograd.Function):
                     x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, wt, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-wino%d" % wt + detail[5:],
                     exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino_bwd_weight")
+            elif (half and WGRAD_HALO and stride == 1 and KH == KW and 2 * pad == KH - 1
+                  and lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH)):
+                ws = workspace(lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH), dev)
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv2d_wgrad_halo(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="wgrad-halo" + detail[5:]), "conv2d_wgrad_halo")
             else:
                 nws = _fn(lib, "conv2d_bwd_weight_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, stride, pad)
                 ws = workspace(nws, dev)

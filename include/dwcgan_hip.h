@@ -301,6 +301,14 @@ int dwc_bf16_conv2d_bwd_data_ring(const void* dy, const void* w_dgrad, const voi
 int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K);
 int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
                               int Cout, int K, int act, int reflect, void* stream);
+/* Halo form of the weight gradient of the same layers (reflect padding): a workgroup stages the (8+K-1)x(16+K-1) patch of x
+ * and the 8x16 block of dY once and forms all 9 taps of a 3x3 / one filter row of a 5x5 from it; pixel ranges are split into
+ * fp32 slabs in `ws` that a second kernel sums in a fixed order into dw ([cout_real][cin_real][K][K], fp32).  ws_bytes == 0:
+ * shape not handled (K in {3,5}, H % 8 == 0, W % 16 == 0, Cin a power of two >= 64, Cout a multiple of 64) - use
+ * dwc_bf16_conv2d_bwd_weight. */
+size_t dwc_bf16_conv2d_wgrad_halo_ws_bytes(int B, int H, int W, int Cin, int Cout, int K);
+int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K,
+                               int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream);
 /* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
 size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
