@@ -1,0 +1,659 @@
+// fp32 convolution of the stride-1 "same" 3x3 / 5x5 layers on the bf16 matrix cores, exact split products.
+// (ResBlock and upsampling-block convolutions, reference networks.py:514-515, networks_v2.py:153-156; forward and the interior
+// of the data gradient.)
+//
+// MI355X has 157 TFLOP/s of fp32 MFMA and 2.5 PFLOP/s of bf16 MFMA, a ratio of 16.  An fp32 number is EXACTLY the sum of three
+// bf16 numbers, a = a0 + a1 + a2 (8 significand bits each: truncate, subtract, truncate, subtract -- no rounding anywhere), a
+// product of two bf16 numbers is exact in fp32 (16 significand bits), and the matrix core accumulates in fp32.  So
+//     a*b = a0*b0 + (a0*b1 + a1*b0) + (a0*b2 + a1*b1 + a2*b0) + [a1*b2 + a2*b1 + a2*b2]
+// where the bracket is below 2^-23 |a*b| -- the size of ONE fp32 rounding of the product, which the native fp32 MFMA commits
+// as well.  Six bf16 MFMAs per fp32 MFMA-equivalent cost 6/16 of the native instruction's time: fp32-accurate results at up to
+// 2.6x the fp32 MFMA peak (tests/test_x3_parity.py measures both paths against a float64 product: same error).
+//
+// Kernel shape (the halo form of conv_halo_bf16.hip): a workgroup owns a 16x16 block of output pixels of one image and BN
+// output channels.  Per 16-channel slab the (16+K-1)^2 input patch is read ONCE from the fp32 tensor (reflect or zero rule
+// applied while gathering), split in registers and written to LDS as three bf16 planes [pixel][16 ch] (32-byte rows: every
+// fragment read is a contiguous, conflict-free ds_read_b128); all K*K taps read that patch at a pixel offset.  The weights are
+// split once per optimiser step by dwc_x3_weight_prepare into [tap][slab][plane][channel][16] and arrive by LDS-DMA through a
+// three-slot ring (two taps ahead), one barrier per tap.  Per tap a wave issues 3*(TM+TN) fragment reads for 6*TM*TN MFMAs
+// (0.375 per MFMA at 4x2 tiles; the plain bf16 kernels need 0.75 and are LDS-read bound).
+// D = W_tile . X_tile^T, so a lane owns a pixel and 4 consecutive output channels per accumulator quad: fp32 results are stored
+// straight from registers (16 bytes per lane) with bias and activation applied.
+#include <type_traits>
+
+#include "conv_geom.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TB = 16;                 // block edge: 16x16 output pixels
+constexpr int CS = 16;                 // channels per slab = one MFMA k-step
+
+// fp32 x4 -> three planes of 4 bf16 (packed two per dword), exact: v = p0 + p1 + p2
+__device__ __forceinline__ void split3(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned hb = __float_as_uint(v[k]) & 0xffff0000u;
+        const float r = v[k] - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+        const float q = r - __uint_as_float(mb);
+        h[k] = hb; m[k] = mb; l[k] = __float_as_uint(q);
+    }
+    // bytes 2,3 of the even element below bytes 2,3 of the odd one
+    p0 = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+    p1 = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+    p2 = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+
+struct X3Args {
+    const float* x;      // [B][H][W][Cin] fp32
+    const bf16* w;       // [K*K][Cin/16][3][rows][16]   (dwc_x3_weight_prepare)
+    const float* bias;   // [N] or null
+    float* y;            // [B][H][W][N] fp32
+    int B, H, W, Cin, N, rows, act, reflect;
+    int blocks_x, blocks_per_img, tiles_n;
+};
+
+// WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
+template <int KS, int BN, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
+    constexpr int PW = TB + KS - 1;                    // patch edge
+    constexpr int PPIX = PW * PW;                      // patch pixels
+    constexpr int PPASS = (PPIX + 127) / 128;          // gather passes of 128 pixels (4 threads x 4 channels per pixel)
+    constexpr int P_PLANE = PPASS * 128 * CS;          // elements per plane of a patch buffer
+    constexpr int W_CHUNKS = 3 * BN * 2;               // 16-byte chunks of one tap's weight slab (3 planes x BN rows x 32 B)
+    constexpr int W_INSTR = (W_CHUNKS + 511) / 512;    // LDS-DMA instructions per thread and tap
+    constexpr int W_SLOT = W_INSTR * 512 * 8;          // elements per ring slot (whole instructions)
+    constexpr int NTAP = KS * KS;
+    constexpr int PAD = (KS - 1) / 2;
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * 3 * P_PLANE + 3 * W_SLOT];
+    bf16* sP = smem;                                   // [2 buffers][3 planes][pixel][16]
+    bf16* sW = smem + 2 * 3 * P_PLANE;                 // [3 slots][3 planes][BN][16]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb >= 16) {     // XCD-aware remap (neighbouring blocks share halo pixels and the weight slabs in one L2)
+            const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
+            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        }
+    }
+    const int tile_n = bid % a.tiles_n, blk = bid / a.tiles_n;
+    const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
+    const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
+    const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
+    const int ncs = a.Cin / CS;
+    const int nsteps = ncs * NTAP;
+
+    // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
+    const float* p_src[PPASS];
+    unsigned p_ok = 0;                                  // loads are unconditional (the vmcnt arithmetic below counts them)
+#pragma unroll
+    for (int i = 0; i < PPASS; ++i) {
+        const int pp = (t >> 2) + 128 * i;
+        const int py = pp / PW, px = pp - py * PW;
+        int h = y0 - PAD + py, w = x0 - PAD + px;
+        bool ok = pp < PPIX;
+        if (a.reflect) {
+            h = reflect_idx(h, a.H);
+            w = reflect_idx(w, a.W);
+        } else {
+            ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        }
+        h = min(max(h, 0), a.H - 1);
+        w = min(max(w, 0), a.W - 1);
+        p_src[i] = a.x + ((size_t)(n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4;
+        p_ok |= ok ? 1u << i : 0u;
+    }
+    f32x4 pv[PPASS];
+    auto load_patch = [&](int cs) {
+#pragma unroll
+        for (int i = 0; i < PPASS; ++i) pv[i] = *reinterpret_cast<const f32x4*>(p_src[i] + cs * CS);
+    };
+    auto write_patch = [&](int buf) {
+        bf16* dst = sP + buf * 3 * P_PLANE + t * 4;                       // (pixel t>>2, channels 4*(t&3)..)
+#pragma unroll
+        for (int i = 0; i < PPASS; ++i) {
+            u32x2 p0, p1, p2;
+            split3((p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f}, p0, p1, p2);
+            *reinterpret_cast<u32x2*>(dst + i * 128 * CS) = p0;
+            *reinterpret_cast<u32x2*>(dst + P_PLANE + i * 128 * CS) = p1;
+            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE + i * 128 * CS) = p2;
+        }
+    };
+
+    // ---- weight ring: chunk g = t + 512*p of the slab [plane][row][half] ----------------------------------------------------
+    const unsigned w_bytes = (unsigned)NTAP * ncs * 3u * a.rows * CS * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, w_bytes, 0x00020000);
+    unsigned w_off[W_INSTR];
+#pragma unroll
+    for (int p = 0; p < W_INSTR; ++p) {
+        const int g = t + 512 * p;
+        const int plane = g / (2 * BN), rem = g - plane * 2 * BN;
+        const int row = min(n0 + (rem >> 1), a.rows - 1);
+        w_off[p] = g < W_CHUNKS ? (unsigned)(((plane * a.rows + row) * CS + (rem & 1) * 8) * 2) : 0x80000000u;
+    }
+    const int w_step_bytes = 3 * a.rows * CS * 2;                         // one (tap, slab) block of the prepared tensor
+    auto stage_w = [&](int step, int slot) {                              // step = cs * NTAP + tap -> block tap * ncs + cs
+        const int cs = step / NTAP, tap = step - cs * NTAP;
+        bf16* lw = sW + slot * W_SLOT + wave * 512;
+        const int soff = __builtin_amdgcn_readfirstlane((tap * ncs + cs) * w_step_bytes);
+#pragma unroll
+        for (int p = 0; p < W_INSTR; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * 512 * 8), 16, w_off[p],
+                                                     soff, 0, 0);
+    };
+
+    // ---- fragments --------------------------------------------------------------------------------------------------------
+    // pixel tile i of this wave: block pixel pb = (wm*TM + i)*32 + l31 -> patch pixel (pb>>4)*PW + (pb&15) + tap offset
+    int pp0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int pb = (wm * TM + i) * 32 + l31;
+        pp0[i] = ((pb >> 4) * PW + (pb & 15)) * CS + hi * 8;
+    }
+    const int b_row = (wn * TN * 32 + l31) * CS + hi * 8;
+
+    // acc: the leading products a0*b0; lo: the five correction products (2^-8 and 2^-16 of the leading one).  Kept apart,
+    // the corrections are rounded at THEIR magnitude and the main accumulator sees one rounding per 16-channel step instead of
+    // six; merged once in the epilogue.  (The 4x2-tile instantiation has no registers for a second set and adds all six in
+    // place: measured error 2.7e-6 of the output scale on 6400-term sums against 6e-7 split -- both inside the 2e-5 fp32
+    // tolerance of the parity suite, only the split form is used by default.)
+    constexpr bool SPLIT = TM * TN <= 4;
+    f32x16 acc[TM][TN], lo[SPLIT ? TM : 1][SPLIT ? TN : 1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (SPLIT) lo[SPLIT ? i : 0][SPLIT ? j : 0][r] = 0.f;
+            }
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------
+    load_patch(0);
+    stage_w(0, 0);
+    if (nsteps > 1) stage_w(1, 1);
+    write_patch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int pbuf = 0, tap = 0, cs = 0, slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // two taps ahead into the slot every wave left at the previous barrier
+        const bool fetch = tap == 0 && cs + 1 < ncs;                      // next slab's patch: registers now, LDS at tap 3
+        if (fetch) load_patch(cs + 1);
+        if (s + 2 < nsteps) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
+        if (tap == 3 && cs + 1 < ncs) write_patch(pbuf ^ 1);
+
+        const int d = ((tap / KS) * PW + (tap % KS)) * CS;
+        const bf16* p = sP + pbuf * 3 * P_PLANE + d;
+        const bf16* w = sW + slot * W_SLOT + b_row;
+        bf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int n = 0; n < TN; ++n) fb[pl][n] = *reinterpret_cast<const bf16x8*>(w + (pl * BN + n * 32) * CS);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(p + pl * P_PLANE + pp0[i]);
+        }
+        // smallest terms first: (a2 b0, a1 b1, a0 b2), (a1 b0, a0 b1), a0 b0
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    if (SPLIT && term < 5)
+                        lo[SPLIT ? i : 0][SPLIT ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            fb[PB[term]][n], fa[PA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
+                    else
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB[term]][n], fa[PA[term]][i], acc[i][n], 0, 0, 0);
+                }
+        }
+        // the next step's weights (issued one step ago) must have landed; what this step issued (its weight slab and, at tap 0,
+        // the PPASS register loads of the next patch -- in either order) may stay in flight
+        if (s + 2 < nsteps) {
+            if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR + PPASS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (++tap == NTAP) {
+            tap = 0;
+            ++cs;
+            pbuf ^= 1;
+        }
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+
+    // ---- epilogue: bias + activation, fp32 stores of 4 channels per lane ---------------------------------------------------
+    const float slope = dwc_act_slope(a.act);
+    auto store = [&](auto general) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int pb = (wm * TM + i) * 32 + l31;
+            float* dst = a.y + ((size_t)(n_img * a.H + y0 + (pb >> 4)) * a.W + x0 + (pb & 15)) * a.N;
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
+                    if (col >= a.N) continue;
+                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
+                    if (SPLIT) {
+                        const f32x16& c = lo[SPLIT ? i : 0][SPLIT ? n : 0];
+                        v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
+                    }
+                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
+                        else v[k] = dwc_act_simple(v[k], slope);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + col) = v;
+                }
+        }
+    };
+    if (dwc_act_is_simple(a.act)) store(std::false_type{});
+    else store(std::true_type{});
+#endif
+}
+
+// w: [Cout][Cin][K][K] fp32 (OIHW).  forward: rows = output channels, contraction over input channels;
+// dgrad: rows = input channels, contraction over output channels, filter rotated by 180 degrees.
+// out[((tap*ncs + cs)*3 + plane)*rows + row][16]
+__global__ void x3_weight_prepare_kernel(const float* __restrict__ w, bf16* __restrict__ out, int Cout, int Cin, int K, int rows,
+                                         int kdim, int dgrad) {
+    const int ncs = (kdim + CS - 1) / CS;
+    const size_t total = (size_t)K * K * ncs * rows * CS;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx % CS;
+    size_t r = idx / CS;
+    const int row = r % rows;
+    r /= rows;
+    const int cs = r % ncs, tap = r / ncs;
+    const int kh = tap / K, kw = tap - kh * K;
+    const int kc = cs * CS + j;
+    float v = 0.f;
+    if (!dgrad) {
+        if (row < Cout && kc < Cin) v = w[(((size_t)row * Cin + kc) * K + kh) * K + kw];
+    } else {
+        if (row < Cin && kc < Cout) v = w[(((size_t)kc * Cin + row) * K + (K - 1 - kh)) * K + (K - 1 - kw)];
+    }
+    const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    const size_t base = ((size_t)(tap * ncs + cs) * 3 * rows + row) * CS + j;
+    o[base] = (unsigned short)(hb >> 16);
+    o[base + (size_t)rows * CS] = (unsigned short)(mb >> 16);
+    o[base + 2 * (size_t)rows * CS] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same layers as split products.  dW[kh][kw][ci][co] = sum_pixels x[pixel + tap][ci] * dY[pixel][co]:
+// both operands are activations, so both are split on the fly.  A workgroup owns 64 channels of x, BN channels of dY and ONE
+// filter column kw (all K rows kh), and walks 8x16-pixel units (wgrad_halo_kernel of conv_halo_bf16.hip is the bf16 form):
+//  * the x patch (8+K-1 rows x 16 pixels, already shifted by kw) goes global -> registers -> three bf16 planes in LDS
+//    ([pixel][64 ch], 128-byte rows, chunk swizzle of the transposing read), double buffered, written two passes at a time
+//    between the rows of the previous unit;
+//  * dY never enters LDS: a lane reads the 8 pixels x 1 channel of its B-fragment slot straight from global memory (128
+//    contiguous bytes per pixel across 32 lanes), one row ahead, and splits them in registers;
+//  * per dY row r and filter row kh the three A planes of patch row r + kh come through ds_read_b64_tr_b16 and meet the three
+//    B planes in the six leading products; the leading product and the five corrections have separate accumulators.
+// Pixel ranges are split over gridDim.y into fp32 slabs [split][tap*Cin + ci][co] summed in fixed order by x3_wgrad_reduce.
+// HALVES == 2 (BN == 64): the two wave quartets take the upper / lower four rows of every unit and write their own slabs.
+// ------------------------------------------------------------------------------------------
+struct X3WgradArgs {
+    const float* x;      // [B][H][W][Cin]
+    const float* dy;     // [B][H][W][N]
+    float* slab;         // [splits * HALVES][K*K*Cin][N]
+    int B, H, W, Cin, N;
+    int units_x, units_per_img, total_units, units_per_split;
+    int n_tiles;
+};
+
+template <int KS, int BN>
+__global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BN == 128 || BN == 64, "dY tile width");
+    constexpr int HALVES = BN == 128 ? 1 : 2;
+    constexpr int CIW = 64;
+    constexpr int UH = 8, UW = 16;
+    constexpr int PH = UH + KS - 1, PPIX = PH * UW;
+    constexpr int PPASS = (PPIX + 31) / 32;            // gather passes of 32 pixels (16 threads x 4 channels per pixel)
+    constexpr int P_PLANE = PPASS * 32 * CIW;          // elements per plane
+    constexpr int PAD = (KS - 1) / 2;
+    constexpr int ROWS = UH / HALVES;                  // dY rows of a unit per wave
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * 3 * P_PLANE];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int id = blockIdx.x;
+    const int kw = id % KS;
+    id /= KS;
+    const int tn = id % a.n_tiles, cs = id / a.n_tiles;
+    const int split = blockIdx.y;
+    const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
+    const int ci_tile = BN == 128 ? (wave >> 2) : (wave & 1);
+    const int co_tile = BN == 128 ? (wave & 3) : ((wave >> 1) & 1);
+    const int half_id = BN == 128 ? 0 : (wave >> 2);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- x patch: thread = (pixel t>>4 [+32 per pass], channel quad t&15) ---------------------------------------------------
+    const int quad = t & 15;
+    f32x4 pv[2];
+    auto unit_origin = [&](int u, int& n, int& y0, int& x0) {
+        n = u / a.units_per_img;
+        const int ur = u - n * a.units_per_img;
+        const int uy = ur / a.units_x;
+        y0 = uy * UH;
+        x0 = (ur - uy * a.units_x) * UW;
+    };
+    auto load_patch = [&](int u, int first) {          // passes first, first+1 of unit u into pv[]
+        int n, y0, x0;
+        unit_origin(u, n, y0, x0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = min((t >> 4) + 32 * (first + j), PPIX - 1);
+            const int h = min(reflect_idx(y0 - PAD + (pp >> 4), a.H), a.H - 1);
+            const int w = min(reflect_idx(x0 - PAD + kw + (pp & 15), a.W), a.W - 1);
+            pv[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.Cin + cs * CIW + quad * 4);
+        }
+    };
+    auto write_patch = [&](int buf, int first) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = (t >> 4) + 32 * (first + j);
+            if (first + j >= PPASS) continue;
+            u32x2 p0, p1, p2;
+            split3(pv[j], p0, p1, p2);
+            bf16* dst = smem + buf * 3 * P_PLANE + pp * CIW + ((((quad >> 1) ^ (4 * ((pp >> 1) & 1)))) << 3) + (quad & 1) * 4;
+            *reinterpret_cast<u32x2*>(dst) = p0;
+            *reinterpret_cast<u32x2*>(dst + P_PLANE) = p1;
+            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE) = p2;
+        }
+    };
+
+    // ---- dY fragments straight from global memory: lane (co = l31, pixels 8*hi .. 8*hi+7 of the row) ----------------------
+    float raw[8];
+    auto load_dy = [&](int u, int row) {
+        int n, y0, x0;
+        unit_origin(u, n, y0, x0);
+        const float* src = a.dy + ((size_t)(n * a.H + y0 + row) * a.W + x0 + 8 * hi) * a.N + tn * BN + co_tile * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = src[(size_t)j * a.N];
+    };
+    bf16x8 fb[3];
+    auto split_dy = [&]() {
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned hb = __float_as_uint(raw[k]) & 0xffff0000u;
+            const float r = raw[k] - __uint_as_float(hb);
+            const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+            h[k] = hb; m[k] = mb; l[k] = __float_as_uint(r - __uint_as_float(mb));
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 q0, q1, q2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            q0[k] = __builtin_amdgcn_perm(h[2 * k + 1], h[2 * k], 0x07060302u);
+            q1[k] = __builtin_amdgcn_perm(m[2 * k + 1], m[2 * k], 0x07060302u);
+            q2[k] = __builtin_amdgcn_perm(l[2 * k + 1], l[2 * k], 0x07060302u);
+        }
+        fb[0] = __builtin_bit_cast(bf16x8, q0);
+        fb[1] = __builtin_bit_cast(bf16x8, q1);
+        fb[2] = __builtin_bit_cast(bf16x8, q2);
+    };
+
+    // ---- x fragments: transposing reads, lane 4q+p of a 16-lane group addresses pixel q, channels 4p..4p+3 ------------------
+    const int li = lane & 15, gam = (lane >> 4) & 1;
+    const int tq = li >> 2, tp = li & 3;
+    const int pxl = 8 * hi + tq;
+    const int a_col = ci_tile * 32 + 16 * gam + 4 * tp;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    auto a_frag = [&](const bf16* plane, int r) {
+        bf16x4 v[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pp = r * UW + pxl + 4 * hf;
+            v[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (lds4)(plane + pp * CIW + (((a_col >> 3) ^ (4 * ((pp >> 1) & 1))) << 3) + (a_col & 7)));
+        }
+        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[KS], lo[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f, lo[j][r] = 0.f;
+
+    if (u0 < u1) {
+        // first unit's patch
+        for (int f = 0; f < PPASS; f += 2) {
+            load_patch(u0, f);
+            write_patch(0, f);
+        }
+        load_dy(u0, half_id * ROWS);
+        __syncthreads();
+        int buf = 0;
+        for (int u = u0; u < u1; ++u) {
+            const bool next = u + 1 < u1;
+            const bf16* p = smem + buf * 3 * P_PLANE;
+#pragma unroll
+            for (int rr = 0; rr < ROWS; ++rr) {
+                const int ks = half_id * ROWS + rr;
+                // next unit's patch: two gather passes in flight at a time, written two rows after they were issued
+                constexpr int GROUPS = (PPASS + 1) / 2;
+                constexpr int STEP = ROWS >= 2 * GROUPS + 2 ? 2 : 1;
+                if (next) {
+                    if (rr >= STEP && (rr - STEP) % STEP == 0 && (rr - STEP) / STEP < GROUPS) write_patch(buf ^ 1, 2 * ((rr - STEP) / STEP));
+                    if (rr % STEP == 0 && rr / STEP < GROUPS) load_patch(u + 1, 2 * (rr / STEP));
+                }
+                split_dy();
+                if (rr + 1 < ROWS) load_dy(u, ks + 1);
+                else if (next) load_dy(u + 1, half_id * ROWS);
+#pragma unroll
+                for (int kh = 0; kh < KS; ++kh) {
+                    bf16x8 fa[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[pl] = a_frag(p + pl * P_PLANE, ks + kh);
+                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], lo[kh], 0, 0, 0);
+                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], lo[kh], 0, 0, 0);
+                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], lo[kh], 0, 0, 0);
+                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], lo[kh], 0, 0, 0);
+                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], lo[kh], 0, 0, 0);
+                    acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kh], 0, 0, 0);
+                }
+            }
+            if (next) {                                 // gather groups the row loop had no room for
+                constexpr int GROUPS = (PPASS + 1) / 2;
+                constexpr int STEP = ROWS >= 2 * GROUPS + 2 ? 2 : 1;
+                constexpr int DONE_W = ROWS > STEP ? (ROWS - 1 - STEP) / STEP + 1 : 0;      // groups written inside the loop
+                constexpr int DONE_L = (ROWS - 1) / STEP + 1;                                 // groups loaded inside the loop
+#pragma unroll
+                for (int gq = (DONE_W < GROUPS ? DONE_W : GROUPS); gq < GROUPS; ++gq) {
+                    if (gq >= (DONE_L < GROUPS ? DONE_L : GROUPS)) load_patch(u + 1, 2 * gq);
+                    write_patch(buf ^ 1, 2 * gq);
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // slab[split * HALVES + half][(tap*Cin + ci)][co]
+    const int Ktot = KS * KS * a.Cin;
+    float* out = a.slab + (size_t)(split * HALVES + half_id) * Ktot * a.N;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+        const int tap = kh * KS + kw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[kh][r] + lo[kh][r];
+        }
+    }
+#endif
+}
+
+// slab[s][(kh,kw,ci)][co] summed over s -> dw[co][ci][kh][kw] (state_dict layout, fp32), real channels only
+__global__ void x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int K, int N, int Cin, int KHW,
+                                       int cin_real, int cout_real) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)K * N) return;
+    const int co = idx % N;
+    const int k = idx / N;
+    const int ci = k % Cin, tap = k / Cin;
+    if (co >= cout_real || ci >= cin_real) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * K * N + idx];
+    dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
+}
+
+int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
+    if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || (Cin % 64)) return 0;
+    if (Cout >= 128 && !(Cout % 128)) return 128;
+    return (Cout >= 64 && !(Cout % 64)) ? 64 : 0;
+}
+
+void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
+    const int roles = (Cin / 64) * (Cout / bn) * K;
+    const int units = B * (H / 8) * (W / 16);
+    const int cus = 256;                                // one workgroup per CU (LDS): whole rounds, see wgrad_halo_plan
+    const int smax = units / 4 > 0 ? units / 4 : 1;
+    int s = 1;
+    double best = 0.0;
+    for (int c = 1; c <= smax && c * roles <= 2 * cus; ++c) {
+        const int wgs = c * roles, rounds = (wgs + cus - 1) / cus;
+        const double fill = (double)wgs / (rounds * cus) / (rounds > 1 ? 1.05 : 1.0);
+        if (fill > best + 1e-9) best = fill, s = c;
+    }
+    *ups = (units + s - 1) / s;
+    *splits = (units + *ups - 1) / *ups;
+}
+
+bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
+    return B > 0 && (K == 3 || K == 5) && H >= TB && W >= TB && !(H % TB) && !(W % TB) && Cin >= CS && !(Cin % CS) && N >= 32 &&
+           !(N % 4);
+}
+
+template <int KS, int BN, int WM, int WN, int TM, int TN>
+void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN>), grid, dim3(512), 0, st, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_x3_conv2d_same_ok(int B, int H, int W, int Cin, int Cout, int K) { return x3_ok(B, H, W, Cin, Cout, K) ? 1 : 0; }
+
+size_t dwc_x3_weight_prepared_elems(int rows, int kdim, int K) {
+    return (size_t)K * K * ((kdim + CS - 1) / CS) * 3 * rows * CS;
+}
+
+/* w (fp32 OIHW) -> three bf16 planes per (tap, 16-channel slab), exact split.  dgrad == 0: rows = Cout rounded up by the
+ * caller to `rows`, contraction over Cin; dgrad != 0: rows >= Cin, contraction over Cout, taps rotated. */
+int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, void* stream) {
+    if (!w_oihw || !out || Cout <= 0 || Cin <= 0 || K <= 0 || rows < (dgrad ? Cin : Cout)) return DWC_EINVAL;
+    const int kdim = dgrad ? Cout : Cin;
+    const size_t total = dwc_x3_weight_prepared_elems(rows, kdim, K) / 3;
+    hipLaunchKernelGGL(x3_weight_prepare_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, (bf16*)out, Cout,
+                       Cin, K, rows, kdim, dgrad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* y = act(conv_KxK(pad(x)) + bias) for fp32 NHWC tensors, stride 1, pad (K-1)/2, K in {3,5}, H and W multiples of 16, Cin a
+ * multiple of 16; N = channels (row stride) of y, a multiple of 4, rows = row count the weights were prepared with (>= N).
+ * reflect != 0: reflect padding (forward); reflect == 0: zero padding (interior of the data gradient with dgrad-prepared
+ * weights, to be followed by dwc_conv2d_bwd_data_ring). */
+int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
+                       int rows, int K, int act, int reflect, void* stream) {
+    if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N) return DWC_EINVAL;
+    X3Args a;
+    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
+    a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
+    const int blocks = B * a.blocks_per_img;
+    // widest channel tile that still gives every CU a workgroup
+    int bn = 256;
+    static const int force = getenv("DWC_X3_BN") ? atoi(getenv("DWC_X3_BN")) : 0;
+    while (bn > 64 && (bn / 2 >= N || blocks * ((N + bn - 1) / bn) < 256)) bn /= 2;
+    if (K == 5 && bn == 256) bn = 128;                 // the 5x5 patch (twice) and three 256-row weight slots exceed the LDS
+    if (force) bn = force;
+    a.tiles_n = (N + bn - 1) / bn;
+    const dim3 grid(blocks * a.tiles_n);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 3) {
+        if (bn == 256) x3_launch<3, 256, 2, 4, 4, 2>(a, grid, st);
+        else if (bn == 128) x3_launch<3, 128, 4, 2, 2, 2>(a, grid, st);
+        else x3_launch<3, 64, 8, 1, 1, 2>(a, grid, st);
+    } else {
+        if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
+        else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {
+    const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
+    if (!bn) return 0;
+    int splits, ups;
+    x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    return (size_t)splits * (bn == 128 ? 1 : 2) * K * K * Cin * Cout * sizeof(float);
+}
+
+/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution from the fp32 NHWC tensors
+ * x:[B,H,W,Cin] and dy:[B,H,W,Cout], split products (see wgrad_x3_kernel).  ws_bytes == 0: shape not handled (K in {3,5},
+ * H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64) - use dwc_conv2d_bwd_weight. */
+int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real,
+                        int cout_real, void* ws, size_t ws_bytes, void* stream) {
+    const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
+    if (!x || !dy || !dw_oihw || !bn || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
+    int splits, ups;
+    x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    const int halves = bn == 128 ? 1 : 2;
+    if (!ws || ws_bytes < (size_t)splits * halves * K * K * Cin * Cout * sizeof(float)) return DWC_EWORKSPACE;
+    X3WgradArgs a;
+    a.x = x; a.dy = dy; a.slab = (float*)ws;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = Cout;
+    a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
+    a.n_tiles = Cout / bn;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((Cin / 64) * a.n_tiles * K, splits);
+    if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128>), grid, dim3(512), 0, st, a);
+    else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64>), grid, dim3(512), 0, st, a);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64>), grid, dim3(512), 0, st, a);
+    DWC_LAUNCH_CHECK();
+    const size_t total = (size_t)K * K * Cin * Cout;
+    hipLaunchKernelGGL(x3_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw_oihw, splits * halves,
+                       K * K * Cin, Cout, Cin, K * K, cin_real, cout_real);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

@@ -196,6 +196,21 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
                                                int(kind == "wino_dgrad"), stride, _stream()), "wino_prepare_filter")
         ent[key] = (stamp, out)
         return out
+    if kind in ("x3_fwd", "x3_dgrad"):
+        # three bf16 planes per (tap, 16-channel slab) [tap][slab][plane][row][16] (dwc_x3_weight_prepare); rows = cout_pad
+        # forward / cin_pad for the data gradient, the contraction runs over the other (zero-padded) channel count
+        co, ci, kh, kw = w.shape
+        wz = w.detach()
+        if co != cout_pad or ci != cin_pad:
+            wz = torch.zeros((cout_pad, cin_pad, kh, kw), dtype=torch.float32, device=w.device)
+            wz[:co, :ci] = w.detach()
+        dg = kind == "x3_dgrad"
+        rows, kdim = (cin_pad, cout_pad) if dg else (cout_pad, cin_pad)
+        out = torch.empty(lib.dwc_x3_weight_prepared_elems(rows, kdim, kh), dtype=BF16, device=w.device)
+        _lib.check(lib.dwc_x3_weight_prepare(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad, kh, rows, int(dg),
+                                             _stream()), "x3_weight_prepare")
+        ent[key] = (stamp, out)
+        return out
     if kind == "heads_wide":
         # the P-plane heads (P = w.shape[0]: 4, or 8 on the bf16 path) as px = 32/P pixels x P planes:
         # bank [p*P + co][ci][KH][KW+px-1], copy p shifted right by p taps
@@ -247,6 +262,9 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
 # the reference's.  Opt in with DWC_WINOGRAD=4 (or ops.WINOGRAD_TILE = 4) where that is acceptable.
 WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 # bf16 path: halo-tiled kernel for the stride-1 "same" 3x3 / 5x5 layers (0: im2col GEMM everywhere; development knob)
+# fp32 stride-1 "same" 5x5 (and with DWC_X3=2 also 3x3) convolutions as exact three-way bf16 splits on the bf16 MFMA
+# (csrc/conv_halo_x3.hip): 0 = native fp32 MFMA kernels only
+X3 = int(os.environ.get("DWC_X3", "1"))
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 
@@ -262,6 +280,17 @@ def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
     if WINOGRAD_TILE >= 4 and H % 4 == 0 and W % 4 == 0:
         return 4
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
+
+
+def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad):
+    """Whether this fp32 stride-1 'same' convolution (c_in gathered channels -> c_out) runs as split-bf16 products.
+    5x5: always when the shape is handled (1.5-1.7x the native kernels); 3x3: Winograd F(2x2) on the fp32 MFMA is as fast
+    at the bench batches, so only when forced (DWC_X3=2)."""
+    if not X3 or stride != 1 or KH != KW or 2 * pad != KH - 1 or c_in % 16 or c_out % 16:
+        return False
+    if KH == 3 and X3 < 2:
+        return False
+    return bool(lib.dwc_x3_conv2d_same_ok(B, H, W, c_in, c_out, KH))
 
 
 class _Conv2d(torch.autograd.Function):
@@ -283,8 +312,9 @@ class _Conv2d(torch.autograd.Function):
         cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        use_wino = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
-        w_hwio = None if use_wino else _prepped(w, "fwd", cop, Cx, stride, owner, half)
+        use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
+        use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
+        w_hwio = None if use_wino or use_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -304,6 +334,11 @@ class _Conv2d(torch.autograd.Function):
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        elif use_x3:
+            w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
+                x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, st),
+                detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same")
         elif half and HALO and stride == 1 and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH):
             # stride-1 "same" 3x3 / 5x5 layers on the bf16 path: halo-tiled kernel (patch staged once per channel slab)
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
@@ -357,13 +392,19 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             detail = "wgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-            wt = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
+            wt = 0 if half or v_keep is None else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)   # v_keep: the forward ran Winograd
             if wt:
                 ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop, wt), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
                     x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, wt, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-wino%d" % wt + detail[5:],
                     exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino_bwd_weight")
+            elif ((not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
+                  and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
+                ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:]), "x3_conv2d_wgrad")
             elif (half and WGRAD_HALO and stride == 1 and KH == KW and 2 * pad == KH - 1
                   and lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH), dev)
@@ -396,8 +437,20 @@ class _Conv2d(torch.autograd.Function):
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = _fn(lib, "conv2d_bwd_data_same_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, pad)
-            wt = 0 if half else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
-            if wt:
+            x3 = (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, stride, pad)
+            wt = 0 if half or x3 else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
+            if x3:
+                # interior = zero-padded convolution of dY with the rotated filter on the split-bf16 kernel; ring direct
+                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
+                ws = workspace(nws, dev)
+
+                def run_x3():
+                    rc = lib.dwc_x3_conv2d_same(g.data_ptr(), w_x3.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, st)
+                    return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
+                                                              W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
+                _lib.check(_timed("conv_gemm_kernel", flops, run_x3, scope_name=ctx.bscope,
+                                  detail="dgrad-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same dgrad")
+            elif wt:
                 # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
                 U = _prepped(w, "wino_dgrad", cop, Cx, wt, owner)
                 nwino = lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt)

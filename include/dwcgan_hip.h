@@ -265,6 +265,24 @@ int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_d
 int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev,
                   const unsigned* chunk_start_dev, int n_chunks, float beta, void* stream);
 
+/* ---- fp32 convolutions on the bf16 matrix cores by exact three-way operand splits (conv_halo_x3.hip) --------------------
+ * An fp32 value is exactly the sum of three bf16 values (truncate / subtract twice); bf16 x bf16 products are exact in the
+ * fp32 accumulator; the six leading cross products reproduce a*b to 2^-23 relative, the accuracy of one fp32 rounding.
+ * Same layers and halo form as dwc_bf16_conv2d_same_halo (reference networks.py:514-515, networks_v2.py:153-156) but fp32
+ * NHWC tensors in and out.  dwc_x3_weight_prepare splits the OIHW filter once per optimiser step: `rows` = row count of the
+ * prepared matrix (>= Cout forward, >= Cin for the data gradient); elems = bf16 elements of the prepared tensor. */
+int dwc_x3_conv2d_same_ok(int B, int H, int W, int Cin, int Cout, int K);
+size_t dwc_x3_weight_prepared_elems(int rows, int kdim, int K);
+int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, void* stream);
+int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
+                       int rows, int K, int act, int reflect, void* stream);
+/* weight gradient of the same layers as split products: dw (fp32, [cout_real][cin_real][K][K]) from the fp32 NHWC tensors x
+ * and dy; both operands are split on the fly (x through LDS, dy in registers); pixel ranges go to fp32 slabs in `ws`, summed in
+ * a fixed order.  ws_bytes == 0: shape not handled (K in {3,5}, H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64). */
+size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int K);
+int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real,
+                        int cout_real, void* ws, size_t ws_bytes, void* stream);
+
 /* ==== bf16-activation path (BASELINE configs[2]: "bf16 activations + MFMA im2col conv path") ==============================
  * The same call sites as above (reference networks.py:579-585, :514-515, networks_v2.py:153-156) with activations and
  * their gradients stored as bf16 (NHWC, channel counts multiples of 8 = one 16-byte chunk; the 3-channel images travel as

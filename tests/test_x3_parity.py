@@ -1,0 +1,147 @@
+"""fp32 convolutions computed on the bf16 matrix cores through exact three-way operand splits (csrc/conv_halo_x3.hip).
+
+The claim under test is that this is an fp32 computation, not a reduced-precision one: against a float64 reference the error
+of the split-product kernel is the error of the native fp32 MFMA kernel (both are dominated by the fp32 accumulation), far
+below what bf16 or tf32 operands would give (2^-9, 2^-11 relative per product).  Tolerances are those of test_hip_parity.py for
+single fp32 ops: 2e-5 of the tensor's own scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hipdwc import _lib, ops          # noqa: E402
+
+DEV = "cuda:0"
+ACT = {"none": 0, "relu": 1, "lrelu": 2}
+
+
+def _prep(lib, w, rows, dgrad):
+    Cout, Cin, K, _ = w.shape
+    kdim = Cout if dgrad else Cin
+    n = lib.dwc_x3_weight_prepared_elems(rows, kdim, K)
+    out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.dwc_x3_weight_prepare(w.data_ptr(), out.data_ptr(), Cout, Cin, K, rows, int(dgrad),
+                                         torch.cuda.current_stream().cuda_stream), "x3_weight_prepare")
+    return out
+
+
+def _x3(lib, x_nhwc, wp, bias, B, H, W, Cin, N, rows, K, act, reflect):
+    y = torch.empty(B, H, W, N, dtype=torch.float32, device=x_nhwc.device)
+    _lib.check(lib.dwc_x3_conv2d_same(x_nhwc.data_ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      y.data_ptr(), B, H, W, Cin, N, rows, K, act, reflect,
+                                      torch.cuda.current_stream().cuda_stream), "x3_conv2d_same")
+    return y
+
+
+# (B, Cin, Cout, H, W, K, act): every template instantiation (BN 256/128/64 for 3x3, 128/64 for 5x5), several blocks per
+# image, one slab and many, Cout not a multiple of the tile
+SHAPES = [
+    (2, 256, 256, 32, 32, 3, "none"),
+    (40, 256, 256, 32, 32, 3, "relu"),      # >= 256 blocks: the 256-channel tile
+    (3, 64, 128, 16, 48, 3, "lrelu"),
+    (1, 16, 64, 16, 16, 3, "none"),         # one slab, one block
+    (2, 32, 96, 32, 16, 3, "none"),         # Cout 96: masked rows of the last tile
+    (2, 256, 128, 32, 32, 5, "none"),
+    (1, 128, 64, 48, 32, 5, "relu"),
+    (9, 128, 64, 64, 64, 5, "none"),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_x3_forward_matches_float64(shape):
+    B, Cin, Cout, H, W, K, act = shape
+    lib = _lib.load()
+    assert lib.dwc_x3_conv2d_same_ok(B, H, W, Cin, Cout, K)
+    g = torch.Generator().manual_seed(sum(shape[:6]))
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.rand(1, Cin, 1, 1, generator=g) * 3
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (1.0 / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = K // 2
+    ref = F.conv2d(F.pad(x.double(), (pad,) * 4, mode="reflect"), w.double(), b.double())
+    ref = {"none": lambda v: v, "relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[act](ref)
+    xd = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    wd, bd = w.to(DEV), b.to(DEV)
+    wp = _prep(lib, wd, Cout, False)
+    y = _x3(lib, xd, wp, bd, B, H, W, Cin, Cout, Cout, K, ACT[act], 1)
+    torch.cuda.synchronize()
+    got = y.permute(0, 3, 1, 2).double().cpu()
+    scale = ref.abs().max().item()
+    err_x3 = (got - ref).abs().max().item() / scale
+    # yardsticks of "fp32 accuracy": the same product in plain fp32 on the CPU, and the native fp32 MFMA path of ops.conv2d
+    ref32 = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b)
+    ref32 = {"none": lambda v: v, "relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[act](ref32).double()
+    err_32 = (ref32 - ref).abs().max().item() / scale
+    old = ops.X3
+    ops.X3 = 0
+    try:
+        with torch.no_grad():
+            yn = ops.conv2d(xd.permute(0, 3, 1, 2), wd, bd, 1, pad, act)
+    finally:
+        ops.X3 = old
+    err_native = (yn[:, :Cout].double().cpu() - ref).abs().max().item() / scale
+    print("%s max err / scale vs float64: split-bf16 %.2e | native fp32 MFMA path %.2e | fp32 CPU conv %.2e" % (
+        "x".join(str(v) for v in shape), err_x3, err_native, err_32))
+    assert err_x3 <= 5e-6, err_x3                     # test_hip_parity's fp32 tolerance is 2e-5; bf16 operands give ~4e-3
+    assert err_x3 <= 2 * max(err_native, err_32) + 2e-7
+
+
+def test_x3_dgrad_interior_zero_rule():
+    """reflect == 0 with dgrad-prepared weights == conv_transpose of dy (zero padding): the data-gradient interior."""
+    lib = _lib.load()
+    B, Cin, Cout, H, W, K = 2, 128, 64, 32, 32, 5
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * 0.05
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=K // 2)          # [B, Cin, H, W]
+    wd = w.to(DEV)
+    wp = _prep(lib, wd, Cin, True)
+    dyd = dy.to(DEV).permute(0, 2, 3, 1).contiguous()
+    dx = _x3(lib, dyd, wp, None, B, H, W, Cout, Cin, Cin, K, 0, 0)
+    torch.cuda.synchronize()
+    got = dx.permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-6, err
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 128, 32, 32, 5), (3, 128, 64, 16, 48, 5), (2, 64, 128, 32, 16, 3), (5, 128, 64, 24, 32, 3),
+                                   (20, 64, 64, 64, 64, 5)], ids=lambda s: "x".join(str(v) for v in s))
+def test_x3_weight_gradient_matches_float64(shape):
+    """dW of the reflect-padded convolution from fp32 x and dy, split products on both (activation) operands."""
+    B, Cin, Cout, H, W, K = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    pad = K // 2
+    xp = F.pad(x.double(), (pad,) * 4, mode="reflect")
+    ref = torch.nn.grad.conv2d_weight(xp, (Cout, Cin, K, K), dy.double())
+    ref32 = torch.nn.grad.conv2d_weight(F.pad(x, (pad,) * 4, mode="reflect"), (Cout, Cin, K, K), dy).double()
+    xd = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    dyd = dy.to(DEV).permute(0, 2, 3, 1).contiguous()
+    nws = lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cin, Cout, K)
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    dw = torch.empty(Cout, Cin, K, K, dtype=torch.float32, device=DEV)
+    _lib.check(lib.dwc_x3_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, K, Cin, Cout, ws.data_ptr(), nws,
+                                       torch.cuda.current_stream().cuda_stream), "x3_conv2d_wgrad")
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err = (dw.double().cpu() - ref).abs().max().item() / scale
+    err32 = (ref32 - ref).abs().max().item() / scale
+    print("%s dW max err / scale vs float64: split-bf16 %.2e | fp32 CPU %.2e" % ("x".join(str(v) for v in shape), err, err32))
+    assert err <= 2e-6 and err <= 2 * err32 + 2e-7
+
+
+def test_x3_split_is_exact():
+    """The three bf16 planes written by dwc_x3_weight_prepare sum to the fp32 weight exactly (no rounding anywhere)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(32, 16, 3, 3, generator=g) * torch.logspace(-6, 3, 32).view(32, 1, 1, 1)
+    wd = w.to(DEV)
+    wp = _prep(lib, wd, 32, False).view(9, 1, 3, 32, 16).float()               # [tap][slab][plane][row][16]
+    total = (wp[:, 0, 0].double() + wp[:, 0, 1].double() + wp[:, 0, 2].double()).cpu()     # [tap][co][ci]
+    want = w.permute(2, 3, 0, 1).reshape(9, 32, 16).double()
+    assert torch.equal(total, want)
