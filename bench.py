@@ -119,7 +119,7 @@ def cpu_baseline(gen_sd, dis_sd, cfg, image_size, batch, warmup, timed, thread_c
                           {k: round(v, 3) for k, v in probe.items()})}
 
 
-def traffic_from_profiles(config, dominant):
+def traffic_from_profiles(config, dominant, family="conv_gemm_family"):
     """HBM-side bytes per span of the dominant kernel family from the newest committed PMC summary for this workload
     (profiles/rNN_pmc_hbm_traffic*.json, written by benchmarks/pmc_summary.py from two rocprofv3 --pmc passes with the
     gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md).  bench.py cannot read PMCs itself: the figure is a property of
@@ -131,13 +131,13 @@ def traffic_from_profiles(config, dominant):
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        if d.get("config", "c1") != config or "conv_gemm_family" not in d:
+        if d.get("config", "c1") != config or family not in d:
             continue
         best = (path, d)
     if best is None:
         return None, None
     path, d = best
-    return int(d["conv_gemm_family"]["hbm_bytes_per_span_corrected"]), "%s (profiled at commit %s)" % (
+    return int(d[family]["hbm_bytes_per_span_corrected"]), "%s (profiled at commit %s)" % (
         os.path.relpath(path, REPO), d.get("commit", "of round 1, 11e6a6c"))
 
 
@@ -178,6 +178,9 @@ def main():
                     help="CPU baseline: thread counts to sweep (r02 probe on the 256-hardware-thread GPU box, images/s at batch 4: "
                          "8: 1.10, 16: 1.40, 32: 0.80, 64: 0.33, 128: 0.11 -- this graph gets SLOWER beyond 16 threads)")
     ap.add_argument("--per-gpu-batch", type=int, default=None, help="development knob; overrides the config's per-GPU batch")
+    ap.add_argument("--x3", type=int, default=None, choices=(0, 1, 2),
+                    help="fp32 path: 0 = native fp32 MFMA kernels only; 1 (default) = 5x5 layers as exact bf16x3 split products on "
+                         "the bf16 MFMA; 2 = 3x3 layers too (instead of Winograd)")
     ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
                     help="development knob: Winograd output tile of the fp32 3x3 convolutions (default 2 = F(2x2,3x3); 4 = "
                          "F(4x4,3x3), faster but ~10x the rounding error, see hipdwc/ops.py; 0 = direct)")
@@ -205,6 +208,8 @@ def main():
     ops.set_precision(precision)
     if args.winograd is not None:
         ops.WINOGRAD_TILE = args.winograd
+    if args.x3 is not None:
+        ops.X3 = args.x3
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -294,18 +299,38 @@ def main():
                         ent[k] += v[k]
             return ent
 
-        def rate(ent):
+        X3 = "conv_halo_x3_kernel"          # fp32 layers computed as exact bf16x3 split products: their matrix work is bf16 MFMA
+
+        def rate(ent, roof_peak=None, exec_label="executed"):
             if ent["ms"] <= 0:
                 return None
+            pk = peak if roof_peak is None else roof_peak
             tf, ex = ent["flops"] / (ent["ms"] * 1e-3) / 1e12, ent["exec_flops"] / (ent["ms"] * 1e-3) / 1e12
             return {"launches": ent["launches"], "ms": round(ent["ms"], 3), "tflops": round(tf, 2),
-                    "frac_of_mfma_peak": round(tf / peak, 4), "executed_tflops": round(ex, 2),
-                    "executed_frac_of_mfma_peak": round(ex / peak, 4)}
+                    "frac_of_mfma_peak": round(tf / peak, 4), exec_label + "_tflops": round(ex, 2),
+                    exec_label + "_frac_of_mfma_peak": round(ex / pk, 4), "mfma_peak": pk}
+
+        def stack(pred):
+            """One conv stack, split by the matrix path its launches run on (fractions are against THAT path's dense peak;
+            `tflops` is always the algorithmic fp32-equivalent rate)."""
+            both = total(lambda t: pred(t) and (t.endswith(DOMINANT) or t.endswith(X3)))
+            if both["ms"] <= 0:
+                return None
+            tf = both["flops"] / (both["ms"] * 1e-3) / 1e12
+            out = {"launches": both["launches"], "ms": round(both["ms"], 3), "tflops": round(tf, 2)}
+            native = rate(total(lambda t: pred(t) and t.endswith(DOMINANT)))
+            split = rate(total(lambda t: pred(t) and t.endswith(X3)), MFMA_PEAK_TFLOPS["bf16"], "executed_bf16")
+            if split is None:                      # one path only: the flat record of earlier rounds
+                return native
+            out["native_mfma"] = native
+            out["split_bf16x3"] = split
+            return out
 
         dom = total(lambda t: t.endswith(DOMINANT))
+        x3 = total(lambda t: t.endswith(X3))
         # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)
-        decode_stack = {"forward": rate(total(lambda t: t == "decode/conv_gemm_kernel")),
-                        "backward": rate(total(lambda t: t.startswith("bwd:decode/")))}
+        decode_stack = {"forward": stack(lambda t: t.startswith("decode/")),
+                        "backward": stack(lambda t: t.startswith("bwd:decode/") and "wgrad" not in t)}
         roof = None
         if dom and dom["ms"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -320,6 +345,19 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source,
                     "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                     "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
+        roof_x3 = None
+        if x3["ms"] > 0:
+            # the 5x5 layers of the fp32 path: six bf16 MFMAs per fp32 MFMA-equivalent (exact operand splits), so the roof that
+            # bounds them is the dense bf16 MFMA peak and the executed rate is 6x the algorithmic one
+            alg, ex = x3["flops"] / (x3["ms"] * 1e-3) / 1e12, x3["exec_flops"] / (x3["ms"] * 1e-3) / 1e12
+            roof_x3 = {"bound": "mfma", "kernel": X3, "achieved": round(alg, 2), "achieved_vs_fp32_mfma_peak": round(alg / MFMA_PEAK_TFLOPS["fp32"], 4),
+                       "executed": round(ex, 2), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                       "frac": round(ex / MFMA_PEAK_TFLOPS["bf16"], 4),
+                       "traffic": traffic_from_profiles(args.config, X3, "split_bf16x3_family")[0],
+                       "traffic_source": traffic_from_profiles(args.config, X3, "split_bf16x3_family")[1],
+                       "launches_per_step": x3["launches"],
+                       "avg_launch_us": round(x3["ms"] * 1e3 / x3["launches"], 2),
+                       "algorithmic_gflop_per_launch": round(x3["flops"] / x3["launches"] / 1e9, 3)}
         step_flops = sum(v["flops"] for v in spans.values())            # conv + linear-as-conv launches of ONE step, this rank
         step_tflops = step_flops * world / (elapsed / args.steps) / 1e12
         out = {
@@ -329,7 +367,9 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
                            conf["label"], args.vgg_w,
-                           ", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE if precision == "fp32" else ""),
+                           (", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
+                               ", 5x5 convs as exact bf16x3 split products on the bf16 MFMA (fp32 operands, results and "
+                               "accumulation)" if ops.X3 else "")) if precision == "fp32" else ""),
                        "name": args.config, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
                        "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
             # algorithmic flops of the launches this step actually made (conv + linear kernels; the text encoder's library GEMMs,
@@ -341,6 +381,7 @@ def main():
             "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
             "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
             "roofline": roof,
+            "roofline_split_bf16x3": roof_x3,
             "decode_conv_stack": decode_stack,
             "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                  "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},

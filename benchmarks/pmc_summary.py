@@ -6,7 +6,8 @@ TCC has 4 counter slots, they cost 3 + 2).  Produces profiles/rNN_pmc_hbm_traffi
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
     python benchmarks/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_pmc_hbm_traffic_c1.json 3 225 c1 <commit>
-    (arguments: fetch dir, write dir, output, iterations profiled, conv spans per iteration, bench --config, commit profiled)
+    (arguments: fetch dir, write dir, output, iterations profiled, conv spans per iteration, bench --config, commit profiled,
+     [split-bf16 spans per iteration]; benchmarks/collect_profiles.sh runs the whole set)
 
 Units and corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads, so it is doubled; WRITE_SIZE is exact.
@@ -50,7 +51,8 @@ def main():
             "gemm_kernel_h", "conv_halo_kernel", "gemm_strips_kernel_h", "wgrad_kernel_h", "wgrad_reduce_kernel_h", "fold_ring_kernel_h",
             "fold_reflect_kernel_h", "splitk_reduce_kernel_h", "in_bwd_partial", "upsample2x_bwd_kernel", "ln_bwd_apply",
             "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
-            "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd")
+            "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd",
+            "conv_halo_x3_kernel", "wgrad_x3_kernel", "x3_wgrad_reduce_kernel", "wgrad_halo_kernel", "wgrad_halo_reduce_kernel")
     res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 "
                       "--warmup 1 --no-cpu-baseline",
            "note": "units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
@@ -77,6 +79,13 @@ def main():
     total = sum((2 * fetch[k][0] + write[k][0]) * 1024 for k in family if k in fetch and k in write)
     res["conv_gemm_family"] = {"kernels": list(family), "iterations_profiled": steps, "spans_per_iteration": spans_per_step,
                                "hbm_bytes_per_span_corrected": int(total / steps / spans_per_step)}
+    # the fp32 layers that run as split-bf16 products (bench.py's `roofline_split_bf16x3`): one span = one conv_halo_x3_kernel
+    # launch (the ring of a data gradient is counted with the family above, its kernels are shared)
+    x3_spans = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+    if x3_spans and "conv_halo_x3_kernel" in fetch and "conv_halo_x3_kernel" in write:
+        t3 = (2 * fetch["conv_halo_x3_kernel"][0] + write["conv_halo_x3_kernel"][0]) * 1024
+        res["split_bf16x3_family"] = {"kernels": ["conv_halo_x3_kernel"], "iterations_profiled": steps, "spans_per_iteration": x3_spans,
+                                      "hbm_bytes_per_span_corrected": int(t3 / steps / x3_spans)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res["conv_gemm_family"], indent=1))

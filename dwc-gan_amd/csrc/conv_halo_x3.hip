@@ -59,17 +59,23 @@ struct X3Args {
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
-template <int KS, int BN, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
+// DBG (development, timing only -- results are wrong when set): 1 no MFMA, 2 no fragment reads, 4 no weight staging in the
+// loop, 8 no barrier, 16 no patch refresh
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
+    // 8 waves, two per SIMD.  (4 "fat" waves, one per SIMD with up to 512 registers -- 4x2 tiles, a second fragment set, all
+    // latency hiding inside the wave's own instruction stream -- compile from the same source and were measured 15-25 % SLOWER.)
+    constexpr int NW = WM * WN, THREADS = 64 * NW;
+    constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
+    static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
     constexpr int PW = TB + KS - 1;                    // patch edge
     constexpr int PPIX = PW * PW;                      // patch pixels
-    constexpr int PPASS = (PPIX + 127) / 128;          // gather passes of 128 pixels (4 threads x 4 channels per pixel)
-    constexpr int P_PLANE = PPASS * 128 * CS;          // elements per plane of a patch buffer
+    constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
+    constexpr int P_PLANE = PPASS * PPT * CS;          // elements per plane of a patch buffer
     constexpr int W_CHUNKS = 3 * BN * 2;               // 16-byte chunks of one tap's weight slab (3 planes x BN rows x 32 B)
-    constexpr int W_INSTR = (W_CHUNKS + 511) / 512;    // LDS-DMA instructions per thread and tap
-    constexpr int W_SLOT = W_INSTR * 512 * 8;          // elements per ring slot (whole instructions)
+    constexpr int W_INSTR = (W_CHUNKS + THREADS - 1) / THREADS;    // LDS-DMA instructions per thread and tap
+    constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
     constexpr int NTAP = KS * KS;
     constexpr int PAD = (KS - 1) / 2;
     __shared__ __attribute__((aligned(16))) bf16 smem[2 * 3 * P_PLANE + 3 * W_SLOT];
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
     unsigned p_ok = 0;                                  // loads are unconditional (the vmcnt arithmetic below counts them)
 #pragma unroll
     for (int i = 0; i < PPASS; ++i) {
-        const int pp = (t >> 2) + 128 * i;
+        const int pp = (t >> 2) + PPT * i;
         const int py = pp / PW, px = pp - py * PW;
         int h = y0 - PAD + py, w = x0 - PAD + px;
         bool ok = pp < PPIX;
@@ -127,9 +133,9 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
         for (int i = 0; i < PPASS; ++i) {
             u32x2 p0, p1, p2;
             split3((p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f}, p0, p1, p2);
-            *reinterpret_cast<u32x2*>(dst + i * 128 * CS) = p0;
-            *reinterpret_cast<u32x2*>(dst + P_PLANE + i * 128 * CS) = p1;
-            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE + i * 128 * CS) = p2;
+            *reinterpret_cast<u32x2*>(dst + i * PPT * CS) = p0;
+            *reinterpret_cast<u32x2*>(dst + P_PLANE + i * PPT * CS) = p1;
+            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE + i * PPT * CS) = p2;
         }
     };
 
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
     unsigned w_off[W_INSTR];
 #pragma unroll
     for (int p = 0; p < W_INSTR; ++p) {
-        const int g = t + 512 * p;
+        const int g = t + THREADS * p;
         const int plane = g / (2 * BN), rem = g - plane * 2 * BN;
         const int row = min(n0 + (rem >> 1), a.rows - 1);
         w_off[p] = g < W_CHUNKS ? (unsigned)(((plane * a.rows + row) * CS + (rem & 1) * 8) * 2) : 0x80000000u;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
         const int soff = __builtin_amdgcn_readfirstlane((tap * ncs + cs) * w_step_bytes);
 #pragma unroll
         for (int p = 0; p < W_INSTR; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * 512 * 8), 16, w_off[p],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * THREADS * 8), 16, w_off[p],
                                                      soff, 0, 0);
     };
 
@@ -190,56 +196,106 @@ __global__ __launch_bounds__(512) void conv_halo_x3_kernel(X3Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int pbuf = 0, tap = 0, cs = 0, slot = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        // two taps ahead into the slot every wave left at the previous barrier
-        const bool fetch = tap == 0 && cs + 1 < ncs;                      // next slab's patch: registers now, LDS at tap 3
-        if (fetch) load_patch(cs + 1);
-        if (s + 2 < nsteps) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
-        if (tap == 3 && cs + 1 < ncs) write_patch(pbuf ^ 1);
-
-        const int d = ((tap / KS) * PW + (tap % KS)) * CS;
-        const bf16* p = sP + pbuf * 3 * P_PLANE + d;
-        const bf16* w = sW + slot * W_SLOT + b_row;
-        bf16x8 fa[3][TM], fb[3][TN];
+    // ---- main loop: one step = one filter tap of one 16-channel slab, one barrier per step -----------------------------------
+    // Software pipeline (PIPE, the 1x2 tile shape; 2x2 with split accumulators and 4x2 have no registers for a second fragment
+    // set -- 115+ spills): the
+    // barrier sits after two thirds of a step's MFMAs, right behind it the NEXT step's 3*(TM+TN) fragments are requested, and
+    // the last third of the MFMAs runs while they arrive; the patch conversion (VALU + ds_write) is placed between MFMA groups
+    // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
+    // eight waves of the one resident workgroup reach every phase together.)
+    constexpr bool PIPE = NW == 4 || TM * TN <= 2;
+    bf16x8 fa[PIPE ? 2 : 1][3][TM], fb[PIPE ? 2 : 1][3][TN];
+    auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
+        constexpr int set = decltype(setc)::value;
+        const int d = ((tap_ / KS) * PW + (tap_ % KS)) * CS;
+        const bf16* p = sP + pbuf_ * 3 * P_PLANE + d;
+        const bf16* w = sW + slot_ * W_SLOT + b_row;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int n = 0; n < TN; ++n) fb[pl][n] = *reinterpret_cast<const bf16x8*>(w + (pl * BN + n * 32) * CS);
+            for (int n = 0; n < TN; ++n) {
+                if (DBG & 2) { for (int e = 0; e < 8; ++e) fb[set][pl][n][e] = (bf16)(float)(lane + tap_ + pl); }
+                else fb[set][pl][n] = *reinterpret_cast<const bf16x8*>(w + (pl * BN + n * 32) * CS);
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[pl][i] = *reinterpret_cast<const bf16x8*>(p + pl * P_PLANE + pp0[i]);
+            for (int i = 0; i < TM; ++i) {
+                if (DBG & 2) { for (int e = 0; e < 8; ++e) fa[set][pl][i][e] = (bf16)(float)(lane + i + pl); }
+                else fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(p + pl * P_PLANE + pp0[i]);
+            }
         }
-        // smallest terms first: (a2 b0, a1 b1, a0 b2), (a1 b0, a0 b1), a0 b0
+    };
+    // terms [t0, t1) of the six products, smallest first: (a2 b0, a1 b1, a0 b2), (a1 b0, a0 b1), a0 b0
+    auto mfma_terms = [&](auto setc, auto t0c, auto t1c) {
+        constexpr int set = decltype(setc)::value, t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
-            constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-            constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+        for (int term = t0; term < t1; ++term)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
+                    if (DBG & 1) {
+                        asm volatile("" ::"v"(fa[set][PA[term]][i]), "v"(fb[set][PB[term]][n]));
+                        continue;
+                    }
                     if (SPLIT && term < 5)
                         lo[SPLIT ? i : 0][SPLIT ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            fb[PB[term]][n], fa[PA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
+                            fb[set][PB[term]][n], fa[set][PA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
                     else
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB[term]][n], fa[PA[term]][i], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][PB[term]][n], fa[set][PA[term]][i], acc[i][n], 0, 0,
+                                                                            0);
                 }
-        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 4> I4;
+    typedef std::integral_constant<int, 6> I6;
+
+    int pbuf = 0, tap = 0, cs = 0, slot = 0;
+    auto step = [&](auto curc, auto nxtc, int s) {
+        const bool fetch = tap == 0 && cs + 1 < ncs && !(DBG & 16);       // next slab's patch: registers now, LDS at tap 3
+        if (fetch) load_patch(cs + 1);
+        if (!PIPE) read_frags(curc, tap, pbuf, slot);
+        mfma_terms(curc, I0{}, I2{});
+        // (the compiler waits for the patch registers with a vmcnt that also covers every younger load: convert them BEFORE
+        // this step's weight slab is issued, so that wait only sees loads that are at least a step old)
+        if (tap == 3 && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
+        // two taps ahead, into the slot every wave left before the previous barrier
+        if (s + 2 < nsteps && !(DBG & 4)) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
+        mfma_terms(curc, I2{}, I4{});
+        if (!PIPE) mfma_terms(curc, I4{}, I6{});
         // the next step's weights (issued one step ago) must have landed; what this step issued (its weight slab and, at tap 0,
-        // the PPASS register loads of the next patch -- in either order) may stay in flight
+        // the PPASS register loads of the next patch) may stay in flight
         if (s + 2 < nsteps) {
             if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR + PPASS) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        // raw barrier: __syncthreads() would add a fence that drains vmcnt to 0, i.e. wait for the slab issued a moment ago
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's patch writes and fragment reads are done
+        if (!(DBG & 8)) __builtin_amdgcn_s_barrier();
         if (++tap == NTAP) {
             tap = 0;
             ++cs;
             pbuf ^= 1;
         }
         slot = slot == 2 ? 0 : slot + 1;
+        if (PIPE) {
+            if (s + 1 < nsteps) read_frags(nxtc, tap, pbuf, slot);
+            mfma_terms(curc, I4{}, I6{});
+        }
+    };
+    if (PIPE) {
+        read_frags(I0{}, 0, 0, 0);
+        for (int s = 0; s < nsteps; s += 2) {
+            step(I0{}, I1{}, s);
+            if (s + 1 < nsteps) step(I1{}, I0{}, s + 1);
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(I0{}, I0{}, s);
     }
 
     // ---- epilogue: bias + activation, fp32 stores of 4 channels per lane ---------------------------------------------------
@@ -498,7 +554,8 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
                     write_patch(buf ^ 1, 2 * gq);
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // patch writes done; raw barrier: the next unit's first dY
+            __builtin_amdgcn_s_barrier();                                // row stays in flight (no vmcnt drain as in __syncthreads)
             buf ^= 1;
         }
     }
@@ -558,9 +615,9 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN>), grid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 
 }  // namespace
@@ -611,7 +668,11 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
         else if (bn == 128) x3_launch<3, 128, 4, 2, 2, 2>(a, grid, st);
         else x3_launch<3, 64, 8, 1, 1, 2>(a, grid, st);
     } else {
-        if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
+        static const int dbg = getenv("DWC_X3_DBG") ? atoi(getenv("DWC_X3_DBG")) : 0;      // dev ablations (timing only)
+        if (bn == 128 && dbg == 1) x3_launch<5, 128, 4, 2, 2, 2, 1>(a, grid, st);
+        else if (bn == 128 && dbg == 2) x3_launch<5, 128, 4, 2, 2, 2, 2>(a, grid, st);
+        else if (bn == 128 && dbg == 30) x3_launch<5, 128, 4, 2, 2, 2, 30>(a, grid, st);
+        else if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
         else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
     }
     DWC_LAUNCH_CHECK();

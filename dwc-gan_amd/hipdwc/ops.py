@@ -336,9 +336,9 @@ class _Conv2d(torch.autograd.Function):
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
         elif use_x3:
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, st),
-                detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same")
+                detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
         elif half and HALO and stride == 1 and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH):
             # stride-1 "same" 3x3 / 5x5 layers on the bf16 path: halo-tiled kernel (patch staged once per channel slab)
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
@@ -402,9 +402,9 @@ class _Conv2d(torch.autograd.Function):
             elif ((not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
-                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
+                _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
                     x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
-                    scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:]), "x3_conv2d_wgrad")
+                    scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:], exec_flops=6 * flops), "x3_conv2d_wgrad")
             elif (half and WGRAD_HALO and stride == 1 and KH == KW and 2 * pad == KH - 1
                   and lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH), dev)
@@ -448,7 +448,7 @@ class _Conv2d(torch.autograd.Function):
                     rc = lib.dwc_x3_conv2d_same(g.data_ptr(), w_x3.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, st)
                     return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
                                                               W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
-                _lib.check(_timed("conv_gemm_kernel", flops, run_x3, scope_name=ctx.bscope,
+                _lib.check(_timed("conv_halo_x3_kernel", flops, run_x3, scope_name=ctx.bscope, exec_flops=6 * flops,
                                   detail="dgrad-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same dgrad")
             elif wt:
                 # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
