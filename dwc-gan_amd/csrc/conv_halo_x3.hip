@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
     auto step = [&](auto curc, auto nxtc, int s) {
         const bool fetch = tap == 0 && cs + 1 < ncs && !(DBG & 16);       // next slab's patch: registers now, LDS at tap 3
         if (fetch) load_patch(cs + 1);
-        if (!PIPE) read_frags(curc, tap, pbuf, slot);
+        if constexpr (!PIPE) read_frags(curc, tap, pbuf, slot);
         mfma_terms(curc, I0{}, I2{});
         // (the compiler waits for the patch registers with a vmcnt that also covers every younger load: convert them BEFORE
         // this step's weight slab is issued, so that wait only sees loads that are at least a step old)
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
         // two taps ahead, into the slot every wave left before the previous barrier
         if (s + 2 < nsteps && !(DBG & 4)) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
         mfma_terms(curc, I2{}, I4{});
-        if (!PIPE) mfma_terms(curc, I4{}, I6{});
+        if constexpr (!PIPE) mfma_terms(curc, I4{}, I6{});
         // the next step's weights (issued one step ago) must have landed; what this step issued (its weight slab and, at tap 0,
         // the PPASS register loads of the next patch) may stay in flight
         if (s + 2 < nsteps) {
@@ -283,12 +283,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
             pbuf ^= 1;
         }
         slot = slot == 2 ? 0 : slot + 1;
-        if (PIPE) {
+        if constexpr (PIPE) {
             if (s + 1 < nsteps) read_frags(nxtc, tap, pbuf, slot);
             mfma_terms(curc, I4{}, I6{});
         }
     };
-    if (PIPE) {
+    if constexpr (PIPE) {
         read_frags(I0{}, 0, 0, 0);
         for (int s = 0; s < nsteps; s += 2) {
             step(I0{}, I1{}, s);
