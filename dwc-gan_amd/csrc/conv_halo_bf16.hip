@@ -327,11 +327,22 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // 1-D grid, XCD-aware (see wgrad_x3_kernel): the roles of one pixel split are consecutive virtual ids on one XCD and share
+    // its L2 for the pixels of x and dY they all re-read
     int id = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb >= 16) {
+            const int q = nb >> 3, r = nb & 7, x = id & 7, y = id >> 3;
+            id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        }
+    }
+    const int roles = (a.Cin / (BN == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups;
+    const int split = id / roles;
+    id -= split * roles;
     const int tgp = id % a.tap_groups;                  // 5x5: the filter column kw of this workgroup
     id /= a.tap_groups;
     const int tn = id % a.n_tiles, cs = id / a.n_tiles;
-    const int split = blockIdx.y;
     const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
     const int ci_tile = BN == 128 ? (wave >> 2) : (wave >> 1);
     const int co_tile = BN == 128 ? (wave & 3) : (wave & 1);
@@ -587,7 +598,7 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
     a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
     a.n_tiles = Cout / bn; a.tap_groups = K == 3 ? 1 : K;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((Cin / (bn == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups, splits);
+    const dim3 grid((Cin / (bn == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups * splits);
     static const int dbg = getenv("DWC_WGRAD_HALO_DBG") ? atoi(getenv("DWC_WGRAD_HALO_DBG")) : 0;   // dev ablation (3x3)
     if (K == 3 && dbg == 4) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 4>), grid, dim3(512), 0, st, a);
     else if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);

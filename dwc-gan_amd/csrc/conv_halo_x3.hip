@@ -384,7 +384,7 @@ struct X3WgradArgs {
     float* slab;         // [splits * HALVES][K*K*Cin][N]
     int B, H, W, Cin, N;
     int units_x, units_per_img, total_units, units_per_split;
-    int n_tiles;
+    int n_tiles, roles;
 };
 
 template <int KS, int BN>
@@ -403,11 +403,22 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // 1-D grid, XCD-aware: hardware workgroup i runs on XCD i % 8; virtual ids are laid out so that each XCD gets a contiguous
+    // range, and the roles (ci slab, dY tile, filter column) of one pixel split are consecutive virtual ids -- the workgroups
+    // that re-read the same pixels of x and dY share an L2 (r02 PMC: 2.3 GB of HBM-side traffic per launch before this)
     int id = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if (nb >= 16) {
+            const int q = nb >> 3, r = nb & 7, x = id & 7, y = id >> 3;
+            id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        }
+    }
+    const int split = id / a.roles;
+    id -= split * a.roles;
     const int kw = id % KS;
     id /= KS;
     const int tn = id % a.n_tiles, cs = id / a.n_tiles;
-    const int split = blockIdx.y;
     const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
     const int ci_tile = BN == 128 ? (wave >> 2) : (wave & 1);
     const int co_tile = BN == 128 ? (wave & 3) : ((wave >> 1) & 1);
@@ -703,8 +714,9 @@ int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, 
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = Cout;
     a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
     a.n_tiles = Cout / bn;
+    a.roles = (Cin / 64) * a.n_tiles * K;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((Cin / 64) * a.n_tiles * K, splits);
+    const dim3 grid(a.roles * splits);
     if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128>), grid, dim3(512), 0, st, a);
     else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128>), grid, dim3(512), 0, st, a);
