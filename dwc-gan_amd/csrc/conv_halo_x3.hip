@@ -665,11 +665,27 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     const int blocks = B * a.blocks_per_img;
-    // widest channel tile that still gives every CU a workgroup
-    int bn = 256;
+    // channel tile: measured MFMA utilisation of a full round of workgroups by tile width (256: 65 %, 128: 52 %, 64: 43 %)
+    // times the fill of the last round of 256 CUs; e.g. 192 blocks x 256 channels: one 256-wide workgroup on 192 CUs (0.49)
+    // beats 384 128-wide ones in two rounds (0.39)
+    int bn = 64;
     static const int force = getenv("DWC_X3_BN") ? atoi(getenv("DWC_X3_BN")) : 0;
-    while (bn > 64 && (bn / 2 >= N || blocks * ((N + bn - 1) / bn) < 256)) bn /= 2;
-    if (K == 5 && bn == 256) bn = 128;                 // the 5x5 patch (twice) and three 256-row weight slots exceed the LDS
+    {
+        double best = 0.0;
+        const int widths[3] = {256, 128, 64};
+        const double eff[3] = {0.65, 0.52, 0.43};
+        for (int i = 0; i < 3; ++i) {
+            const int w = widths[i];
+            // 256-wide tiles (4x2 accumulators per wave) have no registers for the separate correction accumulators: 1.6e-6
+            // against 6.4e-7 of the output scale on the 3x3 layers, for +1.2 % on the c1 step -- opt-in only (DWC_X3_WIDE=1)
+            static const int wide = getenv("DWC_X3_WIDE") ? atoi(getenv("DWC_X3_WIDE")) : 0;
+            if (w == 256 && (K == 5 || !wide)) continue;   // (5x5: the patch twice + three 256-row weight slots exceed the LDS)
+            if (w > 64 && w / 2 >= N) continue;        // more than half of the tile would be padding
+            const long wgs = (long)blocks * ((N + w - 1) / w);
+            const double score = eff[i] * (double)wgs / (double)((wgs + 255) / 256 * 256);
+            if (score > best) best = score, bn = w;
+        }
+    }
     if (force) bn = force;
     a.tiles_n = (N + bn - 1) / bn;
     const dim3 grid(blocks * a.tiles_n);

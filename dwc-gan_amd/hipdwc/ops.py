@@ -282,13 +282,14 @@ def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
 
-def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad):
+def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad, free=False):
     """Whether this fp32 stride-1 'same' convolution (c_in gathered channels -> c_out) runs as split-bf16 products.
-    5x5: always when the shape is handled (1.5-1.7x the native kernels); 3x3: Winograd F(2x2) on the fp32 MFMA is as fast
-    at the bench batches, so only when forced (DWC_X3=2)."""
+    5x5: always when the shape is handled (1.5-1.8x the native kernels).  3x3: Winograd F(2x2) on the fp32 MFMA is about as
+    fast, and its forward hands the transformed input to the weight gradient -- so only where nothing is lost (``free``: a
+    data gradient, or a forward whose weights need no gradient; 5-20 % faster there), or everywhere when forced (DWC_X3=2)."""
     if not X3 or stride != 1 or KH != KW or 2 * pad != KH - 1 or c_in % 16 or c_out % 16:
         return False
-    if KH == 3 and X3 < 2:
+    if KH == 3 and X3 < 2 and not free:
         return False
     return bool(lib.dwc_x3_conv2d_same_ok(B, H, W, c_in, c_out, KH))
 
@@ -312,7 +313,7 @@ class _Conv2d(torch.autograd.Function):
         cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
+        use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not ctx.needs_input_grad[1])
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         w_hwio = None if use_wino or use_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
@@ -437,7 +438,7 @@ class _Conv2d(torch.autograd.Function):
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = _fn(lib, "conv2d_bwd_data_same_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, pad)
-            x3 = (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, stride, pad)
+            x3 = (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, stride, pad, free=True)
             wt = 0 if half or x3 else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
             if x3:
                 # interior = zero-padded convolution of dY with the rotated filter on the split-bf16 kernel; ring direct
