@@ -141,7 +141,10 @@ def test_x3_split_is_exact():
     g = torch.Generator().manual_seed(5)
     w = torch.randn(32, 16, 3, 3, generator=g) * torch.logspace(-6, 3, 32).view(32, 1, 1, 1)
     wd = w.to(DEV)
-    wp = _prep(lib, wd, 32, False).view(9, 1, 3, 32, 16).float()               # [tap][slab][plane][row][16]
-    total = (wp[:, 0, 0].double() + wp[:, 0, 1].double() + wp[:, 0, 2].double()).cpu()     # [tap][co][ci]
+    wp = _prep(lib, wd, 32, False).view(9, 1, 3, 32, 2, 8).float().cpu()      # [tap][slab][plane][row][half][8]
+    swap = ((torch.arange(32) >> 3) & 1).bool()                                # rows 8-15, 24-31 store their halves swapped
+    wp[:, :, :, swap] = wp[:, :, :, swap].flip(4)
+    wp = wp.reshape(9, 1, 3, 32, 16)
+    total = wp[:, 0, 0].double() + wp[:, 0, 1].double() + wp[:, 0, 2].double()              # [tap][co][ci]
     want = w.permute(2, 3, 0, 1).reshape(9, 32, 16).double()
     assert torch.equal(total, want)
