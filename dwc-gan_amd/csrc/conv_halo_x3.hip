@@ -234,11 +234,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
             }
         }
     };
-    // terms [t0, t1) of the six products, smallest first: (a2 b0, a1 b1, a0 b2), (a1 b0, a0 b1), a0 b0
+    // terms [t0, t1) of the six products.  Split accumulators: in the order their fragments arrive from LDS (planes are read
+    // 0, 1, 2), the leading product first -- its accumulator is separate, so the order costs no accuracy and the first MFMAs do
+    // not wait for the last reads.  One accumulator (4x2 tiles): smallest terms first.
     auto mfma_terms = [&](auto setc, auto t0c, auto t1c) {
         constexpr int set = decltype(setc)::value, t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int PA[6] = {SPLIT ? 0 : 2, 1, 0, SPLIT ? 2 : 1, SPLIT ? 1 : 0, 0};
+        constexpr int PB[6] = {0, SPLIT ? 0 : 1, SPLIT ? 1 : 2, 0, 1, SPLIT ? 2 : 0};
 #pragma unroll
         for (int term = t0; term < t1; ++term)
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
                         asm volatile("" ::"v"(fa[set][PA[term]][i]), "v"(fb[set][PB[term]][n]));
                         continue;
                     }
-                    if (SPLIT && term < 5)
+                    if (SPLIT && (PA[term] | PB[term]) != 0)
                         lo[SPLIT ? i : 0][SPLIT ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             fb[set][PB[term]][n], fa[set][PA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
                     else
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
         mfma_terms(curc, I0{}, I2{});
         // (the compiler waits for the patch registers with a vmcnt that also covers every younger load: convert them BEFORE
         // this step's weight slab is issued, so that wait only sees loads that are at least a step old)
-        if (tap == 3 && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
+        // (waves w and w+4 share a SIMD: they convert one tap apart, so one of them is always free to feed the matrix pipe)
+        if (tap == 3 + (wave >> 2) && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
         // two taps ahead, into the slot every wave left before the previous barrier
         if (s + 2 < nsteps && !(DBG & 4)) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
         mfma_terms(curc, I2{}, I4{});
