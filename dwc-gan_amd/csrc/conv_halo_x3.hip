@@ -61,11 +61,16 @@ struct X3Args {
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
 // DBG (development, timing only -- results are wrong when set): 1 no MFMA, 2 no fragment reads, 4 no weight staging in the
 // loop, 8 no barrier, 16 no patch refresh
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
+// PB: patch buffers.  2: the next slab's patch is converted during the taps of the current one.  1: it is converted at the slab
+// boundary (exposed, but the workgroup then fits TWICE on a CU: 4-wave workgroups of 256 pixels x 64 channels, <= 80 KB of
+// LDS and 256 registers -- two independent workgroups per CU drift out of phase, so one's MFMAs run beside the other's
+// fragment reads, staging and barriers, which the eight lock-stepped waves of one workgroup never do).
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2>
+__global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // 8 waves, two per SIMD.  (4 "fat" waves, one per SIMD with up to 512 registers -- 4x2 tiles, a second fragment set, all
-    // latency hiding inside the wave's own instruction stream -- compile from the same source and were measured 15-25 % SLOWER.)
+    // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
+    // SIMD with up to 512 registers -- 4x2 tiles, a second fragment set, all latency hiding inside the wave's own instruction
+    // stream -- compile from the same source and were measured 15-25 % SLOWER.)
     constexpr int NW = WM * WN, THREADS = 64 * NW;
     constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
@@ -83,9 +88,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
     constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
     constexpr int NTAP = KS * KS;
     constexpr int PAD = (KS - 1) / 2;
-    __shared__ __attribute__((aligned(16))) bf16 smem[2 * 3 * P_PLANE + 3 * W_SLOT];
-    bf16* sP = smem;                                   // [2 buffers][3 planes][pixel][16]
-    bf16* sW = smem + 2 * 3 * P_PLANE;                 // [3 slots][3 planes][BN][16]
+    __shared__ __attribute__((aligned(16))) bf16 smem[PB * 3 * P_PLANE + 3 * W_SLOT];
+    bf16* sP = smem;                                   // [PB buffers][3 planes][pixel][16]
+    bf16* sW = smem + PB * 3 * P_PLANE;                // [3 slots][3 planes][BN][16]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
     // the last third of the MFMAs runs while they arrive; the patch conversion (VALU + ds_write) is placed between MFMA groups
     // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
     // eight waves of the one resident workgroup reach every phase together.)
-    constexpr bool PIPE = NW == 4 || TM * TN <= 2;
+    constexpr bool PIPE = PB == 2 && (NW == 4 || TM * TN <= 2);
     bf16x8 fa[PIPE ? 2 : 1][3][TM], fb[PIPE ? 2 : 1][3][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
@@ -239,8 +244,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
     // not wait for the last reads.  One accumulator (4x2 tiles): smallest terms first.
     auto mfma_terms = [&](auto setc, auto t0c, auto t1c) {
         constexpr int set = decltype(setc)::value, t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        constexpr int PA[6] = {SPLIT ? 0 : 2, 1, 0, SPLIT ? 2 : 1, SPLIT ? 1 : 0, 0};
-        constexpr int PB[6] = {0, SPLIT ? 0 : 1, SPLIT ? 1 : 2, 0, 1, SPLIT ? 2 : 0};
+        constexpr int TA[6] = {SPLIT ? 0 : 2, 1, 0, SPLIT ? 2 : 1, SPLIT ? 1 : 0, 0};
+        constexpr int TBp[6] = {0, SPLIT ? 0 : 1, SPLIT ? 1 : 2, 0, 1, SPLIT ? 2 : 0};
 #pragma unroll
         for (int term = t0; term < t1; ++term)
 #pragma unroll
@@ -248,14 +253,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
                     if (DBG & 1) {
-                        asm volatile("" ::"v"(fa[set][PA[term]][i]), "v"(fb[set][PB[term]][n]));
+                        asm volatile("" ::"v"(fa[set][TA[term]][i]), "v"(fb[set][TBp[term]][n]));
                         continue;
                     }
-                    if (SPLIT && (PA[term] | PB[term]) != 0)
+                    if (SPLIT && (TA[term] | TBp[term]) != 0)
                         lo[SPLIT ? i : 0][SPLIT ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            fb[set][PB[term]][n], fa[set][PA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
+                            fb[set][TBp[term]][n], fa[set][TA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
                     else
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][PB[term]][n], fa[set][PA[term]][i], acc[i][n], 0, 0,
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][TBp[term]][n], fa[set][TA[term]][i], acc[i][n], 0, 0,
                                                                             0);
                 }
     };
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
         // (the compiler waits for the patch registers with a vmcnt that also covers every younger load: convert them BEFORE
         // this step's weight slab is issued, so that wait only sees loads that are at least a step old)
         // (waves w and w+4 share a SIMD: they convert one tap apart, so one of them is always free to feed the matrix pipe)
-        if (tap == 3 + (wave >> 2) && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
+        if (PB == 2 && tap == 3 + (wave >> 2) && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
         // two taps ahead, into the slot every wave left before the previous barrier
         if (s + 2 < nsteps && !(DBG & 4)) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
         mfma_terms(curc, I2{}, I4{});
@@ -293,7 +298,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_halo_x3_kernel(X3Args a) {
         if (++tap == NTAP) {
             tap = 0;
             ++cs;
-            pbuf ^= 1;
+            if (PB == 2) {
+                pbuf ^= 1;
+            } else if (cs < ncs && !(DBG & 16)) {
+                // one patch buffer: every wave is past its last read of the old slab (barrier above) -- convert in place
+                write_patch(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
         slot = slot == 2 ? 0 : slot + 1;
         if constexpr (PIPE) {
@@ -640,9 +652,9 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 
 }  // namespace
@@ -701,6 +713,19 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
         }
     }
     if (force) bn = force;
+    // Default: two 4-wave workgroups of 256 pixels x 64 channels per CU (single patch buffer, <= 64 KB of LDS each).  Two
+    // independent workgroups drift out of phase, so one's MFMAs run beside the other's fragment reads, staging and barriers;
+    // measured against the best one-workgroup-per-CU tile: 5x5 128->64 +27 %, 5x5 256->128 +5 %, 3x3 256->256 at B=48 +16 %,
+    // small launches (<= 256 workgroups) equal.  DWC_X3_DUO=0: the 8-wave tiles below.
+    static const int duo = getenv("DWC_X3_DUO") ? atoi(getenv("DWC_X3_DUO")) : 1;
+    if (duo && !force) {
+        a.tiles_n = (N + 63) / 64;
+        const dim3 g2(blocks * a.tiles_n);
+        if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
+        else x3_launch<5, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     a.tiles_n = (N + bn - 1) / bn;
     const dim3 grid(blocks * a.tiles_n);
     hipStream_t st = (hipStream_t)stream;
