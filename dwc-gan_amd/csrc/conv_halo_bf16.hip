@@ -44,16 +44,20 @@ struct HaloArgs {
 // boundary, one exposed load per K*K taps -- the 5x5 patch does not fit twice beside the weight slabs)
 // DBG (development, timing only -- results are wrong when set): 1 no MFMA, 2 no fragment reads in the loop, 4 no weight staging
 // in the loop, 8 no vmcnt wait, 16 no barrier
+// 8 waves: one workgroup per CU.  4 waves (PB == 1, <= 80 KB of LDS): TWO independent workgroups per CU -- they drift out of
+// phase, so one's MFMAs run beside the other's fragment reads, staging and barriers, which the lock-stepped waves of a single
+// workgroup never do (conv_halo_x3.hip measured +5..27 % from exactly this).
 template <int KS, int BN, int WM, int WN, int TM, int TN, int PB, int DBG = 0>
-__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_kernel(HaloArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(WM * WN == 8 && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
+    constexpr int NW = WM * WN, THREADS = 64 * NW, RP = 8 * NW;      // rows (pixels / channels) staged per pass
+    static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN && BN % RP == 0, "tile shape");
     constexpr int PW = TB + KS - 1;                    // patch edge
     constexpr int PPIX = PW * PW;                      // patch pixels
-    constexpr int PPASS = (PPIX + 63) / 64;            // staging passes of 64 pixels (8 waves x 8 pixels)
-    constexpr int P_TILE = PPASS * 64 * BK;            // elements per patch buffer
+    constexpr int PPASS = (PPIX + RP - 1) / RP;        // staging passes of RP pixels (one wave instruction = 8 pixels)
+    constexpr int P_TILE = PPASS * RP * BK;            // elements per patch buffer
     constexpr int W_TILE = BN * BK;
-    constexpr int W_PASSES = BN / 64;
+    constexpr int W_PASSES = BN / RP;
     constexpr int LDC = BN + 8;
     constexpr int OPER = PB * P_TILE + 2 * W_TILE;
     constexpr int SMEM = OPER > 256 * LDC ? OPER : 256 * LDC;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     unsigned p_off[PPASS];
 #pragma unroll
     for (int i = 0; i < PPASS; ++i) {
-        const int pp = prow + 64 * i;
+        const int pp = prow + RP * i;
         const int py = pp / PW, px = pp - py * PW;
         int h = y0 - PAD + py, w = x0 - PAD + px;
         bool ok = pp < PPIX;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     unsigned w_off[W_PASSES];
 #pragma unroll
     for (int p = 0; p < W_PASSES; ++p) {
-        const int row = prow + 64 * p;
+        const int row = prow + RP * p;
         const int lc = (t & 7) ^ ((row >> 1) & 7);
         w_off[p] = ((unsigned)min(n0 + row, a.N - 1) * a.Kp + lc * 8) * 2u;
     }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #pragma unroll
         for (int i = 0; i < PPASS; ++i) {
             if (i < first || i >= last) continue;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * 64 * BK), 16, p_off[i],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * RP * BK), 16, p_off[i],
                                                      soff, 0, 0);
         }
     };
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
         const int soff = __builtin_amdgcn_readfirstlane((tap * a.Cin + cs * BK) * 2);
 #pragma unroll
         for (int p = 0; p < W_PASSES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * 64 * BK), 16, w_off[p],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * RP * BK), 16, w_off[p],
                                                      soff, 0, 0);
     };
 
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     else to_lds(std::true_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;
-    for (int idx = t; idx < 256 * CPR; idx += 512) {
+    for (int idx = t; idx < 256 * CPR; idx += THREADS) {
         const int row = idx / CPR, ch = idx - row * CPR;
         const int col = n0 + ch * 8;
         if (col >= a.N) continue;
@@ -561,6 +565,25 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
             hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 2>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
+    // DWC_HALO_DUO=1: two 4-wave workgroups per CU (256 pixels x 128 channels for the 3x3, x 64 for the 5x5: <= 80 KB of LDS).
+    // Unlike the split-product kernels (conv_halo_x3.hip: +5..27 %) the plain bf16 kernels gain nothing from it (-7..+4 %):
+    // they are bound by LDS fragment reads and L2->LDS ingest, which a second workgroup shares, not by lock-step -- off.
+    static const int duo = getenv("DWC_HALO_DUO") ? atoi(getenv("DWC_HALO_DUO")) : 0;
+    if (duo) {
+        if (K == 3) {
+            a.tiles_n = (Cout + 127) / 128;
+            if (Cout > 64) hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 1, 2, 4, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
+            else {
+                a.tiles_n = (Cout + 63) / 64;
+                hipLaunchKernelGGL((conv_halo_kernel<3, 64, 4, 1, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
+            }
+        } else {
+            a.tiles_n = (Cout + 63) / 64;
+            hipLaunchKernelGGL((conv_halo_kernel<5, 64, 4, 1, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
+        }
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
