@@ -413,12 +413,14 @@ struct X3WgradArgs {
     int n_tiles, roles;
 };
 
-template <int KS, int BN>
-__global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
+// CIW = 64: 8 waves, one workgroup per CU.  CIW = 32: 4 waves, <= 74 KB of LDS, TWO independent workgroups per CU (see
+// conv_halo_x3_kernel: they drift out of phase and overlap each other's MFMA and load phases).
+template <int KS, int BN, int CIW = 64>
+__global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgrad_x3_kernel(X3WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(BN == 128 || BN == 64, "dY tile width");
+    static_assert((BN == 128 || BN == 64) && (CIW == 64 || CIW == 32), "tile shape");
     constexpr int HALVES = BN == 128 ? 1 : 2;
-    constexpr int CIW = 64;
+    constexpr int QPP = CIW / 4;                       // gather threads per pixel (4 channels each); 32 pixels per pass either way
     constexpr int UH = 8, UW = 16;
     constexpr int PH = UH + KS - 1, PPIX = PH * UW;
     constexpr int PPASS = (PPIX + 31) / 32;            // gather passes of 32 pixels (16 threads x 4 channels per pixel)
@@ -446,13 +448,16 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
     id /= KS;
     const int tn = id % a.n_tiles, cs = id / a.n_tiles;
     const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
-    const int ci_tile = BN == 128 ? (wave >> 2) : (wave & 1);
-    const int co_tile = BN == 128 ? (wave & 3) : ((wave >> 1) & 1);
-    const int half_id = BN == 128 ? 0 : (wave >> 2);
+    const int ci_tile = CIW == 32 ? 0 : (BN == 128 ? (wave >> 2) : (wave & 1));
+    const int co_tile = CIW == 32 ? (BN == 128 ? wave : (wave & 1)) : (BN == 128 ? (wave & 3) : ((wave >> 1) & 1));
+    const int half_id = BN == 128 ? 0 : (CIW == 32 ? (wave >> 1) : (wave >> 2));
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // ---- x patch: thread = (pixel t>>4 [+32 per pass], channel quad t&15) ---------------------------------------------------
-    const int quad = t & 15;
+    // ---- x patch: thread = (pixel t / QPP [+32 per pass], channel quad t % QPP) ----------------------------------------------
+    const int quad = t % QPP;
+    // chunk swizzle of the transposing read: 128-byte rows need it, 64-byte rows (CIW 32) place 4 consecutive pixels on the
+    // four quarters of the 256-byte bank window by themselves
+    auto p_swz = [](int pp) { return CIW == 64 ? 4 * ((pp >> 1) & 1) : 0; };
     f32x4 pv[2];
     auto unit_origin = [&](int u, int& n, int& y0, int& x0) {
         n = u / a.units_per_img;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
         unit_origin(u, n, y0, x0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pp = min((t >> 4) + 32 * (first + j), PPIX - 1);
+            const int pp = min(t / QPP + 32 * (first + j), PPIX - 1);
             const int h = min(reflect_idx(y0 - PAD + (pp >> 4), a.H), a.H - 1);
             const int w = min(reflect_idx(x0 - PAD + kw + (pp & 15), a.W), a.W - 1);
             pv[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.Cin + cs * CIW + quad * 4);
@@ -475,11 +480,11 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
     auto write_patch = [&](int buf, int first) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pp = (t >> 4) + 32 * (first + j);
+            const int pp = t / QPP + 32 * (first + j);
             if (first + j >= PPASS) continue;
             u32x2 p0, p1, p2;
             split3(pv[j], p0, p1, p2);
-            bf16* dst = smem + buf * 3 * P_PLANE + pp * CIW + ((((quad >> 1) ^ (4 * ((pp >> 1) & 1)))) << 3) + (quad & 1) * 4;
+            bf16* dst = smem + buf * 3 * P_PLANE + pp * CIW + (((quad >> 1) ^ p_swz(pp)) << 3) + (quad & 1) * 4;
             *reinterpret_cast<u32x2*>(dst) = p0;
             *reinterpret_cast<u32x2*>(dst + P_PLANE) = p1;
             *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE) = p2;
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(512) void wgrad_x3_kernel(X3WgradArgs a) {
         for (int hf = 0; hf < 2; ++hf) {
             const int pp = r * UW + pxl + 4 * hf;
             v[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (lds4)(plane + pp * CIW + (((a_col >> 3) ^ (4 * ((pp >> 1) & 1))) << 3) + (a_col & 7)));
+                (lds4)(plane + pp * CIW + (((a_col >> 3) ^ p_swz(pp)) << 3) + (a_col & 7)));
         }
         return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
@@ -625,6 +630,13 @@ __global__ void x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __
     dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
 }
 
+// 64: one 8-wave workgroup per CU (default); 32 (DWC_X3_WDUO=1): two 4-wave workgroups per CU -- no gain for this kernel
+// (-3..+1 %: it is bound by the dY fragments it reads straight from L2 / HBM, not by lock-step), kept as a variant
+static int x3_wgrad_ciw() {
+    static const int duo = getenv("DWC_X3_WDUO") ? atoi(getenv("DWC_X3_WDUO")) : 0;
+    return duo ? 32 : 64;
+}
+
 int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
     if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || (Cin % 64)) return 0;
     if (Cout >= 128 && !(Cout % 128)) return 128;
@@ -632,9 +644,10 @@ int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
 }
 
 void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
-    const int roles = (Cin / 64) * (Cout / bn) * K;
+    const int ciw = x3_wgrad_ciw();
+    const int roles = (Cin / ciw) * (Cout / bn) * K;
     const int units = B * (H / 8) * (W / 16);
-    const int cus = 256;                                // one workgroup per CU (LDS): whole rounds, see wgrad_halo_plan
+    const int cus = ciw == 64 ? 256 : 512;              // resident workgroups (LDS): whole rounds, see wgrad_halo_plan
     const int smax = units / 4 > 0 ? units / 4 : 1;
     int s = 1;
     double best = 0.0;
@@ -769,10 +782,16 @@ int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, 
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = Cout;
     a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
     a.n_tiles = Cout / bn;
-    a.roles = (Cin / 64) * a.n_tiles * K;
+    const int ciw = x3_wgrad_ciw();
+    a.roles = (Cin / ciw) * a.n_tiles * K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(a.roles * splits);
-    if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128>), grid, dim3(512), 0, st, a);
+    if (ciw == 32) {
+        if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 32>), grid, dim3(256), 0, st, a);
+        else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 32>), grid, dim3(256), 0, st, a);
+        else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 32>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64, 32>), grid, dim3(256), 0, st, a);
+    } else if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128>), grid, dim3(512), 0, st, a);
     else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64>), grid, dim3(512), 0, st, a);
