@@ -64,6 +64,46 @@ def test_oracle_follows_reference_trajectory_start():
             assert abs(solver.losses[k] - want) <= tol, (it, k, solver.losses[k], want)
 
 
+def test_oracle_follows_reference_trajectory_100_steps():
+    """CPU, all 100 recorded steps of the default-config run at 64x64, batch 4: the oracle (the checker every HIP parity test
+    leans on) against the reference itself, judged exactly like the HIP trainer below -- by the reference's own
+    reproducibility (``_self_drift_envelope``): every step of the first 16 within 5x the envelope, afterwards the median
+    deviation per 10-step window within 4x the reference's, the tail mean within 6 %.  (~4 minutes on 8 cores.)"""
+    from oracle import dwcgan_oracle as orc
+    from solver import Solver
+    env, n = _self_drift_envelope()
+    gold = _rows("s64_b4_default")
+    cfg = synth.make_config(image_size=gold["S"], lstm_dropout=gold["lstm_dropout"])
+    torch.manual_seed(gold["seed"])
+    s = Solver(cfg, torch.device("cpu"), None)
+    solver = orc.OracleSolver(cfg, s.gen.state_dict(), s.dis.state_dict())
+    solver.copy_nets()
+    batch = synth.make_batch(gold["B"], gold["S"], seed=gold["batch_seed"])
+    steps = len(gold["rows"])
+    assert steps == 100
+    dev = {k: [] for k in KEYS}
+    rel_tail = []
+    for it in range(steps):
+        solver.iteration(batch, it)
+        j = min(it + 2, n - 1)
+        for k in KEYS:
+            got, want = solver.losses[k], gold["rows"][it][k]
+            dev[k].append(abs(got - want))
+            if it < 16:
+                tol = max(2e-4 * max(1.0, abs(want)), 5.0 * env[k][j])
+                assert abs(got - want) <= tol, (it, k, got, want, tol)
+        if it >= 80:
+            g, gref = solver.losses["loss_gen_total"], gold["rows"][it]["loss_gen_total"]
+            rel_tail.append(abs(g - gref) / abs(gref))
+    for k in dev:
+        for w0 in range(10, min(steps, n) - 9, 10):
+            mine, ref = float(np.median(dev[k][w0:w0 + 10])), float(np.median(env[k][w0:w0 + 10]))
+            assert mine <= 4.0 * ref + 1e-3, (k, w0, mine, ref)
+    assert float(np.mean(rel_tail)) <= 0.06
+    print("oracle vs reference, 100 steps: max |d loss_gen_total| first 16 steps %.3e, tail mean rel %.4f" % (
+        max(dev["loss_gen_total"][:16]), float(np.mean(rel_tail))))
+
+
 def _run_hip(tag, steps):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "benchmarks"))
