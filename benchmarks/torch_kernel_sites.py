@@ -39,7 +39,7 @@ def main():
         bench.run_iteration(trainer, batch, cfg, it)
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         bench.run_iteration(trainer, batch, cfg, 3)
         torch.cuda.synchronize()
     sites = collections.defaultdict(lambda: [0, 0.0])
@@ -53,7 +53,8 @@ def main():
             if "/dwc-gan_amd/" in fr or "/bench.py" in fr:
                 frame = fr.split("/dwc-gan_amd/")[-1] if "/dwc-gan_amd/" in fr else fr.split("/")[-1]
                 break
-        key = (ev.name, frame)
+        shp = str(getattr(ev, "input_shapes", ""))[:60]
+        key = (ev.name, frame + " " + shp)
         sites[key][0] += nk
         sites[key][1] += sum(k.duration for k in ev.kernels)
     tot_n = sum(v[0] for v in sites.values())
