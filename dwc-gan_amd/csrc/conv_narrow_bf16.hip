@@ -1,0 +1,199 @@
+// bf16 7x7 convolutions from 64 channels to the 8 planes of an NHWC8 image: the fused image heads of the decoder
+// (reference networks.py:218-246: tanh x3 + sigmoid, forward) and the data gradient of the 7x7 stems w.r.t. their input image
+// (reference networks.py:579-585 backward).  The im2col GEMM ran these at 3-10 % of the MFMA peak: N = 8 fills a quarter of a
+// 32-wide tile even in the "wide" form (4 horizontally adjacent pixels x 8 planes = 32 columns, filter bank
+// [32][KH][KW+3][64], see ops._prepped 'heads_wide' / 'dgrad_image'), and every input pixel was re-staged once per tap
+// (70 times).
+//
+// Here a workgroup owns a block of 16 rows x 8 pixel groups (= 32 pixels) of one image:
+//  * the (16+KH-1) x (32+KW+2) input patch (64 channels, 128-byte rows) is staged ONCE by LDS-DMA (reflect or zero rule
+//    applied while staging, chunk swizzle keyed on (patch column >> 2) so that the 8 groups of a row -- 512 bytes apart --
+//    fall on different banks);
+//  * the KH*(KW+3) taps are dealt round-robin to the 8 waves; a wave multiplies its taps against all 4 group tiles
+//    (D[32 columns][32 groups] += W_tap[32][64] . X_tap[64][32 groups]) with its weight fragments read straight from
+//    global memory / L2 one tap ahead -- no wave shares a tap, so weights need no LDS and the tap loop has no barrier;
+//  * the 8 partial sums meet in LDS (fixed order), bias + activation, 8-byte stores of 4 planes.
+// Output [B][OH][OWg][32] bf16 (= the NHWC8 image when OWg*4 is its width); the input window of output (oy, group gx) starts at
+// (oy + off_h, 4*gx + off_w): forward off = -pad with the reflect rule; image gradient off = -(K-1) with the zero rule on
+// the padded grid (OH = H + 2 pad), folded back by dwc_bf16_reflect_pad_adjoint's kernel as before.
+#include "conv_geom.h"
+
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NB_ROWS = 16, NB_GROUPS = 8, NCH = 64;
+
+struct NarrowArgs {
+    const bf16* x;       // [B][IH][IW][64]
+    const bf16* w;       // [32][Kp], k = (kh*KWw + u)*64 + ci   (dwc_bf16_weight_prepare_fwd of the wide bank)
+    const float* bias;   // [32] or null
+    bf16* y;             // [B][OH][OWg][32]
+    int B, IH, IW, OH, OWg, Kp, off_h, off_w, act, reflect;
+    int blocks_x, blocks_y;
+};
+
+template <int KH, int KWW>
+__global__ __launch_bounds__(512) void conv_narrow_kernel(NarrowArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PR = NB_ROWS + KH - 1, PC = 4 * NB_GROUPS + KWW - 1, PPIX = PR * PC;
+    constexpr int PPASS = (PPIX + 63) / 64;
+    constexpr int NTAP = KH * KWW;
+    constexpr int RED = 8 * 2 * 16 * 64;                // floats of one reduction round: [wave][tile][reg][lane]
+    constexpr int SMEM_B = PPASS * 64 * NCH * 2 > RED * 4 ? PPASS * 64 * NCH * 2 : RED * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_B];
+    bf16* sP = reinterpret_cast<bf16*>(smem_raw);
+    float* sR = reinterpret_cast<float*>(smem_raw);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int bid = blockIdx.x;
+    const int bx = bid % a.blocks_x;
+    bid /= a.blocks_x;
+    const int by = bid % a.blocks_y, n = bid / a.blocks_y;
+    const int oy0 = by * NB_ROWS, gx0 = bx * NB_GROUPS;
+
+    // ---- patch: one LDS-DMA pass per 64 pixels; chunk swizzle by (patch column >> 2) ----------------------------------------
+    const unsigned x_bytes = (unsigned)a.B * a.IH * a.IW * NCH * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    {
+        bf16* lp = sP + wave * (8 * NCH);
+#pragma unroll
+        for (int i = 0; i < PPASS; ++i) {
+            const int pp = (t >> 3) + 64 * i;
+            const int pr = pp / PC, pc = pp - pr * PC;
+            int h = oy0 + pr + a.off_h, w = 4 * gx0 + pc + a.off_w;
+            bool ok = pp < PPIX;
+            if (a.reflect) {
+                h = reflect_idx(h, a.IH);
+                w = reflect_idx(w, a.IW);
+                // (blocks that hang over the image edge ask for pixels more than one reflection away: the clamp below picks an
+                // in-range pixel, their outputs are masked)
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.IH && (unsigned)w < (unsigned)a.IW;
+            }
+            h = min(max(h, 0), a.IH - 1);
+            w = min(max(w, 0), a.IW - 1);
+            const int lc = (t & 7) ^ ((pc >> 2) & 7);
+            const unsigned off = ((unsigned)((n * a.IH + h) * a.IW + w) * NCH + (unsigned)(lc * 8)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * 64 * NCH), 16,
+                                                     ok ? off : OOB, 0, 0, 0);
+        }
+    }
+
+    // ---- this wave's taps ---------------------------------------------------------------------------------------------------
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    // group of tile m and lane: g = m*32 + l31 -> (row g >> 3, group-in-row g & 7); patch pixel of tap (kh, u): row + kh, 4*gl + u
+    int g_base[4], g_col[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int g = m * 32 + l31;
+        g_base[m] = (g >> 3) * PC + 4 * (g & 7);
+        g_col[m] = 4 * (g & 7);
+    }
+    const bf16* wrow = a.w + (size_t)l31 * a.Kp + hi * 8;
+    bf16x8 fb[4], fbn[4];
+    auto load_w = [&](int tp, bf16x8* dst) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(wrow + tp * NCH + q * 16);
+    };
+    if (wave < NTAP) load_w(wave, fb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                    // patch landed (every wave's share)
+    for (int tp = wave; tp < NTAP; tp += 8) {
+        const bool more = tp + 8 < NTAP;
+        if (more) load_w(tp + 8, fbn);
+        const int kh = tp / KWW, u = tp - kh * KWW;
+        const int d = kh * PC + u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int pp = g_base[m] + d;
+            const int sw = ((g_col[m] + u) >> 2) & 7;
+            const bf16* p = sP + pp * NCH;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(p + (((2 * q + hi) ^ sw) << 3));
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[q], fa, acc[m], 0, 0, 0);      // D[column][group]
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb[q] = fbn[q];
+        }
+    }
+
+    // ---- the 8 partial sums meet in LDS, two group tiles per round -----------------------------------------------------------
+    const int tile2 = t >> 8, rb = (t >> 6) & 3;        // epilogue thread: tile (of the round), register block, lane
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        __syncthreads();                                // patch (round 0) / previous round's sums fully read
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sR[((wave * 2 + mm) * 16 + r) * 64 + lane] = acc[2 * round + mm][r];
+        __syncthreads();
+        // thread (tile2, rb, lane): registers 4*rb .. 4*rb+3 of lane -> columns 8*rb + 4*hi + k = pixel rb of the group, planes 4*hi+k
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += sR[((w8 * 2 + tile2) * 16 + 4 * rb + k) * 64 + lane];      // fixed order
+            v[k] = s;
+        }
+        const int g = (2 * round + tile2) * 32 + l31;
+        const int oy = oy0 + (g >> 3), gx = gx0 + (g & 7);
+        if (oy < a.OH && gx < a.OWg) {
+            const int c0 = 8 * rb + 4 * hi;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (a.bias) v[k] += a.bias[c0 + k];
+                v[k] = dwc_act_apply(v[k], a.act, c0 + k);
+            }
+            bf16x4 o;
+            o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+            *reinterpret_cast<bf16x4*>(a.y + ((size_t)(n * a.OH + oy) * a.OWg + gx) * 32 + c0) = o;
+        }
+    }
+#endif
+}
+
+bool narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW) {
+    return B > 0 && Cin == NCH && KH == 7 && KWW == 10 && OH > 0 && OWg > 0 && IH >= KH && IW >= KWW &&
+           (size_t)B * IH * IW * NCH * 2 < 0x80000000ull;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW) {
+    return narrow_ok(B, IH, IW, Cin, OH, OWg, KH, KWW) ? 1 : 0;
+}
+
+/* y[B][OH][OWg][32] (bf16; 4 pixels x 8 planes per group) = act(sum over the KH x KWW wide taps and 64 channels + bias32) with
+ * the input window of (oy, gx) starting at (oy + off_h, 4*gx + off_w) of x[B][IH][IW][64]; w_wide = the [32][KH][KWW][64]
+ * bank in dwc_bf16_weight_prepare_fwd layout (row pitch Kp = KH*KWW*64 rounded up to 64).  reflect != 0: reflect rule
+ * (forward heads), else zero rule (image gradient on the padded grid). */
+int dwc_bf16_conv2d_narrow(const void* x, const void* w_wide, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
+                           int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream) {
+    if (!x || !w_wide || !y || !narrow_ok(B, IH, IW, Cin, OH, OWg, KH, KWW)) return DWC_EINVAL;
+    NarrowArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_wide; a.bias = bias32; a.y = (bf16*)y;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg; a.Kp = (KH * KWW * NCH + 63) / 64 * 64;
+    a.off_h = off_h; a.off_w = off_w; a.act = act; a.reflect = reflect;
+    a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + NB_ROWS - 1) / NB_ROWS;
+    hipLaunchKernelGGL((conv_narrow_kernel<7, 10>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

@@ -267,6 +267,7 @@ WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 X3 = int(os.environ.get("DWC_X3", "1"))
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
+NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
 
 
 _WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
@@ -536,10 +537,16 @@ class _HeadsConvWide(torch.autograd.Function):
         y = empty_cl(B, P, H, W, x.device, x.dtype)
         st = _stream()
         flops = 2.0 * B * H * W * 4 * C * KH * KW
-        _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_ex", x)(
-            x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad,
-            ACT["heads8" if P == 8 else "heads"], st), detail="fwd-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)),
-            "conv2d_fwd_ex")
+        if half and NARROW and lib.dwc_bf16_conv2d_narrow_ok(B, H, W, C, H, W // px, KH, KW + px - 1):
+            # patch staged once per 16x32-pixel block, taps dealt to the waves (csrc/conv_narrow_bf16.hip)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_narrow(
+                x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, H, W // px, KH, KW + px - 1, -pad, -pad,
+                ACT["heads8"], 1, st), detail="fwd-heads-narrow B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_narrow")
+        else:
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_ex", x)(
+                x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad,
+                ACT["heads8" if P == 8 else "heads"], st), detail="fwd-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)),
+                "conv2d_fwd_ex")
         ctx.save_for_backward(x, w4, y)
         ctx.owner = owner
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
