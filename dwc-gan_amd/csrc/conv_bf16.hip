@@ -964,16 +964,28 @@ int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx,
     FwdGeom f;
     if (!image_dgrad_geom(dy, ws, B, H, W, Cout, KH, KW, pad, &f, 4)) return DWC_EINVAL;
     if (!ws || ws_bytes < f.dst_elems * sizeof(bf16)) return DWC_EWORKSPACE;
-    static const int narrow = getenv("DWC_BF16_NARROW") ? atoi(getenv("DWC_BF16_NARROW")) : 1;
-    int rc;
-    if (narrow && dwc_bf16_conv2d_narrow_ok(B, H, W, Cout, f.g.OH, f.g.OW, KH, KW + 3))
-        // patch staged once per block, taps dealt to the waves (conv_narrow_bf16.hip) instead of the 128x32 im2col tiles
-        rc = dwc_bf16_conv2d_narrow(dy, w_wide, nullptr, ws, B, H, W, Cout, f.g.OH, f.g.OW, KH, KW + 3, f.g.off_h, f.g.off_w,
-                                    DWC_ACT_NONE, 0, stream);
-    else
-        rc = launch_gemm_h(f.g, (const bf16*)w_wide, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, nullptr, 0, (hipStream_t)stream);
+    const int rc = launch_gemm_h(f.g, (const bf16*)w_wide, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, nullptr, 0,
+                                 (hipStream_t)stream);
     if (rc != DWC_OK) return rc;
     const size_t total = (size_t)B * H * W * 2;       // 8 planes = 2 groups of 4 per pixel
+    hipLaunchKernelGGL(fold_reflect_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)ws,
+                       (bf16*)dx, B, H, W, 2, pad, f.g.OW * 4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* the same gradient on conv_narrow_bf16.hip (patch staged once per block, taps dealt to the waves): w_frag = the wide bank in
+ * fragment order (see dwc_bf16_conv2d_narrow); scratch as dwc_bf16_conv2d_bwd_data_image_ws_bytes */
+int dwc_bf16_conv2d_bwd_data_image_narrow(const void* dy, const void* w_frag, void* dx, int B, int H, int W, int Cout, int KH, int KW,
+                                          int pad, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if (!image_dgrad_geom(dy, ws, B, H, W, Cout, KH, KW, pad, &f, 4)) return DWC_EINVAL;
+    if (!dwc_bf16_conv2d_narrow_ok(B, H, W, Cout, f.g.OH, f.g.OW, KH, KW + 3)) return DWC_EINVAL;
+    if (!ws || ws_bytes < f.dst_elems * sizeof(bf16)) return DWC_EWORKSPACE;
+    const int rc = dwc_bf16_conv2d_narrow(dy, w_frag, nullptr, ws, B, H, W, Cout, f.g.OH, f.g.OW, KH, KW + 3, f.g.off_h, f.g.off_w,
+                                          DWC_ACT_NONE, 0, stream);
+    if (rc != DWC_OK) return rc;
+    const size_t total = (size_t)B * H * W * 2;
     hipLaunchKernelGGL(fold_reflect_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)ws,
                        (bf16*)dx, B, H, W, 2, pad, f.g.OW * 4);
     DWC_LAUNCH_CHECK();

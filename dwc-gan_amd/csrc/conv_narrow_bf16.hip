@@ -24,24 +24,27 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NB_ROWS = 16, NB_GROUPS = 8, NCH = 64;
+constexpr int NB_GROUPS = 8, NCH = 64;
 
 struct NarrowArgs {
     const bf16* x;       // [B][IH][IW][64]
-    const bf16* w;       // [32][Kp], k = (kh*KWw + u)*64 + ci   (dwc_bf16_weight_prepare_fwd of the wide bank)
+    const bf16* w;       // [tap][q][lane][8]: MFMA-fragment order of the wide bank (one contiguous 1 KB read per wave and k-step)
     const float* bias;   // [32] or null
     bf16* y;             // [B][OH][OWg][32]
-    int B, IH, IW, OH, OWg, Kp, off_h, off_w, act, reflect;
+    int B, IH, IW, OH, OWg, off_h, off_w, act, reflect;
     int blocks_x, blocks_y;
 };
 
-template <int KH, int KWW>
-__global__ __launch_bounds__(512) void conv_narrow_kernel(NarrowArgs a) {
+// NB_ROWS = 8: 73.5 KB of LDS and <= 128 registers, so TWO workgroups share a CU and one's patch staging / reduction runs beside
+// the other's tap loop (16 rows, one workgroup per CU: 14.5 us per 512-pixel block, most of it exposed staging latency).
+template <int KH, int KWW, int NB_ROWS>
+__global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(NarrowArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MT = NB_ROWS / 4;                     // 32-group tiles per block (8 groups per row)
     constexpr int PR = NB_ROWS + KH - 1, PC = 4 * NB_GROUPS + KWW - 1, PPIX = PR * PC;
     constexpr int PPASS = (PPIX + 63) / 64;
     constexpr int NTAP = KH * KWW;
-    constexpr int RED = 8 * 2 * 16 * 64;                // floats of one reduction round: [wave][tile][reg][lane]
+    constexpr int RED = 8 * 2 * 16 * 64;                // floats of one reduction round (two tiles): [wave][tile][reg][lane]
     constexpr int SMEM_B = PPASS * 64 * NCH * 2 > RED * 4 ? PPASS * 64 * NCH * 2 : RED * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_B];
     bf16* sP = reinterpret_cast<bf16*>(smem_raw);
@@ -86,24 +89,26 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(NarrowArgs a) {
     }
 
     // ---- this wave's taps ---------------------------------------------------------------------------------------------------
-    f32x16 acc[4];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     // group of tile m and lane: g = m*32 + l31 -> (row g >> 3, group-in-row g & 7); patch pixel of tap (kh, u): row + kh, 4*gl + u
-    int g_base[4], g_col[4];
+    int g_base[MT], g_col[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
         const int g = m * 32 + l31;
         g_base[m] = (g >> 3) * PC + 4 * (g & 7);
         g_col[m] = 4 * (g & 7);
     }
-    const bf16* wrow = a.w + (size_t)l31 * a.Kp + hi * 8;
+    // (read in the prepared [32][Kp] layout a load instruction touched 64 different cache lines -- 17 us per block, all of it
+    // address traffic; fragment order makes it one contiguous kilobyte)
+    const bf16* wlane = a.w + lane * 8;
     bf16x8 fb[4], fbn[4];
     auto load_w = [&](int tp, bf16x8* dst) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(wrow + tp * NCH + q * 16);
+        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(wlane + (tp * 4 + q) * 512);
     };
     if (wave < NTAP) load_w(wave, fb);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(NarrowArgs a) {
         const int kh = tp / KWW, u = tp - kh * KWW;
         const int d = kh * PC + u;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MT; ++m) {
             const int pp = g_base[m] + d;
             const int sw = ((g_col[m] + u) >> 2) & 7;
             const bf16* p = sP + pp * NCH;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(NarrowArgs a) {
     // ---- the 8 partial sums meet in LDS, two group tiles per round -----------------------------------------------------------
     const int tile2 = t >> 8, rb = (t >> 6) & 3;        // epilogue thread: tile (of the round), register block, lane
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < MT / 2; ++round) {
         __syncthreads();                                // patch (round 0) / previous round's sums fully read
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
@@ -180,18 +185,22 @@ int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, i
 }
 
 /* y[B][OH][OWg][32] (bf16; 4 pixels x 8 planes per group) = act(sum over the KH x KWW wide taps and 64 channels + bias32) with
- * the input window of (oy, gx) starting at (oy + off_h, 4*gx + off_w) of x[B][IH][IW][64]; w_wide = the [32][KH][KWW][64]
- * bank in dwc_bf16_weight_prepare_fwd layout (row pitch Kp = KH*KWW*64 rounded up to 64).  reflect != 0: reflect rule
- * (forward heads), else zero rule (image gradient on the padded grid). */
-int dwc_bf16_conv2d_narrow(const void* x, const void* w_wide, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
+ * the input window of (oy, gx) starting at (oy + off_h, 4*gx + off_w) of x[B][IH][IW][64].  w_frag = the [32][KH][KWW][64]
+ * wide bank in MFMA-fragment order [tap][q][hi][row][8] (tap = kh*KWW + u, q = 16-channel step, hi = 8-channel half):
+ * dwc_bf16_weight_prepare_fwd's [32][Kp] layout permuted.  reflect != 0: reflect rule (forward heads), else zero rule (image
+ * gradient on the padded grid). */
+int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream) {
-    if (!x || !w_wide || !y || !narrow_ok(B, IH, IW, Cin, OH, OWg, KH, KWW)) return DWC_EINVAL;
+    if (!x || !w_frag || !y || !narrow_ok(B, IH, IW, Cin, OH, OWg, KH, KWW)) return DWC_EINVAL;
     NarrowArgs a;
-    a.x = (const bf16*)x; a.w = (const bf16*)w_wide; a.bias = bias32; a.y = (bf16*)y;
-    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg; a.Kp = (KH * KWW * NCH + 63) / 64 * 64;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_frag; a.bias = bias32; a.y = (bf16*)y;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg;
     a.off_h = off_h; a.off_w = off_w; a.act = act; a.reflect = reflect;
-    a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + NB_ROWS - 1) / NB_ROWS;
-    hipLaunchKernelGGL((conv_narrow_kernel<7, 10>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    static const int rows16 = getenv("DWC_NARROW_ROWS16") ? atoi(getenv("DWC_NARROW_ROWS16")) : 0;
+    const int nb_rows = rows16 ? 16 : 8;
+    a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + nb_rows - 1) / nb_rows;
+    if (rows16) hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 16>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

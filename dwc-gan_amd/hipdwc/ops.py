@@ -211,6 +211,14 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
                                              _stream()), "x3_weight_prepare")
         ent[key] = (stamp, out)
         return out
+    if kind in ("heads_narrow", "dgrad_image_narrow"):
+        # the wide bank ([32][taps*64] prepared rows) in MFMA-fragment order [tap][q][hi][row][8] for csrc/conv_narrow_bf16.hip
+        base = _prepped(w, "heads_wide" if kind == "heads_narrow" else "dgrad_image", cout_pad, cin_pad, stride, owner, True)
+        ch = cout_pad if kind == "dgrad_image_narrow" else cin_pad          # contraction channels (64)
+        taps = base.numel() // (32 * ch)
+        out = base.view(32, taps, ch // 16, 2, 8).permute(1, 2, 3, 0, 4).contiguous()
+        ent[key] = (stamp, out)
+        return out
     if kind == "heads_wide":
         # the P-plane heads (P = w.shape[0]: 4, or 8 on the bf16 path) as px = 32/P pixels x P planes:
         # bank [p*P + co][ci][KH][KW+px-1], copy p shifted right by p taps
@@ -423,15 +431,23 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0] and Cx == image_planes(dt) and same:
             # gradient w.r.t. an NHWC4 / NHWC8 image (7x7 stems): 32/Cx pixels x Cx planes per GEMM row,
             # see dwc_conv2d_bwd_data_image
-            w_img = _prepped(w, "dgrad_image", cop, Cx, 1, owner, half)
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = _fn(lib, "conv2d_bwd_data_image_ws_bytes", x)(B, H, W, cop, KH, KW, pad)
             ws = workspace(nws, dev)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_image", x)(
-                g.data_ptr(), w_img.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
-                scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
-                "conv2d_bwd_data_image")
+            wg4 = (W + 2 * pad + 3) // 4
+            if half and NARROW and lib.dwc_bf16_conv2d_narrow_ok(B, H, W, cop, H + 2 * pad, wg4, KH, KW + 3):
+                w_frag = _prepped(w, "dgrad_image_narrow", cop, Cx, 1, owner, True)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_bwd_data_image_narrow(
+                    g.data_ptr(), w_frag.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="dgrad-image-narrow B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                    "conv2d_bwd_data_image_narrow")
+            else:
+                w_img = _prepped(w, "dgrad_image", cop, Cx, 1, owner, half)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_image", x)(
+                    g.data_ptr(), w_img.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="dgrad-image B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                    "conv2d_bwd_data_image")
         elif ctx.needs_input_grad[0] and same and min(H, W) >= 2 * pad + 2 and (not half or cop >= 64):
             # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
             w_dg = _prepped(w, "dgrad", cop, Cx, 1, owner, half)
@@ -540,8 +556,9 @@ class _HeadsConvWide(torch.autograd.Function):
         if half and NARROW and lib.dwc_bf16_conv2d_narrow_ok(B, H, W, C, H, W // px, KH, KW + px - 1):
             # patch staged once per 16x32-pixel block, taps dealt to the waves (csrc/conv_narrow_bf16.hip)
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_narrow(
-                x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, H, W // px, KH, KW + px - 1, -pad, -pad,
-                ACT["heads8"], 1, st), detail="fwd-heads-narrow B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_narrow")
+                x.data_ptr(), _prepped(w4, "heads_narrow", 32, C, 1, owner, True).data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W,
+                C, H, W // px, KH, KW + px - 1, -pad, -pad, ACT["heads8"], 1, st),
+                detail="fwd-heads-narrow B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_narrow")
         else:
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_ex", x)(
                 x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad,

@@ -330,11 +330,14 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
 /* 7x7 convolutions from 64 channels to the 8 planes of an NHWC8 image in the "wide" form (4 pixels x 8 planes = 32 columns,
  * bank [32][7][10][64] from dwc_bf16_weight_prepare_fwd): the fused image heads (reference networks.py:218-246; off = -3,
  * reflect rule, DWC_ACT_HEADS8) and the gradient of a 7x7 stem w.r.t. its input image on the padded grid (off = -6, zero
- * rule; dwc_bf16_conv2d_bwd_data_image uses it).  Patch staged once per 16x32-pixel block, taps dealt to the waves, weight
- * fragments straight from L2.  y: [B][OH][OWg][32] bf16. */
+ * rule; dwc_bf16_conv2d_bwd_data_image_narrow = that + the reflect fold).  Patch staged once per 16x32-pixel block, taps dealt
+ * to the waves, weight fragments straight from L2 in fragment order w_frag[tap][q][hi][row][8] (the [32][Kp] layout of
+ * dwc_bf16_weight_prepare_fwd permuted by the caller).  y: [B][OH][OWg][32] bf16. */
 int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW);
-int dwc_bf16_conv2d_narrow(const void* x, const void* w_wide, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
+int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
+int dwc_bf16_conv2d_bwd_data_image_narrow(const void* dy, const void* w_frag, void* dx, int B, int H, int W, int Cout, int KH, int KW,
+                                          int pad, void* ws, size_t ws_bytes, void* stream);
 /* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
 size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
