@@ -322,7 +322,12 @@ class _Conv2d(torch.autograd.Function):
         cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not ctx.needs_input_grad[1])
+        # (inside torch.no_grad() needs_input_grad still reports the parameters' requires_grad.  Measured on c1, same box: treating
+        # those forwards -- 48 3x3 layers per step -- as gradient-free and sending them to the split-product kernel costs 4 ms per
+        # step (206 vs 218 images/s), and so does merely dropping their v_keep buffer so that V lands in the shared scratch arena
+        # (207 vs 220): both decisions therefore follow needs_input_grad alone.)
+        w_grad = ctx.needs_input_grad[1]
+        use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         w_hwio = None if use_wino or use_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
@@ -339,7 +344,7 @@ class _Conv2d(torch.autograd.Function):
             ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop, wt), x.device)
             # the transformed input is what the weight gradient contracts with: keep it instead of transforming x again
             v_keep = torch.empty((wt + 2) ** 2 * B * (H // wt) * (W // wt) * Cx, dtype=torch.float32,
-                                 device=x.device) if ctx.needs_input_grad[1] else None
+                                 device=x.device) if w_grad else None
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
