@@ -171,6 +171,167 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The opposite shape: 7x7 convolutions from the 8 planes of an NHWC8 image to 64 channels -- the stems (forward, reference
+// networks.py:163-166 / :60-66) and the data gradient of the image heads.  K = 49 taps x 8 planes: one MFMA k-step is TWO taps
+// (lane half hi takes tap 2j+hi: 8 planes = one 16-byte pixel of the patch), 25 steps.  The whole filter (25 x 64 x 32 bytes
+// = 50 KB, halves of a row swapped by (row>>3)&1 as in conv_halo_x3.hip) stays in LDS while the workgroup walks over 16x16-pixel
+// blocks (persistent: gridDim.x workgroups stride over the blocks); the patch is 22x22 pixels x 16 bytes.  4 waves, 2x2 tiles
+// of 32 pixels x 32 channels each; output through LDS as 16-byte channel chunks.  The layer is bound by its 64-channel
+// output (128 bytes per pixel), not by the matrix pipe.
+// ------------------------------------------------------------------------------------------
+struct StemArgs {
+    const bf16* x;       // [B][IH][IW][8]
+    const bf16* w;       // [25][64][16]: k-step j, channel co, (tap 2j + h, plane p) at ((h ^ ((co>>3)&1))*8 + p)
+    const float* bias;   // [64] or null
+    bf16* y;             // [B][OH][OW][64]
+    int B, IH, IW, OH, OW, off, act, reflect;
+    int blocks_x, blocks_y, nblocks;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = 7, PW = 16 + KS - 1, PPIX = PW * PW, NKS = 25;
+    constexpr int W_EL = NKS * 64 * 16;                 // 25600 elements = 51200 bytes
+    constexpr int P_EL = 512 * 8;                       // one patch buffer: 484 pixels x 8 planes (whole DMA instructions)
+    constexpr int LDC = 64 + 8;                         // epilogue staging pitch
+    constexpr int OPER = W_EL + P_EL;
+    constexpr int SMEM = OPER + 128 * LDC;             // 77.6 KB: two workgroups per CU; the epilogue stages 128 pixels at a time
+    // (a second patch buffer + 64-pixel epilogue phases, to prefetch the next block's patch, measured 25 % slower: the four
+    // extra barriers per block cost more than the exposed 8 KB patch load)
+    __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];
+    bf16* sW = smem;
+    bf16* sP = smem + W_EL;
+    bf16* sC = smem + OPER;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave;                                // wave w: pixel tiles 2w, 2w+1 (64 pixels); both channel tiles
+    // ---- the filter, once -------------------------------------------------------------------------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, W_EL * 2u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < (W_EL * 2 + 4095) / 4096; ++i) {          // 256 lanes x 16 bytes per instruction
+            const unsigned off = (unsigned)(i * 4096 + t * 16);
+            if (off < W_EL * 2u)                        // (masked lanes write nothing: the tail must not spill zeros over the patch)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sW + i * 2048 + wave * 512),
+                                                         16, off, 0, 0, 0);
+        }
+    }
+    const unsigned x_bytes = (unsigned)a.B * a.IH * a.IW * 16u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
+    auto stage_patch = [&](int blk, int buf) {          // 2 DMA instructions of 256 pixels
+        int bid = blk;
+        const int bx = bid % a.blocks_x;
+        bid /= a.blocks_x;
+        const int by = bid % a.blocks_y, n = bid / a.blocks_y;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pp = t + 256 * i;
+            const int pr = pp / PW, pc = pp - pr * PW;
+            int h = by * 16 + pr + a.off, w = bx * 16 + pc + a.off;
+            bool ok = pp < PPIX;
+            if (a.reflect) {
+                h = reflect_idx(h, a.IH);
+                w = reflect_idx(w, a.IW);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.IH && (unsigned)w < (unsigned)a.IW;
+            }
+            h = min(max(h, 0), a.IH - 1);
+            w = min(max(w, 0), a.IW - 1);
+            const unsigned off = (unsigned)((n * a.IH + h) * a.IW + w) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sP + buf * P_EL + i * 2048 + wave * 512),
+                                                     16, ok ? off : 0x80000000u, 0, 0, 0);
+        }
+    };
+    // fragment addressing: pixel tile i of this wave: block pixel pb = (2*wm + i)*32 + l31 -> patch pixel (pb>>4)*PW + (pb&15)
+    int pp0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pb = (2 * wm + i) * 32 + l31;
+        pp0[i] = (pb >> 4) * PW + (pb & 15);
+    }
+    const int b_off = l31 * 16 + ((hi ^ ((l31 >> 3) & 1)) * 8);
+    const float slope = dwc_act_slope(a.act);
+
+    constexpr int buf = 0;
+    for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
+        int bid = blk;
+        const int bx = bid % a.blocks_x;
+        bid /= a.blocks_x;
+        const int by = bid % a.blocks_y, n = bid / a.blocks_y;
+        const int oy0 = by * 16, ox0 = bx * 16;
+        __syncthreads();                                              // every wave is past the previous block's reads
+        stage_patch(blk, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this block's patch (and, the first time, the filter)
+        __syncthreads();
+        const bf16* p = sP + buf * P_EL;
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 5
+        for (int j = 0; j < NKS; ++j) {
+            const int tp = min(2 * j + hi, KS * KS - 1);             // (tap 49 of the last step has zero weights)
+            const int kh = tp / KS, kw = tp - kh * KS;
+            const int d = kh * PW + kw;
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(p + (pp0[i] + d) * 8);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) fb[c] = *reinterpret_cast<const bf16x8*>(sW + (j * 64 + c * 32) * 16 + b_off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c], fa[i], acc[i][c], 0, 0, 0);
+        }
+        // ---- epilogue: D[channel][pixel]: lane = pixel, 4 consecutive channels per register quad -> LDS -> 16-byte chunks,
+        // 128 pixels (the tiles of two waves) per phase -----------------------------------------------------------------------
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((wm >> 1) == ph) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (2 * (wm & 1) + i) * 32 + l31;       // row inside the phase's 128 pixels
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const int col = c * 32 + 8 * q4 + 4 * hi;
+                            f32x4 v = {acc[i][c][4 * q4], acc[i][c][4 * q4 + 1], acc[i][c][4 * q4 + 2], acc[i][c][4 * q4 + 3]};
+                            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                            bf16x4 o;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) o[k] = (bf16)dwc_act_simple(v[k], slope);
+                            *reinterpret_cast<bf16x4*>(sC + row * LDC + col) = o;
+                        }
+                }
+            }
+            __syncthreads();
+            for (int idx = t; idx < 128 * 8; idx += 256) {
+                const int row = idx >> 3, ch = idx & 7;
+                const int pb = ph * 128 + row;
+                const int yy = oy0 + (pb >> 4), xx = ox0 + (pb & 15);
+                if (yy < a.OH && xx < a.OW)
+                    *reinterpret_cast<bf16x8*>(a.y + ((size_t)(n * a.OH + yy) * a.OW + xx) * 64 + ch * 8) =
+                        *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+            }
+            if (ph == 0) __syncthreads();
+        }
+    }
+#endif
+}
+
+bool stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act) {
+    return B > 0 && K == 7 && IH >= 7 && IW >= 7 && OH > 0 && OW > 0 && act <= DWC_ACT_LRELU &&
+           (size_t)B * IH * IW * 16 < 0x80000000ull;
+}
+
 bool narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW) {
     return B > 0 && Cin == NCH && KH == 7 && KWW == 10 && OH > 0 && OWg > 0 && IH >= KH && IW >= KWW &&
            (size_t)B * IH * IW * NCH * 2 < 0x80000000ull;
@@ -201,6 +362,25 @@ int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias3
     a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + nb_rows - 1) / nb_rows;
     if (rows16) hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 16>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_bf16_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act) { return stem_ok(B, IH, IW, OH, OW, K, act) ? 1 : 0; }
+
+/* y[B][OH][OW][64] = act(conv7x7(x[B][IH][IW][8 planes]) + bias), window of output (oy, ox) starting at (oy + off, ox + off);
+ * reflect != 0: reflect rule (stems forward, off = -3), else zero rule (data gradient of the image heads on the padded grid,
+ * off = -6).  act: none / relu / lrelu.  w_steps: [25][64][16] bf16, element (k-step j, channel co, tap 2j+h, plane p) at
+ * ((h ^ ((co>>3)&1))*8 + p), taps beyond 48 zero (built by the caller from the OIHW filter). */
+int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, void* y, int B, int IH, int IW, int OH, int OW, int K,
+                         int off, int act, int reflect, void* stream) {
+    if (!x || !w_steps || !y || !stem_ok(B, IH, IW, OH, OW, K, act)) return DWC_EINVAL;
+    StemArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_steps; a.bias = bias; a.y = (bf16*)y;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.off = off; a.act = act; a.reflect = reflect;
+    a.blocks_x = (OW + 15) / 16; a.blocks_y = (OH + 15) / 16; a.nblocks = a.blocks_x * a.blocks_y * B;
+    const int grid = a.nblocks < 512 ? a.nblocks : 512;              // two persistent workgroups per CU
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

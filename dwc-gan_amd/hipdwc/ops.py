@@ -211,6 +211,23 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
                                              _stream()), "x3_weight_prepare")
         ent[key] = (stamp, out)
         return out
+    if kind in ("stem_steps", "stem_steps_dgrad"):
+        # csrc/conv_narrow_bf16.hip conv_stem_kernel: [25 k-steps][64 channels][2 taps x 8 planes] bf16, halves of a row swapped
+        # by (co>>3)&1.  stem_steps: w is the stem filter [64][P<=8][7][7]; stem_steps_dgrad: w is the heads filter
+        # [P<=8][64][7][7], rotated and transposed (the data gradient is a convolution of the 8-plane gradient image)
+        wf = w.detach().float()
+        if kind == "stem_steps_dgrad":
+            wf = wf.flip(2, 3).permute(1, 0, 2, 3)                      # [64][P][7][7]
+        co, pl, kh, kw = wf.shape
+        assert co == 64 and pl <= 8 and kh == 7 and kw == 7
+        bank = torch.zeros((64, 50, 8), dtype=torch.float32, device=w.device)      # [co][tap (49 + 1 zero)][plane]
+        bank[:, :49, :pl] = wf.permute(0, 2, 3, 1).reshape(64, 49, pl)
+        steps = bank.view(64, 25, 2, 8).permute(1, 0, 2, 3).contiguous()           # [j][co][h][p]
+        swap = ((torch.arange(64, device=w.device) >> 3) & 1).bool()
+        steps[:, swap] = steps[:, swap].flip(2)
+        out = steps.reshape(25, 64, 16).to(BF16).contiguous()
+        ent[key] = (stamp, out)
+        return out
     if kind in ("heads_narrow", "dgrad_image_narrow"):
         # the wide bank ([32][taps*64] prepared rows) in MFMA-fragment order [tap][q][hi][row][8] for csrc/conv_narrow_bf16.hip
         base = _prepped(w, "heads_wide" if kind == "heads_narrow" else "dgrad_image", cout_pad, cin_pad, stride, owner, True)
@@ -275,6 +292,7 @@ WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 X3 = int(os.environ.get("DWC_X3", "1"))
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
+STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
 
 
@@ -329,7 +347,9 @@ class _Conv2d(torch.autograd.Function):
         w_grad = ctx.needs_input_grad[1]
         use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
-        w_hwio = None if use_wino or use_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
+        use_stem = bool(half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
+                        and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H, W, KH, act))
+        w_hwio = None if use_wino or use_x3 or use_stem else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -354,6 +374,12 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, st),
                 detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
+        elif use_stem:
+            # 7x7 stem on an NHWC8 image: filter resident in LDS, persistent workgroups (csrc/conv_narrow_bf16.hip)
+            w_st = _prepped(w, "stem_steps", cop, Cx, 1, owner, True)
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem(
+                x.data_ptr(), w_st.data_ptr(), _p(bias), y.data_ptr(), B, H, W, H, W, KH, -pad, act, 1, st),
+                detail="fwd-stem B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_stem")
         elif half and HALO and stride == 1 and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH):
             # stride-1 "same" 3x3 / 5x5 layers on the bf16 path: halo-tiled kernel (patch staged once per channel slab)
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(

@@ -338,6 +338,14 @@ int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias3
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
 int dwc_bf16_conv2d_bwd_data_image_narrow(const void* dy, const void* w_frag, void* dx, int B, int H, int W, int Cout, int KH, int KW,
                                           int pad, void* ws, size_t ws_bytes, void* stream);
+/* 7x7 convolutions from the 8 planes of an NHWC8 image to 64 channels: the stems (forward; off = -3, reflect rule) and the
+ * data gradient of the image heads on the padded grid (off = -6, zero rule, OH = H + 6; fold with
+ * dwc_bf16_reflect_pad_adjoint).  The whole filter stays in LDS (w_steps: [25][64][16] bf16, k-step j = taps 2j, 2j+1 x 8
+ * planes; element (j, co, h, p) at ((h ^ ((co>>3)&1))*8 + p)), persistent workgroups walk 16x16-pixel blocks.  act: none / relu
+ * / lrelu.  y: [B][OH][OW][64] bf16. */
+int dwc_bf16_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act);
+int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, void* y, int B, int IH, int IW, int OH, int OW, int K,
+                         int off, int act, int reflect, void* stream);
 /* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
 size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
