@@ -620,7 +620,18 @@ class _HeadsConvWide(torch.autograd.Function):
                                                ACT["heads8" if P == 8 else "heads"], ws.data_ptr(), ws.numel(), st), "act_bwd_bias")
         dx = dw = None
         flops = 2.0 * rows * 4 * C * KH * KW
-        if ctx.needs_input_grad[0]:        # data gradient: the ordinary P-channel formulation (N = C columns)
+        if (ctx.needs_input_grad[0] and half and NARROW and STEM and P == 8 and C == 64 and KH == 7 and KW == 7
+                and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H + 2 * pad, W + 2 * pad, KH, 0)):
+            # data gradient = 7x7 convolution of the 8-plane gradient image with the rotated filter on the padded grid (zero
+            # rule), folded by the reflect adjoint: the stem kernel of csrc/conv_narrow_bf16.hip
+            w_st = _prepped(w4, "stem_steps_dgrad", 64, P, 1, ctx.owner, True)
+            dx = empty_cl(B, C, H, W, dev, x.dtype)
+            base = workspace(B * (H + 2 * pad) * (W + 2 * pad) * C * 2, dev).data_ptr()
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem(
+                g.data_ptr(), w_st.data_ptr(), None, base, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0, st),
+                scope_name=ctx.bscope, detail="dgrad-heads-stem B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_stem dgrad")
+            _lib.check(lib.dwc_bf16_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+        elif ctx.needs_input_grad[0]:        # data gradient: the ordinary P-channel formulation (N = C columns)
             w_dg = _prepped(w4, "dgrad", P, C, 1, ctx.owner, half)
             dx = empty_cl(B, C, H, W, dev, x.dtype)
             pad_bytes = (B * (H + 2 * pad) * (W + 2 * pad) * C * (2 if half else 4) + 255) // 256 * 256
