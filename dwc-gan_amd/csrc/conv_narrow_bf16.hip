@@ -332,6 +332,189 @@ bool stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act) {
            (size_t)B * IH * IW * 16 < 0x80000000ull;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradients of both 7x7 shapes: a correlation between an 8-plane image A and a 64-channel tensor Bt over the pixels q of a
+// grid, for the 49 offsets:   C[tap][plane][c] = sum_q A[q + tap + offA][plane] * Bt[q + offB][c].
+//   stems:  A = x image (reflect rule, offA = -3), Bt = dY, grid = H x W            -> dW[c][plane][kh][kw] = C
+//   heads:  A = gradient image g (zero rule, offA = -6), Bt = x (reflect, offB = -3), grid = (H+6) x (W+6) padded positions
+//           -> dW[plane][c][6-kh][6-kw] = C          (x_pad[q] * g[q - tap], summed over the padded grid)
+// The im2col kernel ran them at 5-6 % of the peak.  Here an MFMA row tile is 4 horizontally adjacent taps x 8 planes = the 64
+// contiguous bytes of 4 patch pixels (pixel-major 16-byte rows), fetched with the transposing LDS read at a per-lane pixel
+// offset; 7 filter rows x 2 groups of 4 columns (the 8th column is a dummy) = 14 row tiles, dealt to the 8 waves; contraction
+// over 8x16-pixel units (A patch 14 x 24 pixels = 5 KB, Bt block 16 KB, double buffered); fp32 slabs per pixel split, summed in
+// a fixed order by smallk_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+struct SmallWgradArgs {
+    const bf16* a8;      // [B][AH][AW][8]
+    const bf16* b64;     // [B][BH][BW][64]
+    float* slab;         // [splits][14*32][64]
+    int B, AH, AW, BH, BW, GH, GW, offA, offB, reflA, reflB;
+    int units_x, units_per_img, total_units, units_per_split;
+};
+
+__global__ __launch_bounds__(512, 2) void smallk_wgrad_kernel(SmallWgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PCA = 24, PRA = 14;                   // A patch: (8+6) rows x (16+7 -> 24) pixels
+    constexpr int A_EL = 512 * 8, B_EL = 128 * 64;      // one DMA instruction of pixels; 128 pixels x 64 channels
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * (A_EL + B_EL)];
+    bf16* sA = smem;
+    bf16* sB = smem + 2 * A_EL;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int split = blockIdx.x;
+    const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.a8), 0, (unsigned)a.B * a.AH * a.AW * 16u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.b64), 0, (unsigned)a.B * a.BH * a.BW * 128u, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    auto stage_unit = [&](int u, int buf) {
+        const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
+        const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
+        const int gy0 = uy * 8, gx0 = ux * 16;
+        {   // A patch: lane t = patch pixel t
+            const int pr = t / PCA, pc = t - pr * PCA;
+            int h = gy0 + pr + a.offA, w = gx0 + pc + a.offA;
+            bool ok = t < PRA * PCA;
+            if (a.reflA) {
+                h = reflect_idx(h, a.AH);
+                w = reflect_idx(w, a.AW);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.AH && (unsigned)w < (unsigned)a.AW;
+            }
+            h = min(max(h, 0), a.AH - 1);
+            w = min(max(w, 0), a.AW - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(sA + buf * A_EL + wave * 512), 16,
+                                                     ok ? (unsigned)((n * a.AH + h) * a.AW + w) * 16u : OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // Bt block: chunk id -> (pixel m, slot c); pixels outside the grid contribute zeros
+            const int id = t + 512 * i;
+            const int m = id >> 3, c = id & 7;
+            const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+            int h = gy + a.offB, w = gx + a.offB;
+            bool ok = gy < a.GH && gx < a.GW;
+            if (a.reflB) {
+                h = reflect_idx(h, a.BH);
+                w = reflect_idx(w, a.BW);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.BH && (unsigned)w < (unsigned)a.BW;
+            }
+            h = min(max(h, 0), a.BH - 1);
+            w = min(max(w, 0), a.BW - 1);
+            const int lc = c ^ (4 * ((m >> 1) & 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(sB + buf * B_EL + i * 4096 + wave * 512),
+                                                     16, ok ? ((unsigned)((n * a.BH + h) * a.BW + w) * 64u + (unsigned)(lc * 8)) * 2u : OOB,
+                                                     0, 0, 0);
+        }
+    };
+
+    // this wave's row tiles (tap groups): g = wave and wave + 8 (< 14): filter row g >> 1, columns 4*(g & 1) ..
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
+    const int ng = wave + 8 < 14 ? 2 : 1;
+    const int li = lane & 15, gam = (lane >> 4) & 1, hi = lane >> 5;
+    const int tq = li >> 2, tp = li & 3;
+    const int pxl = 8 * hi + tq;
+    const int row_el = 16 * gam + 4 * tp;               // (tap-in-group, plane) row -> element offset from the tap group's first pixel
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    auto a_frag = [&](const bf16* p, int ks, int g) {
+        const int kh = g >> 1, kw0 = 4 * (g & 1);
+        bf16x4 v[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int pp = (ks + kh) * PCA + pxl + 4 * half + kw0;
+            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + pp * 8 + row_el));
+        }
+        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto b_frag = [&](const bf16* d, int ks, int ct) {
+        const int col = ct * 32 + 16 * gam + 4 * tp;
+        bf16x4 v[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int m = ks * 16 + pxl + 4 * half;
+            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(d + m * 64 + (((col >> 3) ^ (4 * ((m >> 1) & 1))) << 3) + (col & 7)));
+        }
+        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    if (u0 < u1) {
+        stage_unit(u0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int buf = 0;
+        for (int u = u0; u < u1; ++u) {
+            if (u + 1 < u1) stage_unit(u + 1, buf ^ 1);
+            const bf16* p = sA + buf * A_EL;
+            const bf16* d = sB + buf * B_EL;
+#pragma unroll 2
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 fb0 = b_frag(d, ks, 0), fb1 = b_frag(d, ks, 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i < ng) {
+                        const bf16x8 fa = a_frag(p, ks, wave + 8 * i);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb0, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, acc[i][1], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // slab[split][g*32 + row][c]: D[row][c], lane = column c, registers = rows
+    const int l31 = lane & 31;
+    float* out = a.slab + (size_t)split * (14 * 32 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i >= ng) continue;
+        const int g = wave + 8 * i;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(size_t)(g * 32 + row) * 64 + c * 32 + l31] = acc[i][c][r];
+            }
+    }
+#endif
+}
+
+// sum the slabs in a fixed order; (g, row) -> filter row g >> 1, column 4*(g & 1) + (row >> 3) (column 7 is the dummy), plane row & 7;
+// dst index = c * sc + plane * sp + kh' * 7 + kw' with (kh', kw') flipped for the heads
+__global__ void smallk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int planes, int sc, int sp,
+                                     int flip) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 14 * 32 * 64) return;
+    const int c = idx & 63, k = idx >> 6;
+    const int g = k >> 5, row = k & 31;
+    const int kh = g >> 1, kw = 4 * (g & 1) + (row >> 3), pl = row & 7;
+    if (kw >= 7 || pl >= planes) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * (14 * 32 * 64) + idx];
+    const int khd = flip ? 6 - kh : kh, kwd = flip ? 6 - kw : kw;
+    dw[(size_t)c * sc + (size_t)pl * sp + khd * 7 + kwd] = s;
+}
+
+void smallk_plan(int B, int GH, int GW, int* splits, int* ups, int* units_x, int* upi) {
+    *units_x = (GW + 15) / 16;
+    *upi = ((GH + 7) / 8) * *units_x;
+    const int units = B * *upi;
+    int s = 512;                                        // two workgroups per CU
+    if (s > units / 4) s = units / 4 > 0 ? units / 4 : 1;
+    *ups = (units + s - 1) / s;
+    *splits = (units + *ups - 1) / *ups;
+}
+
 bool narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW) {
     return B > 0 && Cin == NCH && KH == 7 && KWW == 10 && OH > 0 && OWg > 0 && IH >= KH && IW >= KWW &&
            (size_t)B * IH * IW * NCH * 2 < 0x80000000ull;
@@ -381,6 +564,40 @@ int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, 
     a.blocks_x = (OW + 15) / 16; a.blocks_y = (OH + 15) / 16; a.nblocks = a.blocks_x * a.blocks_y * B;
     const int grid = a.nblocks < 512 ? a.nblocks : 512;              // two persistent workgroups per CU
     hipLaunchKernelGGL(conv_stem_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+size_t dwc_bf16_conv7_smallk_wgrad_ws_bytes(int B, int H, int W, int heads) {
+    int splits, ups, ux, upi;
+    smallk_plan(B, heads ? H + 6 : H, heads ? W + 6 : W, &splits, &ups, &ux, &upi);
+    return (size_t)splits * 14 * 32 * 64 * sizeof(float);
+}
+
+/* Weight gradient of the two 7x7 layer shapes between an NHWC8 image (img8: [B][H][W][8] bf16) and a 64-channel tensor (t64:
+ * [B][H][W][64] bf16), pad 3, reflect padding in the forward:
+ *   heads == 0 (stems, 8 -> 64): img8 = the input image x, t64 = dY;        dw: [64][planes][7][7] fp32
+ *   heads != 0 (image heads, 64 -> 8): img8 = dY (pre-activation gradient), t64 = the input x;   dw: [planes][64][7][7] fp32
+ * `planes` <= 8 real planes are written.  Scratch: dwc_bf16_conv7_smallk_wgrad_ws_bytes. */
+int dwc_bf16_conv7_smallk_wgrad(const void* img8, const void* t64, float* dw, int B, int H, int W, int planes, int heads, void* ws,
+                                size_t ws_bytes, void* stream) {
+    if (!img8 || !t64 || !dw || B <= 0 || H < 7 || W < 7 || planes < 1 || planes > 8 ||
+        (size_t)B * (H + 6) * (W + 6) * 128 >= 0x80000000ull)
+        return DWC_EINVAL;
+    SmallWgradArgs a;
+    int splits;
+    a.GH = heads ? H + 6 : H; a.GW = heads ? W + 6 : W;
+    smallk_plan(B, a.GH, a.GW, &splits, &a.units_per_split, &a.units_x, &a.units_per_img);
+    if (!ws || ws_bytes < (size_t)splits * 14 * 32 * 64 * sizeof(float)) return DWC_EWORKSPACE;
+    a.a8 = (const bf16*)img8; a.b64 = (const bf16*)t64; a.slab = (float*)ws;
+    a.B = B; a.AH = H; a.AW = W; a.BH = H; a.BW = W;
+    a.offA = heads ? -6 : -3; a.offB = heads ? -3 : 0; a.reflA = heads ? 0 : 1; a.reflB = heads ? 1 : 0;
+    a.total_units = B * a.units_per_img;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smallk_wgrad_kernel, dim3(splits), dim3(512), 0, st, a);
+    DWC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smallk_reduce_kernel, dim3((14 * 32 * 64 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, splits, planes,
+                       heads ? 49 : planes * 49, heads ? 64 * 49 : 49, heads ? 1 : 0);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -94,6 +94,8 @@ SIGNATURES = {
     "dwc_x3_conv2d_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_wgrad_halo_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_bf16_conv2d_wgrad_halo": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv7_smallk_wgrad_ws_bytes": (c_sz, [c_int] * 4),
+    "dwc_bf16_conv7_smallk_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_stem_ok": (c_int, [c_int] * 7),
     "dwc_bf16_conv2d_stem": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
     "dwc_bf16_conv2d_narrow_ok": (c_int, [c_int] * 8),

@@ -440,6 +440,12 @@ class _Conv2d(torch.autograd.Function):
                     x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, wt, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-wino%d" % wt + detail[5:],
                     exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino_bwd_weight")
+            elif half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3 and Cout == 64:
+                # 7x7 stem on an NHWC8 image: 4 taps x 8 planes per MFMA row tile (csrc/conv_narrow_bf16.hip)
+                ws = workspace(lib.dwc_bf16_conv7_smallk_wgrad_ws_bytes(B, H, W, 0), dev)
+                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="wgrad-stem" + detail[5:]), "conv7_smallk_wgrad")
             elif ((not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
@@ -641,7 +647,13 @@ class _HeadsConvWide(torch.autograd.Function):
                 g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, P, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
                 st), scope_name=ctx.bscope, detail="dgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_data")
             _lib.check(_fn(lib, "reflect_pad_adjoint", x)(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
-        if ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
+        if ctx.needs_input_grad[1] and half and NARROW and STEM and P == 8 and C == 64 and KH == 7 and KW == 7:
+            dw = torch.empty((P, C, KH, KW), dtype=torch.float32, device=dev)
+            ws = workspace(lib.dwc_bf16_conv7_smallk_wgrad_ws_bytes(B, H, W, 1), dev)
+            _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
+                g.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, P, 1, ws.data_ptr(), ws.numel(), st), scope_name=ctx.bscope,
+                detail="wgrad-heads-small B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv7_smallk_wgrad")
+        elif ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
             dwide = torch.empty((32, C, KH, KW + px - 1), dtype=torch.float32, device=dev)
             nws = _fn(lib, "conv2d_bwd_weight_ex_ws_bytes", x)(B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad)
             ws = workspace(nws, dev)

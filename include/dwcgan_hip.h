@@ -346,6 +346,13 @@ int dwc_bf16_conv2d_bwd_data_image_narrow(const void* dy, const void* w_frag, vo
 int dwc_bf16_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act);
 int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, void* y, int B, int IH, int IW, int OH, int OW, int K,
                          int off, int act, int reflect, void* stream);
+/* weight gradient of the two 7x7 shapes between an NHWC8 image and a 64-channel tensor (pad 3, reflect): heads == 0: stems
+ * (img8 = x, t64 = dY, dw [64][planes][7][7]); heads != 0: image heads (img8 = gradient of the pre-activation planes, t64 = x,
+ * dw [planes][64][7][7]).  An MFMA row tile is 4 adjacent taps x 8 planes read from the pixel-major patch with the
+ * transposing LDS read; pixel splits -> fp32 slabs in ws -> fixed-order sum. */
+size_t dwc_bf16_conv7_smallk_wgrad_ws_bytes(int B, int H, int W, int heads);
+int dwc_bf16_conv7_smallk_wgrad(const void* img8, const void* t64, float* dw, int B, int H, int W, int planes, int heads, void* ws,
+                                size_t ws_bytes, void* stream);
 /* gradient w.r.t. an NHWC8 image through a stem: 4 pixels x 8 planes per GEMM row, bank [p*8 + plane][co][KH][KW+3] */
 size_t dwc_bf16_conv2d_bwd_data_image_ws_bytes(int B, int H, int W, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_image(const void* dy, const void* w_wide, void* dx, int B, int H, int W, int Cout, int KH, int KW,
