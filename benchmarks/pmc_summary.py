@@ -53,7 +53,7 @@ def main():
             "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
             "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd",
             "conv_halo_x3_kernel", "wgrad_x3_kernel", "x3_wgrad_reduce_kernel", "wgrad_halo_kernel", "wgrad_halo_reduce_kernel",
-            "conv_narrow_kernel", "conv_stem_kernel")
+            "conv_narrow_kernel", "conv_stem_kernel", "smallk_wgrad_kernel", "smallk_reduce_kernel")
     res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 "
                       "--warmup 1 --no-cpu-baseline",
            "note": "units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
