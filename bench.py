@@ -368,8 +368,8 @@ def main():
             "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
                            conf["label"], args.vgg_w,
                            (", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
-                               ", 5x5 convs as exact bf16x3 split products on the bf16 MFMA (fp32 operands, results and "
-                               "accumulation)" if ops.X3 else "")) if precision == "fp32" else ""),
+                               ", 5x5 convs and 3x3 data gradients as exact bf16x3 split products on the bf16 MFMA (fp32 "
+                               "operands, results and accumulation)" if ops.X3 else "")) if precision == "fp32" else ""),
                        "name": args.config, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
                        "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
             # algorithmic flops of the launches this step actually made (conv + linear kernels; the text encoder's library GEMMs,
