@@ -141,95 +141,81 @@ def traffic_from_profiles(config, dominant, family="conv_gemm_family"):
         os.path.relpath(path, REPO), d.get("commit", "of round 1, 11e6a6c"))
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, timeout_s=3600):
     """``python bench.py --gpus N`` without a launcher: start the N ranks as child processes of a parent that never touches
-    the GPU, wait for them, relay their output."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
+    the GPU, supervise ALL of them (the first non-zero exit or the overall timeout terminates the rest instead of leaving
+    rank 0 waiting in a collective), relay rank 0's stdout (the JSON record) and every rank's stderr prefixed by its rank."""
+    import tempfile
+    import threading
+    # file:// rendezvous created by the parent: no port to lose between probing and binding
+    rdv = tempfile.NamedTemporaryFile(prefix="dwc_bench_rdv_", delete=False)
+    rdv.close()
+    os.unlink(rdv.name)
+    procs, pumps = [], []
+
+    def pump(stream, rank):
+        for line in iter(stream.readline, b""):
+            sys.stderr.write("[rank %d] %s" % (rank, line.decode(errors="replace")))
+        stream.close()
+
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, p.wait())
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), DWC_BENCH_INIT="file://" + rdv.name,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(p.stderr, r), daemon=True)
+        t.start()
+        pumps.append(t)
+    out = []
+    reader = threading.Thread(target=lambda: out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline, rc = time.time() + timeout_s, 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            rc = max(abs(c) for c in codes)
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = abs(bad[0]) if bad else 124
+            for p in procs:                      # exactly the children started above, by handle
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    for t in pumps:
+        t.join(timeout=5)
+    if os.path.exists(rdv.name):
+        os.unlink(rdv.name)
+    if out and out[0]:
+        sys.stdout.write(out[0].decode())
+        sys.stdout.flush()
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS),
-                    help="workload = BASELINE.json configs[i] (c1 fp32 128^2 B16, the default and headline; c2 bf16 128^2 B128; "
-                         "c3 fp32 128^2 B64; c4 (alias c5) fp32 256^2 B8)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-warmup", type=int, default=3, help="CPU baseline: untimed iterations per thread count (BASELINE.md: >= 3)")
-    ap.add_argument("--cpu-timed", type=int, default=5, help="CPU baseline: timed iterations per thread count (BASELINE.md: >= 5)")
-    ap.add_argument("--cpu-threads", default="8,16,32,64",
-                    help="CPU baseline: thread counts to sweep (r02 probe on the 256-hardware-thread GPU box, images/s at batch 4: "
-                         "8: 1.10, 16: 1.40, 32: 0.80, 64: 0.33, 128: 0.11 -- this graph gets SLOWER beyond 16 threads)")
-    ap.add_argument("--per-gpu-batch", type=int, default=None, help="development knob; overrides the config's per-GPU batch")
-    ap.add_argument("--x3", type=int, default=None, choices=(0, 1, 2),
-                    help="fp32 path: 0 = native fp32 MFMA kernels only; 1 (default) = 5x5 layers as exact bf16x3 split products on "
-                         "the bf16 MFMA; 2 = 3x3 layers too (instead of Winograd)")
-    ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
-                    help="development knob: Winograd output tile of the fp32 3x3 convolutions (default 2 = F(2x2,3x3); 4 = "
-                         "F(4x4,3x3), faster but ~10x the rounding error, see hipdwc/ops.py; 0 = direct)")
-    ap.add_argument("--vgg-w", type=float, default=0.0,
-                    help="development knob: perceptual-loss weight (the reference's shipped default is 0.1) with a RANDOMLY "
-                         "initialised VGG16 (the trained weights cannot be fetched here); the contract workload is 0")
-    args = ap.parse_args()
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args))
-
-    # stdout carries exactly ONE line, the JSON record: anything native libraries print there (RCCL's version banner is
-    # written to the C stdout buffer and flushed at exit, i.e. AFTER the record) is diverted to stderr
-    sys.stdout.flush()
-    record_fd = os.dup(1)
-    os.dup2(2, 1)
+def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
+    """One workload: build the trainer, `warmup` untimed + `steps` timed full iterations between barriers / device
+    synchronisations (MAX over ranks), HIP-event spans of the conv launches of the last timed step.  Returns
+    (record dict on rank 0 else None, initial G / D state dicts for the CPU baseline)."""
+    import contextlib
+    import io
 
     import torch
     from hipdwc import host, ops, synth
+    from solver import Solver
 
-    conf = CONFIGS[args.config]
+    conf = CONFIGS[config_name]
     image_size, precision = conf["image_size"], conf["precision"]
     per_gpu_batch = args.per_gpu_batch or conf["per_gpu_batch"]
     peak = MFMA_PEAK_TFLOPS[precision]
     ops.set_precision(precision)
-    if args.winograd is not None:
-        ops.WINOGRAD_TILE = args.winograd
-    if args.x3 is not None:
-        ops.X3 = args.x3
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    force_dp = world == 1 and os.environ.get("DWC_FORCE_DP") == "1"      # development: drive the RCCL data-parallel path on ONE rank
-    if world > 1 or force_dp:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        if force_dp:
-            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
-        else:
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
-
-    from solver import Solver
     cfg = synth.make_config(image_size=image_size)           # shipped config, vgg_w = 0 (weights not obtainable offline)
     if args.vgg_w > 0:
         import tempfile
@@ -240,8 +226,6 @@ def main():
         torch.save(Vgg16().state_dict(), os.path.join(vgg_dir, "models", "vgg16.weight"))
         cfg["vgg_w"], cfg["vgg_model_path"] = args.vgg_w, vgg_dir
     torch.manual_seed(1234)                                  # same seed on every rank: identical initial weights
-    import io
-    import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         trainer = Solver(cfg, dev, None).to(dev)
     trainer.copy_nets()
@@ -268,13 +252,13 @@ def main():
             torch.cuda.synchronize()
 
     it = 0
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         run_iteration(trainer, batches[it % 4], cfg, it)
         it += 1
     sync()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        if s == args.steps - 1:
+    for s in range(steps):
+        if s == steps - 1:
             ops.TIMER = ops.KernelTimer()                    # HIP events around the conv launches of the last timed step
         run_iteration(trainer, batches[it % 4], cfg, it)
         it += 1
@@ -285,115 +269,223 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if rank != 0:
+        return None, None
+
+    images = per_gpu_batch * world * steps
+    value = images / elapsed
+    spans = timer.summary() if timer is not None else {}
+
+    def total(pred):
+        ent = {"launches": 0, "ms": 0.0, "flops": 0.0, "exec_flops": 0.0}
+        for tag, v in spans.items():
+            if pred(tag):
+                for k in ent:
+                    ent[k] += v[k]
+        return ent
+
+    X3 = "conv_halo_x3_kernel"          # fp32 layers computed as bf16x3 split products: their matrix work is bf16 MFMA
+
+    def rate(ent, roof_peak=None, exec_label="executed"):
+        if ent["ms"] <= 0:
+            return None
+        pk = peak if roof_peak is None else roof_peak
+        tf, ex = ent["flops"] / (ent["ms"] * 1e-3) / 1e12, ent["exec_flops"] / (ent["ms"] * 1e-3) / 1e12
+        return {"launches": ent["launches"], "ms": round(ent["ms"], 3), "tflops": round(tf, 2),
+                "frac_of_mfma_peak": round(tf / peak, 4), exec_label + "_tflops": round(ex, 2),
+                exec_label + "_frac_of_mfma_peak": round(ex / pk, 4), "mfma_peak": pk}
+
+    def stack(pred):
+        """One conv stack, split by the matrix path its launches run on (fractions are against THAT path's dense peak;
+        `tflops` is always the algorithmic fp32-equivalent rate)."""
+        both = total(lambda t: pred(t) and (t.endswith(DOMINANT) or t.endswith(X3)))
+        if both["ms"] <= 0:
+            return None
+        tf = both["flops"] / (both["ms"] * 1e-3) / 1e12
+        out = {"launches": both["launches"], "ms": round(both["ms"], 3), "tflops": round(tf, 2)}
+        native = rate(total(lambda t: pred(t) and t.endswith(DOMINANT)))
+        split = rate(total(lambda t: pred(t) and t.endswith(X3)), MFMA_PEAK_TFLOPS["bf16"], "executed_bf16")
+        if split is None:                      # one path only: the flat record of earlier rounds
+            return native
+        out["native_mfma"] = native
+        out["split_bf16x3"] = split
+        return out
+
+    dom = total(lambda t: t.endswith(DOMINANT))
+    x3 = total(lambda t: t.endswith(X3))
+    # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)
+    decode_stack = {"forward": stack(lambda t: t.startswith("decode/")),
+                    "backward": stack(lambda t: t.startswith("bwd:decode/") and "wgrad" not in t)}
+    roof = None
+    if dom and dom["ms"] > 0:
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        executed = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic, traffic_source = traffic_from_profiles("c4" if config_name == "c5" else config_name, DOMINANT)
+        # achieved: ALGORITHMIC flops (the direct convolution's, SURVEY.md 8(d)) over the spans' time.  On the fp32 path the
+        # 3x3 layers run as Winograd F(2x2,3x3) and issue 2.25x fewer multiply-adds than that, so `executed` (what the
+        # matrix cores actually did, transforms' time included in the spans) is the figure to hold against the MFMA roof.
+        roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                "traffic": traffic, "traffic_source": traffic_source,
+                "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
+    roof_x3 = None
+    if x3["ms"] > 0:
+        # the fp32 layers that run as split products: six bf16 MFMAs per fp32 MFMA-equivalent (6 of the 9 partial products of
+        # the three-way operand split; the dropped ones are below one fp32 rounding), so the roof that bounds them is the
+        # dense bf16 MFMA peak and the executed rate is 6x the algorithmic one
+        alg, ex = x3["flops"] / (x3["ms"] * 1e-3) / 1e12, x3["exec_flops"] / (x3["ms"] * 1e-3) / 1e12
+        tr = traffic_from_profiles(config_name, X3, "split_bf16x3_family")
+        roof_x3 = {"bound": "mfma", "kernel": X3, "achieved": round(alg, 2), "achieved_vs_fp32_mfma_peak": round(alg / MFMA_PEAK_TFLOPS["fp32"], 4),
+                   "executed": round(ex, 2), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                   "frac": round(ex / MFMA_PEAK_TFLOPS["bf16"], 4),
+                   "traffic": tr[0], "traffic_source": tr[1],
+                   "launches_per_step": x3["launches"],
+                   "avg_launch_us": round(x3["ms"] * 1e3 / x3["launches"], 2),
+                   "algorithmic_gflop_per_launch": round(x3["flops"] / x3["launches"] / 1e9, 3)}
+    step_flops = sum(v["flops"] for v in spans.values())            # conv + linear-as-conv launches of ONE step, this rank
+    step_tflops = step_flops * world / (elapsed / steps) / 1e12
+    out = {
+        "metric": "CelebA %dx%d training images/sec" % (image_size, image_size), "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
+                       conf["label"], args.vgg_w,
+                       (", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
+                           ", 5x5 convs and 3x3 data gradients as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 "
+                           "operands, results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)"
+                           if ops.X3 else "")) if precision == "fp32" else ""),
+                   "name": config_name, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
+                   "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
+        # algorithmic (direct-convolution, fp32-equivalent) flops of the launches this step actually made (conv + linear
+        # kernels; the text encoder's library GEMMs, < 0.01 %, are not counted) over the step time.  NOT a fraction of any one
+        # roof on the fp32 path (Winograd launches issue 2.25x fewer multiply-adds, split-product launches run on the bf16
+        # pipe): the per-pipe fractions are `roofline`, `roofline_split_bf16x3` and `decode_conv_stack`.
+        "whole_step_tflops": round(step_tflops, 2),
+        "algorithmic_gflop_per_image_executed": round(step_flops / per_gpu_batch / 1e9, 2),
+        "algorithmic_gflop_per_image_survey": round(ALGO_GFLOP_PER_IMAGE_128 * (image_size / 128.0) ** 2, 2),
+        "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
+        "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
+        "roofline": roof,
+        "roofline_split_bf16x3": roof_x3,
+        "decode_conv_stack": decode_stack,
+        "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
+    }
+    if precision == "bf16":             # one pipe only: here the whole-step rate IS a fraction of a roof
+        out["whole_step_frac_of_bf16_mfma_peak"] = round(step_tflops / (peak * world), 4)
+    else:
+        out["whole_step_fp32_equiv_tflops_vs_fp32_mfma_peak"] = round(step_tflops / (peak * world), 4)
+    if getattr(trainer, "_reducers", None):
+        out["data_parallel"] = {k: {"buckets": len(r.buckets), "bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in r.buckets],
+                                    "all_reduces": r.calls, "launched_from_inside_backward": r.launched_early}
+                                for k, r in trainer._reducers.items()}
+    return out, (init_gen, init_dis)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c1", choices=sorted(CONFIGS),
+                    help="workload = BASELINE.json configs[i] (c1 fp32 128^2 B16, the default and headline; c2 bf16 128^2 B128; "
+                         "c3 fp32 128^2 B64; c4 (alias c5) fp32 256^2 B8)")
+    ap.add_argument("--also", default=None,
+                    help="comma list of further workloads measured after the main one in the same process and reported under "
+                         "\"also\": {name: record} (default: c2 when the main workload is c1 on one GPU, so that the bf16 "
+                         "configuration's images/s and roofline sit in every driver-timed record; 'none' switches it off)")
+    ap.add_argument("--also-steps", type=int, default=10)
+    ap.add_argument("--also-warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="CPU baseline: untimed iterations per thread count (BASELINE.md: >= 3)")
+    ap.add_argument("--cpu-timed", type=int, default=5, help="CPU baseline: timed iterations per thread count (BASELINE.md: >= 5)")
+    ap.add_argument("--cpu-threads", default="8,16,32,64",
+                    help="CPU baseline: thread counts to sweep (r02 probe on the 256-hardware-thread GPU box, images/s at batch 4: "
+                         "8: 1.10, 16: 1.40, 32: 0.80, 64: 0.33, 128: 0.11 -- this graph gets SLOWER beyond 16 threads)")
+    ap.add_argument("--per-gpu-batch", type=int, default=None, help="development knob; overrides the config's per-GPU batch")
+    ap.add_argument("--x3", type=int, default=None, choices=(0, 1, 2),
+                    help="fp32 path: 0 = native fp32 MFMA kernels only; 1 (default) = 5x5 layers as fp32-accurate bf16x3 split "
+                         "products on the bf16 MFMA; 2 = 3x3 layers too (instead of Winograd)")
+    ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
+                    help="development knob: Winograd output tile of the fp32 3x3 convolutions (default 2 = F(2x2,3x3); 4 = "
+                         "F(4x4,3x3), faster but ~10x the rounding error, see hipdwc/ops.py; 0 = direct)")
+    ap.add_argument("--vgg-w", type=float, default=0.0,
+                    help="development knob: perceptual-loss weight (the reference's shipped default is 0.1) with a RANDOMLY "
+                         "initialised VGG16 (the trained weights cannot be fetched here); the contract workload is 0")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+
+    # stdout carries exactly ONE line, the JSON record: anything native libraries print there (RCCL's version banner is
+    # written to the C stdout buffer and flushed at exit, i.e. AFTER the record) is diverted to stderr
+    sys.stdout.flush()
+    record_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    from hipdwc import ops, synth
+
+    if args.winograd is not None:
+        ops.WINOGRAD_TILE = args.winograd
+    if args.x3 is not None:
+        ops.X3 = args.x3
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    force_dp = world == 1 and os.environ.get("DWC_FORCE_DP") == "1"      # development: drive the RCCL data-parallel path on ONE rank
+    if world > 1 or force_dp:
+        import torch.distributed as dist
+        init = os.environ.get("DWC_BENCH_INIT")              # file:// rendezvous of the self-spawning parent
+        if init and not force_dp:
+            dist.init_process_group("nccl", device_id=dev, init_method=init, rank=rank, world_size=world)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            if force_dp:
+                dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            else:
+                dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    out, init_sd = measure(args, args.config, args.steps, args.warmup, dev, dist, rank, world, force_dp)
+
+    also = args.also
+    if also is None:
+        also = "c2" if (args.config == "c1" and world == 1 and not force_dp and args.per_gpu_batch is None) else "none"
+    extra = {}
+    for name in [n for n in also.split(",") if n and n != "none"]:
+        if name not in CONFIGS:
+            raise SystemExit("--also: unknown workload %r" % name)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        rec, _ = measure(args, name, args.also_steps, args.also_warmup, dev, dist, rank, world, force_dp)
+        if rec is not None:
+            rec.pop("kernel_spans", None)
+            extra[name] = rec
+    ops.set_precision(CONFIGS[args.config]["precision"])
 
     if rank == 0:
-        images = per_gpu_batch * world * args.steps
-        value = images / elapsed
-        spans = timer.summary() if timer is not None else {}
-
-        def total(pred):
-            ent = {"launches": 0, "ms": 0.0, "flops": 0.0, "exec_flops": 0.0}
-            for tag, v in spans.items():
-                if pred(tag):
-                    for k in ent:
-                        ent[k] += v[k]
-            return ent
-
-        X3 = "conv_halo_x3_kernel"          # fp32 layers computed as exact bf16x3 split products: their matrix work is bf16 MFMA
-
-        def rate(ent, roof_peak=None, exec_label="executed"):
-            if ent["ms"] <= 0:
-                return None
-            pk = peak if roof_peak is None else roof_peak
-            tf, ex = ent["flops"] / (ent["ms"] * 1e-3) / 1e12, ent["exec_flops"] / (ent["ms"] * 1e-3) / 1e12
-            return {"launches": ent["launches"], "ms": round(ent["ms"], 3), "tflops": round(tf, 2),
-                    "frac_of_mfma_peak": round(tf / peak, 4), exec_label + "_tflops": round(ex, 2),
-                    exec_label + "_frac_of_mfma_peak": round(ex / pk, 4), "mfma_peak": pk}
-
-        def stack(pred):
-            """One conv stack, split by the matrix path its launches run on (fractions are against THAT path's dense peak;
-            `tflops` is always the algorithmic fp32-equivalent rate)."""
-            both = total(lambda t: pred(t) and (t.endswith(DOMINANT) or t.endswith(X3)))
-            if both["ms"] <= 0:
-                return None
-            tf = both["flops"] / (both["ms"] * 1e-3) / 1e12
-            out = {"launches": both["launches"], "ms": round(both["ms"], 3), "tflops": round(tf, 2)}
-            native = rate(total(lambda t: pred(t) and t.endswith(DOMINANT)))
-            split = rate(total(lambda t: pred(t) and t.endswith(X3)), MFMA_PEAK_TFLOPS["bf16"], "executed_bf16")
-            if split is None:                      # one path only: the flat record of earlier rounds
-                return native
-            out["native_mfma"] = native
-            out["split_bf16x3"] = split
-            return out
-
-        dom = total(lambda t: t.endswith(DOMINANT))
-        x3 = total(lambda t: t.endswith(X3))
-        # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)
-        decode_stack = {"forward": stack(lambda t: t.startswith("decode/")),
-                        "backward": stack(lambda t: t.startswith("bwd:decode/") and "wgrad" not in t)}
-        roof = None
-        if dom and dom["ms"] > 0:
-            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            executed = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
-            traffic, traffic_source = traffic_from_profiles("c4" if args.config == "c5" else args.config, DOMINANT)
-            # achieved: ALGORITHMIC flops (the direct convolution's, SURVEY.md 8(d)) over the spans' time.  On the fp32 path the
-            # 3x3 layers run as Winograd F(2x2,3x3) and issue 2.25x fewer multiply-adds than that, so `executed` (what the
-            # matrix cores actually did, transforms' time included in the spans) is the figure to hold against the MFMA roof.
-            roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": peak,
-                    "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-                    "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
-        roof_x3 = None
-        if x3["ms"] > 0:
-            # the 5x5 layers of the fp32 path: six bf16 MFMAs per fp32 MFMA-equivalent (exact operand splits), so the roof that
-            # bounds them is the dense bf16 MFMA peak and the executed rate is 6x the algorithmic one
-            alg, ex = x3["flops"] / (x3["ms"] * 1e-3) / 1e12, x3["exec_flops"] / (x3["ms"] * 1e-3) / 1e12
-            roof_x3 = {"bound": "mfma", "kernel": X3, "achieved": round(alg, 2), "achieved_vs_fp32_mfma_peak": round(alg / MFMA_PEAK_TFLOPS["fp32"], 4),
-                       "executed": round(ex, 2), "peak": MFMA_PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
-                       "frac": round(ex / MFMA_PEAK_TFLOPS["bf16"], 4),
-                       "traffic": traffic_from_profiles(args.config, X3, "split_bf16x3_family")[0],
-                       "traffic_source": traffic_from_profiles(args.config, X3, "split_bf16x3_family")[1],
-                       "launches_per_step": x3["launches"],
-                       "avg_launch_us": round(x3["ms"] * 1e3 / x3["launches"], 2),
-                       "algorithmic_gflop_per_launch": round(x3["flops"] / x3["launches"] / 1e9, 3)}
-        step_flops = sum(v["flops"] for v in spans.values())            # conv + linear-as-conv launches of ONE step, this rank
-        step_tflops = step_flops * world / (elapsed / args.steps) / 1e12
-        out = {
-            "metric": "CelebA %dx%d training images/sec" % (image_size, image_size), "value": round(value, 3), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
-                           conf["label"], args.vgg_w,
-                           (", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
-                               ", 5x5 convs and 3x3 data gradients as exact bf16x3 split products on the bf16 MFMA (fp32 "
-                               "operands, results and accumulation)" if ops.X3 else "")) if precision == "fp32" else ""),
-                       "name": args.config, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
-                       "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
-            # algorithmic flops of the launches this step actually made (conv + linear kernels; the text encoder's library GEMMs,
-            # < 0.01 %, are not counted) over the step time; SURVEY's "necessary work" figure is printed beside it
-            "whole_step_tflops": round(step_tflops, 2),
-            "whole_step_frac_of_mfma_peak": round(step_tflops / (peak * world), 4),
-            "algorithmic_gflop_per_image_executed": round(step_flops / per_gpu_batch / 1e9, 2),
-            "algorithmic_gflop_per_image_survey": round(ALGO_GFLOP_PER_IMAGE_128 * (image_size / 128.0) ** 2, 2),
-            "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
-            "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
-            "roofline": roof,
-            "roofline_split_bf16x3": roof_x3,
-            "decode_conv_stack": decode_stack,
-            "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                 "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
-        }
-        if getattr(trainer, "_reducers", None):
-            out["data_parallel"] = {k: {"buckets": len(r.buckets), "bucket_mb": [round(b["flat"].numel() * 4 / 2 ** 20, 1) for b in r.buckets],
-                                        "all_reduces": r.calls, "launched_from_inside_backward": r.launched_early}
-                                    for k, r in trainer._reducers.items()}
+        if extra:
+            out["also"] = extra
         if world == 1 and not args.no_cpu_baseline and not force_dp:
+            import contextlib
+            import io
+            from solver import Solver
             # always the fp32 parity workload (128x128, batch 16): the reference's own arithmetic on the host cores
+            ops.set_precision("fp32")
             cpu_cfg = synth.make_config(image_size=128)
-            if image_size != 128:                            # different architecture (D head sizes): fresh seeded weights
+            init_gen, init_dis = init_sd
+            if CONFIGS[args.config]["image_size"] != 128:     # different architecture (D head sizes): fresh seeded weights
                 torch.manual_seed(1234)
                 with contextlib.redirect_stdout(io.StringIO()):
                     ref = Solver(cpu_cfg, torch.device("cpu"), None)

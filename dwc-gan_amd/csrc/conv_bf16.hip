@@ -814,12 +814,15 @@ int wgrad_launch_h(const FwdGeom& f, const bf16* dy, float* dw_oihw, int Cin, in
     if (!ws || ws_bytes < (size_t)splits * g.K * Cout * sizeof(float)) return DWC_EWORKSPACE;
     float* slab = (float*)ws;
     const int tk = (g.K + 127) / 128;
-    static const int dbg = getenv("DWC_WGRAD_DBG") ? atoi(getenv("DWC_WGRAD_DBG")) : 0;     // development: timing ablations
+#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only by `make ABLATIONS=1`, never in the shipped .so
+    static const int dbg = getenv("DWC_WGRAD_DBG") ? atoi(getenv("DWC_WGRAD_DBG")) : 0;
     if (Cout > 64 && dbg) {
 #define WG_DBG(D) case D: hipLaunchKernelGGL((wgrad_kernel_h<128, 2, 2, 2, 2, D>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk); break;
         switch (dbg) { WG_DBG(1) WG_DBG(2) WG_DBG(3) WG_DBG(4) WG_DBG(7) default: return DWC_EINVAL; }
 #undef WG_DBG
-    } else if (Cout > 64) {
+    } else
+#endif
+    if (Cout > 64) {
         hipLaunchKernelGGL((wgrad_kernel_h<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy, Cout, slab,
                            chunk);
     } else if (Cout > 32) {

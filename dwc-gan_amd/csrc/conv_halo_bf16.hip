@@ -543,7 +543,8 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         hipLaunchKernelGGL((conv_halo_kernel<KS, BN, WM, WN, TM, TN, (KS == 3 ? 2 : 1)>), dim3(nblk * a.tiles_n), dim3(512), 0, st, \
                            a);                                                                                            \
     } while (0)
-    static const int dbg = getenv("DWC_HALO_DBG") ? atoi(getenv("DWC_HALO_DBG")) : 0;     // development: timing ablations
+#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only by `make ABLATIONS=1`, never in the shipped .so
+    static const int dbg = getenv("DWC_HALO_DBG") ? atoi(getenv("DWC_HALO_DBG")) : 0;
     if (dbg && K == 3 && Cout > 128) {
         a.tiles_n = (Cout + 255) / 256;
 #define HALO_DBG(D)                                                                                                         \
@@ -558,6 +559,7 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
+#endif
     static const int bn128 = getenv("DWC_HALO_BN128") ? atoi(getenv("DWC_HALO_BN128")) : 0;   // development: 1 -> PB 1, 2 -> PB 2
     if (K == 3 && Cout > 128 && bn128) {
         a.tiles_n = (Cout + 127) / 128;
@@ -626,9 +628,12 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
     a.n_tiles = Cout / bn; a.tap_groups = K == 3 ? 1 : K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((Cin / (bn == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups * splits);
-    static const int dbg = getenv("DWC_WGRAD_HALO_DBG") ? atoi(getenv("DWC_WGRAD_HALO_DBG")) : 0;   // dev ablation (3x3)
+#ifdef DWC_DEV_ABLATIONS      // timing-only ablation (WRONG results)
+    static const int dbg = getenv("DWC_WGRAD_HALO_DBG") ? atoi(getenv("DWC_WGRAD_HALO_DBG")) : 0;
     if (K == 3 && dbg == 4) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 4>), grid, dim3(512), 0, st, a);
-    else if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);
+    else
+#endif
+    if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64>), grid, dim3(512), 0, st, a);
     DWC_LAUNCH_CHECK();

@@ -725,7 +725,11 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
             if (score > best) best = score, bn = w;
         }
     }
-    if (force) bn = force;
+    if (force) {
+        if (force != 64 && force != 128 && force != 256) return DWC_EINVAL;      // DWC_X3_BN: only the tile widths that exist
+        if (force == 256 && K == 5) return DWC_EINVAL;
+        bn = force;
+    }
     // Default: two 4-wave workgroups of 256 pixels x 64 channels per CU (single patch buffer, <= 64 KB of LDS each).  Two
     // independent workgroups drift out of phase, so one's MFMAs run beside the other's fragment reads, staging and barriers;
     // measured against the best one-workgroup-per-CU tile: 5x5 128->64 +27 %, 5x5 256->128 +5 %, 3x3 256->256 at B=48 +16 %,
@@ -747,11 +751,14 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
         else if (bn == 128) x3_launch<3, 128, 4, 2, 2, 2>(a, grid, st);
         else x3_launch<3, 64, 8, 1, 1, 2>(a, grid, st);
     } else {
-        static const int dbg = getenv("DWC_X3_DBG") ? atoi(getenv("DWC_X3_DBG")) : 0;      // dev ablations (timing only)
+#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only by `make ABLATIONS=1`, never in the shipped .so
+        static const int dbg = getenv("DWC_X3_DBG") ? atoi(getenv("DWC_X3_DBG")) : 0;
         if (bn == 128 && dbg == 1) x3_launch<5, 128, 4, 2, 2, 2, 1>(a, grid, st);
         else if (bn == 128 && dbg == 2) x3_launch<5, 128, 4, 2, 2, 2, 2>(a, grid, st);
         else if (bn == 128 && dbg == 30) x3_launch<5, 128, 4, 2, 2, 2, 30>(a, grid, st);
-        else if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
+        else
+#endif
+        if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
         else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
     }
     DWC_LAUNCH_CHECK();

@@ -56,7 +56,7 @@ __device__ __forceinline__ float dwc_block_sum_256(float v, float* sm) {
 
 __device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
     switch (act) {
-        case DWC_ACT_RELU: return fmaxf(v, 0.f);
+        case DWC_ACT_RELU: return v < 0.f ? 0.f : v;            // (not fmaxf: a NaN must stay a NaN, as in torch)
         case DWC_ACT_LRELU: return v > 0.f ? v : 0.1f * v;
         case DWC_ACT_TANH: return tanhf(v);
         case DWC_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
@@ -66,14 +66,16 @@ __device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
     }
 }
 
-// The activations without a transcendental (none / ReLU / LeakyReLU 0.1) as three ALU operations and no branch:
-// max(v,0) + slope*min(v,0) with slope 1 / 0 / 0.1 (exact for all three).  Epilogues take this form in one loop nest and
+// The activations without a transcendental (none / ReLU / LeakyReLU 0.1) in one branch-free form: v < 0 ? slope*v : v with
+// slope 1 / 0 / 0.1 (a compare, a multiply, a select; the slope == 0 select is wave-uniform).  Non-finite values behave as in
+// torch: a NaN stays a NaN (NaN < 0 is false -> v), ReLU(-inf) = 0 (not 0 * -inf), LReLU(-inf) = -inf -- the max/min form
+// this replaces dropped NaNs (fmaxf/fminf return the other operand).  Epilogues take this form in one loop nest and
 // the general dwc_act_apply in a SEPARATE one: with the switch inside the fully unrolled per-element code every GEMM
 // kernel carried ~25 000 instructions of inlined tanhf/expf between its hot instructions (r02: a halo kernel with an EMPTY
 // main loop still took half the full kernel's time, instruction fetch of that epilogue).
 __device__ __forceinline__ bool dwc_act_is_simple(int act) { return act <= DWC_ACT_LRELU; }
 __device__ __forceinline__ float dwc_act_slope(int act) { return act == DWC_ACT_NONE ? 1.f : (act == DWC_ACT_RELU ? 0.f : 0.1f); }
-__device__ __forceinline__ float dwc_act_simple(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float dwc_act_simple(float v, float slope) { return v < 0.f ? (slope == 0.f ? 0.f : slope * v) : v; }
 
 // derivative expressed through the activation OUTPUT y
 __device__ __forceinline__ float dwc_act_grad(float y, int act, int ch) {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
         f32x4 v = (ld4(x, i) - reinterpret_cast<const f32x4*>(mean)[s]) * sc;
         if (beta) v += reinterpret_cast<const f32x4*>(beta)[s];
         if (relu) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
         }
         if (residual) v += ld4(residual, i);
         st4(y, i, v);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void in_fused_fwd(const T* __restrict__ x, con
         const size_t i = base + (size_t)r * cq;
         f32x4 v = (ld4(x, i) - mu) * sc + sh;
         if (relu) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
         }
         if (residual) v += ld4(residual, i);
         st4(y, i, v);
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
         const f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
         f32x4 v = (ld4(x, i) - mu) * iv * ga + be;
         if (relu) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
         }
         st4(y, i, v);
     }

@@ -28,16 +28,7 @@ from networks.networks import MsImageDis
 from networks.networks_v2 import AdaINGen_v2
 from tools import dist_sampling_split
 
-try:                                   # the reference's own vocabulary when dropped into its tree
-    from vocab import Vocab
-except ImportError:                    # stand-alone: only the sizes/indices matter on this path
-    class Vocab(object):
-        """102 tokens: PAD=0, BOS=1, EOS=2, UNK=3 + 98 words (reference vocab.py:5,177-185)."""
-
-        def __init__(self, dataset="CelebA", with_SE=True):
-            self.itos = ["<_>", "<bos>", "<eos>", "<unk>"] + ["w%d" % i for i in range(98)]
-            self.stoi = {w: i for i, w in enumerate(self.itos)}
-            self.size, self.padding_idx, self.unk_idx, self.start_idx, self.end_idx = len(self.itos), 0, 3, 1, 2
+from vocab import Vocab
 
 
 @contextlib.contextmanager
@@ -81,6 +72,11 @@ class Solver(nn.Module):
         self._ema = None
         self._gen_steps = 0            # bumped whenever G's parameters change: validity of the cached content code
         self._content_cache = None
+        # D updates per G update (reference train.py:31,105 keeps it in `opts`, out of the solver's sight).  dis_update tapes
+        # enc_content(x_real) for the gen_update that follows ONLY on the iterations that have one; a caller that runs
+        # n_critic > 1 without setting this attribute is detected (a taped content code left unconsumed) and taping stops.
+        self.n_critic = 1
+        self._tape_content = True
 
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
         # torch.optim.Adam subclasses (same param_groups / state_dict / scheduler interface) whose step()
@@ -215,8 +211,15 @@ class Solver(nn.Module):
         # The content code of x_real is a deterministic function of x_real and G, and G does not change between this step
         # and the generator step that follows: computed ONCE, on the tape, and handed to gen_update (the reference
         # encodes x_real again there, solver.py:155, with identical values).
-        content_taped = self.gen.enc_content(x4)
-        self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
+        if self._content_cache is not None:            # the last taped code was never consumed: no gen_update follows every
+            self._tape_content = False                 # dis_update (n_critic > 1, reference train.py:105) -- stop taping
+        if self._tape_content and (iters + 1) % max(1, int(self.n_critic)) == 0:
+            content_taped = self.gen.enc_content(x4)
+            self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
+        else:
+            self._content_cache = None
+            with torch.no_grad():
+                content_taped = self.gen.enc_content(x4)
         with torch.no_grad():
             content = content_taped.detach()
             style_real = torch.cat(style_real, dim=1)

@@ -1,0 +1,197 @@
+"""BASELINE configs[2] (bf16 activations, batch 128 per GPU) under a checker AT ITS OWN BATCH.
+
+Tile and kernel selection in the bf16 path depends on the grid (halo tile width by Cout, narrow / stem kernels at 3B = 384
+images, split planners of the weight gradients, XCD remap of >= 16 blocks), so the small-batch cases of
+tests/test_bf16_parity.py do not exercise the instantiations and grids the benchmark launches.  Here:
+
+  * every hot convolution shape of the step at B = 128 and B = 384 (the 2B / 3B batched passes): forward, data gradient,
+    weight and bias gradient.  Checker (a): the CPU oracle (oracle.conv_block, fp32) on a SAMPLE of the batch's images --
+    first, middle, last: samples are independent through a convolution, so y and dx of those images must match whatever the
+    batch around them is.  Checker (b), all images and the batch-summed weight gradient: torch's own fp32 convolution on the
+    device (MIOpen / rocBLAS: an implementation that shares nothing with this library) on the same bf16-rounded operands.
+    Tolerances are those of tests/test_bf16_parity.py.
+  * forward passes of the generator (encode, decode) and the discriminator at B = 128 against the fp32 CPU oracle run in
+    chunks of 16 (outside the text encoder samples are independent), per sample.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from hipdwc import host, ops, synth          # noqa: E402
+from oracle import dwcgan_oracle as orc      # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rb(t):
+    return t.to(BF).float()
+
+
+def relerr(a, b):
+    a, b = a.detach().float(), b.detach().float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(autouse=True)
+def bf16_mode():
+    ops.set_precision("bf16")
+    yield
+    ops.set_precision("fp32")
+
+
+# (B, Cin, Cout, H, k, stride, pad, act): the conv calls of one c2 step with their real batch (B = 128 per-GPU batch; the
+# decoder / re-encode / D passes are batched 2B and 3B)
+HOT = [
+    (128, 256, 256, 32, 3, 1, 1, "none"),     # ResBlock 3x3, halo BN = 256 (content encoder on x_real)
+    (384, 256, 256, 32, 3, 1, 1, "none"),     # ... in the 3B decode / re-encode passes
+    (128, 256, 128, 64, 5, 1, 2, "none"),     # first upsampling 5x5, halo BN = 128
+    (384, 256, 128, 64, 5, 1, 2, "none"),
+    (128, 128, 64, 128, 5, 1, 2, "none"),     # second upsampling 5x5, halo BN = 64
+    (384, 128, 64, 128, 5, 1, 2, "none"),
+    (384, 3, 64, 128, 7, 1, 3, "relu"),       # 7x7 stem on NHWC8 images (stem kernel, image data gradient on the narrow kernel)
+    (384, 64, 128, 128, 4, 2, 1, "relu"),     # stride-2 4x4 (im2col GEMM, parity-class data gradient + fold)
+    (384, 128, 256, 64, 4, 2, 1, "relu"),
+    (384, 3, 64, 128, 4, 2, 1, "lrelu"),      # D stem on images, 3B
+    (384, 256, 512, 16, 4, 2, 1, "lrelu"),    # D tail
+    (384, 512, 512, 8, 4, 2, 1, "lrelu"),
+]
+
+
+def _torch_conv(x, w, b, stride, pad, act):
+    y = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect") if pad else x, w, b, stride)
+    return orc.activation(y, act)
+
+
+@pytest.mark.parametrize("shape", HOT, ids=lambda s: "x".join(str(v) for v in s))
+def test_bf16_hot_shapes_at_bench_batch(shape):
+    B, ci, co, H, k, s, p, act = shape
+    g = torch.Generator().manual_seed(sum(v for v in shape if isinstance(v, int)) + 3)
+    x = rb(torch.randn(B, ci, H, H, generator=g))
+    w = torch.randn(co, ci, k, k, generator=g) * (1.0 / (ci * k * k) ** 0.5)
+    b = torch.randn(co, generator=g) * 0.1
+    Ho = (H + 2 * p - k) // s + 1
+    gy = rb(torch.randn(B, co, Ho, Ho, generator=g))
+    plain = act == "none"
+    # --- HIP ---
+    image = ci == 3
+    if image:
+        x0 = x.to(DEV).requires_grad_(True)
+        xd = ops.pack_image(x0)
+    else:
+        x0 = xd = x.to(DEV).to(BF).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, bd, s, p, act)
+    assert yd.dtype == BF and yd.shape == (B, co, Ho, Ho)
+    (yd.float() * gy.to(DEV)).sum().backward()
+    # --- checker (b): torch's fp32 convolution on the device, all images ---
+    xt = x.to(DEV).requires_grad_(True)
+    wt, bt = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yt = _torch_conv(xt, rb(wt.detach()) + (wt - wt.detach()), bt, s, p, act)
+    (yt * gy.to(DEV)).sum().backward()
+    assert relerr(yd, yt) <= 6e-3, ("y vs torch", relerr(yd, yt))
+    assert relerr(x0.grad, xt.grad) <= (6e-3 if plain else 1.5e-2), ("dx vs torch", relerr(x0.grad, xt.grad))
+    assert relerr(wd.grad, wt.grad) <= (3e-4 if plain else 1e-2), ("dw vs torch", relerr(wd.grad, wt.grad))
+    assert relerr(bd.grad, bt.grad) <= (3e-4 if plain else 1e-2), ("db vs torch", relerr(bd.grad, bt.grad))
+    # --- checker (a): the CPU oracle on sampled images ---
+    idx = [0, B // 2, B - 1]
+    xs = x[idx].clone().requires_grad_(True)
+    ys = orc.conv_block(xs, rb(w), b, s, p, act=act)
+    (ys * gy[idx]).sum().backward()
+    assert relerr(yd[idx].cpu(), ys) <= 6e-3, ("y vs oracle", relerr(yd[idx].cpu(), ys))
+    assert relerr(x0.grad[idx].cpu(), xs.grad) <= (6e-3 if plain else 1.5e-2), ("dx vs oracle", relerr(x0.grad[idx].cpu(), xs.grad))
+
+
+@pytest.mark.parametrize("B", [128, 384])
+def test_bf16_image_heads_at_bench_batch(B):
+    """The fused tanh x3 + sigmoid heads (64 -> 8 planes, 7x7) at 128x128 on the narrow kernel, stem-form data gradient and
+    small-channel weight gradient: device fp32 reference on all images, CPU oracle on three."""
+    C, H = 64, 128
+    g = torch.Generator().manual_seed(B)
+    x = rb(torch.randn(B, C, H, H, generator=g))
+    w = torch.randn(4, C, 7, 7, generator=g) * (1.0 / (C * 49) ** 0.5)
+    b = torch.randn(4, generator=g) * 0.1
+    gy = rb(torch.randn(B, 4, H, H, generator=g))
+    xd = x.to(DEV).to(BF).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yd = ops.conv2d_heads(xd, torch.cat([wd, wd.new_zeros(4, C, 7, 7)], 0), torch.cat([bd, bd.new_zeros(4)], 0))
+    assert yd.shape == (B, 8, H, H) and float(yd[:, 4:].abs().max()) == 0.0
+    gy8 = torch.cat([gy, torch.zeros(B, 4, H, H)], 1).to(DEV)
+    (yd.float() * gy8).sum().backward()
+
+    def heads(pre):
+        return torch.cat([torch.tanh(pre[:, :3]), torch.sigmoid(pre[:, 3:4])], 1)
+    xt, wt, bt = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yt = heads(_torch_conv(xt, rb(wt.detach()) + (wt - wt.detach()), bt, 1, 3, "none"))
+    (yt * gy.to(DEV)).sum().backward()
+    assert relerr(yd[:, :4], yt) <= 6e-3
+    assert relerr(xd.grad, xt.grad) <= 1.5e-2
+    assert relerr(wd.grad, wt.grad) <= 1e-2
+    assert relerr(bd.grad, bt.grad) <= 1e-2
+    idx = [0, B // 2, B - 1]
+    xs = x[idx].clone().requires_grad_(True)
+    ys = heads(orc.conv_block(xs, rb(w), b, 1, 3))
+    (ys * gy[idx]).sum().backward()
+    assert relerr(yd[idx, :4].cpu(), ys) <= 6e-3
+    assert relerr(xd.grad[idx].cpu(), xs.grad) <= 1.5e-2
+
+
+def test_bf16_forward_passes_b128_vs_oracle_chunks():
+    """encode (content + style heads), decode (with attention head) and the two-scale discriminator at the c2 batch, forward
+    only, against the fp32 CPU oracle evaluated in chunks of 16 samples.  bf16 activations through 10-20 layers: every output
+    within 5e-2 of the tensor's scale at its worst element and within 8e-3 on average."""
+    from solver import Solver
+    B, S, CH = 128, 128, 16
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
+    gcfg, dcfg = cfg["gen"], cfg["dis"]
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(1234)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        s.eval()
+        G = {k: v.detach().cpu() for k, v in s.gen.state_dict().items()}
+        D = {k: v.detach().cpu() for k, v in s.dis.state_dict().items()}
+        batch = synth.make_batch(B, S, seed=21)
+        x = batch["x_real"]
+        g = torch.Generator().manual_seed(22)
+        style = torch.randn(B, gcfg["num_cls"] * cfg["c_dim"], generator=g) * 0.5
+        noise = orc.GlobalCpuNoise()
+        with torch.no_grad():
+            x4 = ops.pack_image(x.to(DEV))
+            content, mus, lvs = s.gen.encode(x4)
+            img, att = s.gen.decode(content, style.to(DEV))
+            outs = s.dis(x4)
+            ref = {"content": [], "mu": [], "img": [], "att": [], "src0": [], "cls0": [], "src1": [], "cls1": []}
+            for c0 in range(0, B, CH):
+                xc = x[c0:c0 + CH]
+                rc, rmu, _ = orc.gen_encode(G, xc, gcfg, noise, training=False)
+                # the decoder is compared on the HIP path's own content code (its input), so that this leg measures the decoder
+                ri, ra = orc.gen_decode(G, content[c0:c0 + CH].float().cpu(), style[c0:c0 + CH], gcfg)
+                ro = orc.dis_forward(D, xc, dcfg)
+                ref["content"].append(rc)
+                ref["mu"].append(torch.cat(rmu, 1))
+                ref["img"].append(ri)
+                ref["att"].append(ra)
+                for sc in range(2):
+                    ref["src%d" % sc].append(ro[sc][0])
+                    ref["cls%d" % sc].append(ro[sc][1])
+        got = {"content": content, "mu": torch.cat(mus, 1), "img": img, "att": att, "src0": outs[0][0], "cls0": outs[0][1],
+               "src1": outs[1][0], "cls1": outs[1][1]}
+        report = {}
+        for k, parts in ref.items():
+            r = torch.cat(parts).float()
+            h = got[k].detach().float().cpu().reshape(r.shape)
+            scale = r.abs().max().item()
+            worst, mean = (h - r).abs().max().item() / scale, (h - r).abs().mean().item() / scale
+            # per sample: no sample may be off as a whole (a mis-addressed block in a large grid would show here)
+            per = ((h - r).abs().flatten(1).mean(1) / scale)
+            report[k] = (round(worst, 5), round(mean, 6), round(per.max().item(), 6))
+            assert worst <= 5e-2 and mean <= 8e-3 and per.max().item() <= 1.6e-2, (k, report[k])
+        print("B=128 forward vs fp32 oracle (worst, mean, worst per-sample mean; relative to max|ref|):", report)
+    finally:
+        host.set_noise(host.DeviceNoise())

@@ -31,3 +31,25 @@ def test_two_rank_rccl_training_step():
     assert r0["gen_grad_rel_err"] <= 5e-2, r0          # (G-step gradients see a D that differs by one 1e-4 Adam step: looser)
     log = out.stdout + out.stderr
     assert "nranks 2" in log or "nRanks 2" in log, "RCCL did not report a 2-rank communicator:\n" + log[-2000:]
+
+
+def test_one_rank_rccl_path_equals_plain_trainer(tmp_path):
+    """The default data-parallel path (OverlappedGradReducer on RCCL: flat-bucket gradient views, ReduceOp.AVG, async
+    all-reduce from the post-accumulate hook) driven for real on ONE GPU through a world_size-1 group with the collectives
+    forced: two tiny iterations must reproduce the plain trainer's gradients and parameters exactly (averaging over one rank
+    is the identity), with all-reduces launched from inside backward.  Runs IN this process (file:// rendezvous): a pytest
+    process that has initialised the GPU must not spawn programs on the GPU boxes."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(HERE, "helpers"))
+    import dp_force_worker
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=dev, init_method="file://" + str(tmp_path / "rdv"), rank=0, world_size=1)
+    try:
+        r = dp_force_worker.compare(dev)
+    finally:
+        dist.destroy_process_group()
+    assert r["avg_op"] and r["grad_keys_equal"], r
+    assert r["buckets"]["gen"] >= 2 and r["all_reduces"]["gen"] >= 2 * r["buckets"]["gen"], r
+    assert r["launched_early"]["gen"] >= 1 and r["launched_early"]["dis"] >= 1, r
+    assert r["max_grad_diff"] == 0.0 and r["max_param_diff"] == 0.0, r

