@@ -1,0 +1,126 @@
+// Laboratory for the bf16 halo-tiled convolution kernels (development aid, not part of libdwcgan_hip.so).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dwc-gan_amd/csrc benchmarks/halo_lab.hip -o benchmarks/bin/halo_lab
+//   benchmarks/bin/halo_lab [rounds]
+// Runs the layer shapes of BASELINE configs[2] through the compiler-scheduled 32x32x16 kernels (DWC_HALO16=0) and the
+// hand-scheduled 16x16x32 kernels (DWC_HALO16=1, the default) of dwc_bf16_conv2d_same_halo on the same RANDOM bf16 operands
+// (zero-filled operands clock higher: cdna_hip_programming.md rule 25), variants interleaved in ONE process (rule 24), checks
+// that the two agree, and prints median / min microseconds and TFLOP/s against the 2.5 PF dense bf16 roof.
+#include "../dwc-gan_amd/csrc/conv_halo_bf16.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static unsigned short f2bf(float f) {
+    unsigned u;
+    memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+}
+static float bf2f(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Shape { const char* name; int B, H, Cin, Cout, K; };
+
+int main(int argc, char** argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 12;
+    const Shape shapes[] = {
+        {"3x3 256>256 @32 B128", 128, 32, 256, 256, 3}, {"3x3 256>256 @32 B384", 384, 32, 256, 256, 3},
+        {"5x5 256>128 @64 B128", 128, 64, 256, 128, 5}, {"5x5 256>128 @64 B384", 384, 64, 256, 128, 5},
+        {"5x5 128>64 @128 B128", 128, 128, 128, 64, 5}, {"5x5 128>64 @128 B384", 384, 128, 128, 64, 5},
+        {"5x5 128>256 @64 B128 (dgrad)", 128, 64, 128, 256, 5}, {"5x5 64>128 @128 B128 (dgrad)", 128, 128, 64, 128, 5},
+        {"3x3 64>128 @32 B8", 8, 32, 64, 128, 3}, {"3x3 128>64 @48 B3", 3, 48, 128, 64, 3},
+    };
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    srand(1234);
+    for (const Shape& s : shapes) {
+        const size_t nx = (size_t)s.B * s.H * s.H * s.Cin, ny = (size_t)s.B * s.H * s.H * s.Cout;
+        const int Kp = (s.K * s.K * s.Cin + 63) / 64 * 64;
+        const size_t nw = (size_t)s.Cout * Kp;
+        std::vector<unsigned short> hx(nx), hw(nw);
+        for (auto& v : hx) v = f2bf((float)rand() / RAND_MAX * 2.f - 1.f);
+        for (auto& v : hw) v = f2bf(((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f);
+        std::vector<float> hb(s.Cout);
+        for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
+        void *dx, *dw, *dy[2];
+        float* db;
+        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dy[0], ny * 2)); CK(hipMalloc(&dy[1], ny * 2));
+        CK(hipMalloc(&db, s.Cout * 4));
+        CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), s.Cout * 4, hipMemcpyHostToDevice));
+        const double flops = 2.0 * s.B * s.H * s.H * (double)s.Cout * s.Cin * s.K * s.K;
+        std::vector<float> tms[2];
+        double maxdiff[2] = {0, 0};
+        for (int reflect = 1; reflect >= 0; --reflect) {
+            for (int v = 0; v < 2; ++v) {
+                CK(hipMemset(dy[v], 0xFF, ny * 2));
+                setenv("DWC_HALO16", v ? "1" : "0", 1);
+            }
+            // the dispatcher reads DWC_HALO16 once (static): call the kernels directly instead
+            for (int r = 0; r < (reflect ? rounds : 1); ++r)
+                for (int v = 0; v < 2; ++v) {
+                    HaloArgs a;
+                    a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = reflect ? db : nullptr; a.y = (bf16*)dy[v];
+                    a.B = s.B; a.H = s.H; a.W = s.H; a.Cin = s.Cin; a.logCin = dwc_ilog2_exact(s.Cin); a.N = s.Cout; a.K = s.K;
+                    a.Kp = Kp; a.act = reflect ? DWC_ACT_RELU : DWC_ACT_NONE; a.reflect = reflect;
+                    a.blocks_x = s.H / 16; a.blocks_per_img = (s.H / 16) * (s.H / 16);
+                    const int nblk = s.B * a.blocks_per_img;
+                    CK(hipEventRecord(e0, st));
+#define L32(KS, BN, WM, WN, TM, TN) do { a.tiles_n = (s.Cout + BN - 1) / BN; hipLaunchKernelGGL((conv_halo_kernel<KS, BN, WM, WN, TM, TN, (KS == 3 ? 2 : 1)>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a); } while (0)
+#define L16(KS, BN, WM, WN, PB) do { a.tiles_n = (s.Cout + BN - 1) / BN; hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a); } while (0)
+                    if (v == 0) {
+                        if (s.K == 3) { if (s.Cout > 128) L32(3, 256, 2, 4, 4, 2); else if (s.Cout > 64) L32(3, 128, 4, 2, 2, 2); else L32(3, 64, 4, 2, 2, 1); }
+                        else { if (s.Cout > 128) L32(5, 256, 2, 4, 4, 2); else if (s.Cout > 64) L32(5, 128, 4, 2, 2, 2); else L32(5, 64, 4, 2, 2, 1); }
+                    } else {
+                        if (s.K == 3) { if (s.Cout > 128) L16(3, 256, 2, 4, 2); else if (s.Cout > 64) L16(3, 128, 4, 2, 2); else L16(3, 64, 4, 2, 2); }
+                        else { if (s.Cout > 128) L16(5, 256, 2, 4, 1); else if (s.Cout > 64) L16(5, 128, 4, 2, 1); else L16(5, 64, 4, 2, 1); }
+                    }
+                    CK(hipGetLastError());
+                    CK(hipEventRecord(e1, st));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (reflect && r >= 2) tms[v].push_back(ms);
+                }
+            std::vector<unsigned short> y0(ny), y1(ny);
+            CK(hipMemcpy(y0.data(), dy[0], ny * 2, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(y1.data(), dy[1], ny * 2, hipMemcpyDeviceToHost));
+            double md = 0, scale = 0;
+            size_t nbad = 0;
+            for (size_t i = 0; i < ny; ++i) {
+                const double a0 = bf2f(y0[i]), a1 = bf2f(y1[i]);
+                scale = std::max(scale, std::fabs(a0));
+                const double d = std::fabs(a0 - a1);
+                if (!(d <= 1e30)) ++nbad;
+                md = std::max(md, d);
+            }
+            maxdiff[reflect] = md / (scale > 0 ? scale : 1);
+            if (nbad) printf("  !! %zu non-finite differences (reflect=%d)\n", nbad, reflect);
+        }
+        auto stat = [&](std::vector<float>& t, double& med, double& mn) {
+            std::sort(t.begin(), t.end());
+            med = t[t.size() / 2];
+            mn = t[0];
+        };
+        double m0, n0, m1, n1;
+        stat(tms[0], m0, n0);
+        stat(tms[1], m1, n1);
+        printf("%-30s %8.1f GFLOP | 32x32x16: med %8.1f us min %8.1f (%5.1f%% of 2.5PF) | 16x16x32 hand: med %8.1f us min %8.1f (%5.1f%%) | x%.3f | maxdiff/scale fwd %.2e dgrad %.2e\n",
+               s.name, flops / 1e9, m0 * 1e3, n0 * 1e3, flops / (m0 * 1e-3) / 2.5e15 * 100, m1 * 1e3, n1 * 1e3,
+               flops / (m1 * 1e-3) / 2.5e15 * 100, m0 / m1, maxdiff[1], maxdiff[0]);
+        fflush(stdout);
+        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(db));
+    }
+    return 0;
+}

@@ -623,6 +623,39 @@ __global__ void fold_reflect_kernel_h(const bf16* __restrict__ gp, bf16* __restr
     reinterpret_cast<bf16x4*>(dx)[idx] = pack4(s[0], s[1], s[2], s[3]);
 }
 
+// the same with 16-byte accesses (8 channels per lane) and a (W*C8 / 256, H, B) grid: no per-element 64-bit divisions.  r02: the
+// 8-byte form ran at 3.5 TB/s on the stride-2 data gradients of configs[2] (3.4 ms per step).
+__global__ __launch_bounds__(256) void fold_reflect_kernel_h8(const bf16* __restrict__ gp, bf16* __restrict__ dx, int H, int W, int C8,
+                                                              int pad, int Wp) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * C8) return;
+    const int w = idx / C8, c = idx - w * C8;
+    const int h = blockIdx.y;
+    const size_t n = blockIdx.z;
+    const int Hp = H + 2 * pad;
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    const bf16x8* g8 = reinterpret_cast<const bf16x8*>(gp);
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            const bf16x8 v = g8[((n * Hp + hs[a]) * (size_t)Wp + ws[b]) * C8 + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+        }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (bf16)s[k];
+    reinterpret_cast<bf16x8*>(dx)[((n * H + h) * (size_t)W + w) * C8 + c] = o;
+}
+
 // dx (bf16, holds the interior) += the fp32 border ring folded back by the reflect rule (see fold_ring_kernel, conv_igemm.hip)
 __global__ void fold_ring_kernel_h(bf16* __restrict__ dx, const float* __restrict__ ring, size_t off_bottom, size_t off_left,
                                    size_t off_right, int parts, size_t part_stride, int B, int H, int W, int C4, int pad) {
@@ -908,6 +941,12 @@ int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int
 
 int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || pad < 0 || pad >= H || pad >= W) return DWC_EINVAL;
+    if (!(C & 7) && H <= 65535 && B <= 65535) {
+        hipLaunchKernelGGL(fold_reflect_kernel_h8, dim3((W * (C / 8) + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)dxp, (bf16*)dx, H, W, C / 8, pad, W + 2 * pad);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     const size_t total = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(fold_reflect_kernel_h, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxp,
                        (bf16*)dx, B, H, W, C / 4, pad, W + 2 * pad);

@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #endif
 }
 
+#include "conv_halo16_bf16.inc"
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient of the same layers, halo form.  dW[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dY[pixel][co]: the
 // im2col form (conv_bf16.hip) re-stages x once per tap (r02 ablation: staging is 40-45 % of that kernel's time).  Here a
@@ -567,6 +569,27 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
             hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
         else
             hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 2>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
+    // Default: the hand-scheduled 16x16x32 kernel (conv_halo16_bf16.inc).  DWC_HALO16=0: the compiler-scheduled 32x32x16 kernels below.
+    static const int h16 = getenv("DWC_HALO16") ? atoi(getenv("DWC_HALO16")) : 1;
+    if (h16) {
+#define HALO16_LAUNCH(KS, BN, WM, WN, PB)                                                                                  \
+    do {                                                                                                                  \
+        a.tiles_n = (Cout + BN - 1) / BN;                                                                                 \
+        hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);        \
+    } while (0)
+        if (K == 3) {
+            if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);
+            else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
+            else HALO16_LAUNCH(3, 64, 4, 2, 2);
+        } else {
+            if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
+            else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
+            else HALO16_LAUNCH(5, 64, 4, 2, 1);
+        }
+#undef HALO16_LAUNCH
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }

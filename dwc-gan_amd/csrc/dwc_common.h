@@ -26,6 +26,47 @@ __device__ __forceinline__ void st4(dwc_bf16* p, size_t i4, f32x4 v) {
 }
 #endif
 
+#ifdef __HIPCC__
+// Elements per thread and access: V = 16 bytes worth (4 fp32 / 8 bf16) -- 8-byte accesses reach only 0.54-0.70 of the 16-byte
+// rate on MI355X (MI355X_MICROARCH.md), and r02's bf16 norm kernels (4 bf16 = 8 bytes per lane) sat at 3.8-4.3 TB/s.
+template <typename T> struct VecOf { static constexpr int V = 4; };
+template <> struct VecOf<dwc_bf16> { static constexpr int V = 8; };
+
+__device__ __forceinline__ void ldv(const float* p, size_t iv, float (&o)[4]) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(p)[iv];
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+__device__ __forceinline__ void ldv(const dwc_bf16* p, size_t iv, float (&o)[8]) {
+    const dwc_bf16x8 v = reinterpret_cast<const dwc_bf16x8*>(p)[iv];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (float)v[k];
+}
+__device__ __forceinline__ void stv(float* p, size_t iv, const float (&o)[4]) {
+    reinterpret_cast<f32x4*>(p)[iv] = f32x4{o[0], o[1], o[2], o[3]};
+}
+__device__ __forceinline__ void stv(dwc_bf16* p, size_t iv, const float (&o)[8]) {
+    dwc_bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (dwc_bf16)o[k];
+    reinterpret_cast<dwc_bf16x8*>(p)[iv] = r;
+}
+// V consecutive fp32 values (per-(n,c) statistics / affine parameters) starting at element e (a multiple of V)
+template <int V>
+__device__ __forceinline__ void ldf(const float* p, size_t e, float (&o)[V]) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(p + e)[q];
+        o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
+    }
+}
+template <int V>
+__device__ __forceinline__ void stf(float* p, size_t e, const float (&o)[V]) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) reinterpret_cast<f32x4*>(p + e)[q] = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+}
+
+#endif
+
 #define DWC_LAUNCH_CHECK()                                   \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return DWC_ELAUNCH; \

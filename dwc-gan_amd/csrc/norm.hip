@@ -19,7 +19,7 @@
 
 namespace {
 
-// rows-per-sample are split into `chunks`; geometry shared by the statistics kernels
+// rows-per-sample are split into `chunks`; geometry shared by the statistics kernels (one partial per chunk)
 struct RowSplit {
     int chunks, rows_per_chunk;
 };
@@ -36,6 +36,43 @@ RowSplit plan_rows(int B, int HW) {
     return r;
 }
 
+// The apply passes carry no partials, so they split finer: a 256-thread block = (256 / cq) row groups x cq column groups
+// (cq = C / V) walks about eight rows per thread; grid (row chunks, B).  The per-(n,c) statistics and affine parameters are
+// loaded ONCE per thread (they used to be re-fetched, behind a 64-bit division, for every 4 elements).
+RowSplit plan_apply(int B, int HW, int C, int V) {
+    const int cq = C / V > 0 ? C / V : 1;
+    const int groups = 256 / cq > 0 ? 256 / cq : 1;
+    int rpc = groups * 8;
+    while ((long)B * ((HW + rpc - 1) / rpc) > 16384 && rpc < HW) rpc *= 2;     // bound the grid on huge tensors
+    RowSplit r;
+    r.rows_per_chunk = rpc < HW ? rpc : HW;
+    r.chunks = (HW + r.rows_per_chunk - 1) / r.rows_per_chunk;
+    return r;
+}
+
+// sum of `groups` row-group partials held in LDS (fixed order: bitwise reproducible), for the thread with rg == 0
+template <int V>
+__device__ __forceinline__ void colsum_groups(float (&a)[V], float (&b)[V], float* sm, int groups, int cq, int col, int rg) {
+    // layout sm[plane][t][V] with t = rg * cq + col
+    float* s0 = sm;
+    float* s1 = sm + 256 * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        s0[threadIdx.x * V + k] = a[k];
+        s1[threadIdx.x * V + k] = b[k];
+    }
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < groups; ++g) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                a[k] += s0[(g * cq + col) * V + k];
+                b[k] += s1[(g * cq + col) * V + k];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // instance norm
 // ---------------------------------------------------------------------------------------
@@ -43,33 +80,51 @@ RowSplit plan_rows(int B, int HW) {
 template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int rows_per_chunk, size_t plane) {
-    __shared__ f32x4 sm[2][256];
-    const int cq = C >> 2;
+    constexpr int V = VecOf<T>::V;
+    __shared__ float sm[2 * 256 * V];
+    const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const T* xs = x + (size_t)n * HW * C;
-    const f32x4 piv = ld4(xs, col);
+    float piv[V];
+    ldv(xs, col, piv);
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(HW, r0 + rows_per_chunk);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    if (rg < groups)
-        for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 v = ld4(xs, (size_t)r * cq + col) - piv;
-            s1 += v;
-            s2 += v * v;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+    if (rg < groups) {
+        int r = r0 + rg;
+        for (; r + 3 * groups < r1; r += 4 * groups) {           // four rows in flight per thread
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldv(xs, (size_t)(r + u * groups) * cq + col, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    const float d = v[u][k] - piv[k];
+                    s1[k] += d;
+                    s2[k] += d * d;
+                }
         }
-    sm[0][threadIdx.x] = s1;
-    sm[1][threadIdx.x] = s2;
-    __syncthreads();
+        for (; r < r1; r += groups) {
+            float v[V];
+            ldv(xs, (size_t)r * cq + col, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float d = v[k] - piv[k];
+                s1[k] += d;
+                s2[k] += d * d;
+            }
+        }
+    }
+    colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
-        for (int g = 1; g < groups; ++g) {
-            s1 += sm[0][g * cq + col];
-            s2 += sm[1][g * cq + col];
-        }
-        const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * 4;
-        *reinterpret_cast<f32x4*>(part + o) = s1;
-        *reinterpret_cast<f32x4*>(part + plane + o) = s2;
+        const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
+        stf<V>(part, o, s1);
+        stf<V>(part + plane, o, s2);
     }
 }
 
@@ -95,33 +150,60 @@ template <typename T>
 __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const T* __restrict__ residual,
-                                                T* __restrict__ y, int HW, int C, size_t total4, int relu) {
-    const int cq = C >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = i % cq;
-        const size_t n = i / ((size_t)HW * cq);
-        const size_t s = n * cq + c4;
-        f32x4 sc = reinterpret_cast<const f32x4*>(rstd)[s];
-        if (gamma) sc *= reinterpret_cast<const f32x4*>(gamma)[s];
-        f32x4 v = (ld4(x, i) - reinterpret_cast<const f32x4*>(mean)[s]) * sc;
-        if (beta) v += reinterpret_cast<const f32x4*>(beta)[s];
-        if (relu) {
-            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
+                                                T* __restrict__ y, int HW, int C, int rows_per_chunk, int relu) {
+    constexpr int V = VecOf<T>::V;
+    const int cq = C / V;
+    const int groups = 256 / cq;
+    const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
+    if (rg >= groups) return;
+    const int n = blockIdx.y;
+    const size_t s = (size_t)n * C + col * V;
+    float mu[V], sc[V], sh[V];
+    ldf<V>(mean, s, mu);
+    ldf<V>(rstd, s, sc);
+    if (gamma) {
+        float ga[V];
+        ldf<V>(gamma, s, ga);
+#pragma unroll
+        for (int k = 0; k < V; ++k) sc[k] *= ga[k];
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) sh[k] = 0.f;
+    if (beta) ldf<V>(beta, s, sh);
+    const size_t base = (size_t)n * HW * cq + col;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(HW, r0 + rows_per_chunk);
+    auto one = [&](const float (&v)[V], const float* res, float (&o)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float t = (v[k] - mu[k]) * sc[k] + sh[k];
+            if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
+            o[k] = res ? t + res[k] : t;
         }
-        if (residual) v += ld4(residual, i);
-        st4(y, i, v);
+    };
+    int r = r0 + rg;
+    for (; r + groups < r1; r += 2 * groups) {            // two rows in flight per thread
+        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+        float v0[V], v1[V], q0[V], q1[V], o0[V], o1[V];
+        ldv(x, i0, v0);
+        ldv(x, i1, v1);
+        if (residual) {
+            ldv(residual, i0, q0);
+            ldv(residual, i1, q1);
+        }
+        one(v0, residual ? q0 : nullptr, o0);
+        one(v1, residual ? q1 : nullptr, o1);
+        stv(y, i0, o0);
+        stv(y, i1, o1);
     }
-}
-
-// effective upstream gradient: masks by the ReLU that followed the norm
-__device__ __forceinline__ f32x4 relu_mask(f32x4 dy, f32x4 pre, int relu) {
-    if (relu) {
-        dy[0] = pre[0] > 0.f ? dy[0] : 0.f;
-        dy[1] = pre[1] > 0.f ? dy[1] : 0.f;
-        dy[2] = pre[2] > 0.f ? dy[2] : 0.f;
-        dy[3] = pre[3] > 0.f ? dy[3] : 0.f;
+    for (; r < r1; r += groups) {
+        const size_t i0 = base + (size_t)r * cq;
+        float v0[V], q0[V], o0[V];
+        ldv(x, i0, v0);
+        if (residual) ldv(residual, i0, q0);
+        one(v0, residual ? q0 : nullptr, o0);
+        stv(y, i0, o0);
     }
-    return dy;
 }
 
 template <typename T>
@@ -130,41 +212,60 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part, int HW, int C, int rows_per_chunk, size_t plane,
                                                       int relu) {
-    __shared__ f32x4 sm[2][256];
-    const int cq = C >> 2;
+    constexpr int V = VecOf<T>::V;
+    __shared__ float sm[2 * 256 * V];
+    const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    const size_t base = (size_t)n * HW * cq;
-    const T* xs = x + base * 4;
-    const T* ds = dy + base * 4;
-    const size_t s = (size_t)n * cq + col;
-    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[s];
-    const f32x4 rs = reinterpret_cast<const f32x4*>(rstd)[s];
-    f32x4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
-    if (gamma) ga = reinterpret_cast<const f32x4*>(gamma)[s];
-    if (beta) be = reinterpret_cast<const f32x4*>(beta)[s];
+    const size_t base = (size_t)n * HW * cq + col;
+    const size_t s = (size_t)n * C + col * V;
+    float mu[V], rs[V], ga[V], be[V];
+    ldf<V>(mean, s, mu);
+    ldf<V>(rstd, s, rs);
+#pragma unroll
+    for (int k = 0; k < V; ++k) ga[k] = 1.f, be[k] = 0.f;
+    if (gamma) ldf<V>(gamma, s, ga);
+    if (beta) ldf<V>(beta, s, be);
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(HW, r0 + rows_per_chunk);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    if (rg < groups)
-        for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 xh = (ld4(xs, (size_t)r * cq + col) - mu) * rs;
-            const f32x4 g = relu_mask(ld4(ds, (size_t)r * cq + col), xh * ga + be, relu);
-            s1 += g;
-            s2 += g * xh;
+    float s1[V], s2[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s1[k] = s2[k] = 0.f;
+    auto acc = [&](const float (&xv)[V], const float (&dv)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            float g = dv[k];
+            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            s1[k] += g;
+            s2[k] += g * xh;
         }
-    sm[0][threadIdx.x] = s1;
-    sm[1][threadIdx.x] = s2;
-    __syncthreads();
+    };
+    if (rg < groups) {
+        int r = r0 + rg;
+        for (; r + groups < r1; r += 2 * groups) {
+            const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+            float x0[V], x1[V], d0[V], d1[V];
+            ldv(x, i0, x0);
+            ldv(x, i1, x1);
+            ldv(dy, i0, d0);
+            ldv(dy, i1, d1);
+            acc(x0, d0);
+            acc(x1, d1);
+        }
+        for (; r < r1; r += groups) {
+            float x0[V], d0[V];
+            ldv(x, base + (size_t)r * cq, x0);
+            ldv(dy, base + (size_t)r * cq, d0);
+            acc(x0, d0);
+        }
+    }
+    colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
-        for (int g = 1; g < groups; ++g) {
-            s1 += sm[0][g * cq + col];
-            s2 += sm[1][g * cq + col];
-        }
-        const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * 4;
-        *reinterpret_cast<f32x4*>(part + o) = s1;
-        *reinterpret_cast<f32x4*>(part + plane + o) = s2;
+        const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
+        stf<V>(part, o, s1);
+        stf<V>(part + plane, o, s2);
     }
 }
 
@@ -190,146 +291,59 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, T* __restrict__ dx, int HW, int C, int BC,
-                                                    size_t total4, int relu) {
-    const int cq = C >> 2;
+                                                    int rows_per_chunk, int relu) {
+    constexpr int V = VecOf<T>::V;
+    const int cq = C / V;
+    const int groups = 256 / cq;
+    const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
+    if (rg >= groups) return;
+    const int n = blockIdx.y;
+    const size_t s = (size_t)n * C + col * V;
     const float inv_hw = 1.f / (float)HW;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = i % cq;
-        const size_t n = i / ((size_t)HW * cq);
-        const size_t s = n * cq + c4;
-        const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[s];
-        const f32x4 rs = reinterpret_cast<const f32x4*>(rstd)[s];
-        f32x4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
-        if (gamma) ga = reinterpret_cast<const f32x4*>(gamma)[s];
-        if (beta) be = reinterpret_cast<const f32x4*>(beta)[s];
-        const f32x4 s1 = reinterpret_cast<const f32x4*>(sums)[s];
-        const f32x4 s2 = reinterpret_cast<const f32x4*>(sums + BC)[s];
-        const f32x4 xh = (ld4(x, i) - mu) * rs;
-        const f32x4 g = relu_mask(ld4(dy, i), xh * ga + be, relu);
-        st4(dx, i, ga * rs * (g - s1 * inv_hw - xh * (s2 * inv_hw)));
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// instance norm, ONE launch per direction for the maps that dominate the step (the 32x32 ResBlock / AdaIN layers): a
-// workgroup owns one sample and 32 channels (HW rows x 128 bytes fp32 / 64 bytes bf16 -- at most 512 KB, so its second pass
-// re-reads what it has just pulled through L2), reduces the statistics through LDS in a fixed order, and applies.  Replaces
-// three launches (partial statistics, combine, apply) and one of the two (forward) / two of the four (backward) HBM reads.
-// ---------------------------------------------------------------------------------------
-constexpr int IN_CG = 32;                // channels per workgroup
-constexpr int IN_RG = 256 / (IN_CG / 4); // row groups: 32
-
-// sum over the IN_RG row groups of two f32x4 per thread; result valid for threads with rg == 0 ... all (broadcast through LDS)
-__device__ __forceinline__ void in_block_reduce(f32x4& s1, f32x4& s2, f32x4 (*sm)[256]) {
-    const int t = threadIdx.x, col = t % (IN_CG / 4);
-    sm[0][t] = s1;
-    sm[1][t] = s2;
-    __syncthreads();
-    if (t < IN_CG / 4) {
-        f32x4 a = sm[0][t], b = sm[1][t];
-        for (int g = 1; g < IN_RG; ++g) {            // fixed order: bitwise reproducible
-            a += sm[0][g * (IN_CG / 4) + t];
-            b += sm[1][g * (IN_CG / 4) + t];
-        }
-        sm[0][t] = a;
-        sm[1][t] = b;
-    }
-    __syncthreads();
-    s1 = sm[0][col];
-    s2 = sm[1][col];
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void in_fused_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
-                                                    float* __restrict__ mean, float* __restrict__ rstd, int HW, int C, float eps,
-                                                    int relu) {
-    __shared__ f32x4 sm[2][256];
-    const int cq = C >> 2;
-    const int col = threadIdx.x % (IN_CG / 4), rg = threadIdx.x / (IN_CG / 4);
-    const int n = blockIdx.y, c4 = blockIdx.x * (IN_CG / 4) + col;
-    const size_t base = (size_t)n * HW * cq + c4;
-    const f32x4 piv = ld4(x, base);
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    for (int r = rg; r < HW; r += IN_RG) {
-        const f32x4 v = ld4(x, base + (size_t)r * cq) - piv;
-        s1 += v;
-        s2 += v * v;
-    }
-    in_block_reduce(s1, s2, sm);
-    const float inv = 1.f / (float)HW;
-    const f32x4 d = s1 * inv;
-    f32x4 var = s2 * inv - d * d;
-    f32x4 mu, rs;
+    float mu[V], rs[V], ga[V], be[V], k1[V], k2[V];
+    ldf<V>(mean, s, mu);
+    ldf<V>(rstd, s, rs);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        mu[k] = piv[k] + d[k];
-        rs[k] = 1.f / sqrtf(fmaxf(var[k], 0.f) + eps);
-    }
-    const size_t sidx = (size_t)n * cq + c4;
-    if (rg == 0) {
-        reinterpret_cast<f32x4*>(mean)[sidx] = mu;
-        reinterpret_cast<f32x4*>(rstd)[sidx] = rs;
-    }
-    f32x4 sc = rs, sh = {0, 0, 0, 0};
-    if (gamma) sc *= reinterpret_cast<const f32x4*>(gamma)[sidx];
-    if (beta) sh = reinterpret_cast<const f32x4*>(beta)[sidx];
-    for (int r = rg; r < HW; r += IN_RG) {
-        const size_t i = base + (size_t)r * cq;
-        f32x4 v = (ld4(x, i) - mu) * sc + sh;
-        if (relu) {
-            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
+    for (int k = 0; k < V; ++k) ga[k] = 1.f, be[k] = 0.f;
+    if (gamma) ldf<V>(gamma, s, ga);
+    if (beta) ldf<V>(beta, s, be);
+    ldf<V>(sums, s, k1);
+    ldf<V>(sums + BC, s, k2);
+#pragma unroll
+    for (int k = 0; k < V; ++k) k1[k] *= inv_hw, k2[k] *= inv_hw;
+    const size_t base = (size_t)n * HW * cq + col;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(HW, r0 + rows_per_chunk);
+    auto one = [&](const float (&xv)[V], const float (&dv)[V], float (&o)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            float g = dv[k];
+            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            o[k] = ga[k] * rs[k] * (g - k1[k] - xh * k2[k]);
         }
-        if (residual) v += ld4(residual, i);
-        st4(y, i, v);
+    };
+    int r = r0 + rg;
+    for (; r + groups < r1; r += 2 * groups) {
+        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+        float x0[V], x1[V], d0[V], d1[V], o0[V], o1[V];
+        ldv(x, i0, x0);
+        ldv(x, i1, x1);
+        ldv(dy, i0, d0);
+        ldv(dy, i1, d1);
+        one(x0, d0, o0);
+        one(x1, d1, o1);
+        stv(dx, i0, o0);
+        stv(dx, i1, o1);
     }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void in_fused_bwd(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, T* __restrict__ dx, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int HW, int C, int relu) {
-    __shared__ f32x4 sm[2][256];
-    const int cq = C >> 2;
-    const int col = threadIdx.x % (IN_CG / 4), rg = threadIdx.x / (IN_CG / 4);
-    const int n = blockIdx.y, c4 = blockIdx.x * (IN_CG / 4) + col;
-    const size_t base = (size_t)n * HW * cq + c4;
-    const size_t sidx = (size_t)n * cq + c4;
-    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[sidx];
-    const f32x4 rs = reinterpret_cast<const f32x4*>(rstd)[sidx];
-    f32x4 ga = {1, 1, 1, 1}, be = {0, 0, 0, 0};
-    if (gamma) ga = reinterpret_cast<const f32x4*>(gamma)[sidx];
-    if (beta) be = reinterpret_cast<const f32x4*>(beta)[sidx];
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    for (int r = rg; r < HW; r += IN_RG) {
-        const size_t i = base + (size_t)r * cq;
-        const f32x4 xh = (ld4(x, i) - mu) * rs;
-        const f32x4 g = relu_mask(ld4(dy, i), xh * ga + be, relu);
-        s1 += g;
-        s2 += g * xh;
+    for (; r < r1; r += groups) {
+        const size_t i0 = base + (size_t)r * cq;
+        float x0[V], d0[V], o0[V];
+        ldv(x, i0, x0);
+        ldv(dy, i0, d0);
+        one(x0, d0, o0);
+        stv(dx, i0, o0);
     }
-    in_block_reduce(s1, s2, sm);
-    if (rg == 0) {
-        if (dgamma) reinterpret_cast<f32x4*>(dgamma)[sidx] = s2;
-        if (dbeta) reinterpret_cast<f32x4*>(dbeta)[sidx] = s1;
-    }
-    const float inv_hw = 1.f / (float)HW;
-    const f32x4 k1 = s1 * inv_hw, k2 = s2 * inv_hw, gs = ga * rs;
-    for (int r = rg; r < HW; r += IN_RG) {
-        const size_t i = base + (size_t)r * cq;
-        const f32x4 xh = (ld4(x, i) - mu) * rs;
-        const f32x4 g = relu_mask(ld4(dy, i), xh * ga + be, relu);
-        st4(dx, i, gs * (g - k1 - xh * k2));
-    }
-}
-
-// Opt-in (DWC_IN_FUSED=1): measured 1 % SLOWER than the three-launch form on both bench configurations (c1 219.3 vs 221.8,
-// c2 975 vs 986 images/s) -- one 256-thread workgroup per (sample, 32 channels) walks its slice twice at far less memory
-// parallelism than the chunked statistics + grid-wide apply passes, and that costs more than the launches and the re-read save.
-static bool in_fused_ok(int B, int HW, int C) {
-    static const int on = getenv("DWC_IN_FUSED") ? atoi(getenv("DWC_IN_FUSED")) : 0;
-    return on && !(C % IN_CG) && HW <= 4096 && HW >= IN_RG && (long)B * (C / IN_CG) >= 16;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -338,18 +352,38 @@ static bool in_fused_ok(int B, int HW, int C) {
 template <typename T>
 __global__ __launch_bounds__(256) void ln_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                         int rows_per_chunk) {
+    constexpr int V = VecOf<T>::V;
     __shared__ float sm[4];
-    const int cq = C >> 2;
+    const int cq = C / V;
     const int n = blockIdx.y, chunk = blockIdx.x;
     const T* xs = x + (size_t)n * HW * C;
     const float piv = (float)x[(size_t)n * HW * C];
     const size_t e0 = (size_t)chunk * rows_per_chunk * cq;
     const size_t e1 = min((size_t)HW * cq, e0 + (size_t)rows_per_chunk * cq);
     float s1 = 0.f, s2 = 0.f;
-    for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
-        const f32x4 v = ld4(xs, e) - piv;
-        s1 += (v[0] + v[1]) + (v[2] + v[3]);
-        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    auto acc = [&](const float (&v)[V]) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = v[k] - piv;
+            a += d;
+            b += d * d;
+        }
+        s1 += a;
+        s2 += b;
+    };
+    size_t e = e0 + threadIdx.x;
+    for (; e + 768 < e1; e += 1024) {
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ldv(xs, e + 256 * u, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc(v[u]);
+    }
+    for (; e < e1; e += 256) {
+        float v[V];
+        ldv(xs, e, v);
+        acc(v);
     }
     s1 = dwc_block_sum_256(s1, sm);
     s2 = dwc_block_sum_256(s2, sm);
@@ -380,20 +414,46 @@ __global__ void ln_stats_final(const T* __restrict__ x, const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ inv, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, T* __restrict__ y, int HW, int C, size_t total4,
+                                                const float* __restrict__ beta, T* __restrict__ y, int HW, int C, int rows_per_chunk,
                                                 int relu) {
-    const int cq = C >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = i % cq;
-        const size_t n = i / ((size_t)HW * cq);
-        const float mu = mean[n], iv = inv[n];
-        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
-        const f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
-        f32x4 v = (ld4(x, i) - mu) * iv * ga + be;
-        if (relu) {
-            v[0] = v[0] < 0.f ? 0.f : v[0]; v[1] = v[1] < 0.f ? 0.f : v[1]; v[2] = v[2] < 0.f ? 0.f : v[2]; v[3] = v[3] < 0.f ? 0.f : v[3];   // NaN-preserving
+    constexpr int V = VecOf<T>::V;
+    const int cq = C / V;
+    const int groups = 256 / cq;
+    const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
+    if (rg >= groups) return;
+    const int n = blockIdx.y;
+    const float mu = mean[n], iv = inv[n];
+    float sc[V], sh[V];
+    ldf<V>(gamma, (size_t)col * V, sc);
+    ldf<V>(beta, (size_t)col * V, sh);
+#pragma unroll
+    for (int k = 0; k < V; ++k) sc[k] *= iv;
+    const size_t base = (size_t)n * HW * cq + col;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(HW, r0 + rows_per_chunk);
+    auto one = [&](const float (&v)[V], float (&o)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float t = (v[k] - mu) * sc[k] + sh[k];
+            o[k] = (relu && t < 0.f) ? 0.f : t;          // NaN-preserving
         }
-        st4(y, i, v);
+    };
+    int r = r0 + rg;
+    for (; r + groups < r1; r += 2 * groups) {
+        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+        float v0[V], v1[V], o0[V], o1[V];
+        ldv(x, i0, v0);
+        ldv(x, i1, v1);
+        one(v0, o0);
+        one(v1, o1);
+        stv(y, i0, o0);
+        stv(y, i1, o1);
+    }
+    for (; r < r1; r += groups) {
+        float v0[V], o0[V];
+        ldv(x, base + (size_t)r * cq, v0);
+        one(v0, o0);
+        stv(y, base + (size_t)r * cq, o0);
     }
 }
 
@@ -405,45 +465,65 @@ __global__ __launch_bounds__(256) void ln_bwd_partial(const T* __restrict__ dy, 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part_s, float* __restrict__ part_c, int HW, int C,
                                                       int rows_per_chunk, int relu) {
-    __shared__ f32x4 sm[2][256];
+    constexpr int V = VecOf<T>::V;
+    __shared__ float sm[2 * 256 * V];
     __shared__ float sr[4];
-    const int cq = C >> 2;
+    const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     const int n = blockIdx.y, chunk = blockIdx.x;
-    const size_t base = (size_t)n * HW * cq;
-    const T* xs = x + base * 4;
-    const T* ds = dy + base * 4;
+    const size_t base = (size_t)n * HW * cq + col;
     const float mu = mean[n], iv = inv[n];
-    const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[col];
-    const f32x4 be = reinterpret_cast<const f32x4*>(beta)[col];
+    float ga[V], be[V];
+    ldf<V>(gamma, (size_t)col * V, ga);
+    ldf<V>(beta, (size_t)col * V, be);
     const int r0 = chunk * rows_per_chunk;
     const int r1 = min(HW, r0 + rows_per_chunk);
-    f32x4 dg = {0, 0, 0, 0}, db = {0, 0, 0, 0};
+    float dg[V], db[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) dg[k] = db[k] = 0.f;
     float t1 = 0.f, t2 = 0.f;
-    if (rg < groups)
-        for (int r = r0 + rg; r < r1; r += groups) {
-            const f32x4 xc = ld4(xs, (size_t)r * cq + col) - mu;
-            const f32x4 xh = xc * iv;
-            const f32x4 d = relu_mask(ld4(ds, (size_t)r * cq + col), xh * ga + be, relu);
-            dg += d * xh;
-            db += d;
-            const f32x4 g = d * ga;
-            t1 += (g[0] + g[1]) + (g[2] + g[3]);
-            const f32x4 gx = g * xc;
-            t2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+    auto acc = [&](const float (&xv)[V], const float (&dv)[V]) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xc = xv[k] - mu;
+            const float xh = xc * iv;
+            float d = dv[k];
+            if (relu) d = (xh * ga[k] + be[k]) > 0.f ? d : 0.f;
+            dg[k] += d * xh;
+            db[k] += d;
+            const float g = d * ga[k];
+            a += g;
+            b += g * xc;
         }
-    sm[0][threadIdx.x] = dg;
-    sm[1][threadIdx.x] = db;
-    __syncthreads();
+        t1 += a;
+        t2 += b;
+    };
+    if (rg < groups) {
+        int r = r0 + rg;
+        for (; r + groups < r1; r += 2 * groups) {
+            const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+            float x0[V], x1[V], d0[V], d1[V];
+            ldv(x, i0, x0);
+            ldv(x, i1, x1);
+            ldv(dy, i0, d0);
+            ldv(dy, i1, d1);
+            acc(x0, d0);
+            acc(x1, d1);
+        }
+        for (; r < r1; r += groups) {
+            float x0[V], d0[V];
+            ldv(x, base + (size_t)r * cq, x0);
+            ldv(dy, base + (size_t)r * cq, d0);
+            acc(x0, d0);
+        }
+    }
+    colsum_groups<V>(dg, db, sm, groups, cq, col, rg);
     const size_t blk = (size_t)n * gridDim.x + chunk;
     if (rg == 0) {
-        for (int g = 1; g < groups; ++g) {
-            dg += sm[0][g * cq + col];
-            db += sm[1][g * cq + col];
-        }
-        *reinterpret_cast<f32x4*>(part_c + blk * 2 * C + col * 4) = dg;
-        *reinterpret_cast<f32x4*>(part_c + blk * 2 * C + C + col * 4) = db;
+        stf<V>(part_c, blk * 2 * C + col * V, dg);
+        stf<V>(part_c, blk * 2 * C + C + col * V, db);
     }
     t1 = dwc_block_sum_256(t1, sr);
     t2 = dwc_block_sum_256(t2, sr);
@@ -510,35 +590,60 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
                                                     const float* __restrict__ mean, const float* __restrict__ inv,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, T* __restrict__ dx, int HW, int C,
-                                                    size_t total4, float eps, int relu) {
-    const int cq = C >> 2;
+                                                    int rows_per_chunk, float eps, int relu) {
+    constexpr int V = VecOf<T>::V;
+    const int cq = C / V;
+    const int groups = 256 / cq;
+    const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
+    if (rg >= groups) return;
+    const int n = blockIdx.y;
     const float N = (float)HW * (float)C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c4 = i % cq;
-        const size_t n = i / ((size_t)HW * cq);
-        const float mu = mean[n], iv = inv[n];
-        const float sigma = 1.f / iv - eps;
-        const float mean_g = sums[n * 2] / N;
-        // d/dx of 1/(sigma+eps): -(1/(sigma+eps))^2 * (x-mu)/((N-1)*sigma), times sum g*(x-mu)
-        const float k2 = sigma > 0.f ? iv * iv * sums[n * 2 + 1] / ((N - 1.f) * sigma) : 0.f;
-        const f32x4 ga = reinterpret_cast<const f32x4*>(gamma)[c4];
-        const f32x4 be = reinterpret_cast<const f32x4*>(beta)[c4];
-        const f32x4 xc = ld4(x, i) - mu;
-        const f32x4 d = relu_mask(ld4(dy, i), xc * iv * ga + be, relu);
-        st4(dx, i, (d * ga - mean_g) * iv - xc * k2);
+    const float mu = mean[n], iv = inv[n];
+    const float sigma = 1.f / iv - eps;
+    const float mean_g = sums[n * 2] / N;
+    // d/dx of 1/(sigma+eps): -(1/(sigma+eps))^2 * (x-mu)/((N-1)*sigma), times sum g*(x-mu)
+    const float k2 = sigma > 0.f ? iv * iv * sums[n * 2 + 1] / ((N - 1.f) * sigma) : 0.f;
+    float ga[V], be[V];
+    ldf<V>(gamma, (size_t)col * V, ga);
+    ldf<V>(beta, (size_t)col * V, be);
+    const size_t base = (size_t)n * HW * cq + col;
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(HW, r0 + rows_per_chunk);
+    auto one = [&](const float (&xv)[V], const float (&dv)[V], float (&o)[V]) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xc = xv[k] - mu;
+            float d = dv[k];
+            if (relu) d = (xc * iv * ga[k] + be[k]) > 0.f ? d : 0.f;
+            o[k] = (d * ga[k] - mean_g) * iv - xc * k2;
+        }
+    };
+    int r = r0 + rg;
+    for (; r + groups < r1; r += 2 * groups) {
+        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
+        float x0[V], x1[V], d0[V], d1[V], o0[V], o1[V];
+        ldv(x, i0, x0);
+        ldv(x, i1, x1);
+        ldv(dy, i0, d0);
+        ldv(dy, i1, d1);
+        one(x0, d0, o0);
+        one(x1, d1, o1);
+        stv(dx, i0, o0);
+        stv(dx, i1, o1);
+    }
+    for (; r < r1; r += groups) {
+        const size_t i0 = base + (size_t)r * cq;
+        float x0[V], d0[V], o0[V];
+        ldv(x, i0, x0);
+        ldv(dy, i0, d0);
+        one(x0, d0, o0);
+        stv(dx, i0, o0);
     }
 }
 
-bool norm_shape_ok(int B, int HW, int C) {
+bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 1 <= C / V <= 256 column groups
     const int l = dwc_ilog2_exact(C);
-    return B > 0 && HW > 0 && l >= 2 && C <= 1024;
-}
-
-int grid_for(size_t total4) {
-    size_t b = (total4 + 255) / 256;
-    if (b > 4096) b = 4096;
-    if (b < 1) b = 1;
-    return (int)b;
+    return B > 0 && HW > 0 && l >= 2 && C >= V && C <= 1024;
 }
 
 }  // namespace
@@ -553,15 +658,9 @@ size_t instnorm_ws_bytes(int B, int HW, int C) {
 template <typename T>
 int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y, float* mean,
                      float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
-    if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
+    if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (in_fused_ok(B, HW, C)) {
-        hipLaunchKernelGGL(in_fused_fwd<T>, dim3(C / IN_CG, B), dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, HW, C, eps,
-                           relu);
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
@@ -570,9 +669,9 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     hipLaunchKernelGGL(in_stats_final<T>, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
                        plane, eps);
     DWC_LAUNCH_CHECK();
-    const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(in_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
-                       total4, relu);
+    const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
+    hipLaunchKernelGGL(in_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
+                       ra.rows_per_chunk, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -581,15 +680,9 @@ template <typename T>
 int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
                      size_t ws_bytes, void* stream) {
-    if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
+    if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (in_fused_ok(B, HW, C)) {
-        hipLaunchKernelGGL(in_fused_bwd<T>, dim3(C / IN_CG, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta,
-                           HW, C, relu);
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
@@ -600,9 +693,9 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     hipLaunchKernelGGL(in_bwd_final, dim3((B * C + 255) / 256), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks,
                        plane);
     DWC_LAUNCH_CHECK();
-    const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(in_bwd_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
-                       B * C, total4, relu);
+    const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
+    hipLaunchKernelGGL(in_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
+                       B * C, ra.rows_per_chunk, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -615,7 +708,7 @@ size_t layernorm_ws_bytes(int B, int HW, int C) {
 template <typename T>
 int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* inv, int B, int HW,
                       int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
-    if (!norm_shape_ok(B, HW, C) || (size_t)HW * C < 2) return DWC_EINVAL;
+    if (!norm_shape_ok(B, HW, C, VecOf<T>::V) || (size_t)HW * C < 2) return DWC_EINVAL;
     if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
@@ -624,8 +717,8 @@ int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, flo
     DWC_LAUNCH_CHECK();
     hipLaunchKernelGGL(ln_stats_final<T>, dim3((B + 63) / 64), dim3(64), 0, st, x, part, mean, inv, B, HW, C, rs.chunks, eps);
     DWC_LAUNCH_CHECK();
-    const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(ln_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, total4, relu);
+    const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
+    hipLaunchKernelGGL(ln_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, ra.rows_per_chunk, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -634,7 +727,7 @@ template <typename T>
 int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv, const float* gamma,
                     const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
                       void* ws, size_t ws_bytes, void* stream) {
-    if (!norm_shape_ok(B, HW, C)) return DWC_EINVAL;
+    if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
@@ -647,9 +740,9 @@ int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv
     hipLaunchKernelGGL(ln_bwd_final, dim3(B + (C + 63) / 64), dim3(1024), 0, st, part_s, part_c, sums, dgamma, dbeta, B, C,
                        rs.chunks);
     DWC_LAUNCH_CHECK();
-    const size_t total4 = (size_t)B * HW * (C / 4);
-    hipLaunchKernelGGL(ln_bwd_apply<T>, dim3(grid_for(total4)), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,
-                       total4, eps, relu);
+    const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
+    hipLaunchKernelGGL(ln_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,
+                       ra.rows_per_chunk, eps, relu);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -22,31 +22,59 @@ template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy, const T* __restrict__ y,
                                                        T* __restrict__ g, float* __restrict__ part, int rows, int C,
                                                        int rows_per_chunk, int act) {
-    __shared__ f32x4 sm[256];
-    const int cq = C >> 2;
-    const int cqb = cq < 256 ? cq : 256;           // f4 columns handled by this block
+    constexpr int V = VecOf<T>::V;                 // 16-byte accesses: 4 fp32 / 8 bf16 per lane
+    __shared__ float sm[256 * V];
+    const int cq = C / V;
+    const int cqb = cq < 256 ? cq : 256;           // column groups handled by this block
     const int groups = 256 / cqb;
     const int col = blockIdx.y * 256 + threadIdx.x % cqb, rg = threadIdx.x / cqb;
     const int r0 = blockIdx.x * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
-    f32x4 s = {0, 0, 0, 0};
-    for (int r = r0 + rg; r < r1; r += groups) {
-        const size_t i = (size_t)r * cq + col;
-        f32x4 d = ld4(dy, i);
-        if (act != DWC_ACT_NONE) {
-            const f32x4 yy = ld4(y, i);
+    float s[V];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] *= dwc_act_grad(yy[k], act, col * 4 + k);
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+    auto one = [&](float (&d)[V], const float (&yy)[V]) {
+        if (act != DWC_ACT_NONE) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) d[k] *= dwc_act_grad(yy[k], act, col * V + k);
         }
-        if (g) st4(g, i, d);
-        s += d;
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += d[k];
+    };
+    int r = r0 + rg;
+    for (; r + groups < r1; r += 2 * groups) {      // two rows in flight per thread
+        const size_t i0 = (size_t)r * cq + col, i1 = i0 + (size_t)groups * cq;
+        float d0[V], d1[V], y0[V], y1[V];
+        ldv(dy, i0, d0);
+        ldv(dy, i1, d1);
+        if (act != DWC_ACT_NONE) {
+            ldv(y, i0, y0);
+            ldv(y, i1, y1);
+        }
+        one(d0, y0);
+        one(d1, y1);
+        if (g) {
+            stv(g, i0, d0);
+            stv(g, i1, d1);
+        }
+    }
+    for (; r < r1; r += groups) {
+        const size_t i0 = (size_t)r * cq + col;
+        float d0[V], y0[V];
+        ldv(dy, i0, d0);
+        if (act != DWC_ACT_NONE) ldv(y, i0, y0);
+        one(d0, y0);
+        if (g) stv(g, i0, d0);
     }
     if (!part) return;
-    sm[threadIdx.x] = s;
+#pragma unroll
+    for (int k = 0; k < V; ++k) sm[threadIdx.x * V + k] = s[k];
     __syncthreads();
     if (rg == 0) {
-        for (int k = 1; k < groups; ++k) s += sm[k * cqb + threadIdx.x % cqb];
-        *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * C + col * 4) = s;
+        for (int q = 1; q < groups; ++q)
+#pragma unroll
+            for (int k = 0; k < V; ++k) s[k] += sm[(q * cqb + threadIdx.x % cqb) * V + k];
+        stf<V>(part, (size_t)blockIdx.x * C + col * V, s);
     }
 }
 
@@ -91,71 +119,90 @@ __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float
     l0 = 1.f - l1;
 }
 
+// One thread = one INPUT pixel x V channels: it reads the 3x3 neighbourhood (neighbours come from L1/L2: every input byte
+// leaves HBM once) and writes the 2x2 output quad, all 16-byte accesses; grid (W*cq / 256, H, B) -- no per-element divisions.
+// Output row 2i reads rows (i-1: 0.25, i: 0.75), row 2i+1 reads (i: 0.75, i+1: 0.25); at the borders the missing neighbour is
+// the pixel itself (torch clamps the source coordinate), which the clamped index reproduces exactly.
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq,
-                                                             size_t total4) {
-    const T* xs = x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = i % cq;
-        size_t r = i / cq;
-        const int ox = r % (2 * W);
-        r /= (2 * W);
-        const int oy = r % (2 * H);
-        const size_t n = r / (2 * H);
-        int y0, y1, x0, x1;
-        float ly0, ly1, lx0, lx1;
-        up_taps(oy, H, y0, y1, ly0, ly1);
-        up_taps(ox, W, x0, x1, lx0, lx1);
-        const size_t b = n * H * W;
-        const f32x4 p00 = ld4(xs, (b + (size_t)y0 * W + x0) * cq + c), p01 = ld4(xs, (b + (size_t)y0 * W + x1) * cq + c);
-        const f32x4 p10 = ld4(xs, (b + (size_t)y1 * W + x0) * cq + c), p11 = ld4(xs, (b + (size_t)y1 * W + x1) * cq + c);
-        st4(y, i, ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11));
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq) {
+    constexpr int V = VecOf<T>::V;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * cq) return;
+    const int ix = idx / cq, c = idx - ix * cq;
+    const int iy = blockIdx.y;
+    const size_t n = blockIdx.z;
+    const int ym = max(iy - 1, 0), yp = min(iy + 1, H - 1), xm = max(ix - 1, 0), xp = min(ix + 1, W - 1);
+    const size_t b = n * H * W;
+    float p[3][3][V];
+    const int ys[3] = {ym, iy, yp}, xs[3] = {xm, ix, xp};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ldv(x, (b + (size_t)ys[a] * W + xs[q]) * cq + c, p[a][q]);
+    // horizontal pass: h[a][0] = 0.25*left + 0.75*mid, h[a][1] = 0.75*mid + 0.25*right
+    float h[3][2][V];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            h[a][0][k] = 0.75f * p[a][1][k] + 0.25f * p[a][0][k];
+            h[a][1][k] = 0.75f * p[a][1][k] + 0.25f * p[a][2][k];
+        }
+    const size_t ob = (n * (2 * H) + 2 * iy) * (size_t)(2 * W) + 2 * ix;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        float o0[V], o1[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            o0[k] = 0.75f * h[1][d][k] + 0.25f * h[0][d][k];      // output row 2*iy
+            o1[k] = 0.75f * h[1][d][k] + 0.25f * h[2][d][k];      // output row 2*iy + 1
+        }
+        stv(y, (ob + d) * cq + c, o0);
+        stv(y, (ob + (size_t)(2 * W) + d) * cq + c, o1);
     }
 }
 
-// adjoint, gather form: every input pixel collects from the <=4x4 output pixels that read it
+// adjoint, gather form: input pixel i collects from output rows 2i-1 (0.25), 2i, 2i+1 (0.75 each), 2i+2 (0.25); rows outside the
+// image do not exist and the clamped border taps fold onto rows 0 / 2H-1 (weight 1 there instead of 0.75).  4x4 gather.
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int cq,
-                                                             size_t total4) {
-    const T* ds = dy;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = i % cq;
-        size_t r = i / cq;
-        const int ix = r % W;
-        r /= W;
-        const int iy = r % H;
-        const size_t n = r / H;
-        float wy[5], wx[5];
-        int oy0 = 2 * iy - 2, ox0 = 2 * ix - 2;
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int cq) {
+    constexpr int V = VecOf<T>::V;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * cq) return;
+    const int ix = idx / cq, c = idx - ix * cq;
+    const int iy = blockIdx.y;
+    const size_t n = blockIdx.z;
+    float wy[4], wx[4];
+    wy[0] = iy > 0 ? 0.25f : 0.f;
+    wy[1] = iy > 0 ? 0.75f : 1.f;
+    wy[2] = iy < H - 1 ? 0.75f : 1.f;
+    wy[3] = iy < H - 1 ? 0.25f : 0.f;
+    wx[0] = ix > 0 ? 0.25f : 0.f;
+    wx[1] = ix > 0 ? 0.75f : 1.f;
+    wx[2] = ix < W - 1 ? 0.75f : 1.f;
+    wx[3] = ix < W - 1 ? 0.25f : 0.f;
+    const size_t base = n * (size_t)(2 * H) * (2 * W);
+    float s[V];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            int a, b;
-            float l0, l1;
-            const int oy = oy0 + k, ox = ox0 + k;
-            wy[k] = 0.f;
-            wx[k] = 0.f;
-            if (oy >= 0 && oy < 2 * H) {
-                up_taps(oy, H, a, b, l0, l1);
-                wy[k] = (a == iy ? l0 : 0.f) + (b == iy ? l1 : 0.f);
-            }
-            if (ox >= 0 && ox < 2 * W) {
-                up_taps(ox, W, a, b, l0, l1);
-                wx[k] = (a == ix ? l0 : 0.f) + (b == ix ? l1 : 0.f);
-            }
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int oy = min(max(2 * iy - 1 + a, 0), 2 * H - 1);      // clamped rows carry weight 0
+        float row[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) row[k] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ox = min(max(2 * ix - 1 + q, 0), 2 * W - 1);
+            float v[V];
+            ldv(dy, (base + (size_t)oy * (2 * W) + ox) * cq + c, v);
+#pragma unroll
+            for (int k = 0; k < V; ++k) row[k] += wx[q] * v[k];
         }
-        f32x4 s = {0, 0, 0, 0};
-        const size_t base = n * (size_t)(2 * H) * (2 * W);
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            if (wy[a] == 0.f) continue;
-            f32x4 row = {0, 0, 0, 0};
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-                if (wx[b] != 0.f) row += wx[b] * ld4(ds, (base + (size_t)(oy0 + a) * (2 * W) + (ox0 + b)) * cq + c);
-            s += wy[a] * row;
-        }
-        st4(dx, i, s);
+        for (int k = 0; k < V; ++k) s[k] += wy[a] * row[k];
     }
+    stv(dx, ((n * H + iy) * (size_t)W + ix) * cq + c, s);
 }
 
 template <typename T>
@@ -463,8 +510,9 @@ namespace {
 
 template <typename T>
 int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes, void* stream) {
-    if (rows <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
-    const int cq = C >> 2;
+    constexpr int V = VecOf<T>::V;
+    if (rows <= 0 || C <= 0 || (C % V)) return DWC_EINVAL;
+    const int cq = C / V;
     if (cq < 256 ? (256 % cq) != 0 : (cq % 256) != 0) return DWC_EINVAL;
     if (act != DWC_ACT_NONE && !y) return DWC_EINVAL;
     if (db && (!ws || ws_bytes < act_bwd_ws(rows, C))) return DWC_EWORKSPACE;
@@ -483,20 +531,20 @@ int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, in
 
 template <typename T>
 int upsample2x_fwd_t(const T* x, T* y, int B, int H, int W, int C, void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
-    const size_t total4 = (size_t)B * 4 * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4,
-                       total4);
+    constexpr int V = VecOf<T>::V;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % V) || H > 65535 || B > 65535) return DWC_EINVAL;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3((W * (C / V) + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
+                       C / V);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
 template <typename T>
 int upsample2x_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, void* stream) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return DWC_EINVAL;
-    const size_t total4 = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3(grid_for(total4, 8192)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, C / 4,
-                       total4);
+    constexpr int V = VecOf<T>::V;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % V) || H > 65535 || B > 65535) return DWC_EINVAL;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((W * (C / V) + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W,
+                       C / V);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -528,8 +528,8 @@ def test_tiny_three_iterations_vs_reference(tiny):
         host.set_noise(host.DeviceNoise())
 
 
-@pytest.mark.parametrize("S,B", [(128, 2), (256, 1), (128, 64), (256, 8)])
-def test_full_size_iteration_vs_oracle(S, B):
+@pytest.mark.parametrize("S,B,what", [(128, 2, "all"), (256, 1, "all"), (128, 64, "dis"), (256, 8, "dis")])
+def test_full_size_iteration_vs_oracle(S, B, what):
     """The shipped network sizes (dim 64, 4 ResBlocks, 5-layer 2-scale D) at 128x128 and at the 256x256 of
     BASELINE configs[4]: one full iteration, every loss scalar against the CPU oracle run from the same
     weights, batch and random stream.  Exercises the real layer shapes (128x128 tiles, split-K tails,
@@ -549,10 +549,21 @@ def test_full_size_iteration_vs_oracle(S, B):
         oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in s.gen.state_dict().items()},
                                   {k: v.cpu() for k, v in s.dis.state_dict().items()})
         oracle.copy_nets()
-        oracle.iteration(batch, 0)
-        torch.set_rng_state(rng)
         db = {k: v.to(DEV) for k, v in batch.items()}
         a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
+        if what == "dis":
+            oracle.dis_update(batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"], batch["label_src"],
+                              batch["label_trg"], cfg, 0)
+            torch.set_rng_state(rng)
+            s.dis_update(*a)
+            for k in ("loss_dis", "loss_dis_all"):
+                got, want = float(getattr(s, k)), float(oracle.losses[k])
+                assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), (k, got, want)
+            for name in ("cnns_feat.0.0.conv.weight", "cnns_feat.0.4.conv.weight", "cnns_feat.1.2.conv.weight", "cnns_cls.0.weight"):
+                close(dict(s.dis.named_parameters())[name].grad, oracle.last_dis_grads[name], rel=1e-2, msg=name)
+            return
+        oracle.iteration(batch, 0)
+        torch.set_rng_state(rng)
         s.dis_update(*a)
         s.gen_update(*a)
         for k, want in oracle.losses.items():
