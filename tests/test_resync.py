@@ -122,17 +122,17 @@ def test_hip_resync_24_steps_s128_b16():
 def test_hip_resync_bf16_24_steps_s64_b4():
     """The bf16 path (BASELINE configs[2]'s arithmetic) over 24 optimiser steps, re-synchronised like the fp32 runs above:
     the fp32 CPU oracle takes the bf16 trainer's state (fp32 master weights, Adam moments) before every step, both run
-    the step, and every one of the 16 scalars must agree within the bf16 tolerance of tests/test_bf16_parity.py
-    (3e-2 * max(1, |value|): bf16 activations carry 8 significant bits, losses are fp32 means of them).  A whole-iteration
+    the step, and every one of the 16 scalars must agree within 5e-3 * max(1, |value|) (bf16 activations carry 8
+    significant bits, losses are fp32 means over >= 10^3 of them; measured r03: worst 1.4e-3 (loss_dis), all others <= 7e-4).  A whole-iteration
     comparison over one or two steps cannot see a systematic bias of the bf16 weight gradients working through Adam --
     this can: the state the oracle is synchronised TO is the one bf16 gradients produced, so a bias would move the
     operating point step after step, and the mean SIGNED error over the run (which averages rounding noise out and keeps
-    a bias) is bounded at a third of the per-step tolerance."""
-    worst, signed = _resync_run(64, 4, 24, precision="bf16", tol=3e-2, check=list(range(6)) + list(range(6, 24, 3)))
+    a bias) is bounded at 1e-3 (measured: <= 2.6e-4)."""
+    worst, signed = _resync_run(64, 4, 24, precision="bf16", tol=5e-3, check=list(range(6)) + list(range(6, 24, 3)))
     print("bf16 worst |rel err| per scalar over 24 steps:", dict(zip(SCALARS, np.round(worst, 5))))
     print("bf16 mean signed rel err per scalar:", dict(zip(SCALARS, np.round(signed.mean(axis=0), 6))))
     # drift of the error itself: the second half of the run must not be systematically worse than the first
     first, second = np.abs(signed[:6]).mean(axis=0), np.abs(signed[6:]).mean(axis=0)
     print("bf16 mean |rel err| first / second half:", dict(zip(SCALARS, zip(np.round(first, 5), np.round(second, 5)))))
-    assert np.abs(signed.mean(axis=0)).max() <= 1e-2, signed.mean(axis=0)
-    assert (second <= 3.0 * first + 2e-3).all(), (first, second)
+    assert np.abs(signed.mean(axis=0)).max() <= 1e-3, signed.mean(axis=0)
+    assert (second <= 3.0 * first + 1e-3).all(), (first, second)
