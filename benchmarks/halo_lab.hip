@@ -120,6 +120,38 @@ int main(int argc, char** argv) {
                s.name, flops / 1e9, m0 * 1e3, n0 * 1e3, flops / (m0 * 1e-3) / 2.5e15 * 100, m1 * 1e3, n1 * 1e3,
                flops / (m1 * 1e-3) / 2.5e15 * 100, m0 / m1, maxdiff[1], maxdiff[0]);
         fflush(stdout);
+        // timeline of the hand-scheduled kernel (diagnostic instantiation; shader cycles of wave 0, median over workgroups)
+        if (s.B >= 128 && (s.K == 3 || s.Cout <= 128)) {
+            HaloArgs a;
+            a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = db; a.y = (bf16*)dy[1];
+            a.B = s.B; a.H = s.H; a.W = s.H; a.Cin = s.Cin; a.logCin = dwc_ilog2_exact(s.Cin); a.N = s.Cout; a.K = s.K;
+            a.Kp = Kp; a.act = DWC_ACT_RELU; a.reflect = 1;
+            a.blocks_x = s.H / 16; a.blocks_per_img = (s.H / 16) * (s.H / 16);
+            const int nblk = s.B * a.blocks_per_img;
+            int tiles = 1;
+            unsigned long long* dp;
+#define LP(KS, BN, WM, WN, PB) do { a.tiles_n = tiles = (s.Cout + BN - 1) / BN; CK(hipMalloc(&dp, (size_t)nblk * tiles * 64)); CK(hipMemset(dp, 0, (size_t)nblk * tiles * 64)); for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB, 1>), dim3(nblk * tiles), dim3(512), 0, st, a, dp); } while (0)
+            if (s.K == 3) { if (s.Cout > 128) LP(3, 256, 2, 4, 2); else if (s.Cout > 64) LP(3, 128, 4, 2, 2); else LP(3, 64, 4, 2, 2); }
+            else { if (s.Cout > 64) LP(5, 128, 4, 2, 1); else LP(5, 64, 4, 2, 1); }
+            CK(hipStreamSynchronize(st));
+            const size_t nb = (size_t)nblk * tiles;
+            std::vector<unsigned long long> hp(nb * 8);
+            CK(hipMemcpy(hp.data(), dp, nb * 64, hipMemcpyDeviceToHost));
+            std::vector<double> pro, loop, epi, clk;
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (size_t b = 0; b < nb; ++b) {
+                const unsigned long long* q = &hp[b * 8];
+                pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
+                if (q[5] > q[4]) clk.push_back((double)(q[3] - q[0]) / (double)(q[5] - q[4]) * 100.0);     // MHz (100 MHz realtime)
+                tmin = std::min(tmin, q[4]); tmax = std::max(tmax, q[5]);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            const int nsteps = (s.Cin / 64) * s.K * s.K;
+            printf("    timeline (cycles, median over %zu workgroups): prologue %.0f | main loop %.0f = %.0f per (tap,slab) step | epilogue %.0f | "
+                   "shader clock %.0f MHz | launch span %.1f us\n", nb, med(pro), med(loop), med(loop) / nsteps, med(epi), med(clk),
+                   (double)(tmax - tmin) / 100.0);
+            CK(hipFree(dp));
+        }
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(db));
     }
     return 0;

@@ -37,12 +37,14 @@ RowSplit plan_rows(int B, int HW) {
 }
 
 // The apply passes carry no partials, so they split finer: a 256-thread block = (256 / cq) row groups x cq column groups
-// (cq = C / V) walks about eight rows per thread; grid (row chunks, B).  The per-(n,c) statistics and affine parameters are
+// (cq = C / V) walks up to 32 rows per thread; grid (row chunks, B).  The per-(n,c) statistics and affine parameters are
 // loaded ONCE per thread (they used to be re-fetched, behind a 64-bit division, for every 4 elements).
 RowSplit plan_apply(int B, int HW, int C, int V) {
     const int cq = C / V > 0 ? C / V : 1;
     const int groups = 256 / cq > 0 ? 256 / cq : 1;
-    int rpc = groups * 8;
+    int rpc = groups * 32;                                                       // ~32 rows per thread: the per-thread statistics
+                                                                                 // loads (up to 6 x 32 bytes) are paid once per block
+    while (rpc > groups * 4 && (long)B * ((HW + rpc - 1) / rpc) < 1024) rpc /= 2;   // keep >= ~4 blocks per CU
     while ((long)B * ((HW + rpc - 1) / rpc) > 16384 && rpc < HW) rpc *= 2;     // bound the grid on huge tensors
     RowSplit r;
     r.rows_per_chunk = rpc < HW ? rpc : HW;
@@ -182,19 +184,19 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
         }
     };
     int r = r0 + rg;
-    for (; r + groups < r1; r += 2 * groups) {            // two rows in flight per thread
-        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
-        float v0[V], v1[V], q0[V], q1[V], o0[V], o1[V];
-        ldv(x, i0, v0);
-        ldv(x, i1, v1);
+    for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows in flight per thread
+        float v[4][V], q[4][V], o[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ldv(x, base + (size_t)(r + u * groups) * cq, v[u]);
         if (residual) {
-            ldv(residual, i0, q0);
-            ldv(residual, i1, q1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldv(residual, base + (size_t)(r + u * groups) * cq, q[u]);
         }
-        one(v0, residual ? q0 : nullptr, o0);
-        one(v1, residual ? q1 : nullptr, o1);
-        stv(y, i0, o0);
-        stv(y, i1, o1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            one(v[u], residual ? q[u] : nullptr, o[u]);
+            stv(y, base + (size_t)(r + u * groups) * cq, o[u]);
+        }
     }
     for (; r < r1; r += groups) {
         const size_t i0 = base + (size_t)r * cq;
@@ -324,17 +326,18 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
         }
     };
     int r = r0 + rg;
-    for (; r + groups < r1; r += 2 * groups) {
-        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
-        float x0[V], x1[V], d0[V], d1[V], o0[V], o1[V];
-        ldv(x, i0, x0);
-        ldv(x, i1, x1);
-        ldv(dy, i0, d0);
-        ldv(dy, i1, d1);
-        one(x0, d0, o0);
-        one(x1, d1, o1);
-        stv(dx, i0, o0);
-        stv(dx, i1, o1);
+    for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
+        float xv[4][V], dv[4][V], o[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ldv(x, base + (size_t)(r + u * groups) * cq, xv[u]);
+            ldv(dy, base + (size_t)(r + u * groups) * cq, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            one(xv[u], dv[u], o[u]);
+            stv(dx, base + (size_t)(r + u * groups) * cq, o[u]);
+        }
     }
     for (; r < r1; r += groups) {
         const size_t i0 = base + (size_t)r * cq;
@@ -619,17 +622,18 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
         }
     };
     int r = r0 + rg;
-    for (; r + groups < r1; r += 2 * groups) {
-        const size_t i0 = base + (size_t)r * cq, i1 = i0 + (size_t)groups * cq;
-        float x0[V], x1[V], d0[V], d1[V], o0[V], o1[V];
-        ldv(x, i0, x0);
-        ldv(x, i1, x1);
-        ldv(dy, i0, d0);
-        ldv(dy, i1, d1);
-        one(x0, d0, o0);
-        one(x1, d1, o1);
-        stv(dx, i0, o0);
-        stv(dx, i1, o1);
+    for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
+        float xv[4][V], dv[4][V], o[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ldv(x, base + (size_t)(r + u * groups) * cq, xv[u]);
+            ldv(dy, base + (size_t)(r + u * groups) * cq, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            one(xv[u], dv[u], o[u]);
+            stv(dx, base + (size_t)(r + u * groups) * cq, o[u]);
+        }
     }
     for (; r < r1; r += groups) {
         const size_t i0 = base + (size_t)r * cq;

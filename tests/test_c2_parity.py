@@ -144,7 +144,8 @@ def test_bf16_hot_shapes_at_bench_batch(shape):
     per_img = (y_big - y_c).abs().flatten(1).mean(1) / y_c.abs().mean()
     assert per_img.max().item() <= 1e-3, ("an image of the big launch is off as a whole", per_img.argmax().item(), per_img.max().item())
     per_img = (dx_big - dx_c).abs().flatten(1).mean(1) / dx_c.abs().mean()
-    assert per_img.max().item() <= 2e-3, ("dx of an image is off as a whole", per_img.argmax().item(), per_img.max().item())
+    # (a mis-addressed block or image would show as ~1; a few flipped derivative signs on an 8x8 map reach ~1e-2)
+    assert per_img.max().item() <= (2e-3 if plain else 5e-2), ("dx of an image is off as a whole", per_img.argmax().item(), per_img.max().item())
     assert relerr(dw_big, dw_c) <= (2e-4 if plain else 3e-3), ("dw vs sum over chunks", relerr(dw_big, dw_c))
     assert relerr(db_big, db_c) <= (2e-4 if plain else 3e-3), ("db vs sum over chunks", relerr(db_big, db_c))
 
