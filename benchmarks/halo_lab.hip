@@ -52,24 +52,21 @@ int main(int argc, char** argv) {
         for (auto& v : hw) v = f2bf(((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f);
         std::vector<float> hb(s.Cout);
         for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
-        void *dx, *dw, *dy[2];
+        void *dx, *dw, *dy[3];
         float* db;
-        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dy[0], ny * 2)); CK(hipMalloc(&dy[1], ny * 2));
+        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dy[0], ny * 2)); CK(hipMalloc(&dy[1], ny * 2)); CK(hipMalloc(&dy[2], ny * 2));
         CK(hipMalloc(&db, s.Cout * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(db, hb.data(), s.Cout * 4, hipMemcpyHostToDevice));
         const double flops = 2.0 * s.B * s.H * s.H * (double)s.Cout * s.Cin * s.K * s.K;
-        std::vector<float> tms[2];
-        double maxdiff[2] = {0, 0};
+        std::vector<float> tms[3];
+        double maxdiff[2] = {0, 0}, maxdiff_p[2] = {0, 0};
         for (int reflect = 1; reflect >= 0; --reflect) {
-            for (int v = 0; v < 2; ++v) {
-                CK(hipMemset(dy[v], 0xFF, ny * 2));
-                setenv("DWC_HALO16", v ? "1" : "0", 1);
-            }
+            for (int v = 0; v < 3; ++v) CK(hipMemset(dy[v], 0xFF, ny * 2));
             // the dispatcher reads DWC_HALO16 once (static): call the kernels directly instead
             for (int r = 0; r < (reflect ? rounds : 1); ++r)
-                for (int v = 0; v < 2; ++v) {
+                for (int v = 0; v < 3; ++v) {
                     HaloArgs a;
                     a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = reflect ? db : nullptr; a.y = (bf16*)dy[v];
                     a.B = s.B; a.H = s.H; a.W = s.H; a.Cin = s.Cin; a.logCin = dwc_ilog2_exact(s.Cin); a.N = s.Cout; a.K = s.K;
@@ -82,9 +79,14 @@ int main(int argc, char** argv) {
                     if (v == 0) {
                         if (s.K == 3) { if (s.Cout > 128) L32(3, 256, 2, 4, 4, 2); else if (s.Cout > 64) L32(3, 128, 4, 2, 2, 2); else L32(3, 64, 4, 2, 2, 1); }
                         else { if (s.Cout > 128) L32(5, 256, 2, 4, 4, 2); else if (s.Cout > 64) L32(5, 128, 4, 2, 2, 2); else L32(5, 64, 4, 2, 2, 1); }
-                    } else {
+                    } else if (v == 1) {
                         if (s.K == 3) { if (s.Cout > 128) L16(3, 256, 2, 4, 2); else if (s.Cout > 64) L16(3, 128, 4, 2, 2); else L16(3, 64, 4, 2, 2); }
                         else { if (s.Cout > 128) L16(5, 256, 2, 4, 1); else if (s.Cout > 64) L16(5, 128, 4, 2, 1); else L16(5, 64, 4, 2, 1); }
+                    } else {
+#define L16D(KS, BN, WM, WN) do { a.tiles_n = (s.Cout + BN - 1) / BN; hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a, nullptr); } while (0)
+                        // two 4-wave workgroups per CU: 256 pixels x 128 channels (wave tile 128 x 64) / x 64 channels (128 x 32)
+                        if (s.K == 3) { if (s.Cout > 64) L16D(3, 128, 2, 2); else L16D(3, 64, 2, 2); }
+                        else L16D(5, 64, 2, 2);      // (5x5 x 128 channels: 85 KB of LDS, one workgroup per CU only)
                     }
                     CK(hipGetLastError());
                     CK(hipEventRecord(e1, st));
@@ -93,19 +95,22 @@ int main(int argc, char** argv) {
                     CK(hipEventElapsedTime(&ms, e0, e1));
                     if (reflect && r >= 2) tms[v].push_back(ms);
                 }
-            std::vector<unsigned short> y0(ny), y1(ny);
+            std::vector<unsigned short> y0(ny), y1(ny), y2(ny);
             CK(hipMemcpy(y0.data(), dy[0], ny * 2, hipMemcpyDeviceToHost));
             CK(hipMemcpy(y1.data(), dy[1], ny * 2, hipMemcpyDeviceToHost));
-            double md = 0, scale = 0;
+            CK(hipMemcpy(y2.data(), dy[2], ny * 2, hipMemcpyDeviceToHost));
+            double md = 0, md2 = 0, scale = 0;
             size_t nbad = 0;
             for (size_t i = 0; i < ny; ++i) {
-                const double a0 = bf2f(y0[i]), a1 = bf2f(y1[i]);
+                const double a0 = bf2f(y0[i]), a1 = bf2f(y1[i]), a2 = bf2f(y2[i]);
                 scale = std::max(scale, std::fabs(a0));
-                const double d = std::fabs(a0 - a1);
-                if (!(d <= 1e30)) ++nbad;
+                const double d = std::fabs(a0 - a1), d2 = std::fabs(a0 - a2);
+                if (!(d <= 1e30) || !(d2 <= 1e30)) ++nbad;
                 md = std::max(md, d);
+                md2 = std::max(md2, d2);
             }
             maxdiff[reflect] = md / (scale > 0 ? scale : 1);
+            maxdiff_p[reflect] = md2 / (scale > 0 ? scale : 1);
             if (nbad) printf("  !! %zu non-finite differences (reflect=%d)\n", nbad, reflect);
         }
         auto stat = [&](std::vector<float>& t, double& med, double& mn) {
@@ -113,12 +118,14 @@ int main(int argc, char** argv) {
             med = t[t.size() / 2];
             mn = t[0];
         };
-        double m0, n0, m1, n1;
+        double m0, n0, m1, n1, m2, n2;
         stat(tms[0], m0, n0);
         stat(tms[1], m1, n1);
-        printf("%-30s %8.1f GFLOP | 32x32x16: med %8.1f us min %8.1f (%5.1f%% of 2.5PF) | 16x16x32 hand: med %8.1f us min %8.1f (%5.1f%%) | x%.3f | maxdiff/scale fwd %.2e dgrad %.2e\n",
-               s.name, flops / 1e9, m0 * 1e3, n0 * 1e3, flops / (m0 * 1e-3) / 2.5e15 * 100, m1 * 1e3, n1 * 1e3,
-               flops / (m1 * 1e-3) / 2.5e15 * 100, m0 / m1, maxdiff[1], maxdiff[0]);
+        stat(tms[2], m2, n2);
+        printf("%-30s %8.1f GFLOP | 32x32x16: med %8.1f us (%5.1f%% of 2.5PF) | 16x16x32 hand: med %8.1f us min %8.1f (%5.1f%%) x%.3f | duo (2 WG/CU): med %8.1f us min %8.1f (%5.1f%%) x%.3f | maxdiff/scale hand %.1e/%.1e duo %.1e/%.1e\n",
+               s.name, flops / 1e9, m0 * 1e3, flops / (m0 * 1e-3) / 2.5e15 * 100, m1 * 1e3, n1 * 1e3,
+               flops / (m1 * 1e-3) / 2.5e15 * 100, m0 / m1, m2 * 1e3, n2 * 1e3, flops / (m2 * 1e-3) / 2.5e15 * 100, m0 / m2, maxdiff[1], maxdiff[0],
+               maxdiff_p[1], maxdiff_p[0]);
         fflush(stdout);
         // timeline of the hand-scheduled kernel (diagnostic instantiation; shader cycles of wave 0, median over workgroups)
         if (s.B >= 128 && (s.K == 3 || s.Cout <= 128)) {
@@ -152,7 +159,7 @@ int main(int argc, char** argv) {
                    (double)(tmax - tmin) / 100.0);
             CK(hipFree(dp));
         }
-        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(db));
+        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(dy[2])); CK(hipFree(db));
     }
     return 0;
 }

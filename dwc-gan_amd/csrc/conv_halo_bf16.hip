@@ -572,20 +572,28 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
-    // Default: the hand-scheduled 16x16x32 kernel (conv_halo16_bf16.inc).  DWC_HALO16=0: the compiler-scheduled 32x32x16 kernels below.
-    static const int h16 = getenv("DWC_HALO16") ? atoi(getenv("DWC_HALO16")) : 1;
+    // Default: the hand-scheduled 16x16x32 kernels (conv_halo16_bf16.inc).  DWC_HALO16=0: the compiler-scheduled 32x32x16 kernels
+    // below; DWC_HALO16=1: the 8-wave tiles only (no two-workgroups-per-CU forms).
+    static const int h16 = getenv("DWC_HALO16") ? atoi(getenv("DWC_HALO16")) : 2;
     if (h16) {
 #define HALO16_LAUNCH(KS, BN, WM, WN, PB)                                                                                  \
     do {                                                                                                                  \
         a.tiles_n = (Cout + BN - 1) / BN;                                                                                 \
-        hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);        \
+        hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB>), dim3(nblk * a.tiles_n), dim3(64 * WM * WN), 0, st, a, nullptr); \
     } while (0)
+        // Two 4-wave workgroups per CU (256 pixels x 128 / x 64 channels, single patch buffer, <= 80 KB of LDS) where a full round
+        // of them exists.  r03, same operands, 8-wave tile -> two workgroups per CU (benchmarks/halo_lab.hip, bit-identical
+        // results): 5x5 256->128 B=384 1950 -> 1698 us (52.8 -> 60.7 % of 2.5 PF), B=128 688 -> 603; 5x5 64->128 (data
+        // gradient) 758 -> 689; 3x3 256->256 B=384 401 -> 387, B=128 139 -> 138; 5x5 128->64: 3 % slower (stays 8-wave).
+        const bool duo = h16 >= 2 && (long)nblk * (Cout / 64) >= 512;
         if (K == 3) {
-            if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);
+            if (Cout > 128 && duo && Cout % 128 == 0) HALO16_LAUNCH(3, 128, 2, 2, 1);
+            else if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);
             else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
             else HALO16_LAUNCH(3, 64, 4, 2, 2);
         } else {
-            if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
+            if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
+            else if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
             else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
             else HALO16_LAUNCH(5, 64, 4, 2, 1);
         }

@@ -115,6 +115,7 @@ __device__ __forceinline__ float dwc_act_apply(float v, int act, int ch) {
 // kernel carried ~25 000 instructions of inlined tanhf/expf between its hot instructions (r02: a halo kernel with an EMPTY
 // main loop still took half the full kernel's time, instruction fetch of that epilogue).
 __device__ __forceinline__ bool dwc_act_is_simple(int act) { return act <= DWC_ACT_LRELU; }
+static inline bool dwc_act_is_simple_host(int act) { return act <= DWC_ACT_LRELU; }
 __device__ __forceinline__ float dwc_act_slope(int act) { return act == DWC_ACT_NONE ? 1.f : (act == DWC_ACT_RELU ? 0.f : 0.1f); }
 __device__ __forceinline__ float dwc_act_simple(float v, float slope) { return v < 0.f ? (slope == 0.f ? 0.f : slope * v) : v; }
 

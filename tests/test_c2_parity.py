@@ -146,8 +146,9 @@ def test_bf16_hot_shapes_at_bench_batch(shape):
     per_img = (dx_big - dx_c).abs().flatten(1).mean(1) / dx_c.abs().mean()
     # (a mis-addressed block or image would show as ~1; a few flipped derivative signs on an 8x8 map reach ~1e-2)
     assert per_img.max().item() <= (2e-3 if plain else 5e-2), ("dx of an image is off as a whole", per_img.argmax().item(), per_img.max().item())
-    assert relerr(dw_big, dw_c) <= (2e-4 if plain else 3e-3), ("dw vs sum over chunks", relerr(dw_big, dw_c))
-    assert relerr(db_big, db_c) <= (2e-4 if plain else 3e-3), ("db vs sum over chunks", relerr(db_big, db_c))
+    # (behind an activation: the same few flipped derivative signs, each worth one 0.9 * dy * x term of a sum whose maximum is ~250 terms' worth)
+    assert relerr(dw_big, dw_c) <= (2e-4 if plain else 3e-2), ("dw vs sum over chunks", relerr(dw_big, dw_c))
+    assert relerr(db_big, db_c) <= (2e-4 if plain else 3e-2), ("db vs sum over chunks", relerr(db_big, db_c))
 
 
 @pytest.mark.parametrize("B", [128, 384])
@@ -182,7 +183,7 @@ def test_bf16_image_heads_at_bench_batch(B):
     assert relerr(dx_big[idx].cpu(), xs.grad) <= 2.5e-2
     y_c, dx_c, dw_c, db_c, seen = _chunked(hip, x, gy, chunk=4)
     assert relerr(y_big, y_c) <= 4e-3 and outliers(dx_big, dx_c, 8e-3) <= 5e-4 and relerr(dx_big, dx_c) <= 1e-1
-    assert relerr(dw_big, dw_c) <= 3e-3 and relerr(db_big, db_c) <= 3e-3
+    assert relerr(dw_big, dw_c) <= 3e-2 and relerr(db_big, db_c) <= 3e-2
 
 
 def test_bf16_forward_passes_b128_vs_oracle_chunks():
