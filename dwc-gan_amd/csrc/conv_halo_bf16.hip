@@ -634,6 +634,37 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
     return DWC_OK;
 }
 
+/* 1 when dwc_bf16_conv2d_s2_halo handles this 4x4, stride-2, reflect-pad-1 convolution (else dwc_bf16_conv2d_fwd): H and W
+ * multiples of 32 (16x16 output blocks), Cin a power of two >= 64, Cout a multiple of 64 */
+int dwc_bf16_conv2d_s2_halo_ok(int B, int H, int W, int Cin, int Cout) {
+    return (B > 0 && H >= 32 && W >= 32 && !(H % 32) && !(W % 32) && Cin >= 64 && dwc_ilog2_exact(Cin) >= 6 && Cout >= 64 && !(Cout % 64) &&
+            (size_t)B * H * W * Cin * 2 < 0x80000000ull && (size_t)B * (H / 2) * (W / 2) * Cout * 2 < 0x80000000ull) ? 1 : 0;
+}
+
+/* y = act(conv4x4_stride2(reflect_pad1(x)) + bias) on bf16 NHWC tensors (reference networks.py:90,94,437, networks_v2.py:107-111):
+ * x [B,H,W,Cin] -> y [B,H/2,W/2,Cout]; w prepared by dwc_bf16_weight_prepare_fwd (KH = KW = 4, cout_pad = Cout, cin_pad = Cin).
+ * Halo form over the space-to-depth image (conv_halo16_bf16.inc, S2), two 4-wave workgroups per CU.  No scratch. */
+int dwc_bf16_conv2d_s2_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                            int act, void* stream) {
+    if (!x || !w_prepared || !y || !dwc_bf16_conv2d_s2_halo_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
+    HaloArgs a;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = (bf16*)y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout; a.K = 4;
+    a.Kp = (16 * Cin + BK - 1) / BK * BK; a.act = act; a.reflect = 1;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B * a.blocks_per_img;
+    if (Cout % 128 == 0) {
+        a.tiles_n = Cout / 128;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 128, 2, 2, 1, 0, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    } else {
+        a.tiles_n = Cout / 64;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 64, 2, 2, 1, 0, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 size_t dwc_bf16_conv2d_wgrad_halo_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {
     const int bn = wgrad_halo_bn(B, H, W, Cin, Cout, K);
     if (!bn) return 0;

@@ -1,0 +1,141 @@
+// Refresh of EVERY prepared weight layout of a network in ONE launch, right behind the optimiser step
+// ("fused multi-tensor Adam(+L2 wd)+EMA+KRSC-weight-refresh"; reference solver.py:240,353 are the
+// optimiser steps whose results the conv kernels stream in re-laid-out form).
+//
+// The conv kernels do not read the OIHW master weights: they stream prepared copies -- [N][Kp] im2col rows (fp32 or bf16,
+// forward / data-gradient / transposed-filter data-gradient, four parity classes for stride 2), three-way bf16 split planes
+// (conv_halo_x3.hip) and Winograd F(2x2,3x3) transform-domain banks.  Rounds 1-2 rebuilt each of them lazily with its own
+// launch the first time a layer ran after the step: ~137 launches per iteration (weight_prepare_dgrad 66, _fwd 35,
+// x3_weight_prepare 20, wino_filter 16).  Here a device descriptor table lists every (master weight, prepared tensor, layout)
+// pair; workgroup b rebuilds DWC_OPT_CHUNK work items of descriptor chunk_desc[b] from chunk_start[b].  The element formulas
+// are those of weight_prepare_*_kernel (conv_igemm.hip, conv_bf16.hip), x3_weight_prepare_kernel and wino_filter_kernel --
+// tests/test_hip_parity.py::test_weight_refresh_multi_matches_single_layout_kernels holds the two bit for bit.
+#include "dwc_common.h"
+
+namespace {
+
+typedef __bf16 bf16;
+
+// fwd / dgrad element of the [rows][Kp] im2col layout (conv_igemm.hip: weight_prepare_fwd_kernel / _dgrad_kernel)
+__device__ __forceinline__ float im2col_elem(const dwc_refresh_desc& d, size_t idx, bool dgrad) {
+    const float* w = d.src;
+    if (!dgrad) {
+        const int KHW = d.KH * d.KW;
+        const int k = idx % d.Kp, co = idx / d.Kp;
+        const int ci = k % d.cin_pad, tap = k / d.cin_pad;
+        return (co < d.Cout && ci < d.Cin && tap < KHW) ? w[((size_t)co * d.Cin + ci) * KHW + tap] : 0.f;
+    }
+    const size_t per_class = (size_t)d.cin_pad * d.Kp;
+    const int cls = idx / per_class;
+    const size_t r = idx % per_class;
+    const int k = r % d.Kp, ci = r / d.Kp;
+    const int co = k % d.cout_pad, tapo = k / d.cout_pad;
+    int kh, kw;
+    bool ok = co < d.Cout && ci < d.Cin;
+    if (d.stride == 1) {
+        ok = ok && tapo < d.KH * d.KW;
+        kh = d.KH - 1 - tapo / d.KW;
+        kw = d.KW - 1 - tapo % d.KW;
+    } else {
+        ok = ok && tapo < 4;
+        kh = (cls >> 1) + 2 * (tapo >> 1);
+        kw = (cls & 1) + 2 * (tapo & 1);
+    }
+    // transpose_hw: the layout of the filter with its two spatial axes swapped (square filters: "dgrad_t" of hipdwc.ops)
+    const int off = d.transpose_hw ? kw * d.KH + kh : kh * d.KW + kw;
+    return ok ? w[((size_t)co * d.Cin + ci) * d.KH * d.KW + off] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void weight_refresh_multi_kernel(const dwc_refresh_desc* __restrict__ descs,
+                                                                   const int* __restrict__ chunk_desc,
+                                                                   const unsigned* __restrict__ chunk_start) {
+    const dwc_refresh_desc d = descs[chunk_desc[blockIdx.x]];
+    const size_t i0 = chunk_start[blockIdx.x];
+    const size_t i1 = min((size_t)d.n_items, i0 + DWC_OPT_CHUNK);
+    for (size_t idx = i0 + threadIdx.x; idx < i1; idx += 256) {
+        switch (d.kind) {
+            case DWC_REFRESH_FWD_F32: reinterpret_cast<float*>(d.dst)[idx] = im2col_elem(d, idx, false); break;
+            case DWC_REFRESH_DGRAD_F32: reinterpret_cast<float*>(d.dst)[idx] = im2col_elem(d, idx, true); break;
+            case DWC_REFRESH_FWD_BF16: reinterpret_cast<bf16*>(d.dst)[idx] = (bf16)im2col_elem(d, idx, false); break;
+            case DWC_REFRESH_DGRAD_BF16: reinterpret_cast<bf16*>(d.dst)[idx] = (bf16)im2col_elem(d, idx, true); break;
+            case DWC_REFRESH_X3_FWD:
+            case DWC_REFRESH_X3_DGRAD: {
+                // conv_halo_x3.hip x3_weight_prepare_kernel: out[((tap*ncs + cs)*3 + plane)*rows + row][16], exact bf16 splits
+                const int K = d.KH, rows = d.rows, kdim = d.kdim, CS = 16;
+                const int ncs = (kdim + CS - 1) / CS;
+                const int j = idx % CS;
+                size_t r = idx / CS;
+                const int row = r % rows;
+                r /= rows;
+                const int cs = r % ncs, tap = r / ncs;
+                const int kh = tap / K, kw = tap - kh * K;
+                const int kc = cs * CS + j;
+                float v = 0.f;
+                if (d.kind == DWC_REFRESH_X3_FWD) {
+                    if (row < d.Cout && kc < d.Cin) v = d.src[(((size_t)row * d.Cin + kc) * K + kh) * K + kw];
+                } else {
+                    if (row < d.Cin && kc < d.Cout) v = d.src[(((size_t)kc * d.Cin + row) * K + (K - 1 - kh)) * K + (K - 1 - kw)];
+                }
+                const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+                const float r1 = v - __uint_as_float(hb);
+                const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+                const float r2 = r1 - __uint_as_float(mb);
+                unsigned short* o = reinterpret_cast<unsigned short*>(d.dst);
+                const size_t base = ((size_t)(tap * ncs + cs) * 3 * rows + row) * CS + (j ^ (((row >> 3) & 1) << 3));
+                o[base] = (unsigned short)(hb >> 16);
+                o[base + (size_t)rows * CS] = (unsigned short)(mb >> 16);
+                o[base + 2 * (size_t)rows * CS] = (unsigned short)(__float_as_uint(r2) >> 16);
+                break;
+            }
+            case DWC_REFRESH_WINO2_FWD:
+            case DWC_REFRESH_WINO2_DGRAD: {
+                // conv_igemm.hip wino_filter_kernel: U[16][rows][K] = G g G^T (forward: g = W[co][ci]; data gradient: rotated, transposed)
+                const bool dg = d.kind == DWC_REFRESH_WINO2_DGRAD;
+                const int rows = dg ? d.Cin : d.Cout, K = dg ? d.Cout : d.Cin;
+                const int k = idx % K, row = idx / K;
+                const int co = dg ? k : row, ci = dg ? row : k;
+                const float* gp = d.src + ((size_t)co * d.Cin + ci) * 9;
+                float g[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) g[a][b] = dg ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
+                float t[4][3];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    t[0][b] = g[0][b];
+                    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+                    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+                    t[3][b] = g[2][b];
+                }
+                float* U = reinterpret_cast<float*>(d.dst);
+                const size_t plane = (size_t)rows * K;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    U[(size_t)(a * 4 + 0) * plane + idx] = t[a][0];
+                    U[(size_t)(a * 4 + 1) * plane + idx] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+                    U[(size_t)(a * 4 + 2) * plane + idx] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+                    U[(size_t)(a * 4 + 3) * plane + idx] = t[a][2];
+                }
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dwc_weight_refresh_multi(const dwc_refresh_desc* descs_dev, const int* chunk_desc_dev, const unsigned* chunk_start_dev, int n_chunks,
+                             void* stream) {
+    if (n_chunks <= 0) return DWC_OK;
+    if (!descs_dev || !chunk_desc_dev || !chunk_start_dev) return DWC_EINVAL;
+    hipLaunchKernelGGL(weight_refresh_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, descs_dev, chunk_desc_dev,
+                       chunk_start_dev);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+}  // extern "C"

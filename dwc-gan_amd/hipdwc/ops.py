@@ -8,6 +8,7 @@ from tests only).
 import os
 import weakref
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -194,7 +195,10 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         out = torch.empty(lib.dwc_wino_filter_elems(cout_pad, cin_pad, stride), dtype=torch.float32, device=w.device)
         _lib.check(lib.dwc_wino_prepare_filter(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad,
                                                int(kind == "wino_dgrad"), stride, _stream()), "wino_prepare_filter")
-        ent[key] = (stamp, out)
+        recipe = None
+        if stride == 2 and co == cout_pad and ci == cin_pad:          # (F(2x2,3x3) only; `stride` carries the Winograd tile)
+            recipe = _recipe(w, owners, kind=7 if kind == "wino_dgrad" else 6, n_items=cout_pad * cin_pad, Cout=co, Cin=ci, KH=3, KW=3)
+        ent[key] = (stamp, out, recipe)
         return out
     if kind in ("x3_fwd", "x3_dgrad"):
         # three bf16 planes per (tap, 16-channel slab) [tap][slab][plane][row][16] (dwc_x3_weight_prepare); rows = cout_pad
@@ -209,7 +213,11 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         out = torch.empty(lib.dwc_x3_weight_prepared_elems(rows, kdim, kh), dtype=BF16, device=w.device)
         _lib.check(lib.dwc_x3_weight_prepare(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad, kh, rows, int(dg),
                                              _stream()), "x3_weight_prepare")
-        ent[key] = (stamp, out)
+        recipe = None
+        if co == cout_pad and ci == cin_pad:
+            recipe = _recipe(w, owners, kind=5 if dg else 4, n_items=kh * kh * ((kdim + 15) // 16) * rows * 16, Cout=co, Cin=ci,
+                             KH=kh, KW=kw, rows=rows, kdim=kdim)
+        ent[key] = (stamp, out, recipe)
         return out
     if kind in ("stem_steps", "stem_steps_dgrad"):
         # csrc/conv_narrow_bf16.hip conv_stem_kernel: [25 k-steps][64 channels][2 taps x 8 planes] bf16, halves of a row swapped
@@ -259,7 +267,8 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         return out
     cout, cin, kh, kw = w.shape
     wc = w.detach().contiguous()
-    if kind == "dgrad_t":           # dgrad layout of the filter with its two spatial axes swapped (taps enumerated kw-major)
+    transposed = kind == "dgrad_t"
+    if transposed:                  # dgrad layout of the filter with its two spatial axes swapped (taps enumerated kw-major)
         wc = w.detach().transpose(2, 3).contiguous()
         kind = "dgrad"
     pre = "dwc_bf16_" if half else "dwc_"
@@ -268,11 +277,79 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
     if kind == "fwd":
         _lib.check(getattr(lib, pre + "weight_prepare_fwd")(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, cout_pad, cin_pad,
                                                             _stream()), "weight_prepare_fwd")
+        rows, kdim = cout_pad, kh * kw * cin_pad
     else:
         _lib.check(getattr(lib, pre + "weight_prepare_dgrad")(wc.data_ptr(), out.data_ptr(), cout, cin, kh, kw, stride,
                                                               cout_pad, cin_pad, _stream()), "weight_prepare_dgrad")
-    ent[key] = (stamp, out)
+        rows, kdim = (cin_pad, kh * kw * cout_pad) if stride == 1 else (4 * cin_pad, 4 * cout_pad)
+    recipe = None
+    if (not transposed or kh == kw) and n % rows == 0:
+        # (Kp = the padded row length the single-layout entry point chose: n elements / rows)
+        recipe = _recipe(w, owners, kind=(2 if half else 0) + (kind == "dgrad"), n_items=n, Cout=cout, Cin=cin, KH=kh, KW=kw,
+                         stride=stride, cout_pad=cout_pad, cin_pad=cin_pad, Kp=n // rows, transpose_hw=int(transposed))
+    ent[key] = (stamp, out, recipe)
     return out
+
+
+_REFRESH_DT = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n_items", "<u8"), ("kind", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"),
+                        ("KH", "<i4"), ("KW", "<i4"), ("stride", "<i4"), ("cout_pad", "<i4"), ("cin_pad", "<i4"), ("Kp", "<i4"),
+                        ("rows", "<i4"), ("kdim", "<i4"), ("transpose_hw", "<i4"), ("reserved", "<i4"), ("tail_pad", "<i4")])   # struct dwc_refresh_desc (80 bytes)
+assert _REFRESH_DT.itemsize == 80
+REFRESH_CHUNK = 8192           # DWC_OPT_CHUNK of include/dwcgan_hip.h
+_REFRESH_TABLES = {}           # (src, dst) pointers of a refresh set -> (device descriptor table, chunk maps)
+REFRESH_STATS = {"launches": 0, "layouts": 0}
+
+
+def _recipe(w, owners, **fields):
+    """Descriptor fields with which dwc_weight_refresh_multi can rebuild this layout from the owning parameter's storage, or
+    None when the layout was not built straight from it (derived banks: the fused heads, the NHWC8 stems)."""
+    if len(owners) != 1 or w.data_ptr() != owners[0].data_ptr() or not w.detach().is_contiguous() or w.dtype != torch.float32:
+        return None
+    return fields
+
+
+def refresh_prepared(params):
+    """Rebuild EVERY stale prepared layout of `params` in ONE launch (dwc_weight_refresh_multi; FusedAdam.step calls this right
+    behind the update: SURVEY.md section 8(f) rank 1).  Layouts that were never used, or that are derived through torch ops (no
+    recipe), stay with the lazy per-layout path of _prepped.  Returns the number of layouts rebuilt."""
+    todo = []
+    for p in params:
+        slot = _WCACHE.get(id(p))
+        if slot is None or slot[0]() is not p:
+            continue
+        stamp = ((p._version, p.data_ptr()),)
+        for key, val in slot[1].items():
+            if len(val) > 2 and val[2] is not None and val[0] != stamp:
+                todo.append((p, slot[1], key, val, stamp))
+    if not todo:
+        return 0
+    lib = _lib.load()
+    dev = todo[0][0].device
+    ident = tuple((p.data_ptr(), val[1].data_ptr()) for p, _, _, val, _ in todo)
+    table = _REFRESH_TABLES.get(ident)
+    if table is None:
+        desc = np.zeros(len(todo), dtype=_REFRESH_DT)
+        cd, cs = [], []
+        for i, (p, _, _, val, _) in enumerate(todo):
+            desc[i]["src"], desc[i]["dst"] = p.data_ptr(), val[1].data_ptr()
+            for k, v in val[2].items():
+                desc[i][k] = v
+            for s0 in range(0, int(val[2]["n_items"]), REFRESH_CHUNK):
+                cd.append(i)
+                cs.append(s0)
+        host = torch.from_numpy(desc.view(np.uint8).reshape(-1)).pin_memory()
+        table = (host.to(dev, non_blocking=True), torch.tensor(cd, dtype=torch.int32, device=dev),
+                 torch.tensor(np.array(cs, dtype=np.uint32).view(np.int32), dtype=torch.int32, device=dev), len(cd))
+        if len(_REFRESH_TABLES) > 16:
+            _REFRESH_TABLES.clear()
+        _REFRESH_TABLES[ident] = table
+    _lib.check(lib.dwc_weight_refresh_multi(table[0].data_ptr(), table[1].data_ptr(), table[2].data_ptr(), table[3], _stream()),
+               "weight_refresh_multi")
+    for p, ent, key, val, stamp in todo:
+        ent[key] = (stamp, val[1], val[2])
+    REFRESH_STATS["launches"] += 1
+    REFRESH_STATS["layouts"] += len(todo)
+    return len(todo)
 
 
 # --------------------------------------------------------------------------------------
@@ -294,6 +371,7 @@ HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
+S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 
 
 _WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
@@ -380,6 +458,12 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem(
                 x.data_ptr(), w_st.data_ptr(), _p(bias), y.data_ptr(), B, H, W, H, W, KH, -pad, act, 1, st),
                 detail="fwd-stem B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_stem")
+        elif (half and HALO and S2HALO and stride == 2 and KH == 4 and KW == 4 and pad == 1
+              and lib.dwc_bf16_conv2d_s2_halo_ok(B, H, W, Cx, cop)):
+            # stride-2 4x4 layers on the bf16 path: 2x2 taps over the space-to-depth image, space-to-depth done by the loader
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_s2_halo(
+                x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, st),
+                detail="fwd-s2halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_s2_halo")
         elif half and HALO and stride == 1 and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH):
             # stride-1 "same" 3x3 / 5x5 layers on the bf16 path: halo-tiled kernel (patch staged once per channel slab)
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(

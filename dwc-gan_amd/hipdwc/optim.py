@@ -17,6 +17,7 @@ import torch
 from . import _lib
 
 CHUNK = 8192           # must equal DWC_OPT_CHUNK in include/dwcgan_hip.h
+REFRESH_WITH_STEP = True   # FusedAdam.step() ends with hipdwc.ops.refresh_prepared (False: every layout lazily at its next use)
 
 _ADAM_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u8"),
                      ("step_size", "<f4"), ("bc2_sqrt", "<f4")])      # struct dwc_adam_tensor
@@ -94,7 +95,13 @@ class FusedAdam(torch.optim.Adam):
             del keep
             # the kernel wrote through raw pointers: tell autograd (and the prepared-weight cache in
             # hipdwc.ops, which keys on the version counter) that these tensors changed
-            torch.autograd.graph.increment_version([p for p in params if p.grad is not None])
+            touched = [p for p in params if p.grad is not None]
+            torch.autograd.graph.increment_version(touched)
+            # ... and rebuild every prepared layout of the updated weights in ONE launch, here, instead of one launch per layout
+            # at each layer's next use (Adam + weight refresh as one pass over the parameters)
+            if REFRESH_WITH_STEP:
+                from . import ops
+                ops.refresh_prepared(touched)
         return None
 
 

@@ -265,6 +265,28 @@ int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_d
 int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev,
                   const unsigned* chunk_start_dev, int n_chunks, float beta, void* stream);
 
+/* Refresh of every prepared weight layout of a network in ONE launch behind the optimiser step (SURVEY.md section 8(f) rank 1;
+ * reference solver.py:240,353).  One descriptor per (OIHW master weight, prepared tensor, layout); workgroup b rebuilds
+ * DWC_OPT_CHUNK work items of descriptor chunk_desc[b] starting at chunk_start[b].  Layouts and element formulas are those of
+ * the single-layout entry points: FWD / DGRAD = dwc_weight_prepare_fwd / _dgrad (fp32) and dwc_bf16_weight_prepare_fwd /
+ * _dgrad (work item = output element; n_items = rows * Kp, x 4 parity classes for the stride-2 data gradient; transpose_hw:
+ * the filter with its two spatial axes swapped), X3 = dwc_x3_weight_prepare (work item = one of K*K*ceil(kdim/16)*rows*16
+ * source slots), WINO2 = dwc_wino_prepare_filter with tile 2 (work item = one (row, k) pair, sixteen transform-domain values). */
+enum { DWC_REFRESH_FWD_F32 = 0, DWC_REFRESH_DGRAD_F32 = 1, DWC_REFRESH_FWD_BF16 = 2, DWC_REFRESH_DGRAD_BF16 = 3,
+       DWC_REFRESH_X3_FWD = 4, DWC_REFRESH_X3_DGRAD = 5, DWC_REFRESH_WINO2_FWD = 6, DWC_REFRESH_WINO2_DGRAD = 7 };
+typedef struct {
+    const float* src;            /* fp32 OIHW master weight [Cout][Cin][KH][KW] */
+    void* dst;                   /* prepared tensor */
+    unsigned long long n_items;
+    int kind;                    /* DWC_REFRESH_* */
+    int Cout, Cin, KH, KW, stride, cout_pad, cin_pad, Kp;
+    int rows, kdim;              /* X3: rows of the prepared matrix, contraction length */
+    int transpose_hw;            /* DGRAD: swap the filter's spatial axes */
+    int reserved;
+} dwc_refresh_desc;
+int dwc_weight_refresh_multi(const dwc_refresh_desc* descs_dev, const int* chunk_desc_dev, const unsigned* chunk_start_dev,
+                             int n_chunks, void* stream);
+
 /* ---- fp32 convolutions on the bf16 matrix cores by exact three-way operand splits (conv_halo_x3.hip) --------------------
  * An fp32 value is exactly the sum of three bf16 values (truncate / subtract twice); bf16 x bf16 products are exact in the
  * fp32 accumulator; the six leading cross products reproduce a*b to 2^-23 relative, the accuracy of one fp32 rounding.
@@ -319,6 +341,15 @@ int dwc_bf16_conv2d_bwd_data_ring(const void* dy, const void* w_dgrad, const voi
 int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K);
 int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
                               int Cout, int K, int act, int reflect, void* stream);
+
+/* The stride-2 4x4 reflect-pad-1 convolutions (reference networks.py:90,94,437 -- content encoder / discriminator --,
+ * networks_v2.py:107-111 -- style encoder), forward, bf16 NHWC: x [B,H,W,Cin] -> y [B,H/2,W/2,Cout], halo form over the
+ * space-to-depth image (the loader does the space-to-depth).  w_prepared: dwc_bf16_weight_prepare_fwd with KH = KW = 4,
+ * cout_pad = Cout, cin_pad = Cin.  dwc_bf16_conv2d_s2_halo_ok says whether a shape is handled (H, W multiples of 32, Cin a
+ * power of two >= 64, Cout a multiple of 64); otherwise use dwc_bf16_conv2d_fwd. */
+int dwc_bf16_conv2d_s2_halo_ok(int B, int H, int W, int Cin, int Cout);
+int dwc_bf16_conv2d_s2_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
+                            int act, void* stream);
 /* Halo form of the weight gradient of the same layers (reflect padding): a workgroup stages the (8+K-1)x(16+K-1) patch of x
  * and the 8x16 block of dY once and forms all 9 taps of a 3x3 / one filter row of a 5x5 from it; pixel ranges are split into
  * fp32 slabs in `ws` that a second kernel sums in a fixed order into dw ([cout_real][cin_real][K][K], fp32).  ws_bytes == 0:

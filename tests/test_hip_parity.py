@@ -781,3 +781,41 @@ def test_sample_matches_manual_path():
         rec = s._decode(content, torch.cat(style_real, dim=1), x4)[:, :3]
     s.train()
     close(out[1][1:2], rec, rel=1e-5, msg="reconstruction column")
+
+
+def test_weight_refresh_multi_matches_single_layout_kernels():
+    """after an optimiser step every prepared weight layout is rebuilt by ONE dwc_weight_refresh_multi
+    launch.  Its output must equal, bit for bit, what the single-layout entry points build from the same weights: fp32 and
+    bf16 im2col rows (forward, data gradient, transposed-filter data gradient, the four stride-2 parity classes), the
+    three-plane bf16 splits and the Winograd F(2x2,3x3) banks."""
+    g = torch.Generator().manual_seed(9)
+    cases = [  # (Cout, Cin, k, [(kind, cout_pad, cin_pad, stride, half)])
+        (128, 64, 4, [("fwd", 128, 64, 2, False), ("dgrad", 128, 64, 2, False), ("fwd", 128, 64, 2, True), ("dgrad", 128, 64, 2, True)]),
+        (256, 256, 3, [("fwd", 256, 256, 1, True), ("dgrad", 256, 256, 1, True), ("dgrad_t", 256, 256, 1, True), ("dgrad", 256, 256, 1, False),
+                       ("dgrad_t", 256, 256, 1, False), ("wino_fwd", 256, 256, 2, False), ("wino_dgrad", 256, 256, 2, False),
+                       ("x3_fwd", 256, 256, 1, False), ("x3_dgrad", 256, 256, 1, False)]),
+        (128, 256, 5, [("x3_fwd", 128, 256, 1, False), ("x3_dgrad", 128, 256, 1, False), ("fwd", 128, 256, 1, True), ("dgrad_t", 128, 256, 1, True)]),
+        (61, 20, 3, [("fwd", 64, 20, 1, False), ("dgrad", 64, 20, 1, False), ("fwd", 64, 24, 1, True)]),      # padded rows / channels
+        (8, 512, 4, [("fwd", 8, 512, 1, False), ("dgrad", 8, 512, 1, False)]),
+    ]
+    params = []
+    for co, ci, k, layouts in cases:
+        w = (torch.randn(co, ci, k, k, generator=g) * 0.1).to(DEV).requires_grad_(True)
+        params.append((w, layouts))
+        for kind, cop, cip, st, half in layouts:
+            ops._prepped(w, kind, cop, cip, st, None, half)
+    before = ops.REFRESH_STATS["launches"]
+    with torch.no_grad():
+        for w, _ in params:
+            w.add_(torch.randn(w.shape, generator=g).to(DEV) * 0.05)          # in-place: bumps the version like an optimiser step
+    n = ops.refresh_prepared([w for w, _ in params])
+    assert n == sum(len(l) for _, l in params) and ops.REFRESH_STATS["launches"] == before + 1
+    for w, layouts in params:
+        for kind, cop, cip, st, half in layouts:
+            got = ops._prepped(w, kind, cop, cip, st, None, half)              # cache hit: the refreshed tensor
+            assert ops.refresh_prepared([w]) == 0
+            ref_w = w.detach().clone().requires_grad_(True)                    # a fresh tensor: the single-layout kernels
+            want = ops._prepped(ref_w, kind, cop, cip, st, None, half)
+            assert got.data_ptr() != want.data_ptr()
+            assert torch.equal(got.view(torch.int16) if half or kind.startswith("x3") else got,
+                               want.view(torch.int16) if half or kind.startswith("x3") else want), (kind, cop, cip, st, half)
