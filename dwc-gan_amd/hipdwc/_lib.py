@@ -14,6 +14,11 @@ c_int = ctypes.c_int
 c_sz = ctypes.c_size_t
 c_f = ctypes.c_float
 
+
+class AdvSpec(ctypes.Structure):               # struct dwc_adv_spec (passed by value)
+    _fields_ = [("target", c_f * 4), ("w_src", c_f * 4), ("w_cls", c_f * 4)]
+
+
 # name -> (restype, argtypes): mirrors include/dwcgan_hip.h one to one
 SIGNATURES = {
     "dwc_version": (c_int, []),
@@ -87,6 +92,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
     "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_adv_tail_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
+    "dwc_adv_tail_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_bf16_conv2d_s2_halo_ok": (c_int, [c_int] * 5),
     "dwc_bf16_conv2d_s2_halo": (c_int, [c_fp] * 4 + [c_int] * 6 + [c_fp]),
     "dwc_x3_conv2d_same_ok": (c_int, [c_int] * 6),

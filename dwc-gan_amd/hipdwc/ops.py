@@ -1196,3 +1196,70 @@ def l1_mean(a, b, image=False):
     """mean |a-b| (reference solver.py:113-114).  image=True: internal image buffers (NHWC4 / NHWC8), mean over
     planes 0..2 only."""
     return _L1Mean.apply(a, b, a.shape[1] if image else 0)
+
+
+# --------------------------------------------------------------------------------------
+# loss tails
+# --------------------------------------------------------------------------------------
+class _AdvTail(torch.autograd.Function):
+    """Adversarial loss of ONE discriminator scale over a batched pass (reference networks.py:116-170), one launch each way:
+    sum_s w_src[s] * mean_s((src - target[s])^2) + w_cls[s] * mean_s(bce_with_logits(cls, labels))."""
+
+    @staticmethod
+    def forward(ctx, src, cls, labels, B, targets, w_src, w_cls):
+        _require_device(src)
+        lib = _lib.load()
+        src, cls, labels = src.float().contiguous(), cls.float().contiguous(), labels.float().contiguous()
+        segs = src.shape[0] // B
+        if segs * B != src.shape[0] or cls.shape[0] != src.shape[0] or not 1 <= segs <= 4 or len(targets) != segs:
+            raise ValueError("adv_tail: the batch must be 1..4 segments of B samples")
+        sps, ncls = src[0].numel(), cls[0].numel()
+        if labels.shape[0] != B or labels[0].numel() != ncls:
+            raise ValueError("adv_tail: labels must be [B, ncls]")
+        spec = _lib.AdvSpec()
+        for s in range(segs):
+            spec.target[s], spec.w_src[s], spec.w_cls[s] = float(targets[s]), float(w_src[s]), float(w_cls[s])
+        out = torch.empty((), dtype=torch.float32, device=src.device)
+        _lib.check(lib.dwc_adv_tail_fwd(src.data_ptr(), cls.data_ptr(), labels.data_ptr(), out.data_ptr(), segs, B, sps, ncls, spec,
+                                        _stream()), "adv_tail_fwd")
+        ctx.save_for_backward(src, cls, labels)
+        ctx.geom = (segs, B, sps, ncls, spec)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        src, cls, labels = ctx.saved_tensors
+        segs, B, sps, ncls, spec = ctx.geom
+        dsrc, dcls = torch.empty_like(src), torch.empty_like(cls)
+        _lib.check(lib.dwc_adv_tail_bwd(src.data_ptr(), cls.data_ptr(), labels.data_ptr(), dout.float().contiguous().data_ptr(),
+                                        dsrc.data_ptr(), dcls.data_ptr(), segs, B, sps, ncls, spec, _stream()), "adv_tail_bwd")
+        return dsrc, dcls, None, None, None, None, None
+
+
+def adv_tail(src, cls, labels, B, targets, w_src, w_cls):
+    return _AdvTail.apply(src, cls, labels, int(B), tuple(targets), tuple(w_src), tuple(w_cls))
+
+
+class _WeightedSum(torch.autograd.Function):
+    """sum_i w_i * t_i over 0-dim loss tensors: stack + one dot product forward, ONE scaled copy of the weights backward
+    (the reference's loss_gen_total, solver.py:226-238, is thirteen scalar multiply-adds = ~40 launches with their backward)."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        w = torch.tensor(weights, dtype=torch.float32).to(terms[0].device, non_blocking=True)
+        ctx.save_for_backward(w)
+        return torch.dot(torch.stack([t.float().reshape(()) for t in terms]), w)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w,) = ctx.saved_tensors
+        return (None,) + (dout * w).unbind(0)
+
+
+def weighted_sum(pairs):
+    """pairs: (weight, 0-dim tensor or python number).  Numbers and zero-weight tensors fold into a constant."""
+    const = sum(float(w) * float(t) for w, t in pairs if not torch.is_tensor(t))
+    ts = [(float(w), t) for w, t in pairs if torch.is_tensor(t)]
+    out = _WeightedSum.apply(tuple(w for w, _ in ts), *[t for _, t in ts])
+    return out + const if const != 0.0 else out

@@ -320,6 +320,20 @@ class MsImageDis(nn.Module):
                 p.append([s, c])
         return parts
 
+    def adv_loss(self, outputs, B, labels, targets, w_src, w_cls):
+        """Adversarial objective of a BATCHED pass (segments of B samples: [x_fake | x_fake1 | x_real] in the D step,
+        [x_fake | x_fake1] in the G step), one tail launch per scale (hipdwc.ops.adv_tail) instead of the reference's term-by-term
+        LSGAN / BCE algebra (networks.py:116-170):  sum over scales and segments s of
+        w_src[s] * mean((src_s - targets[s])^2) + w_cls[s] * BCEwithLogits(cls_s, labels).  LSGAN + CelebA/CUB200 only (the
+        shipped configuration); anything else takes the term-by-term methods below."""
+        if self.gan_type != "lsgan" or self.dataset not in ("CelebA", "CUB200"):
+            raise NotImplementedError("adv_loss covers gan_type lsgan with attribute BCE; use dis_loss_terms / gen_loss_terms")
+        loss = None
+        for src, cls in outputs:
+            term = ops.adv_tail(src, cls, labels, B, targets, w_src, w_cls)
+            loss = term if loss is None else loss + term
+        return loss
+
     def dis_loss_terms(self, outs_fake, outs_real, real_cls, weight_gan=1.0, weight_cls=1.0):
         loss = 0.0
         for (src_f, _), (src_r, cls_r) in zip(outs_fake, outs_real):

@@ -231,9 +231,15 @@ class Solver(nn.Module):
         gw, cw = configs["gan_w"], configs["cls_w"]
         # ONE discriminator pass over [x_fake, x_fake1, x_real]; D(x_real) enters both loss terms as
         # in the reference (which evaluates it twice, with identical values)
-        o_fake, o_fake1, o_real = self.dis.split_outputs(self.dis(torch.cat([fakes, x4])), [B, B, B])
-        self.loss_dis = self.dis.dis_loss_terms(o_fake, o_real, label_src, gw, cw) + \
-            self.dis.dis_loss_terms(o_fake1, o_real, label_src, gw, cw)
+        outs = self.dis(torch.cat([fakes, x4]))
+        if self.dis.gan_type == "lsgan" and self.dis.dataset in ("CelebA", "CUB200"):
+            # calc_dis_loss(x_fake, x_real) + calc_dis_loss(x_fake1, x_real) (reference solver.py:333-336), one tail launch per scale
+            self.loss_dis = self.dis.adv_loss(outs, B, label_src, targets=(0.0, 0.0, 1.0), w_src=(gw, gw, 2.0 * gw),
+                                              w_cls=(0.0, 0.0, 2.0 * cw))
+        else:
+            o_fake, o_fake1, o_real = self.dis.split_outputs(outs, [B, B, B])
+            self.loss_dis = self.dis.dis_loss_terms(o_fake, o_real, label_src, gw, cw) + \
+                self.dis.dis_loss_terms(o_fake1, o_real, label_src, gw, cw)
         self.loss_dis_all = self.loss_dis
         self.loss_dis_all.backward()
         self._sync_grads("dis")             # data parallel: average D's gradients over the ranks
@@ -291,9 +297,14 @@ class Solver(nn.Module):
             self.loss_gen_recon_s_rand = self.criterion_l1(style_rand, style1)
             self.loss_gen_cycrecon_x = ops.l1_mean(x_cycle, x4, image=True) if cyc else 0
 
-            o_fake, o_fake1 = self.dis.split_outputs(self.dis(x_all[B:]), [B, B])   # one pass over [x_fake, x_fake1]
-            self.loss_gen_adv = self.dis.gen_loss_terms(o_fake, label_trg, cfg["gan_w"], cfg["cls_w"]) + \
-                self.dis.gen_loss_terms(o_fake1, label_trg, cfg["gan_w"], cfg["cls_w"])
+            outs = self.dis(x_all[B:])                                          # one pass over [x_fake, x_fake1]
+            if self.dis.gan_type == "lsgan" and self.dis.dataset in ("CelebA", "CUB200"):
+                self.loss_gen_adv = self.dis.adv_loss(outs, B, label_trg, targets=(1.0, 1.0), w_src=(cfg["gan_w"],) * 2,
+                                                      w_cls=(cfg["cls_w"],) * 2)
+            else:
+                o_fake, o_fake1 = self.dis.split_outputs(outs, [B, B])
+                self.loss_gen_adv = self.dis.gen_loss_terms(o_fake, label_trg, cfg["gan_w"], cfg["cls_w"]) + \
+                    self.dis.gen_loss_terms(o_fake1, label_trg, cfg["gan_w"], cfg["cls_w"])
 
             if self.dist_mode == "kls":
                 self.loss_kl_x = gmm_kl_distance_sp(style_real, logvar, c_src, self.sigma)
@@ -305,19 +316,21 @@ class Solver(nn.Module):
             if cyc and cfg["vgg_w"] > 0:                 # reference solver.py:221-223
                 self.loss_gen_vgg = self.compute_vgg_loss(self.vgg, x4, x_cycle)
 
-            self.loss_gen_total = self.loss_gen_adv + \
-                cfg["recon_x_w"] * self.loss_gen_recon_x + \
-                cfg["recon_c_w"] * self.loss_gen_recon_c_real + \
-                cfg["recon_c_w"] * self.loss_gen_recon_c_fake + \
-                cfg["recon_c_w"] * self.loss_gen_recon_c_rand + \
-                cfg["recon_s_w"] * self.loss_gen_recon_s_real + \
-                cfg["recon_s_w"] * self.loss_gen_recon_s_fake + \
-                cfg["recon_s_w"] * self.loss_gen_recon_s_rand + \
-                cfg["recon_x_cyc_w"] * self.loss_gen_cycrecon_x + \
-                cfg["kl_w"] * self.loss_kl_x + \
-                cfg["kl_w"] * self.loss_kl_trg + \
-                cfg["vgg_w"] * self.loss_gen_vgg - \
-                self.init_ds_w * self.loss_ds
+            # reference solver.py:226-238, as one weighted sum (one dot product forward, one scaled copy backward)
+            self.loss_gen_total = ops.weighted_sum([
+                (1.0, self.loss_gen_adv),
+                (cfg["recon_x_w"], self.loss_gen_recon_x),
+                (cfg["recon_c_w"], self.loss_gen_recon_c_real),
+                (cfg["recon_c_w"], self.loss_gen_recon_c_fake),
+                (cfg["recon_c_w"], self.loss_gen_recon_c_rand),
+                (cfg["recon_s_w"], self.loss_gen_recon_s_real),
+                (cfg["recon_s_w"], self.loss_gen_recon_s_fake),
+                (cfg["recon_s_w"], self.loss_gen_recon_s_rand),
+                (cfg["recon_x_cyc_w"], self.loss_gen_cycrecon_x),
+                (cfg["kl_w"], self.loss_kl_x),
+                (cfg["kl_w"], self.loss_kl_trg),
+                (cfg["vgg_w"], self.loss_gen_vgg),
+                (-self.init_ds_w, self.loss_ds)])
             self.loss_gen_total.backward()
         self._sync_grads("gen")             # data parallel: average G's gradients over the ranks
         self.gen_opt.step()

@@ -265,6 +265,18 @@ int dwc_adam_multi(const dwc_adam_tensor* tensors_dev, const int* chunk_tensor_d
 int dwc_ema_multi(const dwc_ema_tensor* tensors_dev, const int* chunk_tensor_dev,
                   const unsigned* chunk_start_dev, int n_chunks, float beta, void* stream);
 
+/* Adversarial loss tail of one discriminator scale in one launch (reference networks.py:116-170: LSGAN on the 1-channel src map,
+ * BCE-with-logits on the attribute logits).  The batch is `segs` <= 4 segments of B samples; labels [B][ncls] are shared:
+ *   out = sum_s w_src[s] * mean_s((src - target[s])^2) + w_cls[s] * mean_s(bce_with_logits(cls, labels))
+ * src [segs*B][src_per_sample], cls [segs*B][ncls], all fp32; _bwd writes d out / d src and d out / d cls scaled by dout[0]. */
+typedef struct {
+    float target[4], w_src[4], w_cls[4];
+} dwc_adv_spec;
+int dwc_adv_tail_fwd(const float* src, const float* cls, const float* labels, float* out, int segs, int B, int src_per_sample, int ncls,
+                     dwc_adv_spec spec, void* stream);
+int dwc_adv_tail_bwd(const float* src, const float* cls, const float* labels, const float* dout, float* dsrc, float* dcls, int segs,
+                     int B, int src_per_sample, int ncls, dwc_adv_spec spec, void* stream);
+
 /* Refresh of every prepared weight layout of a network in ONE launch behind the optimiser step (SURVEY.md section 8(f) rank 1;
  * reference solver.py:240,353).  One descriptor per (OIHW master weight, prepared tensor, layout); workgroup b rebuilds
  * DWC_OPT_CHUNK work items of descriptor chunk_desc[b] starting at chunk_start[b].  Layouts and element formulas are those of

@@ -819,3 +819,38 @@ def test_weight_refresh_multi_matches_single_layout_kernels():
             assert got.data_ptr() != want.data_ptr()
             assert torch.equal(got.view(torch.int16) if half or kind.startswith("x3") else got,
                                want.view(torch.int16) if half or kind.startswith("x3") else want), (kind, cop, cip, st, half)
+
+
+@pytest.mark.parametrize("B,hw,segs", [(4, 4, 3), (16, 2, 2), (3, 1, 1), (48, 4, 3)])
+def test_adv_tail_and_weighted_sum_vs_oracle(B, hw, segs):
+    """One-launch adversarial tail of a discriminator scale (LSGAN + BCE-with-logits, reference networks.py:116-170) and the
+    one-launch loss_gen_total sum (solver.py:226-238) against the oracle's term-by-term algebra, values and gradients."""
+    g = torch.Generator().manual_seed(B * 10 + hw + segs)
+    src = torch.randn(segs * B, 1, hw, hw, generator=g)
+    cls = torch.randn(segs * B, 8, generator=g) * 2
+    labels = (torch.rand(B, 8, generator=g) > 0.5).float()
+    targets, w_src, w_cls = (0.0, 0.0, 1.0)[:segs], (1.0, 0.7, 2.0)[:segs], (0.0, 0.3, 2.0)[:segs]
+    sr, cr = src.clone().requires_grad_(True), cls.clone().requires_grad_(True)
+    want = 0
+    for s in range(segs):
+        want = want + w_src[s] * ((sr[s * B:(s + 1) * B] - targets[s]) ** 2).mean() \
+            + w_cls[s] * orc.bce_with_logits_mean(cr[s * B:(s + 1) * B], labels)
+    (want * 1.7).backward()
+    sd, cd = dev(src, True), dev(cls, True)
+    got = ops.adv_tail(sd, cd, labels.to(DEV), B, targets, w_src, w_cls)
+    assert abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    (got * 1.7).backward()
+    close(sd.grad, sr.grad, rel=1e-5, msg="dsrc")
+    close(cd.grad, cr.grad, rel=1e-5, msg="dcls")
+    # weighted sum
+    ts = [torch.randn((), generator=g) for _ in range(5)]
+    ws = [1.0, 10.0, 0.1, -0.99999, 0.0]
+    tr = [t.clone().requires_grad_(True) for t in ts]
+    ref = sum(w * t for w, t in zip(ws, tr)) + 0.5 * 3.0
+    ref.backward()
+    td = [dev(t, True) for t in ts]
+    out = ops.weighted_sum(list(zip(ws, td)) + [(0.5, 3.0), (0.1, 0)])
+    assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    out.backward()
+    for a, b in zip(td, tr):
+        assert abs(float(a.grad) - float(b.grad)) <= 1e-7
