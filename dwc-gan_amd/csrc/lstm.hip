@@ -220,6 +220,171 @@ __global__ __launch_bounds__(256) void lstm_step_bwd(const float* __restrict__ d
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent forward: ALL time steps of both directions in ONE launch ("a persistent bi-LSTM
+// kernel").  Same decomposition as lstm_step_fwd -- workgroup (g, d, z) owns 16 hidden units of direction d for batch chunk z,
+// each wave a quarter of the contraction -- but the workgroup stays resident: its W_hh slice (4 gates x 16 units x H) sits in
+// REGISTERS for the whole sequence (80 fp32 per lane at H = 300; the step kernels re-fetched 1.4 MB per direction from L2
+// every step), its cell state c stays in registers, and only h_t crosses workgroups.  Hand-off per step (the recipe of
+// cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", counter row): every h_t element is stored
+// WRITE-THROUGH (sc1), every storing wave drains vmcnt, the workgroup's barrier, then ONE lane adds 1 to the counter of its
+// (direction, batch chunk) group with an agent-scope atomic; a consumer's first wave polls that counter with relaxed sc1
+// loads (s_sleep between polls, bounded: a missed rendez-vous sets the timeout word and ends the kernel instead of hanging),
+// the workgroup barrier releases the other waves, and EVERY load of h_{t-1} is an sc1 load (no L1 copy can be stale, no
+// acquire needed).  The groups are independent (19 workgroups each at H = 300); the grid (<= 76 workgroups at B <= 128) is
+// far below the 256 CUs and each workgroup declares > 80 KB of LDS, so all of them are resident, one per CU.
+//   ws: [0] timeout word, [16 + d * chunks + z] arrival counters (zeroed by the launcher).
+// ------------------------------------------------------------------------------------------
+typedef unsigned __attribute__((address_space(1))) lstm_gu32;
+
+__device__ __forceinline__ f32x4 lstm_ld_sc1(const __amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    // 16-byte load that bypasses this CU's L1 (aux 16 = sc1)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+
+template <int MT, int NQ>      // NQ: 16-deep contraction blocks per wave (ceil(ceil(H/16)/4))
+__global__ __launch_bounds__(256) void lstm_seq_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
+                                                    const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ c,
+                                                    float* __restrict__ gates, unsigned* __restrict__ ws, int T, int B, int H) {
+    __shared__ float ex[4][4][MT * 16][17];                  // [wave][gate][batch row][unit]
+    __shared__ int s_ok;                                     // (+ dynamic LDS requested by the launcher: > 80 KB in all, one workgroup per CU)
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, z = blockIdx.z, b0 = z * (MT * 16);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
+    const int groups = gridDim.x;
+    const size_t dTB = (size_t)d * T * B;
+    const int unit = u0 + r;
+    lstm_gu32* counter = (lstm_gu32*)(ws + 16 + d * gridDim.z + z);
+    lstm_gu32* timeout = (lstm_gu32*)ws;
+
+    // W_hh slice of this wave's contraction quarter, in registers for the whole sequence
+    const int nq = (H + 15) / 16;
+    const int q0 = wave * NQ;
+    f32x4 wreg[NQ][4];
+    {
+        const float* w0 = w_hh + ((size_t)d * 4 * H + min(unit, H - 1)) * H;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int k = 16 * (q0 + u) + 4 * j;
+            const bool in = (q0 + u < nq) && k < H && unit < H;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                wreg[u][n] = in ? *reinterpret_cast<const f32x4*>(w0 + (size_t)n * H * H + min(k, H - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)gridDim.y * T * B * H * 4), 0x00020000);
+    float cprev[MT];                                         // cell state of this thread's (batch row, unit) pairs
+    int len_k[MT];
+    bool mine[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+        mine[k] = b < B && u < H;
+        len_k[k] = lens[min(b, B - 1)];
+        cprev[k] = 0.f;
+    }
+    bool alive = true;
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int tp = d == 0 ? t - 1 : t + 1;
+        // operands of the cell update that nobody hands off: fetched before the rendez-vous
+        float xpv[MT][4];
+        bool act[MT];
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+            act[k] = mine[k] && t < len_k[k];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xpv[k][n] = act[k] ? xproj[(dTB + (size_t)t * B + b) * 4 * H + (size_t)n * H + u] : 0.f;
+        }
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            // rendez-vous: every workgroup of this (direction, batch chunk) group has published h of step s-1
+            if (threadIdx.x < 64) {
+                bool ok = true;
+                if (threadIdx.x == 0) {
+                    const unsigned want = (unsigned)groups * (unsigned)s;
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 20)) {                        // ~ a second: give up instead of hanging the GPU
+                            __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = false;
+                            break;
+                        }
+                    }
+                    s_ok = ok ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            alive = s_ok != 0;
+            if (!alive) break;                                             // uniform: s_ok is workgroup-wide
+            // h_{t-1}: [B][H] rows of this batch chunk, EVERY load sc1
+            const unsigned row_bytes = (unsigned)H * 4u;
+            const unsigned base = (unsigned)((dTB + (size_t)tp * B) * H * 4);
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int k = 16 * (q0 + u) + 4 * j;
+                const bool kin = (q0 + u < nq) && k < H;
+                f32x4 av[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = b0 + m * 16 + r;
+                    av[m] = lstm_ld_sc1(rsrc_h, base + (unsigned)min(row, B - 1) * row_bytes + (unsigned)min(k, H - 4) * 4u);
+                    if (!(kin && row < B)) av[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][i], wreg[u][n][i], acc[n][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ex[wave][n][m * 16 + 4 * j + i][r] = acc[n][m][i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            if (!mine[k]) continue;
+            const int p = threadIdx.x + 256 * k, bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
+            const size_t row = dTB + (size_t)t * B + b;
+            float hv = 0.f, cv = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+            if (act[k]) {
+                float pre[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) pre[n] = xpv[k][n] + ((ex[0][n][bl][ul] + ex[1][n][bl][ul]) + (ex[2][n][bl][ul] + ex[3][n][bl][ul]));
+                gi = sigmoidf_(pre[0]);
+                gf = sigmoidf_(pre[1]);
+                gg = tanhf(pre[2]);
+                go = sigmoidf_(pre[3]);
+                cv = gf * cprev[k] + gi * gg;
+                hv = go * tanhf(cv);
+            }
+            cprev[k] = cv;
+            // h crosses workgroups: write-through store (sc1).  c and the gates are only read after the launch.
+            __hip_atomic_store((lstm_gu32*)(out + row * H + u), __float_as_uint(hv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c[row * H + u] = cv;
+            float* gs = gates + row * 4 * H + u;
+            gs[0] = gi; gs[H] = gf; gs[2 * H] = gg; gs[3 * H] = go;
+        }
+        // publish: every storing wave drains its stores, the workgroup meets, ONE lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && s + 1 < T) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,6 +402,36 @@ int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* 
             case 3: hipLaunchKernelGGL(lstm_step_fwd<3>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
             default: hipLaunchKernelGGL(lstm_step_fwd<4>, grid, dim3(256), 0, st, xproj, w_hh, lens, out, c, gates, T, B, H, s); break;
         }
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* All T steps of both directions in one launch (lstm_seq_fwd); same tensors as dwc_lstm_fwd plus ws >= dwc_lstm_seq_ws_bytes
+ * (arrival counters + a timeout word: after the launch ws[0] != 0 means a rendez-vous was missed and the results are invalid).
+ * Returns DWC_EINVAL for shapes the persistent form does not take (H > 320, more workgroups than CUs): use dwc_lstm_fwd. */
+size_t dwc_lstm_seq_ws_bytes(int B, int dirs) { return (size_t)(16 + dirs * ((B + 63) / 16 + 1)) * sizeof(unsigned) + 64; }
+
+int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
+                     int dirs, void* ws, size_t ws_bytes, void* stream) {
+    if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
+    const int mt = min(4, (B + 15) / 16);
+    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
+    const int nq = (H + 15) / 16, per = (nq + 3) / 4;
+    if (per > 5 || (size_t)grid.x * grid.y * grid.z > 200 || (size_t)dirs * T * B * H * 4 >= 0x80000000ull) return DWC_EINVAL;
+    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, (dwc_lstm_seq_ws_bytes(B, dirs) + 15) / 16 * 16, st) != hipSuccess) return DWC_ELAUNCH;
+    unsigned* w = (unsigned*)ws;
+    // dynamic LDS on top of the exchange buffer so that a workgroup needs > 80 KB: ONE workgroup per CU (the hand-off form used is
+    // measured for one workgroup per CU, and the residency argument counts CUs)
+    const size_t ex_bytes = (size_t)4 * 4 * mt * 16 * 17 * 4;
+    const unsigned dyn = ex_bytes < 84 * 1024 ? (unsigned)(84 * 1024 - ex_bytes) : 0u;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((lstm_seq_fwd<1, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
+        case 2: hipLaunchKernelGGL((lstm_seq_fwd<2, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
+        case 3: hipLaunchKernelGGL((lstm_seq_fwd<3, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
+        default: hipLaunchKernelGGL((lstm_seq_fwd<4, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
     }
     DWC_LAUNCH_CHECK();
     return DWC_OK;

@@ -92,6 +92,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
     "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_lstm_seq_ws_bytes": (c_sz, [c_int, c_int]),
+    "dwc_lstm_seq_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
     "dwc_adv_tail_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_adv_tail_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_bf16_conv2d_s2_halo_ok": (c_int, [c_int] * 5),
@@ -134,6 +136,7 @@ SIGNATURES = {
     "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
+EINVAL = -1
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
            -3: "DWC_ELAUNCH (kernel launch failed)"}
 

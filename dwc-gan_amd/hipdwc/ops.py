@@ -371,6 +371,7 @@ HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
+LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM forward: all time steps in one persistent launch
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 
 
@@ -904,8 +905,17 @@ class _LSTMBidir(torch.autograd.Function):
         out = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
         c = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
         gates = torch.empty((2, T, B, 4 * H), dtype=torch.float32, device=dev)
-        _lib.check(lib.dwc_lstm_fwd(xproj.data_ptr(), w_hh_c.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(),
-                                    gates.data_ptr(), T, B, H, 2, _stream()), "lstm_fwd")
+        rc = -1
+        if LSTM_SEQ:
+            # all T steps in ONE persistent launch (csrc/lstm.hip lstm_seq_fwd); shapes it does not take fall to the step kernels
+            ws = workspace(lib.dwc_lstm_seq_ws_bytes(B, 2), dev)
+            rc = lib.dwc_lstm_seq_fwd(xproj.data_ptr(), w_hh_c.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(),
+                                      gates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _stream())
+            if rc not in (0, _lib.EINVAL):
+                _lib.check(rc, "lstm_seq_fwd")
+        if rc != 0:
+            _lib.check(lib.dwc_lstm_fwd(xproj.data_ptr(), w_hh_c.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(),
+                                        gates.data_ptr(), T, B, H, 2, _stream()), "lstm_fwd")
         ctx.save_for_backward(X, lens, w_ih, w_hh_c, out, c, gates)
         ctx.shape = (T, B, I, H)
         return out, c

@@ -226,6 +226,14 @@ int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* 
 /* d_out / d_c: gradients arriving at h_t / c_t from outside the recurrence, [dirs][T][B][H] or NULL.
  * w_hh_t:[dirs][H][4H] (transposed).  Output dgates:[dirs][T][B][4H] = gradient of the pre-activation gates, from which
  * the caller forms dW_ih, dW_hh, db and dx with three GEMMs.  dc_carry:[dirs][B][H] scratch. */
+/* The same recurrence, ALL T steps of both directions in ONE launch: persistent workgroups, W_hh slices and cell state in
+ * registers, h_t handed between workgroups inside the launch (write-through stores + agent-scope arrival counter + sc1 loads;
+ * bounded polls).  ws >= dwc_lstm_seq_ws_bytes(B, dirs): [0] timeout word (non-zero after the launch = a rendez-vous was
+ * missed, results invalid), then the counters; zeroed by the call.  DWC_EINVAL for shapes it does not take (H > 320, more
+ * workgroups than fit the CUs): use dwc_lstm_fwd. */
+size_t dwc_lstm_seq_ws_bytes(int B, int dirs);
+int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
+                     int dirs, void* ws, size_t ws_bytes, void* stream);
 int dwc_lstm_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c,
                  const float* gates, float* dgates, float* dc_carry, int T, int B, int H, int dirs, void* stream);
 

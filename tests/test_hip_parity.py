@@ -200,9 +200,12 @@ def test_conv_no_bias_and_cout_not_multiple_of_4():
     (12, 20, 600, 300, None),                         # layer 1 input width, two 16-row tiles
     (6, 70, 12, 20, None),                            # more than 64 sequences (row chunks), H not a multiple of 16
 ])
-def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens):
+@pytest.mark.parametrize("seq", [1, 0], ids=["persistent", "per-step"])
+def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
     """One bidirectional layer on padded input + lengths against torch's nn.LSTM on the PackedSequence (what the
-    reference runs, networks_v2.py:226-233): outputs, final states, and every gradient."""
+    reference runs, networks_v2.py:226-233): outputs, final states, and every gradient -- with the forward recurrence as ONE
+    persistent launch (workgroups hand h_t to each other inside the launch) and as one launch per time step."""
+    monkeypatch.setattr(ops, "LSTM_SEQ", seq)
     g = torch.Generator().manual_seed(T * 1000 + B + H)
     if lens is None:
         lens = sorted((int(v) for v in torch.randint(1, T + 1, (B,), generator=g)), reverse=True)
@@ -224,6 +227,9 @@ def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens):
     par = {n: [dev(getattr(ref, n + "_l0" + suf), True) for suf in ("", "_reverse")] for n in names}
     lens_t = torch.tensor(lens)
     out, cell = ops.lstm_bidir(xd, lens_t.to(torch.int32).to(DEV), *[torch.stack(par[n]) for n in names])
+    if seq:                      # the persistent launch's timeout word (first word of the scratch arena): no rendez-vous was missed
+        torch.cuda.synchronize()
+        assert int(ops.workspace(4, torch.device(DEV))[:4].view(torch.int32)[0]) == 0
     last, cols = (lens_t - 1).to(DEV), torch.arange(B, device=DEV)
     mem_d = torch.cat([out[0], out[1]], -1)
     hn_d = torch.stack([out[0][last, cols], out[1][0]])
