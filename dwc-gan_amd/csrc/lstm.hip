@@ -385,6 +385,159 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd(const float* __restrict__ xp
     }
 }
 
+// Persistent backward: all time steps of both directions in one launch, same hand-off as lstm_seq_fwd.  What crosses
+// workgroups is dgates of the step processed before (each workgroup writes the four gate slices of its 16 units; every
+// workgroup of the group contracts over all 4H of them); the transposed W_hh slice of the workgroup's units (4H values per
+// unit, NQ 16-deep blocks per wave = 76 fp32 per lane at H = 300) and the cell-gradient carry stay in registers.
+template <int MT, int NQ>
+__global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_out, const float* __restrict__ d_c,
+                                                    const float* __restrict__ w_hh_t, const int* __restrict__ lens,
+                                                    const float* __restrict__ c, const float* __restrict__ gates, float* __restrict__ dgates,
+                                                    unsigned* __restrict__ ws, int T, int B, int H) {
+    __shared__ float ex[4][MT * 16][17];
+    __shared__ int s_ok;
+    const int d = blockIdx.y, u0 = blockIdx.x * 16, z = blockIdx.z, b0 = z * (MT * 16);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, j = lane >> 4;
+    const int groups = gridDim.x;
+    const size_t dTB = (size_t)d * T * B;
+    const int unit = u0 + r;
+    const int K = 4 * H;
+    lstm_gu32* counter = (lstm_gu32*)(ws + 16 + d * gridDim.z + z);
+    lstm_gu32* timeout = (lstm_gu32*)ws;
+    const int nq = (K + 15) / 16;
+    const int q0 = wave * NQ;
+    f32x4 wreg[NQ];
+    {
+        const float* w0 = w_hh_t + ((size_t)d * H + min(unit, H - 1)) * K;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int k = 16 * (q0 + u) + 4 * j;
+            const bool in = (q0 + u < nq) && k < K && unit < H;
+            wreg[u] = in ? *reinterpret_cast<const f32x4*>(w0 + min(k, K - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(dgates, 0, (unsigned)((size_t)gridDim.y * T * B * K * 4), 0x00020000);
+    float carry[MT];
+    int len_k[MT];
+    bool mine[MT];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+        mine[k] = b < B && u < H;
+        len_k[k] = lens[min(b, B - 1)];
+        carry[k] = 0.f;
+    }
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;                   // forward direction walks back from the end
+        const int tn = d == 0 ? t + 1 : t - 1;                  // the step processed just before
+        const int tp = d == 0 ? t - 1 : t + 1;                  // forward-order predecessor (its c enters f's gradient)
+        float gv[MT][4], cvv[MT], cpv[MT], dhv[MT], dcv[MT];
+        bool act[MT];
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+            act[k] = mine[k] && t < len_k[k];
+            cvv[k] = cpv[k] = dhv[k] = 0.f;
+            dcv[k] = carry[k];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) gv[k][n] = 0.f;
+            if (act[k]) {
+                const size_t row = dTB + (size_t)t * B + b;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) gv[k][n] = gates[row * K + (size_t)n * H + u];
+                cvv[k] = c[row * H + u];
+                const bool has_prev = d == 0 ? tp >= 0 : tp < len_k[k];   // reverse: the state before the first step is zero
+                if (has_prev) cpv[k] = c[(dTB + (size_t)tp * B + b) * H + u];
+                if (d_out) dhv[k] = d_out[row * H + u];
+                if (d_c) dcv[k] += d_c[row * H + u];
+            }
+        }
+        f32x4 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            if (threadIdx.x == 0) {
+                bool ok = true;
+                const unsigned want = (unsigned)groups * (unsigned)s;
+                unsigned spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 20)) {
+                        __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                }
+                s_ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ok == 0) break;
+            const unsigned row_bytes = (unsigned)K * 4u;
+            const unsigned base = (unsigned)((dTB + (size_t)tn * B) * K * 4);
+            constexpr int CH = 5;
+#pragma unroll
+            for (int uc = 0; uc < NQ; uc += CH) {
+                f32x4 av[CH][MT];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (uc + u >= NQ) continue;
+                    const int k = 16 * (q0 + uc + u) + 4 * j;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int row = b0 + m * 16 + r;
+                        av[u][m] = lstm_ld_sc1(rsrc_g, base + (unsigned)min(row, B - 1) * row_bytes + (unsigned)min(k, K - 4) * 4u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (uc + u >= NQ) continue;
+                    const int k = 16 * (q0 + uc + u) + 4 * j;
+                    const bool kin = (q0 + uc + u < nq) && k < K;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const bool ok = kin && (b0 + m * 16 + r) < B;
+                        const f32x4 a = ok ? av[u][m] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], wreg[uc + u][i], acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ex[wave][m * 16 + 4 * j + i][r] = acc[m][i];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MT; ++k) {
+            if (!mine[k]) continue;
+            const int p = threadIdx.x + 256 * k, bl = p >> 4, ul = p & 15, b = b0 + bl, u = u0 + ul;
+            const size_t row = dTB + (size_t)t * B + b;
+            lstm_gu32* dg = (lstm_gu32*)(dgates + row * K + u);
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            if (act[k]) {
+                const float dh = dhv[k] + ((ex[0][bl][ul] + ex[1][bl][ul]) + (ex[2][bl][ul] + ex[3][bl][ul]));
+                const float gi = gv[k][0], gf = gv[k][1], gg = gv[k][2], go = gv[k][3];
+                const float th = tanhf(cvv[k]);
+                const float dc = dcv[k] + dh * go * (1.f - th * th);
+                o0 = dc * gg * gi * (1.f - gi);
+                o1 = dc * cpv[k] * gf * (1.f - gf);
+                o2 = dc * gi * (1.f - gg * gg);
+                o3 = dh * th * go * (1.f - go);
+                carry[k] = dc * gf;
+            }
+            // (inactive: nothing flows, zeros are stored and the carry is kept -- it is only read again while active)
+            __hip_atomic_store(dg, __float_as_uint(o0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dg + H, __float_as_uint(o1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dg + 2 * H, __float_as_uint(o2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dg + 3 * H, __float_as_uint(o3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0 && s + 1 < T) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -432,6 +585,29 @@ int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, flo
         case 2: hipLaunchKernelGGL((lstm_seq_fwd<2, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
         case 3: hipLaunchKernelGGL((lstm_seq_fwd<3, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
         default: hipLaunchKernelGGL((lstm_seq_fwd<4, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c, const float* gates,
+                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, void* stream) {
+    if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
+    const int mt = min(4, (B + 15) / 16);
+    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
+    const int nq = (4 * H + 15) / 16, per = (nq + 3) / 4;
+    if (per > 19 || (size_t)grid.x * grid.y * grid.z > 200 || (size_t)dirs * T * B * 4 * H * 4 >= 0x80000000ull) return DWC_EINVAL;
+    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, (dwc_lstm_seq_ws_bytes(B, dirs) + 15) / 16 * 16, st) != hipSuccess) return DWC_ELAUNCH;
+    unsigned* w = (unsigned*)ws;
+    const size_t ex_bytes = (size_t)4 * mt * 16 * 17 * 4;
+    const unsigned dyn = (unsigned)(84 * 1024 - ex_bytes);
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((lstm_seq_bwd<1, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
+        case 2: hipLaunchKernelGGL((lstm_seq_bwd<2, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
+        case 3: hipLaunchKernelGGL((lstm_seq_bwd<3, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
+        default: hipLaunchKernelGGL((lstm_seq_bwd<4, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
     }
     DWC_LAUNCH_CHECK();
     return DWC_OK;

@@ -94,6 +94,7 @@ SIGNATURES = {
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
     "dwc_lstm_seq_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_lstm_seq_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
+    "dwc_lstm_seq_bwd": (c_int, [c_fp] * 7 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
     "dwc_adv_tail_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_adv_tail_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_bf16_conv2d_s2_halo_ok": (c_int, [c_int] * 5),

@@ -931,8 +931,16 @@ class _LSTMBidir(torch.autograd.Function):
         w_hh_t = w_hh.transpose(1, 2).contiguous()
         dgates = torch.empty((2, T, B, 4 * H), dtype=torch.float32, device=dev)
         carry = torch.empty((2, B, H), dtype=torch.float32, device=dev)
-        _lib.check(lib.dwc_lstm_bwd(_p(d_out), _p(d_c), w_hh_t.data_ptr(), lens.data_ptr(), c.data_ptr(), gates.data_ptr(),
-                                    dgates.data_ptr(), carry.data_ptr(), T, B, H, 2, _stream()), "lstm_bwd")
+        rc = -1
+        if LSTM_SEQ:
+            ws = workspace(lib.dwc_lstm_seq_ws_bytes(B, 2), dev)
+            rc = lib.dwc_lstm_seq_bwd(_p(d_out), _p(d_c), w_hh_t.data_ptr(), lens.data_ptr(), c.data_ptr(), gates.data_ptr(),
+                                      dgates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _stream())
+            if rc not in (0, _lib.EINVAL):
+                _lib.check(rc, "lstm_seq_bwd")
+        if rc != 0:
+            _lib.check(lib.dwc_lstm_bwd(_p(d_out), _p(d_c), w_hh_t.data_ptr(), lens.data_ptr(), c.data_ptr(), gates.data_ptr(),
+                                        dgates.data_ptr(), carry.data_ptr(), T, B, H, 2, _stream()), "lstm_bwd")
         dG = dgates.view(2, T * B, 4 * H)
         dGt = dG.transpose(1, 2)
         dw_ih = torch.matmul(dGt, X) if ctx.needs_input_grad[2] else None                       # [2,4H,I]

@@ -234,6 +234,8 @@ int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* 
 size_t dwc_lstm_seq_ws_bytes(int B, int dirs);
 int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
                      int dirs, void* ws, size_t ws_bytes, void* stream);
+int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c, const float* gates,
+                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, void* stream);
 int dwc_lstm_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c,
                  const float* gates, float* dgates, float* dc_carry, int T, int B, int H, int dirs, void* stream);
 
