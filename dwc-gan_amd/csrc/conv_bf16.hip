@@ -918,6 +918,30 @@ int dwc_bf16_conv2d_fwd(const void* x, const void* w_prepared, const float* bias
     return launch_gemm_h(f.g, (const bf16*)w_prepared, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
 }
 
+/* The frozen VGG16 trunk of the perceptual loss under bf16 (reference networks.py:639-688): zero-padded stride-1 convolution, forward
+ * (the forward kernel with the zero rule: an out-of-image tap pushes its offset past the buffer descriptor and reads zeros) and
+ * data gradient (the zero-padded correlation with the flipped filter; the adjoint of zero padding is a crop, no ring). */
+int dwc_bf16_conv2d_fwd_zeropad(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if ((Cout & 7) || !fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, MIN_LOG_C)) return DWC_EINVAL;
+    f.g.reflect = 0;
+    return launch_gemm_h(f.g, (const bf16*)w_prepared, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t dwc_bf16_conv2d_bwd_data_zeropad_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
+    FwdGeom f;
+    if ((Cin & 7) || (Cout & 7) || !zeropad_dgrad_geom(nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f)) return 0;
+    return gemm_ws_bytes_h(f.g.M, Cin, f.g.K, 1, f.dst_elems);
+}
+
+int dwc_bf16_conv2d_bwd_data_zeropad(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                     int KW, int pad, void* ws, size_t ws_bytes, void* stream) {
+    FwdGeom f;
+    if ((Cin & 7) || (Cout & 7) || !zeropad_dgrad_geom(dy, dx, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
+    return launch_gemm_h(f.g, (const bf16*)w_dgrad, 0, 1, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int dwc_bf16_conv2d_fwd_ex(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
                            int Cout, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w, int act, void* stream) {
     FwdGeom f;

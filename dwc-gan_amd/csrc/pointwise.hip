@@ -240,9 +240,9 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const T* __restrict__
 
 // ---- 2x2 max pooling (VGG16, reference networks.py:666,671,677) --------------------------------------
 // Ties go to the first element in window scan order, as torch's max_pool2d does (after a ReLU all-zero windows tie).
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int cq,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq,
                                                            size_t total4) {
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
     const int Ho = H / 2, Wo = W / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;
@@ -252,19 +252,17 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restri
         const int oy = r % Ho;
         const size_t n = r / Ho;
         const size_t b = (n * H + 2 * oy) * W + 2 * ox;
-        const f32x4 v0 = xs[b * cq + c], v1 = xs[(b + 1) * cq + c], v2 = xs[(b + W) * cq + c], v3 = xs[(b + W + 1) * cq + c];
+        const f32x4 v0 = ld4(x, b * cq + c), v1 = ld4(x, (b + 1) * cq + c), v2 = ld4(x, (b + W) * cq + c), v3 = ld4(x, (b + W + 1) * cq + c);
         f32x4 m;
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(v0[k], v1[k]), fmaxf(v2[k], v3[k]));
-        reinterpret_cast<f32x4*>(y)[i] = m;
+        st4(y, i, m);
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dx, int H, int W, int cq, size_t total4) {
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x);
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy);
-    f32x4* out = reinterpret_cast<f32x4*>(dx);
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           T* __restrict__ dx, int H, int W, int cq, size_t total4) {
     const int Ho = H / 2, Wo = W / 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % cq;               // one thread per pooled element: it owns its whole 2x2 window of dx
@@ -278,10 +276,10 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
         f32x4 v[4], g[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] = xs[at[j]];
+            v[j] = ld4(x, at[j]);
             g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const f32x4 d = ds[i];
+        const f32x4 d = ld4(dy, i);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int best = 0;
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
                 if (j == best) g[j][k] = d[k];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) out[at[j]] = g[j];
+        for (int j = 0; j < 4; ++j) st4(dx, at[j], g[j]);
     }
 }
 
@@ -651,7 +649,25 @@ int dwc_bf16_avgpool2_bwd(const void* dy, void* dx, int B, int H, int W, int C, 
 int dwc_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_bf16_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<dwc_bf16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const dwc_bf16*)x,
+                       (dwc_bf16*)y, H, W, C / 4, total4);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_bf16_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<dwc_bf16>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const dwc_bf16*)x,
+                       (const dwc_bf16*)dy, (dwc_bf16*)dx, H, W, C / 4, total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -659,7 +675,7 @@ int dwc_maxpool2_fwd(const float* x, float* y, int B, int H, int W, int C, void*
 int dwc_maxpool2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || (C & 3)) return DWC_EINVAL;
     const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C / 4,
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C / 4,
                        total4);
     DWC_LAUNCH_CHECK();
     return DWC_OK;

@@ -92,6 +92,11 @@ SIGNATURES = {
     "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
     "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_bf16_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_data_zeropad_ws_bytes": (c_sz, [c_int] * 8),
+    "dwc_bf16_conv2d_bwd_data_zeropad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_maxpool2_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_maxpool2_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_lstm_seq_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_lstm_seq_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
     "dwc_lstm_seq_bwd": (c_int, [c_fp] * 7 + [c_int] * 4 + [c_fp, c_sz, c_fp]),

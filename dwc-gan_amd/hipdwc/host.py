@@ -141,7 +141,7 @@ def load_vgg16(model_dir):
 
 def vgg_preprocess(batch):
     """Reference utils.py:207-217: RGB -> BGR, [-1, 1] -> [0, 255], subtract the ImageNet BGR means."""
-    r, g, b = torch.chunk(batch[:, :3], 3, dim=1)
+    r, g, b = torch.chunk(batch[:, :3].float(), 3, dim=1)       # fp32 from here (internal images may be bf16 NHWC8)
     out = (torch.cat((b, g, r), dim=1) + 1) * 255 * 0.5
     mean = torch.tensor([103.939, 116.779, 123.680], dtype=out.dtype, device=out.device).view(1, 3, 1, 1)
     return out - mean

@@ -773,19 +773,19 @@ class _Conv2dZeroPad(torch.autograd.Function):
             raise NotImplementedError("zero-padded convolutions are built for frozen weights (no weight gradient)")
         lib = _lib.load()
         x = cl(x)
-        if x.dtype != torch.float32:
-            raise NotImplementedError("the zero-padded (VGG16) convolutions are built for the fp32 path")
+        half = x.dtype == BF16
         B, Cx, H, W = x.shape
         Cout, Cin, KH, KW = w.shape
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
-        cop = _pad4(Cout)
-        wt = _wino_ok(H, W, KH, KW, 1, pad, Cx, cop)
-        w_prep = None if wt else _prepped(w, "fwd", cop, Cx, 1)
+        cop = _padc(Cout, x.dtype)
+        wt = 0 if half else _wino_ok(H, W, KH, KW, 1, pad, Cx, cop)
+        halo = bool(half and HALO and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH))
+        w_prep = None if wt else _prepped(w, "fwd", cop, Cx, 1, None, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
-        y = empty_cl(B, cop, H, W, x.device)
+        y = empty_cl(B, cop, H, W, x.device, x.dtype)
         st = _stream()
         flops = 2.0 * B * H * W * Cout * Cin * KH * KW
         if wt:
@@ -795,10 +795,14 @@ class _Conv2dZeroPad(torch.autograd.Function):
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 0, wt, None, ws.data_ptr(), ws.numel(),
                 st), detail="fwd-zeropad-wino%d B%d %dx%d %d>%d k%d" % (wt, B, H, W, Cx, cop, KH),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        elif halo:               # bf16: the halo-tiled kernel with the zero rule
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
+                x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, act, 0, st),
+                detail="fwd-zeropad-halo B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_same_halo zeropad")
         else:
-            nws = lib.dwc_conv2d_fwd_ws_bytes(B, H, W, Cx, cop, KH, KW, 1, pad)
+            nws = _fn(lib, "conv2d_fwd_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, 1, pad)
             wsp = workspace(nws, x.device).data_ptr() if nws else None
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd_zeropad(
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_zeropad", x)(
                 x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, 1, pad, act, wsp, nws, st),
                 detail="fwd-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_fwd_zeropad")
         ctx.save_for_backward(w, y if act != 0 else None)
@@ -813,16 +817,17 @@ class _Conv2dZeroPad(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             return None, None, None, None, None
         dy = cl(dy)
+        half = dy.dtype == BF16
         dev, st, rows = dy.device, _stream(), B * H * W
         g = dy
         if act != 0:
-            g = empty_cl(B, cop, H, W, dev)
+            g = empty_cl(B, cop, H, W, dev, dy.dtype)
             ws = workspace(lib.dwc_act_bwd_bias_ws_bytes(rows, cop), dev)
-            _lib.check(lib.dwc_act_bwd_bias(dy.data_ptr(), y.data_ptr(), g.data_ptr(), None, rows, cop, act, ws.data_ptr(),
-                                            ws.numel(), st), "act_bwd_bias")
-        dx = empty_cl(B, Cx, H, W, dev)
+            _lib.check(_fn(lib, "act_bwd_bias", dy)(dy.data_ptr(), y.data_ptr(), g.data_ptr(), None, rows, cop, act, ws.data_ptr(),
+                                                    ws.numel(), st), "act_bwd_bias")
+        dx = empty_cl(B, Cx, H, W, dev, dy.dtype)
         flops = 2.0 * rows * Cout * Cin * KH * KW
-        wt = _wino_ok(H, W, KH, KW, 1, pad, cop, Cx)
+        wt = 0 if half else _wino_ok(H, W, KH, KW, 1, pad, cop, Cx)
         if wt:                                                # the adjoint of zero padding is a crop: no ring at all
             U = _prepped(w, "wino_dgrad", cop, Cx, wt)
             ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt), dev)
@@ -831,10 +836,15 @@ class _Conv2dZeroPad(torch.autograd.Function):
                 detail="dgrad-zeropad-wino%d B%d %dx%d %d>%d k%d" % (wt, B, H, W, Cx, cop, KH),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
             return dx, None, None, None, None
-        w_dg = _prepped(w, "dgrad", cop, Cx, 1)
-        nws = lib.dwc_conv2d_bwd_data_zeropad_ws_bytes(B, H, W, Cx, cop, KH, KW, pad)
+        w_dg = _prepped(w, "dgrad", cop, Cx, 1, None, half)
+        if half and HALO and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):
+            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
+                g.data_ptr(), w_dg.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st),
+                detail="dgrad-zeropad-halo B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_same_halo zeropad dgrad")
+            return dx, None, None, None, None
+        nws = _fn(lib, "conv2d_bwd_data_zeropad_ws_bytes", dy)(B, H, W, Cx, cop, KH, KW, pad)
         wsp = workspace(nws, dev).data_ptr() if nws else None
-        _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_bwd_data_zeropad(
+        _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_zeropad", dy)(
             g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, wsp, nws, st),
             detail="dgrad-zeropad B%d %dx%d %d>%d k%d" % (B, H, W, Cx, cop, KH)), "conv2d_bwd_data_zeropad")
         return dx, None, None, None, None
@@ -852,11 +862,9 @@ class _MaxPool2(torch.autograd.Function):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
-        if x.dtype != torch.float32:
-            raise NotImplementedError("max pooling (VGG16) is built for the fp32 path")
         B, C, H, W = x.shape
-        y = empty_cl(B, C, H // 2, W // 2, x.device)
-        _lib.check(lib.dwc_maxpool2_fwd(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "maxpool2_fwd")
+        y = empty_cl(B, C, H // 2, W // 2, x.device, x.dtype)
+        _lib.check(_fn(lib, "maxpool2_fwd", x)(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "maxpool2_fwd")
         ctx.save_for_backward(x)
         return y
 
@@ -865,8 +873,9 @@ class _MaxPool2(torch.autograd.Function):
         lib = _lib.load()
         (x,) = ctx.saved_tensors
         B, C, H, W = x.shape
-        dx = empty_cl(B, C, H, W, x.device)
-        _lib.check(lib.dwc_maxpool2_bwd(x.data_ptr(), cl(dy).data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "maxpool2_bwd")
+        dx = empty_cl(B, C, H, W, x.device, x.dtype)
+        _lib.check(_fn(lib, "maxpool2_bwd", x)(x.data_ptr(), cl(dy.to(x.dtype)).data_ptr(), dx.data_ptr(), B, H, W, C, _stream()),
+                   "maxpool2_bwd")
         return dx
 
 

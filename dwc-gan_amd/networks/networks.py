@@ -371,11 +371,22 @@ class Vgg16(nn.Module):
                 setattr(self, "conv%d_%d" % (blk, i + 1), nn.Conv2d(cin if i == 0 else cout, cout, kernel_size=3, stride=1, padding=1))
 
     def forward(self, X):
-        h = ops.pack_image(X) if X.shape[1] < 4 else X
+        # Under bf16 activations conv1_1 still runs in fp32: its input is the PREPROCESSED image (values in [-124, 152]), which
+        # bf16 would quantise to steps of 0.5-1.0 -- coarser than the bf16 image it came from.  Its 64-channel output is cast to
+        # bf16 and the other twelve convolutions, the poolings and the loss's instance norms run on the bf16 kernels.
+        half = ops.PRECISION == "bf16"
+        if X.shape[1] < 4:
+            h = ops._Pack4.apply(X.float(), False) if half else ops.pack_image(X)
+        else:
+            h = X
+        first = True
         for blk, _, _, n in self.CFG:
             for i in range(n):
                 conv = getattr(self, "conv%d_%d" % (blk, i + 1))
                 h = ops.conv2d_zeropad(h, conv.weight, conv.bias, 1, "relu")
+                if first and half:
+                    h = h.to(ops.BF16)
+                first = False
             if blk <= 3:
                 h = ops.max_pool2(h)
         return h

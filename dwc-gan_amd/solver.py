@@ -91,8 +91,6 @@ class Solver(nn.Module):
         self.criterionL1 = torch.nn.L1Loss()
 
         if configs.get("vgg_w", 0) > 0:                 # reference solver.py:79-83
-            if ops.PRECISION != "fp32":
-                raise NotImplementedError("the VGG16 perceptual loss is built for the fp32 path (vgg_w must be 0 under bf16)")
             from hipdwc.host import load_vgg16
             self.vgg = load_vgg16(configs["vgg_model_path"] + "/models")
             self.vgg = self.vgg.to(device) if device is not None else self.vgg
@@ -176,7 +174,7 @@ class Solver(nn.Module):
         from hipdwc.host import vgg_preprocess
         img_fea = vgg(vgg_preprocess(img))
         target_fea = vgg(vgg_preprocess(target))
-        return torch.mean((ops.instance_norm(img_fea) - ops.instance_norm(target_fea)) ** 2)
+        return torch.mean((ops.instance_norm(img_fea).float() - ops.instance_norm(target_fea).float()) ** 2)
 
     def criterion_l1(self, a, z):
         a = torch.cat(a, dim=1) if isinstance(a, (list, tuple)) else a

@@ -353,6 +353,17 @@ int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const voi
                                   int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
 int dwc_bf16_conv2d_bwd_data_ring(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
                                   int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
+/* bf16 forms of the frozen VGG16 trunk's operators (reference networks.py:639-688; fp32 forms: dwc_conv2d_fwd_zeropad,
+ * dwc_conv2d_bwd_data_zeropad, dwc_maxpool2_*): zero-padded stride-1 convolution forward / data gradient on bf16 NHWC tensors
+ * (weights from dwc_bf16_weight_prepare_fwd / _dgrad), 2x2 max pooling. */
+int dwc_bf16_conv2d_fwd_zeropad(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad, int act, void* ws, size_t ws_bytes, void* stream);
+size_t dwc_bf16_conv2d_bwd_data_zeropad_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
+int dwc_bf16_conv2d_bwd_data_zeropad(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                                     int KW, int pad, void* ws, size_t ws_bytes, void* stream);
+int dwc_bf16_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int dwc_bf16_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+
 /* Halo-tiled form of the stride-1 "same" 3x3 / 5x5 convolutions (the ResBlock and upsampling-block layers, reference
  * networks.py:514-515, networks_v2.py:153-156): a workgroup stages the (16+K-1)^2 input patch of a 16x16 pixel block once
  * per 64-channel slab and walks the K*K taps over it in LDS, instead of re-staging every pixel once per tap as the im2col

@@ -12,6 +12,8 @@ max|ref| like the fp32 tests:
   * fp32 weight / bias gradients behind an activation: 1e-2
   * a whole training iteration: losses within 3e-2 relative of the fp32 oracle's (stated per test).
 """
+import os
+
 import pytest
 import torch
 
@@ -309,3 +311,46 @@ def test_bf16_full_size_iteration_vs_fp32_oracle(S, B):
         assert abs(h[0][k] - o[0][k]) <= 2e-2 * abs(o[0][k]), (k, h[0][k], o[0][k])
     for k in LOSS_KEYS:
         assert abs(h[0][k] - o[0][k]) <= 3e-2 * max(1.0, abs(o[0][k])), (k, h[0][k], o[0][k])
+
+
+def test_bf16_iteration_with_vgg_loss_vs_fp32_oracle(tmp_path):
+    """The shipped configuration's perceptual term (vgg_w 0.1, reference solver.py:221-223,242-247, networks.py:639-688) under
+    bf16 activations: conv1_1 in fp32 on the preprocessed image, twelve zero-padded bf16 convolutions, bf16 max pooling, the
+    loss's instance norms.  One tiny-configuration iteration against the fp32 oracle with a seeded random VGG16: the
+    perceptual loss within 5e-2 relative (thirteen bf16 layers deep), the other scalars within the 3e-2 of the other bf16
+    iterations."""
+    from networks.networks import Vgg16
+    from solver import Solver
+    torch.manual_seed(777)
+    vgg_sd = Vgg16().state_dict()
+    os.makedirs(tmp_path / "models")
+    torch.save(vgg_sd, tmp_path / "models" / "vgg16.weight")
+    cfg = synth.make_config(image_size=32, tiny=True, lstm_dropout=0.0)
+    cfg["vgg_w"], cfg["vgg_model_path"] = 0.1, str(tmp_path)
+    dev = torch.device(DEV)
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(4321)
+        s = Solver(cfg, dev, None).to(dev)
+        s.copy_nets()
+        rng = torch.get_rng_state()
+        batch = synth.make_batch(3, 32, seed=5)
+        oracle = orc.OracleSolver(cfg, {k: v.cpu() for k, v in s.gen.state_dict().items()},
+                                  {k: v.cpu() for k, v in s.dis.state_dict().items()}, vgg_params=vgg_sd)
+        oracle.copy_nets()
+        oracle.iteration(batch, 0)
+        torch.set_rng_state(rng)
+        db = {k: v.to(dev) for k, v in batch.items()}
+        a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
+        s.dis_update(*a)
+        s.gen_update(*a)
+        torch.cuda.synchronize()
+        want = oracle.losses["loss_gen_vgg"]
+        got = float(s.loss_gen_vgg)
+        assert want > 0 and abs(got - want) <= 5e-2 * abs(want), ("loss_gen_vgg", got, want)
+        for k in LOSS_KEYS:
+            assert abs(float(getattr(s, k)) - oracle.losses[k]) <= 3e-2 * max(1.0, abs(oracle.losses[k])), (k, float(getattr(s, k)), oracle.losses[k])
+        for p in s.gen.parameters():
+            assert p.grad is None or torch.isfinite(p.grad).all()
+    finally:
+        host.set_noise(host.DeviceNoise())
