@@ -159,6 +159,50 @@ int main(int argc, char** argv) {
                    (double)(tmax - tmin) / 100.0);
             CK(hipFree(dp));
         }
+        // weight gradient of the same layer (compiler-scheduled halo form): time + timeline
+        if (s.B >= 128 && wgrad_halo_bn(s.B, s.H, s.H, s.Cin, s.Cout, s.K)) {
+            const int bn = wgrad_halo_bn(s.B, s.H, s.H, s.Cin, s.Cout, s.K);
+            int splits, ups;
+            wgrad_halo_plan(s.B, s.H, s.H, s.Cin, s.Cout, s.K, bn, &splits, &ups);
+            float* slab;
+            CK(hipMalloc(&slab, (size_t)splits * s.K * s.K * s.Cin * s.Cout * 4));
+            WgradHaloArgs wa;
+            wa.x = (const bf16*)dx; wa.dy = (const bf16*)dy[1]; wa.slab = slab;
+            wa.B = s.B; wa.H = s.H; wa.W = s.H; wa.Cin = s.Cin; wa.logCin = dwc_ilog2_exact(s.Cin); wa.N = s.Cout;
+            wa.units_x = s.H / 16; wa.units_per_img = (s.H / 8) * (s.H / 16); wa.total_units = s.B * wa.units_per_img; wa.units_per_split = ups;
+            wa.n_tiles = s.Cout / bn; wa.tap_groups = s.K == 3 ? 1 : s.K;
+            const int grid = (s.Cin / (bn == 128 ? 64 : 128)) * wa.n_tiles * wa.tap_groups * splits;
+            unsigned long long* dp;
+            CK(hipMalloc(&dp, (size_t)grid * 64));
+            CK(hipMemset(dp, 0, (size_t)grid * 64));
+            std::vector<float> tw;
+            for (int rep = 0; rep < 8; ++rep) {
+                CK(hipEventRecord(e0, st));
+                if (s.K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
+                else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
+                else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep >= 2) tw.push_back(ms);
+            }
+            std::sort(tw.begin(), tw.end());
+            std::vector<unsigned long long> hp((size_t)grid * 8);
+            CK(hipMemcpy(hp.data(), dp, (size_t)grid * 64, hipMemcpyDeviceToHost));
+            std::vector<double> pro, loop, epi, per;
+            for (int b = 0; b < grid; ++b) {
+                const unsigned long long* q = &hp[(size_t)b * 8];
+                pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
+                if (q[4]) per.push_back((double)(q[2] - q[1]) / (double)q[4]);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            const int taps_wg = s.K == 3 ? 9 : 5;
+            printf("    wgrad (halo form, %d workgroups, %d splits): med %.1f us (%.1f%% of 2.5PF) | cycles: prologue %.0f | loop %.0f = %.0f per 128-pixel unit "
+                   "(MFMA issue per SIMD: %d) | store %.0f\n", grid, splits, tw[tw.size() / 2] * 1e3, flops / (tw[tw.size() / 2] * 1e-3) / 2.5e15 * 100,
+                   med(pro), med(loop), med(per), 8 * taps_wg * 32 * 2, med(epi));
+            CK(hipFree(dp)); CK(hipFree(slab));
+        }
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(dy[2])); CK(hipFree(db));
     }
     return 0;

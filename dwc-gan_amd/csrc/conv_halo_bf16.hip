@@ -313,9 +313,12 @@ struct WgradHaloArgs {
     int n_tiles, tap_groups;
 };
 
-template <int KS, int BN, int DBG = 0>
-__global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
+// PROBE (benchmarks/halo_lab.hip only): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
+template <int KS, int BN, int DBG = 0, int PROBE = 0>
+__global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsigned long long* probe = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long stamp[4] = {0, 0, 0, 0};
+    if constexpr (PROBE) stamp[0] = __builtin_amdgcn_s_memtime();
     static_assert(BN == 128 || BN == 64, "dY tile width");
     constexpr int TH = KS, TW = KS == 3 ? 3 : 1;        // taps of one workgroup: TH filter rows x TW filter columns
     constexpr int CIW = BN == 128 ? 64 : 128;           // channels of x per workgroup (8 waves = CIW/32 x BN/32 tiles)
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
         stage_unit(u0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (PROBE) stamp[1] = __builtin_amdgcn_s_memtime();
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
             if (u + 1 < u1 && !(DBG & 4)) stage_unit(u + 1, buf ^ 1);
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
             buf ^= 1;
         }
     }
+    if constexpr (PROBE) stamp[2] = __builtin_amdgcn_s_memtime();
     // slab[split][(tap*Cin + ci)][co]
     const int l31 = lane & 31;
     const int Ktot = KS * KS * a.Cin;
@@ -465,6 +470,14 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[j][r];
+        }
+    }
+    if constexpr (PROBE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[3] = __builtin_amdgcn_s_memtime();
+        if (t == 0 && probe) {
+            for (int k = 0; k < 4; ++k) probe[(size_t)blockIdx.x * 8 + k] = stamp[k];
+            probe[(size_t)blockIdx.x * 8 + 4] = (unsigned long long)(u1 - u0);
         }
     }
 #endif
