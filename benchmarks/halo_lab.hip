@@ -174,33 +174,54 @@ int main(int argc, char** argv) {
             const int grid = (s.Cin / (bn == 128 ? 64 : 128)) * wa.n_tiles * wa.tap_groups * splits;
             unsigned long long* dp;
             CK(hipMalloc(&dp, (size_t)grid * 64));
-            CK(hipMemset(dp, 0, (size_t)grid * 64));
-            std::vector<float> tw;
-            for (int rep = 0; rep < 8; ++rep) {
-                CK(hipEventRecord(e0, st));
-                if (s.K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
-                else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
-                else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64, 0, 1>), dim3(grid), dim3(512), 0, st, wa, dp);
-                CK(hipEventRecord(e1, st));
-                CK(hipEventSynchronize(e1));
-                float ms;
-                CK(hipEventElapsedTime(&ms, e0, e1));
-                if (rep >= 2) tw.push_back(ms);
-            }
-            std::sort(tw.begin(), tw.end());
-            std::vector<unsigned long long> hp((size_t)grid * 8);
-            CK(hipMemcpy(hp.data(), dp, (size_t)grid * 64, hipMemcpyDeviceToHost));
-            std::vector<double> pro, loop, epi, per;
-            for (int b = 0; b < grid; ++b) {
-                const unsigned long long* q = &hp[(size_t)b * 8];
-                pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
-                if (q[4]) per.push_back((double)(q[2] - q[1]) / (double)q[4]);
-            }
-            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
-            const int taps_wg = s.K == 3 ? 9 : 5;
-            printf("    wgrad (halo form, %d workgroups, %d splits): med %.1f us (%.1f%% of 2.5PF) | cycles: prologue %.0f | loop %.0f = %.0f per 128-pixel unit "
-                   "(MFMA issue per SIMD: %d) | store %.0f\n", grid, splits, tw[tw.size() / 2] * 1e3, flops / (tw[tw.size() / 2] * 1e-3) / 2.5e15 * 100,
-                   med(pro), med(loop), med(per), 8 * taps_wg * 32 * 2, med(epi));
+            const size_t slab_n = (size_t)splits * s.K * s.K * s.Cin * s.Cout;
+            std::vector<float> ref_slab;
+            auto run_pf = [&](auto pfc, auto dbgc, auto sprc) {
+                constexpr int PF = decltype(pfc)::value, DBGV = decltype(dbgc)::value, SPR = decltype(sprc)::value;
+                CK(hipMemset(dp, 0, (size_t)grid * 64));
+                std::vector<float> tw;
+                for (int rep = 0; rep < 8; ++rep) {
+                    CK(hipEventRecord(e0, st));
+                    if (s.K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, DBGV, 1, PF, SPR>), dim3(grid), dim3(512), 0, st, wa, dp);
+                    else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128, DBGV, 1, PF, SPR>), dim3(grid), dim3(512), 0, st, wa, dp);
+                    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64, DBGV, 1, PF, SPR>), dim3(grid), dim3(512), 0, st, wa, dp);
+                    CK(hipEventRecord(e1, st));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep >= 2) tw.push_back(ms);
+                }
+                std::sort(tw.begin(), tw.end());
+                std::vector<unsigned long long> hp((size_t)grid * 8);
+                CK(hipMemcpy(hp.data(), dp, (size_t)grid * 64, hipMemcpyDeviceToHost));
+                std::vector<float> hs(slab_n);
+                CK(hipMemcpy(hs.data(), slab, slab_n * 4, hipMemcpyDeviceToHost));
+                double md = 0.0;
+                if (DBGV) md = -1.0;
+                else if (ref_slab.empty()) ref_slab = hs;
+                else for (size_t i = 0; i < slab_n; ++i) md = std::max(md, (double)fabsf(hs[i] - ref_slab[i]));
+                std::vector<double> pro, loop, epi, per;
+                for (int b = 0; b < grid; ++b) {
+                    const unsigned long long* q = &hp[(size_t)b * 8];
+                    pro.push_back((double)(q[1] - q[0])); loop.push_back((double)(q[2] - q[1])); epi.push_back((double)(q[3] - q[2]));
+                    if (q[4]) per.push_back((double)(q[2] - q[1]) / (double)q[4]);
+                }
+                auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+                const int taps_wg = s.K == 3 ? 9 : 5;
+                printf("    wgrad (halo form, ablation %d, fragment prefetch %d rows, staging %s, %d workgroups, %d splits): med %.1f us (%.1f%% of 2.5PF) | cycles: prologue %.0f | "
+                       "loop %.0f = %.0f per 128-pixel unit (MFMA issue per SIMD: %d) | store %.0f | maxdiff vs prefetch 0: %.1e\n", DBGV, PF, SPR ? "spread" : "burst", grid, splits,
+                       tw[tw.size() / 2] * 1e3, flops / (tw[tw.size() / 2] * 1e-3) / 2.5e15 * 100, med(pro), med(loop), med(per), 8 * taps_wg * 32 * 2,
+                       med(epi), md);
+            };
+            typedef std::integral_constant<int, 0> Z;
+            typedef std::integral_constant<int, 1> One;
+            run_pf(Z{}, Z{}, Z{});
+            run_pf(One{}, Z{}, Z{});
+            run_pf(Z{}, Z{}, One{});
+            run_pf(One{}, Z{}, One{});
+            run_pf(std::integral_constant<int, 2>{}, Z{}, One{});
+            run_pf(One{}, One{}, One{});                                // no MFMA
+            run_pf(One{}, std::integral_constant<int, 4>{}, One{});     // no staging inside the loop
             CK(hipFree(dp)); CK(hipFree(slab));
         }
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy[0])); CK(hipFree(dy[1])); CK(hipFree(dy[2])); CK(hipFree(db));

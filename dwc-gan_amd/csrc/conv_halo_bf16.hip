@@ -314,7 +314,9 @@ struct WgradHaloArgs {
 };
 
 // PROBE (benchmarks/halo_lab.hip only): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
-template <int KS, int BN, int DBG = 0, int PROBE = 0>
+// DBG (timing only, results wrong; lab and -DDWC_DEV_ABLATIONS builds): 1 no MFMA, 2 no fragment reads, 4 no staging in the
+// loop, 8 no wait + barrier per unit.
+template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 1>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsigned long long* probe = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long stamp[4] = {0, 0, 0, 0};
@@ -369,12 +371,14 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     auto p_swz = [](int pp) { return CIW == 64 ? 4 * ((pp >> 1) & 1) : 4 * (pp & 3); };
     auto d_swz = [](int m) { return BN == 64 ? 4 * ((m >> 1) & 1) : 4 * (m & 3); };
 
-    auto stage_unit = [&](int u, int buf) {
+    // staging of one unit = PPASS + D_PASSES LDS-DMA pieces per thread; their global offsets first (unit_offsets), the pieces
+    // themselves one at a time (dma_piece) so the main loop can place them between the MFMAs of successive patch rows
+    constexpr int NPIECE = PPASS + D_PASSES;
+    unsigned s_off[NPIECE];
+    auto unit_offsets = [&](int u) {
         const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
         const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
         const int y0 = uy * UH, x0 = ux * UW;
-        bf16* lp = sP + buf * P_TILE + wave * 512;
-        bf16* ld = sD + buf * D_TILE + wave * 512;
 #pragma unroll
         for (int i = 0; i < PPASS; ++i) {
             const int pp = t / PCH + P_RPP * i;
@@ -382,17 +386,24 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
             const int h = min(reflect_idx(y0 - PAD + py, a.H), a.H - 1), w = min(reflect_idx(x0 - PAD + kw0 + px, a.W), a.W - 1);
             const int lc = (t % PCH) ^ p_swz(pp);
             const unsigned off = ((unsigned)(((n * a.H + h) * a.W + w) << a.logCin) + (unsigned)(cs * CIW + lc * 8)) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * P_RPP * CIW), 16,
-                                                     pp < PPIX ? off : OOB, 0, 0, 0);
+            s_off[i] = pp < PPIX ? off : OOB;
         }
 #pragma unroll
         for (int p = 0; p < D_PASSES; ++p) {
             const int dr = t / DCH + D_RPP * p;
             const int lc = (t % DCH) ^ d_swz(dr);
             const unsigned pix = (unsigned)((n * a.H + y0 + (dr >> 4)) * a.W + x0 + (dr & 15));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (__attribute__((address_space(3))) void*)(ld + p * D_RPP * BN), 16,
-                                                     (pix * a.N + tn * BN + lc * 8) * 2u, 0, 0, 0);
+            s_off[PPASS + p] = (pix * a.N + tn * BN + lc * 8) * 2u;
         }
+    };
+    auto dma_piece = [&](auto ic, int buf) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < PPASS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sP + buf * P_TILE + wave * 512 + i * P_RPP * CIW),
+                                                     16, s_off[i], 0, 0, 0);
+        else if constexpr (i < NPIECE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (__attribute__((address_space(3))) void*)(sD + buf * D_TILE + wave * 512 + (i - PPASS) * D_RPP * BN),
+                                                     16, s_off[i], 0, 0, 0);
     };
 
     f32x16 acc[NT];
@@ -407,54 +418,100 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     const int pxl = 8 * hi + tq;                         // pixel (column) inside the row's 16, first half (+4: second)
     const int a_col = ci_tile * 32 + 16 * gam + 4 * tp;  // channel inside the CIW-channel patch
     const int d_col = co_tile * 32 + 16 * gam + 4 * tp;  // channel inside the BN-wide dY tile
-    typedef __attribute__((address_space(3))) bf16x4* lds4;
-    auto a_frag = [&](const bf16* p, int r, int kw) {
-        bf16x4 v[2];
+    // Fragment reads are asm statements, waited for by hand (lgkmcnt counted, tied to the fragment registers so the MFMAs
+    // stay behind them).  Left to hipcc as builtins they cost the whole staging latency: an LDS-DMA is a vector-memory
+    // operation that WRITES LDS, the compiler cannot prove that a later LDS read does not alias it, and puts `s_waitcnt
+    // vmcnt(0)` in front of the next ds_read -- the "prefetch" of the next unit was drained before the first MFMA of this
+    // one (r03 ablation: 4 900 cycles per 5x5 unit = 3 070 of staging alone + 2 740 of reads and MFMAs alone, no overlap).
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    auto tr_read = [](bf16x4& dst, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr)); };
+    auto a_frag = [&](bf16x4 (&v)[2], unsigned pbase, int r, int kw) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int pp = r * PW + pxl + 4 * half + kw;
-            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + pp * CIW + (((a_col >> 3) ^ p_swz(pp)) << 3) + (a_col & 7)));
+            tr_read(v[half], pbase + (unsigned)(pp * CIW + (((a_col >> 3) ^ p_swz(pp)) << 3) + (a_col & 7)) * 2u);
         }
-        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
-    auto d_frag = [&](const bf16* d, int ks) {
-        bf16x4 v[2];
+    auto d_frag = [&](bf16x4 (&v)[2], unsigned dbase, int ks) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int m = ks * 16 + pxl + 4 * half;
-            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(d + m * BN + (((d_col >> 3) ^ d_swz(m)) << 3) + (d_col & 7)));
+            tr_read(v[half], dbase + (unsigned)(m * BN + (((d_col >> 3) ^ d_swz(m)) << 3) + (d_col & 7)) * 2u);
         }
-        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
     if (u0 < u1) {
-        stage_unit(u0, 0);
+        unit_offsets(u0);
+        h16_for<NPIECE>([&](auto ic) { dma_piece(ic, 0); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if constexpr (PROBE) stamp[1] = __builtin_amdgcn_s_memtime();
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
-            if (u + 1 < u1 && !(DBG & 4)) stage_unit(u + 1, buf ^ 1);
-            const bf16* p = sP + buf * P_TILE;
-            const bf16* d = sD + buf * D_TILE;
-            bf16x8 fb[TH];                               // dY rows r, r-1, ... r-TH+1 (index = row % TH)
+            // the next unit's pieces: SPREAD = one per patch row, each behind that row's MFMAs (r03 ablation: issued as one burst
+            // at the top of the unit -- all eight waves at once, ~100 cycles of issue per piece -- staging and MFMA time ADDED UP:
+            // 4 900 cycles per unit for 3 070 of staging alone and 2 740 of reads + MFMAs alone)
+            const bool stage_next = u + 1 < u1 && !(DBG & 4);
+            if (stage_next) {
+                unit_offsets(u + 1);
+                if constexpr (!SPREAD) h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1); });
+            }
+            const unsigned pbase = lds0 + (unsigned)(buf * P_TILE) * 2u, dbase = lds0 + (unsigned)(2 * P_TILE + buf * D_TILE) * 2u;
+            // Fragment reads run PF patch rows ahead of the MFMAs that use them (register rings).
+            constexpr int PF = PFT < 0 ? 1 : PFT;     // PFT: benchmarks/halo_lab.hip compares depths
+            constexpr int FA = PF + 1, FB = TH + PF;     // ring sizes: x rows r..r+PF, dY rows r-TH+1..r+PF
+            bf16x4 fa[FA][TW][2], fb[FB][2];
+            auto row_reads = [](int r) { return r < PH ? 2 * TW + (r < UH ? 2 : 0) : 0; };     // ds_read instructions of row r
+            auto fetch_row = [&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (r < PH) {
 #pragma unroll
-            for (int r = 0; r < PH; ++r) {
-                bf16x8 fa[TW];
+                    for (int kw = 0; kw < TW; ++kw) {
+                        if constexpr (DBG & 2) { for (int e = 0; e < 4; ++e) fa[r % FA][kw][0][e] = fa[r % FA][kw][1][e] = (bf16)(float)(lane + r + kw); }
+                        else a_frag(fa[r % FA][kw], pbase, r, kw);
+                    }
+                    if constexpr (r < UH) {
+                        if constexpr (DBG & 2) { for (int e = 0; e < 4; ++e) fb[r % FB][0][e] = fb[r % FB][1][e] = (bf16)(float)(lane - r); }
+                        else d_frag(fb[r % FB], dbase, r);
+                    }
+                }
+            };
+            h16_for<PF>([&](auto rc) { fetch_row(rc); });
+            h16_for<PH>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                fetch_row(std::integral_constant<int, r + PF>{});
+                // rows <= r have landed when at most the reads of rows r+1 .. r+PF are still in flight
+                constexpr int younger = [&] { int n = 0; for (int q = r + 1; q <= r + PF; ++q) n += row_reads(q); return n < 15 ? n : 15; }();   // (4-bit counter)
+                if constexpr (!(DBG & 2)) {
 #pragma unroll
-                for (int kw = 0; kw < TW; ++kw) fa[kw] = a_frag(p, r, kw);
-                if (r < UH) fb[r % TH] = d_frag(d, r);
+                    for (int kw = 0; kw < TW; ++kw)
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa[r % FA][kw][0]), "+v"(fa[r % FA][kw][1]) : "n"(younger));
+                    if constexpr (r < UH) asm volatile("" : "+v"(fb[r % FB][0]), "+v"(fb[r % FB][1]));
+                }
 #pragma unroll
                 for (int kh = 0; kh < TH; ++kh) {
                     const int ks = r - kh;               // x row r is tap row kh of output row ks
                     if (ks < 0 || ks >= UH) continue;
 #pragma unroll
-                    for (int kw = 0; kw < TW; ++kw)
-                        acc[kh * TW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kw], fb[ks % TH], acc[kh * TW + kw], 0, 0, 0);
+                    for (int kw = 0; kw < TW; ++kw) {
+                        const bf16x8 av = __builtin_shufflevector(fa[r % FA][kw][0], fa[r % FA][kw][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        const bf16x8 bv = __builtin_shufflevector(fb[ks % FB][0], fb[ks % FB][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        if constexpr (DBG & 1) asm volatile("" ::"v"(av), "v"(bv));
+                        else acc[kh * TW + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[kh * TW + kw], 0, 0, 0);
+                    }
                 }
+                if constexpr (SPREAD) {
+                    static_assert(NPIECE <= PH, "one staging piece per patch row");
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (stage_next) dma_piece(rc, buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // every fragment of this unit is in registers (the last row's wait was lgkmcnt(0)): the barrier below releases the buffer
+            if constexpr (!(DBG & 8)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             buf ^= 1;
         }
     }
