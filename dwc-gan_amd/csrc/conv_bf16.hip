@@ -509,56 +509,86 @@ __global__ __launch_bounds__(256) void wgrad_kernel_h(Gather g, const bf16* __re
     }
     // rows advance by 4 (second half) and 16 (next m-step): both keep (m & 3); for 128-byte rows the swizzle uses bit 1 of
     // m, unchanged by +4 and +16 as well
-    typedef __attribute__((address_space(3))) bf16x4* lds4;
-    bf16x8 fa[2][TM], fb[2][TN];
-    auto load_ops = [&](int set, int buf, int ms) {
+    // Fragment reads are asm statements with hand-counted waits (tied to the fragment registers, so the MFMAs stay behind
+    // them): as builtins hipcc cannot tell them from the LDS-DMA's target and drains vmcnt(0) -- the slab staged a moment
+    // ago -- in front of the next read (see wgrad_halo_kernel).
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+    bf16x4 fa[2][TM][2], fb[2][TN][2];
+    constexpr int NREAD = 2 * (TM + TN);                 // ds_read instructions of one load_ops
+    auto tr_read = [](bf16x4& dst, unsigned addr, auto offc) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(offc)::value));
+    };
+    auto load_ops = [&](auto setc, int buf, int ms) {
+        constexpr int set = decltype(setc)::value;
         if ((DBG & 2) && ms != 0) return;
-        const bf16* a = sA + buf * A_TILE + ms * 16 * 128;
-        const bf16* b = sB + buf * B_TILE + ms * 16 * BN;
+        const unsigned a = lds0 + (unsigned)(buf * A_TILE + ms * 16 * 128) * 2u;
+        const unsigned b = lds0 + (unsigned)(2 * A_TILE + buf * B_TILE + ms * 16 * BN) * 2u;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a + a_off[i]));
-            const bf16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(a + a_off[i] + 4 * 128));
-            fa[set][i] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+            tr_read(fa[set][i][0], a + (unsigned)a_off[i] * 2u, std::integral_constant<int, 0>{});
+            tr_read(fa[set][i][1], a + (unsigned)a_off[i] * 2u, std::integral_constant<int, 4 * 128 * 2>{});
         }
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + b_off[n]));
-            const bf16x4 hh = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(b + b_off[n] + 4 * BN));
-            fb[set][n] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+            tr_read(fb[set][n][0], b + (unsigned)b_off[n] * 2u, std::integral_constant<int, 0>{});
+            tr_read(fb[set][n][1], b + (unsigned)b_off[n] * 2u, std::integral_constant<int, 4 * BN * 2>{});
         }
     };
-    auto mfma_ops = [&](int set) {
+    // fragments of `set` have landed when at most `younger` later reads are in flight
+    auto wait_ops = [&](auto setc, auto youngerc) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            bf16x4 &r0 = fa[set][i][0], &r1 = fa[set][i][1];    // (asm operands inside a generic lambda: bind first)
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(decltype(youngerc)::value));
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            bf16x4 &r0 = fb[set][n][0], &r1 = fb[set][n][1];
+            asm volatile("" : "+v"(r0), "+v"(r1));
+        }
+    };
+    auto mfma_ops = [&](auto setc) {
+        constexpr int set = decltype(setc)::value;
         if (DBG & 1) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[set][i]));
+            for (int i = 0; i < TM; ++i) { const bf16x4 r0 = fa[set][i][0], r1 = fa[set][i][1]; asm volatile("" ::"v"(r0), "v"(r1)); }
 #pragma unroll
-            for (int n = 0; n < TN; ++n) asm volatile("" ::"v"(fb[set][n]));
+            for (int n = 0; n < TN; ++n) { const bf16x4 r0 = fb[set][n][0], r1 = fb[set][n][1]; asm volatile("" ::"v"(r0), "v"(r1)); }
             return;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int n = 0; n < TN; ++n)
-                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][i], fb[set][n], acc[i][n], 0, 0, 0);
+                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_shufflevector(fa[set][i][0], fa[set][i][1], 0, 1, 2, 3, 4, 5, 6, 7),
+                    __builtin_shufflevector(fb[set][n][0], fb[set][n][1], 0, 1, 2, 3, 4, 5, 6, 7), acc[i][n], 0, 0, 0);
     };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, NREAD> YR;
     if (m_begin < m_end) {
         stage_slab(m_begin, 0);
         lds_dma_barrier();
         int buf = 0;
-        load_ops(0, 0, 0);
+        load_ops(S0{}, 0, 0);
         for (int mb = m_begin; mb < m_end; mb += MS) {
             const bool more = mb + MS < m_end;
             if (more && !(DBG & 4)) stage_slab(mb + MS, buf ^ 1);
-            load_ops(1, buf, 1);
-            mfma_ops(0);
-            load_ops(0, buf, 2);
-            mfma_ops(1);
-            load_ops(1, buf, 3);
-            mfma_ops(0);
+            load_ops(S1{}, buf, 1);
+            wait_ops(S0{}, YR{});
+            mfma_ops(S0{});
+            load_ops(S0{}, buf, 2);
+            wait_ops(S1{}, YR{});
+            mfma_ops(S1{});
+            load_ops(S1{}, buf, 3);
+            wait_ops(S0{}, YR{});
+            mfma_ops(S0{});
+            wait_ops(S1{}, S0{});                        // every read of this buffer is in registers before the barrier frees it
             lds_dma_barrier();
-            if (more) load_ops(0, buf ^ 1, 0);
-            mfma_ops(1);
+            if (more) load_ops(S0{}, buf ^ 1, 0);
+            mfma_ops(S1{});
             buf ^= 1;
         }
     }

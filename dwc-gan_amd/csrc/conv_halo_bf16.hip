@@ -316,7 +316,7 @@ struct WgradHaloArgs {
 // PROBE (benchmarks/halo_lab.hip only): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
 // DBG (timing only, results wrong; lab and -DDWC_DEV_ABLATIONS builds): 1 no MFMA, 2 no fragment reads, 4 no staging in the
 // loop, 8 no wait + barrier per unit.
-template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 1>
+template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 0>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsigned long long* probe = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long stamp[4] = {0, 0, 0, 0};
@@ -448,9 +448,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
         if constexpr (PROBE) stamp[1] = __builtin_amdgcn_s_memtime();
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
-            // the next unit's pieces: SPREAD = one per patch row, each behind that row's MFMAs (r03 ablation: issued as one burst
-            // at the top of the unit -- all eight waves at once, ~100 cycles of issue per piece -- staging and MFMA time ADDED UP:
-            // 4 900 cycles per unit for 3 070 of staging alone and 2 740 of reads + MFMAs alone)
+            // the next unit's pieces, issued as one burst here (SPREAD, lab only: one piece behind each patch row's MFMAs -- measured
+            // 5-30 % slower: the pieces then queue behind a busy LDS instead of in front of it)
             const bool stage_next = u + 1 < u1 && !(DBG & 4);
             if (stage_next) {
                 unit_offsets(u + 1);
