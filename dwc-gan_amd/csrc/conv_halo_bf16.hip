@@ -308,8 +308,8 @@ struct WgradHaloArgs {
     const bf16* x;      // [B][H][W][Cin]
     const bf16* dy;     // [B][H][W][N]
     float* slab;        // [splits][K*K*Cin][N]
-    int B, H, W, Cin, logCin, N;
-    int units_x, units_per_img, total_units, units_per_split;
+    int B, H, W, Cin, logCin, N;          // H, W: x; the dY grid is H x W (stride 1) or H/2 x W/2 (KS == 4: stride 2)
+    int units_x, units_per_img, total_units, units_per_split;      // 8x16-pixel units of the dY grid
     int n_tiles, tap_groups;
 };
 
@@ -322,7 +322,11 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     unsigned long long stamp[4] = {0, 0, 0, 0};
     if constexpr (PROBE) stamp[0] = __builtin_amdgcn_s_memtime();
     static_assert(BN == 128 || BN == 64, "dY tile width");
-    constexpr int TH = KS, TW = KS == 3 ? 3 : 1;        // taps of one workgroup: TH filter rows x TW filter columns
+    // KS == 4: the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111).  Tap (kh, kw) =
+    // (2 th + dy, 2 tw + dx) reads input pixel (2 (oy + th) + dy - 1, 2 (ox + tw) + dx - 1): per input-pixel parity (dy, dx) a
+    // 2x2-tap stride-1 problem over the space-to-depth image, and the loader does the space-to-depth (one parity = one tap group).
+    constexpr bool S2 = KS == 4;
+    constexpr int TH = S2 ? 2 : KS, TW = S2 ? 2 : (KS == 3 ? 3 : 1);   // taps of one workgroup: TH filter rows x TW filter columns
     constexpr int CIW = BN == 128 ? 64 : 128;           // channels of x per workgroup (8 waves = CIW/32 x BN/32 tiles)
     constexpr int UH = 8, UW = 16;                      // unit: 8 rows x 16 columns = 128 pixels, one MFMA k-step per row
     constexpr int PW = UW + TW - 1, PH = UH + TH - 1, PPIX = PH * PW;
@@ -362,8 +366,10 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     const int ci_tile = BN == 128 ? (wave >> 2) : (wave >> 1);
     const int co_tile = BN == 128 ? (wave & 3) : (wave & 1);
     const int kw0 = TW == 1 ? tgp : 0;                  // column shift applied when the patch is staged
+    const int par_y = S2 ? tgp >> 1 : 0, par_x = S2 ? tgp & 1 : 0;
+    const int OH = S2 ? a.H >> 1 : a.H, OW = S2 ? a.W >> 1 : a.W;
 
-    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u, dy_bytes = (unsigned)a.B * a.H * a.W * a.N * 2u;
+    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u, dy_bytes = (unsigned)a.B * OH * OW * a.N * 2u;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.dy), 0, dy_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
         for (int i = 0; i < PPASS; ++i) {
             const int pp = t / PCH + P_RPP * i;
             const int py = pp / PW, px = pp - py * PW;
-            const int h = min(reflect_idx(y0 - PAD + py, a.H), a.H - 1), w = min(reflect_idx(x0 - PAD + kw0 + px, a.W), a.W - 1);
+            const int h = min(reflect_idx(S2 ? 2 * (y0 + py) + par_y - 1 : y0 - PAD + py, a.H), a.H - 1);
+            const int w = min(reflect_idx(S2 ? 2 * (x0 + px) + par_x - 1 : x0 - PAD + kw0 + px, a.W), a.W - 1);
             const int lc = (t % PCH) ^ p_swz(pp);
             const unsigned off = ((unsigned)(((n * a.H + h) * a.W + w) << a.logCin) + (unsigned)(cs * CIW + lc * 8)) * 2u;
             s_off[i] = pp < PPIX ? off : OOB;
@@ -392,7 +399,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
         for (int p = 0; p < D_PASSES; ++p) {
             const int dr = t / DCH + D_RPP * p;
             const int lc = (t % DCH) ^ d_swz(dr);
-            const unsigned pix = (unsigned)((n * a.H + y0 + (dr >> 4)) * a.W + x0 + (dr & 15));
+            const unsigned pix = (unsigned)((n * OH + y0 + (dr >> 4)) * OW + x0 + (dr & 15));
             s_off[PPASS + p] = (pix * a.N + tn * BN + lc * 8) * 2u;
         }
     };
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     float* out = a.slab + (size_t)split * Ktot * a.N;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int tap = (j / TW) * KS + kw0 + (j % TW);
+        const int tap = S2 ? (2 * (j / TW) + par_y) * 4 + 2 * (j % TW) + par_x : (j / TW) * KS + kw0 + (j % TW);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -554,9 +561,11 @@ __global__ void wgrad_halo_reduce_kernel(const float* __restrict__ slab, float* 
 }
 
 // BN (channels of dY per workgroup) of a handled shape, 0 otherwise
+// (K == 4 is the stride-2 form: H, W are the dimensions of x, the dY grid is H/2 x W/2)
 int wgrad_halo_bn(int B, int H, int W, int Cin, int Cout, int K) {
-    if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || dwc_ilog2_exact(Cin) < 6 ||
-        (size_t)B * H * W * Cin * 2 >= 0x80000000ull || (size_t)B * H * W * Cout * 2 >= 0x80000000ull)
+    const int OH = K == 4 ? H / 2 : H, OW = K == 4 ? W / 2 : W;
+    if (B <= 0 || (K != 3 && K != 5 && K != 4) || (K == 4 && ((H | W) & 1)) || OH < 8 || OW < 16 || (OH % 8) || (OW % 16) || Cin < 64 ||
+        dwc_ilog2_exact(Cin) < 6 || (size_t)B * H * W * Cin * 2 >= 0x80000000ull || (size_t)B * OH * OW * Cout * 2 >= 0x80000000ull)
         return 0;
     if (Cout >= 128 && !(Cout % 128)) return 128;
     return (K == 5 && Cout >= 64 && !(Cout % 64) && !(Cin % 128)) ? 64 : 0;
@@ -564,8 +573,8 @@ int wgrad_halo_bn(int B, int H, int W, int Cin, int Cout, int K) {
 
 void wgrad_halo_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
     const int ciw = bn == 128 ? 64 : 128;
-    const int roles = (Cin / ciw) * (Cout / bn) * (K == 3 ? 1 : K);
-    const int units = B * (H / 8) * (W / 16);
+    const int roles = (Cin / ciw) * (Cout / bn) * (K == 3 ? 1 : K);        // (K == 4: the four input-pixel parities)
+    const int units = K == 4 ? B * (H / 16) * (W / 32) : B * (H / 8) * (W / 16);
     // pixel splits: fill the 256 CUs (one workgroup each: LDS) in whole rounds - 260 workgroups cost two rounds, 240 one -
     // with at least 4 units per workgroup; among equally full launches the fewest splits (slab traffic)
     const int cus = 256;
@@ -742,9 +751,9 @@ size_t dwc_bf16_conv2d_wgrad_halo_ws_bytes(int B, int H, int W, int Cin, int Cou
     return (size_t)splits * K * K * Cin * Cout * sizeof(float);
 }
 
-/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution from x:[B,H,W,Cin] and
- * dy:[B,H,W,Cout] (both bf16), halo form (see wgrad_halo_kernel); dwc_bf16_conv2d_wgrad_halo_ws_bytes == 0 means the shape
- * is not handled (use dwc_bf16_conv2d_bwd_weight). */
+/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution (K = 3, 5) from x:[B,H,W,Cin]
+ * and dy:[B,H,W,Cout], or of the 4x4 stride-2 reflect-pad-1 convolution (K = 4; dy:[B,H/2,W/2,Cout]) -- both bf16, halo form (see
+ * wgrad_halo_kernel); dwc_bf16_conv2d_wgrad_halo_ws_bytes == 0 means the shape is not handled (use dwc_bf16_conv2d_bwd_weight). */
 int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K,
                                int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
     const int bn = wgrad_halo_bn(B, H, W, Cin, Cout, K);
@@ -755,7 +764,8 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
     WgradHaloArgs a;
     a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.slab = (float*)ws;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout;
-    a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
+    const int OH = K == 4 ? H / 2 : H, OW = K == 4 ? W / 2 : W;
+    a.units_x = OW / 16; a.units_per_img = (OH / 8) * (OW / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
     a.n_tiles = Cout / bn; a.tap_groups = K == 3 ? 1 : K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((Cin / (bn == 128 ? 64 : 128)) * a.n_tiles * a.tap_groups * splits);
@@ -765,6 +775,7 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
     else
 #endif
     if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);
+    else if (K == 4) hipLaunchKernelGGL((wgrad_halo_kernel<4, 128>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64>), grid, dim3(512), 0, st, a);
     DWC_LAUNCH_CHECK();

@@ -537,7 +537,8 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
                     x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
                     scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:], exec_flops=6 * flops), "x3_conv2d_wgrad")
-            elif (half and WGRAD_HALO and stride == 1 and KH == KW and 2 * pad == KH - 1
+            elif (half and WGRAD_HALO and KH == KW and ((stride == 1 and KH in (3, 5) and 2 * pad == KH - 1)
+                                                         or (S2HALO and stride == 2 and KH == 4 and pad == 1))
                   and lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv2d_wgrad_halo(

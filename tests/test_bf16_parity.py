@@ -73,6 +73,7 @@ CONV_SHAPES = [
     (3, 64, 64, 16, 3, 1, 1, "none"),       # 3x3, BN = 64, one block per image
     (1, 128, 256, 48, 3, 1, 1, "none"),     # 3x3, BN = 256, 9 blocks, two channel slabs (double-buffered patch)
     (2, 256, 128, 32, 5, 1, 2, "lrelu"),    # 5x5, BN = 128, four channel slabs (patch restaged in place)
+    (2, 128, 256, 64, 4, 2, 1, "lrelu"),    # stride-2 4x4 on the halo kernels (forward + weight gradient: space-to-depth in the loader)
 ]
 
 
