@@ -65,7 +65,12 @@ struct X3Args {
 // boundary (exposed, but the workgroup then fits TWICE on a CU: 4-wave workgroups of 256 pixels x 64 channels, <= 80 KB of
 // LDS and 256 registers -- two independent workgroups per CU drift out of phase, so one's MFMAs run beside the other's
 // fragment reads, staging and barriers, which the eight lock-stepped waves of one workgroup never do).
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2>
+// S2 (KS == 2): the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) as 2x2-tap
+// stride-1 convolutions over the space-to-depth image, the space-to-depth done by the patch gather: a "slab" is (input-pixel
+// parity (dy, dx), 16-channel slab), patch pixel (py, px) of it is input pixel (2 (y0 + py) + dy - 1, 2 (x0 + px) + dx - 1) under
+// the reflect rule, and tap (th, tw) of that slab is filter tap (2 th + dy, 2 tw + dx) of the ordinary K = 4 prepared weights.
+// a.H, a.W are the input dimensions, the output is H/2 x W/2.
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0>
 __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
@@ -74,6 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     constexpr int NW = WM * WN, THREADS = 64 * NW;
     constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
+    static_assert(!S2 || (KS == 2 && PB == 1), "stride-2 form: 2x2 taps per parity, single patch buffer");
     constexpr int PW = TB + KS - 1;                    // patch edge
     constexpr int PPIX = PW * PW;                      // patch pixels
     constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
@@ -109,36 +115,57 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
     const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
     const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
-    const int ncs = a.Cin / CS;
+    const int OH = S2 ? a.H >> 1 : a.H, OW = S2 ? a.W >> 1 : a.W;      // output grid (the blocks tile it)
+    const int ncsr = a.Cin / CS;                                        // 16-channel slabs of the input tensor
+    const int ncs = S2 ? 4 * ncsr : ncsr;                               // slabs walked: x 4 input-pixel parities
     const int nsteps = ncs * NTAP;
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
-    const float* p_src[PPASS];
+    const float* p_src[S2 ? 1 : PPASS];
+    // S2: element offset of the patch pixel's input pixel for parity (0, 0), and what the odd row / column parity adds to it
+    // (kept as base + masked delta: indexing a register array by the parity would send it to scratch)
+    int p_base[S2 ? PPASS : 1], p_drow[S2 ? PPASS : 1], p_dcol[S2 ? PPASS : 1];
     int p_dst[PPASS];                                   // LDS element offset of (py, px), channels 4*(t&3)..
     unsigned p_ok = 0, p_in = 0;                        // loads are unconditional (the vmcnt arithmetic below counts them)
 #pragma unroll
     for (int i = 0; i < PPASS; ++i) {
         const int pp = (t >> 2) + PPT * i;
         const int py = pp / PW, px = pp - py * PW;
-        int h = y0 - PAD + py, w = x0 - PAD + px;
         bool ok = pp < PPIX;
-        if (a.reflect) {
-            h = reflect_idx(h, a.H);
-            w = reflect_idx(w, a.W);
+        if constexpr (S2) {
+            const int h0 = min(reflect_idx(2 * (y0 + py) - 1, a.H), a.H - 1), h1 = min(reflect_idx(2 * (y0 + py), a.H), a.H - 1);
+            const int w0 = min(reflect_idx(2 * (x0 + px) - 1, a.W), a.W - 1), w1 = min(reflect_idx(2 * (x0 + px), a.W), a.W - 1);
+            p_base[i] = ((n_img * a.H + h0) * a.W + w0) * a.Cin;
+            p_drow[i] = (h1 - h0) * a.W * a.Cin;
+            p_dcol[i] = (w1 - w0) * a.Cin;
         } else {
-            ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            int h = y0 - PAD + py, w = x0 - PAD + px;
+            if (a.reflect) {
+                h = reflect_idx(h, a.H);
+                w = reflect_idx(w, a.W);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            }
+            h = min(max(h, 0), a.H - 1);
+            w = min(max(w, 0), a.W - 1);
+            p_src[i] = a.x + ((size_t)(n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4;
         }
-        h = min(max(h, 0), a.H - 1);
-        w = min(max(w, 0), a.W - 1);
-        p_src[i] = a.x + ((size_t)(n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4;
         p_dst[i] = py * PITCH + px * CS + (t & 3) * 4;
         p_ok |= ok ? 1u << i : 0u;
         p_in |= pp < PPIX ? 1u << i : 0u;
     }
     f32x4 pv[PPASS];
     auto load_patch = [&](int cs) {
+        if constexpr (S2) {
+            const int par = cs / ncsr, csl = cs - par * ncsr;
+            const float* base = a.x + csl * CS + (t & 3) * 4;
+            const int my = -(par >> 1), mx = -(par & 1);
 #pragma unroll
-        for (int i = 0; i < PPASS; ++i) pv[i] = *reinterpret_cast<const f32x4*>(p_src[i] + cs * CS);
+            for (int i = 0; i < PPASS; ++i) pv[i] = *reinterpret_cast<const f32x4*>(base + (p_base[i] + (p_drow[i] & my) + (p_dcol[i] & mx)));
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPASS; ++i) pv[i] = *reinterpret_cast<const f32x4*>(p_src[i] + cs * CS);
+        }
     };
     auto write_patch = [&](int buf) {
         bf16* dst = sP + buf * 3 * P_PLANE;
@@ -154,7 +181,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     };
 
     // ---- weight ring: chunk g = t + 512*p of the slab [plane][row][half] ----------------------------------------------------
-    const unsigned w_bytes = (unsigned)NTAP * ncs * 3u * a.rows * CS * 2u;
+    const unsigned w_bytes = (unsigned)(S2 ? 16 : NTAP) * ncsr * 3u * a.rows * CS * 2u;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, w_bytes, 0x00020000);
     unsigned w_off[W_INSTR];
 #pragma unroll
@@ -168,7 +195,14 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     auto stage_w = [&](int step, int slot) {                              // step = cs * NTAP + tap -> block tap * ncs + cs
         const int cs = step / NTAP, tap = step - cs * NTAP;
         bf16* lw = sW + slot * W_SLOT + wave * 512;
-        const int soff = __builtin_amdgcn_readfirstlane((tap * ncs + cs) * w_step_bytes);
+        int blk;
+        if constexpr (S2) {
+            const int par = cs / ncsr, csl = cs - par * ncsr;
+            blk = ((2 * (tap >> 1) + (par >> 1)) * 4 + 2 * (tap & 1) + (par & 1)) * ncsr + csl;
+        } else {
+            blk = tap * ncs + cs;
+        }
+        const int soff = __builtin_amdgcn_readfirstlane(blk * w_step_bytes);
 #pragma unroll
         for (int p = 0; p < W_INSTR; ++p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * THREADS * 8), 16, w_off[p],
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int pb = (wm * TM + i) * 32 + l31;
-            float* dst = a.y + ((size_t)(n_img * a.H + y0 + (pb >> 4)) * a.W + x0 + (pb & 15)) * a.N;
+            float* dst = a.y + ((size_t)(n_img * OH + y0 + (pb >> 4)) * OW + x0 + (pb & 15)) * a.N;
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
@@ -665,9 +699,14 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2>), grid, dim3(64 * WM * WN), 0, st, a);
+}
+
+bool x3_s2_ok(int B, int H, int W, int Cin, int N) {
+    return B > 0 && H >= 2 * TB && W >= 2 * TB && !(H % (2 * TB)) && !(W % (2 * TB)) && Cin >= CS && !(Cin % CS) && N >= 32 && !(N % 4) &&
+           (size_t)B * H * W * Cin < 0x7fffffffull;
 }
 
 }  // namespace
@@ -761,6 +800,24 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
         if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
         else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
     }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_x3_conv2d_s2_ok(int B, int H, int W, int Cin, int Cout) { return x3_s2_ok(B, H, W, Cin, Cout) ? 1 : 0; }
+
+/* y = act(conv4x4_stride2(reflect_pad1(x)) + bias) for fp32 NHWC tensors as split products (see conv_halo_x3_kernel, S2):
+ * x:[B,H,W,Cin], y:[B,H/2,W/2,N], H and W multiples of 32, Cin a multiple of 16; w_prepared = dwc_x3_weight_prepare(K = 4, forward)
+ * with `rows` >= N rows. */
+int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                     int act, void* stream) {
+    if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N) return DWC_EINVAL;
+    X3Args a;
+    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = 1;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    a.tiles_n = (N + 63) / 64;
+    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

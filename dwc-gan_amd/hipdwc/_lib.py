@@ -108,6 +108,8 @@ SIGNATURES = {
     "dwc_x3_weight_prepared_elems": (c_sz, [c_int] * 3),
     "dwc_x3_weight_prepare": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "dwc_x3_conv2d_same": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
+    "dwc_x3_conv2d_s2_ok": (c_int, [c_int] * 5),
+    "dwc_x3_conv2d_s2": (c_int, [c_fp] * 4 + [c_int] * 7 + [c_fp]),
     "dwc_x3_conv2d_wgrad_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_x3_conv2d_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_wgrad_halo_ws_bytes": (c_sz, [c_int] * 6),

@@ -372,6 +372,7 @@ WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
 LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM forward: all time steps in one persistent launch
+X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 
 
@@ -425,10 +426,12 @@ class _Conv2d(torch.autograd.Function):
         # (207 vs 220): both decisions therefore follow needs_input_grad alone.)
         w_grad = ctx.needs_input_grad[1]
         use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
+        use_x3s2 = bool((not half) and X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1 and cop % 64 == 0
+                        and lib.dwc_x3_conv2d_s2_ok(B, H, W, Cx, cop))
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         use_stem = bool(half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
                         and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H, W, KH, act))
-        w_hwio = None if use_wino or use_x3 or use_stem else _prepped(w, "fwd", cop, Cx, stride, owner, half)
+        w_hwio = None if use_wino or use_x3 or use_x3s2 or use_stem else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -453,6 +456,12 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, st),
                 detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
+        elif use_x3s2:
+            # stride-2 4x4 layers, fp32: split products, 2x2 taps per input-pixel parity, space-to-depth in the patch gather
+            w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2(
+                x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, st),
+                detail="fwd-x3s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_s2")
         elif use_stem:
             # 7x7 stem on an NHWC8 image: filter resident in LDS, persistent workgroups (csrc/conv_narrow_bf16.hip)
             w_st = _prepped(w, "stem_steps", cop, Cx, 1, owner, True)

@@ -320,6 +320,12 @@ size_t dwc_x3_weight_prepared_elems(int rows, int kdim, int K);
 int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, void* stream);
 int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
                        int rows, int K, int act, int reflect, void* stream);
+/* The 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) on the same kernel: 2x2 taps
+ * per input-pixel parity over the space-to-depth image, the space-to-depth done by the patch gather.  x:[B,H,W,Cin] ->
+ * y:[B,H/2,W/2,N]; H, W multiples of 32, Cin a multiple of 16; w_prepared = dwc_x3_weight_prepare(K = 4, forward). */
+int dwc_x3_conv2d_s2_ok(int B, int H, int W, int Cin, int Cout);
+int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                     int act, void* stream);
 /* weight gradient of the same layers as split products: dw (fp32, [cout_real][cin_real][K][K]) from the fp32 NHWC tensors x
  * and dy; both operands are split on the fly (x through LDS, dy in registers); pixel ranges go to fp32 slabs in `ws`, summed in
  * a fixed order.  ws_bytes == 0: shape not handled (K in {3,5}, H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64). */

@@ -41,6 +41,7 @@ CONV_SHAPES = [
     (1, 4, 64, 21, 7, 1, 3, "none"),        # same, odd size: padded width 27 -> pitch 32
     (3, 4, 32, 16, 5, 1, 2, "lrelu"),       # same, 5x5 / 32 gathered channels
     (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
+    (2, 128, 256, 64, 4, 2, 1, "lrelu"),    # downsample, several blocks per image (split-product forward, stride-2 form)
     (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv (Winograd F(2x2,3x3) forward and data-gradient interior)
     (3, 64, 128, 12, 3, 1, 1, "relu"),      # Winograd, rectangular channel counts, non power-of-two size
     (2, 64, 64, 10, 3, 1, 1, "none"),       # size not a multiple of 4: F(2x2,3x3)

@@ -88,6 +88,45 @@ def test_x3_forward_matches_float64(shape):
     assert err_x3 <= 2 * max(err_native, err_32) + 2e-7
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 32, "relu"), (3, 128, 256, 64, 64, "lrelu"), (1, 16, 64, 32, 32, "none"),
+                                   (2, 256, 256, 32, 32, "none"), (24, 64, 128, 128, 128, "relu")], ids=lambda s: "x".join(str(v) for v in s))
+def test_x3_stride2_forward_matches_float64(shape):
+    """The 4x4 stride-2 reflect-pad-1 layers on the split-product kernel (2x2 taps per input-pixel parity, space-to-depth in the patch
+    gather; dwc_x3_conv2d_s2) against a float64 convolution: fp32 accuracy, as for the stride-1 layers."""
+    B, Cin, Cout, H, W, act = shape
+    lib = _lib.load()
+    assert lib.dwc_x3_conv2d_s2_ok(B, H, W, Cin, Cout)
+    g = torch.Generator().manual_seed(sum(shape[:5]))
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.rand(1, Cin, 1, 1, generator=g) * 3
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * (1.0 / (Cin * 16) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    fn = {"none": lambda v: v, "relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[act]
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ref = fn(F.conv2d(F.pad(xd.double(), (1,) * 4, mode="reflect"), wd.double(), bd.double(), stride=2))
+    ref32 = fn(F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), w, b, stride=2)).double() if B <= 3 else None
+    xn = xd.permute(0, 2, 3, 1).contiguous()
+    wp = _prep(lib, wd, Cout, False)
+    y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.float32, device=DEV)
+    _lib.check(lib.dwc_x3_conv2d_s2(xn.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, Cout, ACT[act],
+                                    torch.cuda.current_stream().cuda_stream), "x3_conv2d_s2")
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err_x3 = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
+    old = ops.X3_S2
+    ops.X3_S2 = 0
+    try:
+        with torch.no_grad():
+            yn = ops.conv2d(xd, wd, bd, 2, 1, act)
+    finally:
+        ops.X3_S2 = old
+    err_native = (yn[:, :Cout].double() - ref).abs().max().item() / scale
+    err_32 = (ref32 - ref.cpu()).abs().max().item() / scale if ref32 is not None else 0.0
+    print("s2 %s max err / scale vs float64: split-bf16 %.2e | native fp32 MFMA path %.2e | fp32 CPU conv %.2e" % (
+        "x".join(str(v) for v in shape), err_x3, err_native, err_32))
+    assert err_x3 <= 5e-6, err_x3
+    assert err_x3 <= 2 * max(err_native, err_32) + 2e-7
+
+
 def test_x3_dgrad_interior_zero_rule():
     """reflect == 0 with dgrad-prepared weights == conv_transpose of dy (zero padding): the data-gradient interior."""
     lib = _lib.load()
