@@ -440,7 +440,7 @@ __global__ void x3_weight_prepare_kernel(const float* __restrict__ w, bf16* __re
 // ------------------------------------------------------------------------------------------
 struct X3WgradArgs {
     const float* x;      // [B][H][W][Cin]
-    const float* dy;     // [B][H][W][N]
+    const float* dy;     // [B][H][W][N]   (KS == 4, the stride-2 form: [B][H/2][W/2][N])
     float* slab;         // [splits * HALVES][K*K*Cin][N]
     int B, H, W, Cin, N;
     int units_x, units_per_img, total_units, units_per_split;
@@ -455,8 +455,13 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     static_assert((BN == 128 || BN == 64) && (CIW == 64 || CIW == 32), "tile shape");
     constexpr int HALVES = BN == 128 ? 1 : 2;
     constexpr int QPP = CIW / 4;                       // gather threads per pixel (4 channels each); 32 pixels per pass either way
-    constexpr int UH = 8, UW = 16;
-    constexpr int PH = UH + KS - 1, PPIX = PH * UW;
+    // KS == 4: the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111).  Tap (kh, kw) of
+    // output pixel (oy, ox) reads input pixel (2 oy + kh - 1, 2 ox + kw - 1): for the workgroup's filter column kw the "patch" is
+    // the stride-2 column set 2 (x0 + c) + kw - 1 of input rows 2 y0 - 1 .. 2 y0 + 2 UH, and (output row ks, filter row kh) reads
+    // patch row 2 ks + kh.  Units are 4 rows high (10 patch rows: the LDS holds two buffers of three planes).
+    constexpr bool S2 = KS == 4;
+    constexpr int UH = S2 ? 4 : 8, UW = 16;
+    constexpr int PH = S2 ? 2 * UH + 2 : UH + KS - 1, PPIX = PH * UW;
     constexpr int PPASS = (PPIX + 31) / 32;            // gather passes of 32 pixels (16 threads x 4 channels per pixel)
     constexpr int P_PLANE = PPASS * 32 * CIW;          // elements per plane
     constexpr int PAD = (KS - 1) / 2;
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     const int co_tile = CIW == 32 ? (BN == 128 ? wave : (wave & 1)) : (BN == 128 ? (wave & 3) : ((wave >> 1) & 1));
     const int half_id = BN == 128 ? 0 : (CIW == 32 ? (wave >> 1) : (wave >> 2));
     const int l31 = lane & 31, hi = lane >> 5;
+    const int OH = S2 ? a.H >> 1 : a.H, OW = S2 ? a.W >> 1 : a.W;     // the dY grid (units tile it)
 
     // ---- x patch: thread = (pixel t / QPP [+32 per pass], channel quad t % QPP) ----------------------------------------------
     const int quad = t % QPP;
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int pp = min(t / QPP + 32 * (first + j), PPIX - 1);
-            const int h = min(reflect_idx(y0 - PAD + (pp >> 4), a.H), a.H - 1);
-            const int w = min(reflect_idx(x0 - PAD + kw + (pp & 15), a.W), a.W - 1);
+            const int h = min(reflect_idx(S2 ? 2 * y0 - 1 + (pp >> 4) : y0 - PAD + (pp >> 4), a.H), a.H - 1);
+            const int w = min(reflect_idx(S2 ? 2 * (x0 + (pp & 15)) + kw - 1 : x0 - PAD + kw + (pp & 15), a.W), a.W - 1);
             pv[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.Cin + cs * CIW + quad * 4);
         }
     };
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     auto load_dy = [&](int u, int row) {
         int n, y0, x0;
         unit_origin(u, n, y0, x0);
-        const float* src = a.dy + ((size_t)(n * a.H + y0 + row) * a.W + x0 + 8 * hi) * a.N + tn * BN + co_tile * 32 + l31;
+        const float* src = a.dy + ((size_t)(n * OH + y0 + row) * OW + x0 + 8 * hi) * a.N + tn * BN + co_tile * 32 + l31;
 #pragma unroll
         for (int j = 0; j < 8; ++j) raw[j] = src[(size_t)j * a.N];
     };
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
                 for (int kh = 0; kh < KS; ++kh) {
                     bf16x8 fa[3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fa[pl] = a_frag(p + pl * P_PLANE, ks + kh);
+                    for (int pl = 0; pl < 3; ++pl) fa[pl] = a_frag(p + pl * P_PLANE, S2 ? 2 * ks + kh : ks + kh);
                     lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], lo[kh], 0, 0, 0);
                     lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], lo[kh], 0, 0, 0);
                     lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], lo[kh], 0, 0, 0);
@@ -671,8 +677,11 @@ static int x3_wgrad_ciw() {
     return duo ? 32 : 64;
 }
 
+// (K == 4 is the stride-2 form: H, W are the dimensions of x, the dY grid is H/2 x W/2 and is cut into 4x16-pixel units)
 int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
-    if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || (Cin % 64)) return 0;
+    if (K == 4) {
+        if (B <= 0 || H < 8 || W < 32 || (H % 8) || (W % 32) || Cin < 64 || (Cin % 64)) return 0;
+    } else if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || (Cin % 64)) return 0;
     if (Cout >= 128 && !(Cout % 128)) return 128;
     return (Cout >= 64 && !(Cout % 64)) ? 64 : 0;
 }
@@ -680,7 +689,7 @@ int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
 void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
     const int ciw = x3_wgrad_ciw();
     const int roles = (Cin / ciw) * (Cout / bn) * K;
-    const int units = B * (H / 8) * (W / 16);
+    const int units = K == 4 ? B * (H / 8) * (W / 32) : B * (H / 8) * (W / 16);
     const int cus = ciw == 64 ? 256 : 512;              // resident workgroups (LDS): whole rounds, see wgrad_halo_plan
     const int smax = units / 4 > 0 ? units / 4 : 1;
     int s = 1;
@@ -830,9 +839,10 @@ size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int 
     return (size_t)splits * (bn == 128 ? 1 : 2) * K * K * Cin * Cout * sizeof(float);
 }
 
-/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution from the fp32 NHWC tensors
- * x:[B,H,W,Cin] and dy:[B,H,W,Cout], split products (see wgrad_x3_kernel).  ws_bytes == 0: shape not handled (K in {3,5},
- * H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64) - use dwc_conv2d_bwd_weight. */
+/* dw (fp32 OIHW, [cout_real][cin_real][K][K]) of a reflect-padded stride-1 "same" K x K convolution (K in {3,5}) from the fp32 NHWC
+ * tensors x:[B,H,W,Cin] and dy:[B,H,W,Cout], or of the 4x4 stride-2 reflect-pad-1 convolution (K = 4, dy:[B,H/2,W/2,Cout]), split
+ * products (see wgrad_x3_kernel).  ws_bytes == 0: shape not handled (K in {3,5}: H % 8 == 0, W % 16 == 0; K = 4: H % 8 == 0,
+ * W % 32 == 0; Cin and Cout multiples of 64) - use dwc_conv2d_bwd_weight. */
 int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real,
                         int cout_real, void* ws, size_t ws_bytes, void* stream) {
     const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
@@ -844,13 +854,22 @@ int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, 
     X3WgradArgs a;
     a.x = x; a.dy = dy; a.slab = (float*)ws;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = Cout;
-    a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16); a.total_units = B * a.units_per_img; a.units_per_split = ups;
+    if (K == 4) {
+        a.units_x = W / 32; a.units_per_img = (H / 8) * (W / 32);      // 4x16-pixel units of the H/2 x W/2 dY grid
+    } else {
+        a.units_x = W / 16; a.units_per_img = (H / 8) * (W / 16);
+    }
+    a.total_units = B * a.units_per_img; a.units_per_split = ups;
     a.n_tiles = Cout / bn;
     const int ciw = x3_wgrad_ciw();
     a.roles = (Cin / ciw) * a.n_tiles * K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(a.roles * splits);
-    if (ciw == 32) {
+    if (K == 4) {
+        if (ciw != 64) return DWC_EINVAL;      // (DWC_X3_WDUO has no stride-2 instantiation)
+        if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<4, 128>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<4, 64>), grid, dim3(512), 0, st, a);
+    } else if (ciw == 32) {
         if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 32>), grid, dim3(256), 0, st, a);
         else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 32>), grid, dim3(256), 0, st, a);
         else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 32>), grid, dim3(256), 0, st, a);

@@ -540,7 +540,8 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
                     x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st),
                     scope_name=ctx.bscope, detail="wgrad-stem" + detail[5:]), "conv7_smallk_wgrad")
-            elif ((not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
+            elif ((not half) and (_x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
+                                  or (X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1))
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
                 _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(

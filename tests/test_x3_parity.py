@@ -174,6 +174,34 @@ def test_x3_weight_gradient_matches_float64(shape):
     assert err <= 2e-6 and err <= 2 * err32 + 2e-7
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 64, 32), (3, 128, 256, 32, 64), (2, 64, 64, 16, 32), (16, 64, 128, 128, 128)],
+                         ids=lambda s: "x".join(str(v) for v in s))
+def test_x3_stride2_weight_gradient_matches_float64(shape):
+    """dW of the 4x4 stride-2 reflect-pad-1 convolution on the split-product weight-gradient kernel (K = 4 form: the patch of a filter
+    column is a stride-2 column set of the input, filter row kh of output row ks reads patch row 2 ks + kh)."""
+    B, Cin, Cout, H, W = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g).to(DEV)
+    ref = torch.nn.grad.conv2d_weight(F.pad(x.double(), (1,) * 4, mode="reflect"), (Cout, Cin, 4, 4), dy.double(), stride=2)
+    ref32 = torch.nn.grad.conv2d_weight(F.pad(x.cpu(), (1,) * 4, mode="reflect"), (Cout, Cin, 4, 4), dy.cpu(), stride=2).double()
+    xd = x.permute(0, 2, 3, 1).contiguous()
+    dyd = dy.permute(0, 2, 3, 1).contiguous()
+    nws = lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cin, Cout, 4)
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    dw = torch.empty(Cout, Cin, 4, 4, dtype=torch.float32, device=DEV)
+    _lib.check(lib.dwc_x3_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, 4, Cin, Cout, ws.data_ptr(), nws,
+                                       torch.cuda.current_stream().cuda_stream), "x3_conv2d_wgrad")
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    err = (dw.double() - ref).abs().max().item() / scale
+    err32 = (ref32 - ref.cpu()).abs().max().item() / scale
+    print("s2 %s dW max err / scale vs float64: split-bf16 %.2e | fp32 CPU %.2e" % ("x".join(str(v) for v in shape), err, err32))
+    assert err <= 2e-6 and err <= 2 * err32 + 2e-7
+
+
 def test_x3_split_is_exact():
     """The three bf16 planes written by dwc_x3_weight_prepare sum to the fp32 weight exactly (no rounding anywhere)."""
     lib = _lib.load()
