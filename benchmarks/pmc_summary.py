@@ -53,7 +53,9 @@ def main():
             "in_apply", "in_bwd_apply", "act_bwd_partial", "fold_reflect_kernel", "fold_ring_kernel", "upsample2x_fwd_kernel",
             "ln_apply", "adam_multi_kernel", "ema_multi_kernel", "lstm_step_fwd", "lstm_step_bwd",
             "conv_halo_x3_kernel", "wgrad_x3_kernel", "x3_wgrad_reduce_kernel", "wgrad_halo_kernel", "wgrad_halo_reduce_kernel",
-            "conv_narrow_kernel", "conv_stem_kernel", "smallk_wgrad_kernel", "smallk_reduce_kernel")
+            "conv_narrow_kernel", "conv_stem_kernel", "smallk_wgrad_kernel", "smallk_reduce_kernel",
+            "conv_halo16_kernel", "fold_reflect_kernel_h8", "lstm_seq_fwd", "lstm_seq_bwd", "weight_refresh_multi_kernel",
+            "adv_tail_fwd_kernel", "adv_tail_bwd_kernel", "maxpool2_fwd_kernel", "in_stats_final", "ln_bwd_partial")
     res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --steps 2 "
                       "--warmup 1 --no-cpu-baseline",
            "note": "units KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); "
@@ -71,8 +73,8 @@ def main():
     family = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel",
               "wino_input_kernel", "wino_output_kernel", "fold_ring_kernel",
               # bf16 path (bench --config c2): im2col GEMM, halo-tiled kernel, ring strips + folds, split-K reduce
-              "gemm_kernel_h", "conv_halo_kernel", "conv_narrow_kernel", "conv_stem_kernel", "gemm_strips_kernel_h", "fold_ring_kernel_h",
-              "fold_reflect_kernel_h", "splitk_reduce_kernel_h")
+              "gemm_kernel_h", "conv_halo_kernel", "conv_halo16_kernel", "conv_narrow_kernel", "conv_stem_kernel", "gemm_strips_kernel_h",
+              "fold_ring_kernel_h", "fold_reflect_kernel_h", "fold_reflect_kernel_h8", "splitk_reduce_kernel_h")
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     spans_per_step = int(sys.argv[5]) if len(sys.argv) > 5 else 236
     res["config"] = sys.argv[6] if len(sys.argv) > 6 else "c1"
