@@ -68,7 +68,7 @@ int main(int argc, char** argv) {
             for (int r = 0; r < (reflect ? rounds : 1); ++r)
                 for (int v = 0; v < 3; ++v) {
                     HaloArgs a;
-                    a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = reflect ? db : nullptr; a.y = (bf16*)dy[v];
+                    a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = reflect ? db : nullptr; a.add = nullptr; a.y = (bf16*)dy[v];
                     a.B = s.B; a.H = s.H; a.W = s.H; a.Cin = s.Cin; a.logCin = dwc_ilog2_exact(s.Cin); a.N = s.Cout; a.K = s.K;
                     a.Kp = Kp; a.act = reflect ? DWC_ACT_RELU : DWC_ACT_NONE; a.reflect = reflect;
                     a.blocks_x = s.H / 16; a.blocks_per_img = (s.H / 16) * (s.H / 16);
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
         // timeline of the hand-scheduled kernel (diagnostic instantiation; shader cycles of wave 0, median over workgroups)
         if (s.B >= 128 && (s.K == 3 || s.Cout <= 128)) {
             HaloArgs a;
-            a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = db; a.y = (bf16*)dy[1];
+            a.x = (const bf16*)dx; a.w = (const bf16*)dw; a.bias = db; a.add = nullptr; a.y = (bf16*)dy[1];
             a.B = s.B; a.H = s.H; a.W = s.H; a.Cin = s.Cin; a.logCin = dwc_ilog2_exact(s.Cin); a.N = s.Cout; a.K = s.K;
             a.Kp = Kp; a.act = DWC_ACT_RELU; a.reflect = 1;
             a.blocks_x = s.H / 16; a.blocks_per_img = (s.H / 16) * (s.H / 16);

@@ -34,10 +34,19 @@ struct HaloArgs {
     const bf16* x;       // [B][H][W][Cin]
     const bf16* w;       // [N][Kp], k = (kh*K + kw)*Cin + ci   (dwc_bf16_weight_prepare_fwd / _dgrad layout)
     const float* bias;   // [N] or null
+    const bf16* add;     // [B][H][W][N] or null: added to the result behind bias + activation (a second gradient w.r.t. the same tensor)
     bf16* y;             // [B][H][W][N]
     int B, H, W, Cin, logCin, N, K, Kp, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
 };
+
+// bf16 + bf16 as torch adds them: both to fp32, one rounding of the sum
+__device__ __forceinline__ bf16x8 halo_add8(bf16x8 a, bf16x8 b) {
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (bf16)((float)a[k] + (float)b[k]);
+    return r;
+}
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
 // PB: patch buffers (2: the next channel slab's patch is staged during the taps of the current one; 1: it is staged at the slab
@@ -284,8 +293,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         const int col = n0 + ch * 8;
         if (col >= a.N) continue;
         const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
-        bf16* d = a.y + ((size_t)(n_img * a.H + yy) * a.W + xx) * a.N + col;
-        *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+        const size_t off = ((size_t)(n_img * a.H + yy) * a.W + xx) * a.N + col;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+        if (a.add) v = halo_add8(v, *reinterpret_cast<const bf16x8*>(a.add + off));
+        *reinterpret_cast<bf16x8*>(a.y + off) = v;
     }
 #endif
 }
@@ -607,11 +618,21 @@ int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K) 
  * networks.py:579-585) or zero (reflect == 0: the interior of the data gradient with w in dgrad layout, x := dY,
  * Cin := channels of dY, Cout := channels of dx; bias NULL, act NONE).  w prepared by dwc_bf16_weight_prepare_fwd / _dgrad
  * with cout_pad = Cout, cin_pad = Cin.  No scratch. */
+int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const float* bias, const void* add, void* y, int B, int H,
+                                  int W, int Cin, int Cout, int K, int act, int reflect, void* stream);
 int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
                               int Cout, int K, int act, int reflect, void* stream) {
+    return dwc_bf16_conv2d_same_halo_add(x, w_prepared, bias, nullptr, y, B, H, W, Cin, Cout, K, act, reflect, stream);
+}
+
+/* The same with `add` ([B,H,W,Cout] bf16 or NULL) added to the result behind bias and activation, as one more bf16 addition
+ * (both operands to fp32, one rounding): the data gradient of a ResBlock's first convolution takes the gradient of the identity
+ * branch (reference networks.py:521) here instead of in a separate pass over the tensor. */
+int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const float* bias, const void* add, void* y, int B, int H,
+                                  int W, int Cin, int Cout, int K, int act, int reflect, void* stream) {
     if (!halo_ok(B, H, W, Cin, Cout, K)) return DWC_EINVAL;
     HaloArgs a;
-    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = (bf16*)y;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = (const bf16*)add; a.y = (bf16*)y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout; a.K = K;
     a.Kp = (K * K * Cin + BK - 1) / BK * BK; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
@@ -726,7 +747,7 @@ int dwc_bf16_conv2d_s2_halo(const void* x, const void* w_prepared, const float* 
                             int act, void* stream) {
     if (!x || !w_prepared || !y || !dwc_bf16_conv2d_s2_halo_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
     HaloArgs a;
-    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = (bf16*)y;
+    a.x = (const bf16*)x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = (bf16*)y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.logCin = dwc_ilog2_exact(Cin); a.N = Cout; a.K = 4;
     a.Kp = (16 * Cin + BK - 1) / BK * BK; a.act = act; a.reflect = 1;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);

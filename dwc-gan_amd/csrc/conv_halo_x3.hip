@@ -53,6 +53,7 @@ struct X3Args {
     const float* x;      // [B][H][W][Cin] fp32
     const bf16* w;       // [K*K][Cin/16][3][rows][16]   (dwc_x3_weight_prepare)
     const float* bias;   // [N] or null
+    const float* add;    // [B][H][W][N] or null: added behind bias + activation (a second gradient w.r.t. the same tensor)
     float* y;            // [B][H][W][N] fp32
     int B, H, W, Cin, N, rows, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
                         if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
                         else v[k] = dwc_act_simple(v[k], slope);
                     }
+                    if (a.add) v += *reinterpret_cast<const f32x4*>(a.add + (dst - a.y) + col);
                     *reinterpret_cast<f32x4*>(dst + col) = v;
                 }
         }
@@ -744,11 +746,20 @@ int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int
  * multiple of 16; N = channels (row stride) of y, a multiple of 4, rows = row count the weights were prepared with (>= N).
  * reflect != 0: reflect padding (forward); reflect == 0: zero padding (interior of the data gradient with dgrad-prepared
  * weights, to be followed by dwc_conv2d_bwd_data_ring). */
+int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                           int Cin, int N, int rows, int K, int act, int reflect, void* stream);
 int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
                        int rows, int K, int act, int reflect, void* stream) {
+    return dwc_x3_conv2d_same_add(x, w_prepared, bias, nullptr, y, B, H, W, Cin, N, rows, K, act, reflect, stream);
+}
+
+/* The same with `add` ([B,H,W,N] fp32 or NULL) added to the result behind bias and activation (see
+ * dwc_bf16_conv2d_same_halo_add: the identity-branch gradient of a ResBlock rides on the data gradient of its first convolution). */
+int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                           int Cin, int N, int rows, int K, int act, int reflect, void* stream) {
     if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N) return DWC_EINVAL;
     X3Args a;
-    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = y;
+    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     const int blocks = B * a.blocks_per_img;
@@ -822,7 +833,7 @@ int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, 
                      int act, void* stream) {
     if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N) return DWC_EINVAL;
     X3Args a;
-    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.y = y;
+    a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = 1;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = (N + 63) / 64;

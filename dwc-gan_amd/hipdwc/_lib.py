@@ -91,6 +91,7 @@ SIGNATURES = {
     "dwc_bf16_conv2d_bwd_data_ring": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
     "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
+    "dwc_bf16_conv2d_same_halo_add": (c_int, [c_fp] * 5 + [c_int] * 8 + [c_fp]),
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
     "dwc_bf16_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_bwd_data_zeropad_ws_bytes": (c_sz, [c_int] * 8),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "dwc_x3_weight_prepared_elems": (c_sz, [c_int] * 3),
     "dwc_x3_weight_prepare": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp]),
     "dwc_x3_conv2d_same": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
+    "dwc_x3_conv2d_same_add": (c_int, [c_fp] * 5 + [c_int] * 9 + [c_fp]),
     "dwc_x3_conv2d_s2_ok": (c_int, [c_int] * 5),
     "dwc_x3_conv2d_s2": (c_int, [c_fp] * 4 + [c_int] * 7 + [c_fp]),
     "dwc_x3_conv2d_wgrad_ws_bytes": (c_sz, [c_int] * 6),

@@ -401,16 +401,36 @@ def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad, free=False):
     return bool(lib.dwc_x3_conv2d_same_ok(B, H, W, c_in, c_out, KH))
 
 
+class ResGradToken:
+    """Hands the identity-branch gradient of a residual block (``y = x + f(x)``, reference networks.py:521) from the op that
+    receives it (the norm the add rides on) to the data gradient of f's FIRST convolution, which adds it in its epilogue
+    (dwc_*_conv2d_same*_add) instead of autograd summing the two gradients of x in a pass of its own.  Autograd runs the norm's
+    backward before that convolution's (the convolution's gradient depends on it), every backward pass sets ``g`` afresh."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
+RES_FUSE = int(os.environ.get("DWC_RES_FUSE", "1"))      # 0: autograd adds the two gradients of a ResBlock input itself
+
+
+def res_token(x):
+    """A token for one residual block, or None when nothing would consume it."""
+    return ResGradToken() if RES_FUSE and torch.is_grad_enabled() and x.requires_grad else None
+
+
 class _Conv2d(torch.autograd.Function):
     """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4 (fp32) / 8 (bf16); its dtype is x's.
     ``owner``: the parameter(s) ``w`` is derived from when ``w`` is a fresh tensor on every call (prepared-weight cache)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True, owner=None):
+    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True, owner=None, token=None):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
         half = x.dtype == BF16
+        ctx.token = token
         B, Cx, H, W = x.shape
         Cout, Cin, KH, KW = w.shape
         if Cin > Cx:
@@ -522,6 +542,14 @@ class _Conv2d(torch.autograd.Function):
             if need_db:
                 db = db_full[:Cout]
         dx = dw = None
+        # identity-branch gradient of the residual block this convolution opens (ResGradToken), channels-last like dx
+        g_res = None
+        if ctx.token is not None:
+            g_res, ctx.token.g = ctx.token.g, None
+            if g_res is not None:
+                g_res = cl(g_res)
+                if g_res.shape[1] != Cx or g_res.dtype != dt or not ctx.needs_input_grad[0]:
+                    raise RuntimeError("residual-gradient token: shape / dtype of the identity branch does not match the block input")
         pow2 = (cop & (cop - 1)) == 0
         if ctx.needs_input_grad[1]:
             dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
@@ -596,11 +624,13 @@ class _Conv2d(torch.autograd.Function):
                 ws = workspace(nws, dev)
 
                 def run_x3():
-                    rc = lib.dwc_x3_conv2d_same(g.data_ptr(), w_x3.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, st)
+                    rc = lib.dwc_x3_conv2d_same_add(g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx,
+                                                    KH, 0, 0, st)
                     return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
                                                               W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
                 _lib.check(_timed("conv_halo_x3_kernel", flops, run_x3, scope_name=ctx.bscope, exec_flops=6 * flops,
                                   detail="dgrad-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same dgrad")
+                g_res = None                                   # consumed by the kernel's epilogue
             elif wt:
                 # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
                 U = _prepped(w, "wino_dgrad", cop, Cx, wt, owner)
@@ -620,11 +650,13 @@ class _Conv2d(torch.autograd.Function):
                 ws = workspace(nws, dev)
 
                 def run_halo():
-                    rc = lib.dwc_bf16_conv2d_same_halo(g.data_ptr(), w_dg.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st)
+                    rc = lib.dwc_bf16_conv2d_same_halo_add(g.data_ptr(), w_dg.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx,
+                                                           KH, 0, 0, st)
                     return rc or lib.dwc_bf16_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B,
                                                                    H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
                 _lib.check(_timed("conv_gemm_kernel", flops, run_halo, scope_name=ctx.bscope,
                                   detail="dgrad-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_same_halo dgrad")
+                g_res = None                                   # consumed by the kernel's epilogue
             else:
                 ws = workspace(nws, dev)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_same", x)(
@@ -647,15 +679,17 @@ class _Conv2d(torch.autograd.Function):
                 scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_bwd_data")
             if pad > 0:
                 _lib.check(_fn(lib, "reflect_pad_adjoint", x)(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
-        return dx, dw, db, None, None, None, None, None
+        if g_res is not None and dx is not None:               # no fused form on this path: the plain sum
+            dx = dx + g_res.to(dx.dtype)
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None):
+def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None, token=None):
     """Reflect-padded convolution + bias + activation.  Returns Cout channels (a channel
     slice of the 4-aligned buffer when Cout is not a multiple of 4).  ``bias_grad=False``: the caller feeds the
     result to an instance norm, whose mean subtraction makes the bias gradient identically zero -- it is returned
     as zeros instead of being reduced from dY."""
-    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner)
+    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner, token)
     return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
 
 
@@ -987,8 +1021,9 @@ def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh):
 # --------------------------------------------------------------------------------------
 class _InstNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, relu, eps):
+    def forward(ctx, x, gamma, beta, residual, relu, eps, token=None):
         _require_device(x)
+        ctx.token = token if residual is not None else None
         lib = _lib.load()
         x = cl(x)
         B, C, H, W = x.shape
@@ -1025,12 +1060,16 @@ class _InstNorm(torch.autograd.Function):
         _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                         dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
                                         ws.numel(), _stream()), "instnorm_bwd")
-        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None
+        if ctx.token is not None:                 # the first convolution of the block adds it in its data-gradient epilogue
+            ctx.token.g = dy
+            return dx, dgamma, dbeta, None, None, None, None
+        return dx, dgamma, dbeta, (dy if ctx.has_res else None), None, None, None
 
 
-def instance_norm(x, gamma=None, beta=None, residual=None, relu=False, eps=1e-5):
-    """IN / AdaIN (+ReLU) (+residual add).  gamma/beta: flat [B*C] per-sample scale/shift or None."""
-    return _InstNorm.apply(x, gamma, beta, residual, bool(relu), float(eps))
+def instance_norm(x, gamma=None, beta=None, residual=None, relu=False, eps=1e-5, token=None):
+    """IN / AdaIN (+ReLU) (+residual add).  gamma/beta: flat [B*C] per-sample scale/shift or None.  ``token``: see
+    ResGradToken (the residual's gradient is handed to the block's first convolution instead of being returned)."""
+    return _InstNorm.apply(x, gamma, beta, residual, bool(relu), float(eps), token)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -37,10 +37,10 @@ class AdaptiveInstanceNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
 
-    def forward(self, x, relu=False, residual=None):
+    def forward(self, x, relu=False, residual=None, token=None):
         if self.weight is None or self.bias is None:
             raise AssertionError("Please assign weight and bias before calling AdaIN!")
-        return ops.instance_norm(x, self.weight, self.bias, residual=residual, relu=relu, eps=self.eps)
+        return ops.instance_norm(x, self.weight, self.bias, residual=residual, relu=relu, eps=self.eps, token=token)
 
     def __repr__(self):
         return "%s(%d)" % (type(self).__name__, self.num_features)
@@ -67,8 +67,8 @@ class LayerNorm(nn.Module):
 class _PlainInstanceNorm(nn.InstanceNorm2d):
     """nn.InstanceNorm2d(affine=False) as a marker/parameter-less container (reference networks.py:545)."""
 
-    def forward(self, x, relu=False, residual=None):
-        return ops.instance_norm(x, None, None, residual=residual, relu=relu, eps=self.eps)
+    def forward(self, x, relu=False, residual=None, token=None):
+        return ops.instance_norm(x, None, None, residual=residual, relu=relu, eps=self.eps, token=token)
 
 
 # --------------------------------------------------------------------------------------
@@ -105,19 +105,21 @@ class Conv2dBlock(nn.Module):
             raise NotImplementedError("norm followed by %r is not fused" % activation)
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)  # parameter container
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, conv_token=None, res_token=None):
+        """``conv_token`` / ``res_token`` (hipdwc.ops.ResGradToken, both optional): this block's convolution opens / this block's
+        norm closes a residual block whose identity-branch gradient is added in the convolution's data-gradient epilogue."""
         if x.shape[1] < 4:
             x = ops.pack_image(x)
         if self.norm is None:
-            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, self.act_kind)
+            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, self.act_kind, token=conv_token)
             return y if residual is None else y + residual
         y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, "none",
-                       bias_grad=self.norm_kind == "ln")      # IN / AdaIN subtract the per-(n,c) mean: d/d bias == 0
+                       bias_grad=self.norm_kind == "ln", token=conv_token)   # IN / AdaIN subtract the per-(n,c) mean: d/d bias == 0
         relu = self.act_kind == "relu"
         if self.norm_kind == "ln":
             y = self.norm(y, relu=relu)
             return y if residual is None else y + residual
-        return self.norm(y, relu=relu, residual=residual)
+        return self.norm(y, relu=relu, residual=residual, token=res_token)
 
 
 class ResBlock(nn.Module):
@@ -130,7 +132,11 @@ class ResBlock(nn.Module):
             Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation="none", pad_type=pad_type))
 
     def forward(self, x):
-        return self.model[1](self.model[0](x), residual=x)
+        # the gradient of the identity branch rides on the data gradient of the first convolution (ops.ResGradToken); only when
+        # the closing norm takes the residual itself (IN / AdaIN) -- otherwise autograd sums the two gradients as usual
+        fused = self.model[1].norm_kind in ("in", "adain")
+        token = ops.res_token(x) if fused else None
+        return self.model[1](self.model[0](x, conv_token=token), residual=x, res_token=token)
 
 
 class ResBlocks(nn.Module):

@@ -320,6 +320,10 @@ size_t dwc_x3_weight_prepared_elems(int rows, int kdim, int K);
 int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, void* stream);
 int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
                        int rows, int K, int act, int reflect, void* stream);
+/* dwc_x3_conv2d_same with `add` ([B,H,W,N] fp32 or NULL) added behind bias and activation: the identity-branch gradient of a
+ * ResBlock (reference networks.py:521) rides on the data gradient of its first convolution instead of costing a pass. */
+int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                           int Cin, int N, int rows, int K, int act, int reflect, void* stream);
 /* The 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) on the same kernel: 2x2 taps
  * per input-pixel parity over the space-to-depth image, the space-to-depth done by the patch gather.  x:[B,H,W,Cin] ->
  * y:[B,H/2,W/2,N]; H, W multiples of 32, Cin a multiple of 16; w_prepared = dwc_x3_weight_prepare(K = 4, forward). */
@@ -380,6 +384,10 @@ int dwc_bf16_maxpool2_bwd(const void* x, const void* dy, void* dx, int B, int H,
 int dwc_bf16_conv2d_same_halo_ok(int B, int H, int W, int Cin, int Cout, int K);
 int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin,
                               int Cout, int K, int act, int reflect, void* stream);
+/* ... with `add` ([B,H,W,Cout] bf16 or NULL) added behind bias and activation as one more bf16 addition: the identity-branch
+ * gradient of a ResBlock (reference networks.py:521) rides on the data gradient of its first convolution. */
+int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const float* bias, const void* add, void* y, int B, int H,
+                                  int W, int Cin, int Cout, int K, int act, int reflect, void* stream);
 
 /* The stride-2 4x4 reflect-pad-1 convolutions (reference networks.py:90,94,437 -- content encoder / discriminator --,
  * networks_v2.py:107-111 -- style encoder), forward, bf16 NHWC: x [B,H,W,Cin] -> y [B,H/2,W/2,Cout], halo form over the
