@@ -16,6 +16,8 @@
 // Output [B][OH][OWg][32] bf16 (= the NHWC8 image when OWg*4 is its width); the input window of output (oy, group gx) starts at
 // (oy + off_h, 4*gx + off_w): forward off = -pad with the reflect rule; image gradient off = -(K-1) with the zero rule on
 // the padded grid (OH = H + 2 pad), folded back by dwc_bf16_reflect_pad_adjoint's kernel as before.
+#include <type_traits>
+
 #include "conv_geom.h"
 
 namespace {
@@ -423,27 +425,58 @@ __global__ __launch_bounds__(512, 2) void smallk_wgrad_kernel(SmallWgradArgs a) 
     const int tq = li >> 2, tp = li & 3;
     const int pxl = 8 * hi + tq;
     const int row_el = 16 * gam + 4 * tp;               // (tap-in-group, plane) row -> element offset from the tap group's first pixel
-    typedef __attribute__((address_space(3))) bf16x4* lds4;
-    auto a_frag = [&](const bf16* p, int ks, int g) {
-        const int kh = g >> 1, kw0 = 4 * (g & 1);
-        bf16x4 v[2];
+    // Fragment reads as asm statements with hand-counted waits tied to the fragment registers: as builtins hipcc cannot tell them
+    // from the LDS-DMA's target and drains vmcnt(0) -- the unit staged a moment ago -- in front of the next read (see
+    // wgrad_halo_kernel in conv_halo_bf16.hip).  One k-step (a row of 16 pixels) of fragments is read ahead of the MFMAs.
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sA;
+    const unsigned ldsB = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)sB;
+    auto tr_read = [](bf16x4& dst, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr)); };
+    bf16x4 fa[2][2][2], fb[2][2][2];                    // [set][tile][half]
+    auto fetch = [&](auto setc, unsigned pbase, unsigned dbase, int ks) {
+        constexpr int set = decltype(setc)::value;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int pp = (ks + kh) * PCA + pxl + 4 * half + kw0;
-            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(p + pp * 8 + row_el));
-        }
-        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    auto b_frag = [&](const bf16* d, int ks, int ct) {
-        const int col = ct * 32 + 16 * gam + 4 * tp;
-        bf16x4 v[2];
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = ct * 32 + 16 * gam + 4 * tp;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int m = ks * 16 + pxl + 4 * half;
-            v[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(d + m * 64 + (((col >> 3) ^ (4 * ((m >> 1) & 1))) << 3) + (col & 7)));
+            for (int half = 0; half < 2; ++half) {
+                const int m = ks * 16 + pxl + 4 * half;
+                bf16x4& dst = fb[set][ct][half];
+                tr_read(dst, dbase + (unsigned)(m * 64 + (((col >> 3) ^ (4 * ((m >> 1) & 1))) << 3) + (col & 7)) * 2u);
+            }
         }
-        return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int g = wave + 8 * (i < ng ? i : 0);       // (ng == 1: the second tile re-reads the first, unused)
+            const int kh = g >> 1, kw0 = 4 * (g & 1);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int pp = (ks + kh) * PCA + pxl + 4 * half + kw0;
+                bf16x4& dst = fa[set][i][half];
+                tr_read(dst, pbase + (unsigned)(pp * 8 + row_el) * 2u);
+            }
+        }
     };
+    auto compute = [&](auto setc, auto youngerc) {
+        constexpr int set = decltype(setc)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x4 &a0 = fa[set][i][0], &a1 = fa[set][i][1], &b0 = fb[set][i][0], &b1 = fb[set][i][1];
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : "n"(decltype(youngerc)::value));
+        }
+        const bf16x8 fb0 = __builtin_shufflevector(fb[set][0][0], fb[set][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 fb1 = __builtin_shufflevector(fb[set][1][0], fb[set][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i < ng) {
+                const bf16x8 fav = __builtin_shufflevector(fa[set][i][0], fa[set][i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fav, fb0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fav, fb1, acc[i][1], 0, 0, 0);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 8> Y8;             // the 8 reads of the k-step fetched ahead may stay in flight
 
     if (u0 < u1) {
         stage_unit(u0, 0);
@@ -452,18 +485,17 @@ __global__ __launch_bounds__(512, 2) void smallk_wgrad_kernel(SmallWgradArgs a) 
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
             if (u + 1 < u1) stage_unit(u + 1, buf ^ 1);
-            const bf16* p = sA + buf * A_EL;
-            const bf16* d = sB + buf * B_EL;
-#pragma unroll 2
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 fb0 = b_frag(d, ks, 0), fb1 = b_frag(d, ks, 1);
+            const unsigned pbase = lds0 + (unsigned)(buf * A_EL) * 2u, dbase = ldsB + (unsigned)(buf * B_EL) * 2u;
+            fetch(S0{}, pbase, dbase, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i < ng) {
-                        const bf16x8 fa = a_frag(p, ks, wave + 8 * i);
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb0, acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb1, acc[i][1], 0, 0, 0);
-                    }
+            for (int ks = 0; ks < 8; ks += 2) {
+                fetch(S1{}, pbase, dbase, ks + 1);
+                compute(S0{}, Y8{});
+                if (ks + 2 < 8) {
+                    fetch(S0{}, pbase, dbase, ks + 2);
+                    compute(S1{}, Y8{});
+                } else {
+                    compute(S1{}, S0{});                   // last k-step: everything has landed, the barrier may free the buffer
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
