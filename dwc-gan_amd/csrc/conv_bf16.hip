@@ -342,8 +342,14 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
             const int n_img = m / ohw;
             const int rem = m - n_img * ohw;
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+            const int py = oh * o.os + oph, px = ow * o.os + opw;
+            const size_t prow = ((size_t)n_img * o.OHf + py) * o.OWf + px;
             bf16* d = dst + prow * o.N + col;
+            if (o.crop) {                                 // interior pixels of a padded gradient image go straight to the unpadded tensor
+                const int yy = py - o.crop, xx = px - o.crop;
+                if ((unsigned)yy < (unsigned)o.IH && (unsigned)xx < (unsigned)o.IW)
+                    d = (bf16*)o.inner + (((size_t)n_img * o.IH + yy) * o.IW + xx) * o.N + col;
+            }
             const bf16* s = sC + row * LDC + ch * 8;
             if (wide && col + 8 <= o.N) {
                 *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(s);
@@ -686,6 +692,55 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel_h8(const bf16* __rest
     reinterpret_cast<bf16x8*>(dx)[((n * H + h) * (size_t)W + w) * C8 + c] = o;
 }
 
+// dx (holds the interior of the padded gradient image already: Scatter::crop) += the border ring of gp folded back by the reflect
+// rule.  Only the pixels a ring pixel folds onto are touched: rows 1..pad and H-1-pad..H-2 (row_band launch: whole rows), and
+// columns 1..pad and W-1-pad..W-2 of the other rows (second launch).
+__global__ __launch_bounds__(256) void fold_band_kernel_h8(const bf16* __restrict__ gp, bf16* __restrict__ dx, int H, int W, int C8,
+                                                           int pad, int Wp, int row_band) {
+    const size_t n = blockIdx.z;
+    const int Hp = H + 2 * pad;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int h, w, c;
+    if (row_band) {                                       // grid (W*C8 / 256, 2*pad, B)
+        if (idx >= W * C8) return;
+        h = (int)blockIdx.y < pad ? 1 + blockIdx.y : H - 1 - pad + (blockIdx.y - pad);
+        w = idx / C8;
+        c = idx - w * C8;
+    } else {                                              // grid (2*pad*C8 / 256, H, B)
+        if (idx >= 2 * pad * C8) return;
+        h = blockIdx.y;
+        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;      // done as a whole row
+        const int q = idx / C8;
+        c = idx - q * C8;
+        w = q < pad ? 1 + q : W - 1 - pad + (q - pad);
+    }
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    if (nh * nw == 1) return;
+    const size_t o = ((n * H + h) * (size_t)W + w) * C8 + c;
+    const bf16x8 cur = reinterpret_cast<const bf16x8*>(dx)[o];
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = (float)cur[k];
+    const bf16x8* g8 = reinterpret_cast<const bf16x8*>(gp);
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            if (a == 0 && b == 0) continue;               // the pixel's own (interior) value is in dx already
+            const bf16x8 v = g8[((n * Hp + hs[a]) * (size_t)Wp + ws[b]) * C8 + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+        }
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (bf16)s[k];
+    reinterpret_cast<bf16x8*>(dx)[o] = r;
+}
+
 // dx (bf16, holds the interior) += the fp32 border ring folded back by the reflect rule (see fold_ring_kernel, conv_igemm.hip)
 __global__ void fold_ring_kernel_h(bf16* __restrict__ dx, const float* __restrict__ ring, size_t off_bottom, size_t off_left,
                                    size_t off_right, int parts, size_t part_stride, int B, int H, int W, int C4, int pad) {
@@ -991,6 +1046,34 @@ int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int
     if ((Cin & 7) || !bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, BK, MIN_LOG_C)) return DWC_EINVAL;
     return launch_gemm_h(f.g, (const bf16*)w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes,
                          (hipStream_t)stream);
+}
+
+int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream);
+/* dwc_bf16_conv2d_bwd_data + dwc_bf16_reflect_pad_adjoint in one call: dx ([B,H,W,Cin]) = reflect-pad adjoint of the gradient of
+ * the padded image.  Where the GEMM runs unsplit the interior of that image is written straight into dx and only its border ring
+ * into dxp (scratch for [B,H+2pad,W+2pad,Cin] bf16), a band kernel then folds the ring onto dx: one pass over the tensor instead of
+ * three.  Otherwise (split-K) the two-step form runs. */
+int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
+                                  int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    BwdGeom f;
+    if ((Cin & 7) || pad <= 0 || !bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f, BK, MIN_LOG_C)) return DWC_EINVAL;
+    if (H < 2 * pad + 2 || W < 2 * pad + 2 || H > 65535 - 2 * pad || B > 65535) return DWC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const Plan p = plan_gemm_h(f.g.M, f.o.N, f.g.K, f.classes);
+    const bool direct = p.splits == 1;
+    if (direct) {
+        f.o.crop = pad; f.o.IH = H; f.o.IW = W; f.o.inner = dx;
+    }
+    int rc = launch_gemm_h(f.g, (const bf16*)w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, st);
+    if (rc != DWC_OK) return rc;
+    if (!direct) return dwc_bf16_reflect_pad_adjoint(dxp, dx, B, H, W, Cin, pad, stream);
+    const int C8 = Cin / 8;
+    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((W * C8 + 255) / 256, 2 * pad, B), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, H, W, C8,
+                       pad, W + 2 * pad, 1);
+    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((2 * pad * C8 + 255) / 256, H, B), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, H, W, C8,
+                       pad, W + 2 * pad, 0);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
 }
 
 int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream) {

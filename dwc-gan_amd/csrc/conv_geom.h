@@ -29,6 +29,11 @@ struct Scatter {       // where GEMM row m lands in the destination tensor
     void* dst;         // [B][OHf][OWf][N]
     int N;
     int OHf, OWf, os;  // dst pixel = (oh*os + oph, ow*os + opw)
+    // crop > 0 (data gradients through a reflect pad): dst is the gradient of the PADDED image, of which only the border ring is
+    // wanted there -- a pixel whose cropped coordinate (py - crop, px - crop) lies inside IH x IW goes straight to `inner`
+    // ([B][IH][IW][N], the gradient of the unpadded tensor), the ring pixels to dst; a band fold adds them onto `inner` afterwards
+    int crop = 0, IH = 0, IW = 0;
+    void* inner = nullptr;
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {

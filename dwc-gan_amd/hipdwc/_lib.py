@@ -85,6 +85,7 @@ SIGNATURES = {
     "dwc_bf16_conv2d_fwd_ex": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 12 + [c_fp]),
     "dwc_bf16_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_bf16_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
+    "dwc_bf16_conv2d_bwd_data_fold": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_bf16_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
     "dwc_bf16_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),

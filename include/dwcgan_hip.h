@@ -358,6 +358,12 @@ size_t dwc_bf16_conv2d_bwd_data_ws_bytes(int B, int H, int W, int Cin, int Cout,
 int dwc_bf16_conv2d_bwd_data(const void* dy, const void* w_dgrad, void* dxp, int B, int H, int W, int Cin, int Cout, int KH,
                              int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream);
+/* dwc_bf16_conv2d_bwd_data followed by dwc_bf16_reflect_pad_adjoint, as one call: where the GEMM runs unsplit the interior of the
+ * padded gradient image goes straight into dx and only its border ring into the scratch image dxp ([B,H+2pad,W+2pad,Cin] bf16),
+ * which a band kernel folds onto dx -- one pass over the tensor instead of three (reference: autograd of the reflect pad in
+ * Conv2dBlock.forward, networks.py:579-585, for the stride-2 layers networks.py:90,94,437 / networks_v2.py:107-111). */
+int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
+                                  int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
                                   int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
