@@ -242,7 +242,13 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
                 const int n_img = m / ohw;
                 const int rem = m - n_img * ohw;
                 const int oh = rem / g.OW, ow = rem - oh * g.OW;
-                const size_t prow = ((size_t)n_img * o.OHf + (oh * o.os + oph)) * o.OWf + (ow * o.os + opw);
+                const int py = oh * o.os + oph, px = ow * o.os + opw;
+                float* drow = dst + (((size_t)n_img * o.OHf + py) * o.OWf + px) * o.N;
+                if (o.crop && !partial) {                 // Scatter::crop: interior pixels of a padded gradient image go straight to dx
+                    const int yy = py - o.crop, xx = px - o.crop;
+                    if ((unsigned)yy < (unsigned)o.IH && (unsigned)xx < (unsigned)o.IW)
+                        drow = (float*)o.inner + (((size_t)n_img * o.IH + yy) * o.IW + xx) * o.N;
+                }
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
                     const int col = n0 + (wn * TN + n) * 32 + l31;
@@ -253,7 +259,7 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
                             if constexpr (decltype(general)::value) v = dwc_act_apply(v, act, col);
                             else v = dwc_act_simple(v, slope);
                         }
-                        dst[prow * o.N + col] = v;
+                        drow[col] = v;
                     }
                 }
             }
@@ -630,6 +636,47 @@ __global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restr
     for (int a = 0; a < nh; ++a)
         for (int b = 0; b < nw; ++b) s += g4[((size_t)(n * Hp + hs[a]) * Wp + ws[b]) * C4 + c];
     reinterpret_cast<f32x4*>(dx)[idx] = s;
+}
+
+// dx (holds the interior of the padded gradient image already: Scatter::crop) += the border ring of gp folded back by the reflect
+// rule; only the pixels a ring pixel folds onto are visited (row_band: rows 1..pad and H-1-pad..H-2 whole, grid (W*C4/256, 2*pad,
+// B); else columns 1..pad and W-1-pad..W-2 of the other rows, grid (2*pad*C4/256, H, B)).
+__global__ __launch_bounds__(256) void fold_band_kernel(const float* __restrict__ gp, float* __restrict__ dx, int H, int W, int C4, int pad,
+                                                        int Wp, int row_band) {
+    const size_t n = blockIdx.z;
+    const int Hp = H + 2 * pad;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int h, w, c;
+    if (row_band) {
+        if (idx >= W * C4) return;
+        h = (int)blockIdx.y < pad ? 1 + blockIdx.y : H - 1 - pad + (blockIdx.y - pad);
+        w = idx / C4;
+        c = idx - w * C4;
+    } else {
+        if (idx >= 2 * pad * C4) return;
+        h = blockIdx.y;
+        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;      // done as a whole row
+        const int q = idx / C4;
+        c = idx - q * C4;
+        w = q < pad ? 1 + q : W - 1 - pad + (q - pad);
+    }
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + pad;
+    if (h >= 1 && h <= pad) hs[nh++] = pad - h;
+    if (h >= H - 1 - pad && h <= H - 2) hs[nh++] = pad + 2 * (H - 1) - h;
+    ws[nw++] = w + pad;
+    if (w >= 1 && w <= pad) ws[nw++] = pad - w;
+    if (w >= W - 1 - pad && w <= W - 2) ws[nw++] = pad + 2 * (W - 1) - w;
+    if (nh * nw == 1) return;
+    const size_t o = ((n * H + h) * (size_t)W + w) * C4 + c;
+    f32x4 s = reinterpret_cast<const f32x4*>(dx)[o];
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gp);
+    for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+            if (a == 0 && b == 0) continue;               // the pixel's own (interior) value is in dx already
+            s += g4[((n * Hp + hs[a]) * (size_t)Wp + ws[b]) * C4 + c];
+        }
+    reinterpret_cast<f32x4*>(dx)[o] = s;
 }
 
 // Weight layouts streamed by conv_gemm_kernel: one row per GEMM column n, K contiguous and
@@ -1589,6 +1636,32 @@ int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp, int B
     BwdGeom f;
     if (!bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
     return launch_gemm(f.g, w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
+}
+
+/* dwc_conv2d_bwd_data + dwc_reflect_pad_adjoint as one call (see dwc_bf16_conv2d_bwd_data_fold): where the GEMM runs unsplit the
+ * interior of the padded gradient image goes straight into dx, only its border ring through the scratch image dxp, folded back by a
+ * band kernel. */
+int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                             int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream) {
+    BwdGeom f;
+    if ((Cin & 3) || pad <= 0 || !bwd_geom(dy, dxp, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
+    if (H < 2 * pad + 2 || W < 2 * pad + 2 || H > 65535 - 2 * pad || B > 65535) return DWC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const Plan p = plan_gemm(f.g.M, f.o.N, f.g.K, f.classes);
+    const bool direct = p.splits == 1;
+    if (direct) {
+        f.o.crop = pad; f.o.IH = H; f.o.IW = W; f.o.inner = dx;
+    }
+    int rc = launch_gemm(f.g, w_dgrad, f.wcs, f.classes, f.o, nullptr, DWC_ACT_NONE, f.dst_elems, ws, ws_bytes, st);
+    if (rc != DWC_OK) return rc;
+    if (!direct) return dwc_reflect_pad_adjoint(dxp, dx, B, H, W, Cin, pad, stream);
+    const int C4 = Cin / 4;
+    hipLaunchKernelGGL(fold_band_kernel, dim3((W * C4 + 255) / 256, 2 * pad, B), dim3(256), 0, st, (const float*)dxp, dx, H, W, C4, pad,
+                       W + 2 * pad, 1);
+    hipLaunchKernelGGL(fold_band_kernel, dim3((2 * pad * C4 + 255) / 256, H, B), dim3(256), 0, st, (const float*)dxp, dx, H, W, C4, pad,
+                       W + 2 * pad, 0);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
 }
 
 size_t dwc_conv2d_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad) {

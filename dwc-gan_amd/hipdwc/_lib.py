@@ -29,6 +29,7 @@ SIGNATURES = {
     "dwc_conv2d_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_bwd_data_ws_bytes": (c_sz, [c_int] * 9),
     "dwc_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
+    "dwc_conv2d_bwd_data_fold": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
     "dwc_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
     "dwc_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),

@@ -372,7 +372,7 @@ WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
 LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM forward: all time steps in one persistent launch
-DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # bf16 data gradients through a reflect pad: interior straight into dx + band fold
+DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # data gradients through a reflect pad: interior straight into dx + band fold
 X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 
@@ -675,9 +675,9 @@ class _Conv2d(torch.autograd.Function):
             base = workspace(pad_bytes + nws, dev).data_ptr() if pad_bytes + nws else 0
             target = dx.data_ptr() if pad == 0 else base
             wsp = base + pad_bytes if nws else None
-            if half and pad > 0 and DGRAD_FOLD and min(H, W) >= 2 * pad + 2 and Cx % 8 == 0:
+            if pad > 0 and DGRAD_FOLD and min(H, W) >= 2 * pad + 2 and Cx % (8 if half else 4) == 0:
                 # GEMM + reflect-pad adjoint in one call: interior straight into dx, only the border ring through the padded scratch
-                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_bwd_data_fold(
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_fold", x)(
                     g.data_ptr(), w_dg.data_ptr(), target, dx.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, wsp, nws, st),
                     scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_bwd_data_fold")
             else:

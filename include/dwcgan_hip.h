@@ -80,6 +80,11 @@ int dwc_conv2d_bwd_data(const float* dy, const float* w_dgrad, float* dxp,
 /* Data gradient, step 2: adjoint of the reflect padding — fold dxp back onto dx:[B,H,W,C]. */
 int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, int C, int pad,
                             void* stream);
+/* dwc_conv2d_bwd_data followed by dwc_reflect_pad_adjoint as one call: where the GEMM runs unsplit the interior of the padded
+ * gradient image goes straight into dx and only its border ring through the scratch image dxp ([B,H+2pad,W+2pad,Cin]), which a
+ * band kernel folds onto dx (one pass over the tensor instead of three). */
+int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout, int KH,
+                             int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
 /* Data gradient of a stride-1 "same" convolution (square filter, 2*pad == K-1: the 3x3 ResBlock, 5x5 upsampling and 7x7
  * head convolutions, reference networks.py:514-515, networks_v2.py:155,159-160) in ONE call, dx:[B,H,W,Cin] final.
  * The interior of the padded gradient image is computed on the H x W grid straight into dx; of the padding ring only
