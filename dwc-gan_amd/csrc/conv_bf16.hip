@@ -693,26 +693,33 @@ __global__ __launch_bounds__(256) void fold_reflect_kernel_h8(const bf16* __rest
 }
 
 // dx (holds the interior of the padded gradient image already: Scatter::crop) += the border ring of gp folded back by the reflect
-// rule.  Only the pixels a ring pixel folds onto are touched: rows 1..pad and H-1-pad..H-2 (row_band launch: whole rows), and
-// columns 1..pad and W-1-pad..W-2 of the other rows (second launch).
-__global__ __launch_bounds__(256) void fold_band_kernel_h8(const bf16* __restrict__ gp, bf16* __restrict__ dx, int H, int W, int C8,
-                                                           int pad, int Wp, int row_band) {
-    const size_t n = blockIdx.z;
+// rule.  Only the pixels a ring pixel folds onto are touched: rows 1..pad and H-1-pad..H-2 (whole rows), and columns 1..pad and
+// W-1-pad..W-2 of the other rows.
+__global__ __launch_bounds__(256) void fold_band_kernel_h8(const bf16* __restrict__ gp, bf16* __restrict__ dx, int B, int H, int W, int C8,
+                                                                    int pad, int Wp) {
+    // one thread per (image, band pixel, channel chunk): per image the 2*pad band rows whole (W pixels each), then the 2*pad band
+    // columns of the H - 2*pad other rows
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int rows_done = 2 * pad, rest = H - 2 * pad;          // band rows, other rows
+    const int band = rows_done * W + rest * 2 * pad;            // band pixels per image
+    const size_t total = (size_t)B * band * C8;
+    if (idx >= total) return;
+    const int c = idx % C8;
+    size_t r = idx / C8;
+    const int q = r % band;
+    const size_t n = r / band;
     const int Hp = H + 2 * pad;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    int h, w, c;
-    if (row_band) {                                       // grid (W*C8 / 256, 2*pad, B)
-        if (idx >= W * C8) return;
-        h = (int)blockIdx.y < pad ? 1 + blockIdx.y : H - 1 - pad + (blockIdx.y - pad);
-        w = idx / C8;
-        c = idx - w * C8;
-    } else {                                              // grid (2*pad*C8 / 256, H, B)
-        if (idx >= 2 * pad * C8) return;
-        h = blockIdx.y;
-        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;      // done as a whole row
-        const int q = idx / C8;
-        c = idx - q * C8;
-        w = q < pad ? 1 + q : W - 1 - pad + (q - pad);
+    int h, w;
+    if (q < rows_done * W) {
+        const int br = q / W;
+        w = q - br * W;
+        h = br < pad ? 1 + br : H - 1 - pad + (br - pad);
+    } else {
+        const int q2 = q - rows_done * W;
+        const int hr = q2 / (2 * pad), k = q2 - hr * 2 * pad;
+        // the hr-th row that is NOT a band row: rows 0, pad+1 .. H-2-pad, H-1
+        h = hr == 0 ? 0 : (hr == rest - 1 ? H - 1 : pad + hr);
+        w = k < pad ? 1 + k : W - 1 - pad + (k - pad);
     }
     int hs[3], ws[3], nh = 0, nw = 0;
     hs[nh++] = h + pad;
@@ -735,10 +742,10 @@ __global__ __launch_bounds__(256) void fold_band_kernel_h8(const bf16* __restric
 #pragma unroll
             for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
         }
-    bf16x8 r;
+    bf16x8 res;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = (bf16)s[k];
-    reinterpret_cast<bf16x8*>(dx)[o] = r;
+    for (int k = 0; k < 8; ++k) res[k] = (bf16)s[k];
+    reinterpret_cast<bf16x8*>(dx)[o] = res;
 }
 
 // dx (bf16, holds the interior) += the fp32 border ring folded back by the reflect rule (see fold_ring_kernel, conv_igemm.hip)
@@ -1068,10 +1075,22 @@ int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp
     if (rc != DWC_OK) return rc;
     if (!direct) return dwc_bf16_reflect_pad_adjoint(dxp, dx, B, H, W, Cin, pad, stream);
     const int C8 = Cin / 8;
-    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((W * C8 + 255) / 256, 2 * pad, B), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, H, W, C8,
-                       pad, W + 2 * pad, 1);
-    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((2 * pad * C8 + 255) / 256, H, B), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, H, W, C8,
-                       pad, W + 2 * pad, 0);
+    const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C8;
+    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, B, H, W,
+                       C8, pad, W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* dx (already holding the interior of the padded gradient image dxp) += the border ring of dxp folded back by the reflect rule:
+ * the second half of dwc_bf16_conv2d_bwd_data_fold for producers with their own epilogue (dwc_bf16_conv2d_stem_crop). */
+int dwc_bf16_reflect_pad_adjoint_band(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream) {
+    if (B <= 0 || (C & 7) || pad <= 0 || H < 2 * pad + 2 || W < 2 * pad + 2 || H > 65535 || B > 65535) return DWC_EINVAL;
+    const int C8 = C / 8;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C8;
+    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, B, H, W,
+                       C8, pad, W + 2 * pad);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

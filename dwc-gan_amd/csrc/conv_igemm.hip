@@ -639,26 +639,33 @@ __global__ void fold_reflect_kernel(const float* __restrict__ gp, float* __restr
 }
 
 // dx (holds the interior of the padded gradient image already: Scatter::crop) += the border ring of gp folded back by the reflect
-// rule; only the pixels a ring pixel folds onto are visited (row_band: rows 1..pad and H-1-pad..H-2 whole, grid (W*C4/256, 2*pad,
-// B); else columns 1..pad and W-1-pad..W-2 of the other rows, grid (2*pad*C4/256, H, B)).
-__global__ __launch_bounds__(256) void fold_band_kernel(const float* __restrict__ gp, float* __restrict__ dx, int H, int W, int C4, int pad,
-                                                        int Wp, int row_band) {
-    const size_t n = blockIdx.z;
+// rule; only the pixels a ring pixel folds onto are visited (rows 1..pad and H-1-pad..H-2 whole, columns 1..pad and W-1-pad..W-2
+// of the other rows).
+__global__ __launch_bounds__(256) void fold_band_kernel(const float* __restrict__ gp, float* __restrict__ dx, int B, int H, int W, int C4,
+                                                                 int pad, int Wp) {
+    // one thread per (image, band pixel, channel chunk): per image the 2*pad band rows whole (W pixels each), then the 2*pad band
+    // columns of the H - 2*pad other rows
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int rows_done = 2 * pad, rest = H - 2 * pad;          // band rows, other rows
+    const int band = rows_done * W + rest * 2 * pad;            // band pixels per image
+    const size_t total = (size_t)B * band * C4;
+    if (idx >= total) return;
+    const int c = idx % C4;
+    size_t r = idx / C4;
+    const int q = r % band;
+    const size_t n = r / band;
     const int Hp = H + 2 * pad;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    int h, w, c;
-    if (row_band) {
-        if (idx >= W * C4) return;
-        h = (int)blockIdx.y < pad ? 1 + blockIdx.y : H - 1 - pad + (blockIdx.y - pad);
-        w = idx / C4;
-        c = idx - w * C4;
+    int h, w;
+    if (q < rows_done * W) {
+        const int br = q / W;
+        w = q - br * W;
+        h = br < pad ? 1 + br : H - 1 - pad + (br - pad);
     } else {
-        if (idx >= 2 * pad * C4) return;
-        h = blockIdx.y;
-        if ((h >= 1 && h <= pad) || (h >= H - 1 - pad && h <= H - 2)) return;      // done as a whole row
-        const int q = idx / C4;
-        c = idx - q * C4;
-        w = q < pad ? 1 + q : W - 1 - pad + (q - pad);
+        const int q2 = q - rows_done * W;
+        const int hr = q2 / (2 * pad), k = q2 - hr * 2 * pad;
+        // the hr-th row that is NOT a band row: rows 0, pad+1 .. H-2-pad, H-1
+        h = hr == 0 ? 0 : (hr == rest - 1 ? H - 1 : pad + hr);
+        w = k < pad ? 1 + k : W - 1 - pad + (k - pad);
     }
     int hs[3], ws[3], nh = 0, nw = 0;
     hs[nh++] = h + pad;
@@ -1656,10 +1663,9 @@ int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, 
     if (rc != DWC_OK) return rc;
     if (!direct) return dwc_reflect_pad_adjoint(dxp, dx, B, H, W, Cin, pad, stream);
     const int C4 = Cin / 4;
-    hipLaunchKernelGGL(fold_band_kernel, dim3((W * C4 + 255) / 256, 2 * pad, B), dim3(256), 0, st, (const float*)dxp, dx, H, W, C4, pad,
-                       W + 2 * pad, 1);
-    hipLaunchKernelGGL(fold_band_kernel, dim3((2 * pad * C4 + 255) / 256, H, B), dim3(256), 0, st, (const float*)dxp, dx, H, W, C4, pad,
-                       W + 2 * pad, 0);
+    const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C4;
+    hipLaunchKernelGGL(fold_band_kernel, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const float*)dxp, dx, B, H, W, C4, pad,
+                       W + 2 * pad);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

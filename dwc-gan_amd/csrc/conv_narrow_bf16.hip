@@ -189,6 +189,10 @@ struct StemArgs {
     bf16* y;             // [B][OH][OW][64]
     int B, IH, IW, OH, OW, off, act, reflect;
     int blocks_x, blocks_y, nblocks;
+    // crop > 0 (data gradient of the image heads: y is the gradient of the PADDED tensor): an output pixel whose cropped coordinate
+    // lies inside CH x CW goes straight to `inner` ([B][CH][CW][64]), only the border ring to y; a band fold follows
+    int crop, CH, CW;
+    bf16* inner;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
@@ -319,9 +323,15 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
                 const int row = idx >> 3, ch = idx & 7;
                 const int pb = ph * 128 + row;
                 const int yy = oy0 + (pb >> 4), xx = ox0 + (pb & 15);
-                if (yy < a.OH && xx < a.OW)
-                    *reinterpret_cast<bf16x8*>(a.y + ((size_t)(n * a.OH + yy) * a.OW + xx) * 64 + ch * 8) =
-                        *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+                if (yy < a.OH && xx < a.OW) {
+                    bf16* d = a.y + ((size_t)(n * a.OH + yy) * a.OW + xx) * 64 + ch * 8;
+                    if (a.crop) {
+                        const int cy = yy - a.crop, cx = xx - a.crop;
+                        if ((unsigned)cy < (unsigned)a.CH && (unsigned)cx < (unsigned)a.CW)
+                            d = a.inner + ((size_t)(n * a.CH + cy) * a.CW + cx) * 64 + ch * 8;
+                    }
+                    *reinterpret_cast<bf16x8*>(d) = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
+                }
             }
             if (ph == 0) __syncthreads();
         }
@@ -587,11 +597,23 @@ int dwc_bf16_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int ac
  * reflect != 0: reflect rule (stems forward, off = -3), else zero rule (data gradient of the image heads on the padded grid,
  * off = -6).  act: none / relu / lrelu.  w_steps: [25][64][16] bf16, element (k-step j, channel co, tap 2j+h, plane p) at
  * ((h ^ ((co>>3)&1))*8 + p), taps beyond 48 zero (built by the caller from the OIHW filter). */
+int dwc_bf16_conv2d_stem_crop(const void* x, const void* w_steps, const float* bias, void* y, void* inner, int crop, int B, int IH, int IW,
+                              int OH, int OW, int K, int off, int act, int reflect, void* stream);
 int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, void* y, int B, int IH, int IW, int OH, int OW, int K,
                          int off, int act, int reflect, void* stream) {
-    if (!x || !w_steps || !y || !stem_ok(B, IH, IW, OH, OW, K, act)) return DWC_EINVAL;
+    return dwc_bf16_conv2d_stem_crop(x, w_steps, bias, y, nullptr, 0, B, IH, IW, OH, OW, K, off, act, reflect, stream);
+}
+
+/* The same with the interior of the output grid diverted: output pixel (oy, ox) with (oy - crop, ox - crop) inside
+ * (OH - 2 crop) x (OW - 2 crop) is written to `inner` ([B][OH-2crop][OW-2crop][64]) instead of y -- the data gradient of the image
+ * heads on the padded grid leaves only its border ring in y, for dwc_bf16_reflect_pad_adjoint_band to fold onto `inner`. */
+int dwc_bf16_conv2d_stem_crop(const void* x, const void* w_steps, const float* bias, void* y, void* inner, int crop, int B, int IH, int IW,
+                              int OH, int OW, int K, int off, int act, int reflect, void* stream) {
+    if (!x || !w_steps || !y || !stem_ok(B, IH, IW, OH, OW, K, act) || crop < 0 || (crop > 0 && (!inner || OH <= 2 * crop || OW <= 2 * crop)))
+        return DWC_EINVAL;
     StemArgs a;
     a.x = (const bf16*)x; a.w = (const bf16*)w_steps; a.bias = bias; a.y = (bf16*)y;
+    a.crop = crop; a.CH = OH - 2 * crop; a.CW = OW - 2 * crop; a.inner = (bf16*)inner;
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.off = off; a.act = act; a.reflect = reflect;
     a.blocks_x = (OW + 15) / 16; a.blocks_y = (OH + 15) / 16; a.nblocks = a.blocks_x * a.blocks_y * B;
     const int grid = a.nblocks < 512 ? a.nblocks : 512;              // two persistent workgroups per CU

@@ -88,6 +88,7 @@ SIGNATURES = {
     "dwc_bf16_conv2d_bwd_data": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_bwd_data_fold": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 9 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_reflect_pad_adjoint": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "dwc_bf16_reflect_pad_adjoint_band": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_bf16_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
     "dwc_bf16_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_bwd_data_ring": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
@@ -122,6 +123,7 @@ SIGNATURES = {
     "dwc_bf16_conv7_smallk_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_stem_ok": (c_int, [c_int] * 7),
     "dwc_bf16_conv2d_stem": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
+    "dwc_bf16_conv2d_stem_crop": (c_int, [c_fp] * 5 + [c_int] * 10 + [c_fp]),
     "dwc_bf16_conv2d_narrow_ok": (c_int, [c_int] * 8),
     "dwc_bf16_conv2d_narrow": (c_int, [c_fp] * 4 + [c_int] * 12 + [c_fp]),
     "dwc_bf16_conv2d_bwd_data_image_narrow": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),

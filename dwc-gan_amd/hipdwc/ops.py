@@ -770,20 +770,32 @@ class _HeadsConvWide(torch.autograd.Function):
             w_st = _prepped(w4, "stem_steps_dgrad", 64, P, 1, ctx.owner, True)
             dx = empty_cl(B, C, H, W, dev, x.dtype)
             base = workspace(B * (H + 2 * pad) * (W + 2 * pad) * C * 2, dev).data_ptr()
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem(
-                g.data_ptr(), w_st.data_ptr(), None, base, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0, st),
-                scope_name=ctx.bscope, detail="dgrad-heads-stem B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_stem dgrad")
-            _lib.check(lib.dwc_bf16_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+            if DGRAD_FOLD and min(H, W) >= 2 * pad + 2:
+                # interior of the padded gradient image straight into dx, only its border ring through the scratch image + band fold
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem_crop(
+                    g.data_ptr(), w_st.data_ptr(), None, base, dx.data_ptr(), pad, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0,
+                    st), scope_name=ctx.bscope, detail="dgrad-heads-stem B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_stem dgrad")
+                _lib.check(lib.dwc_bf16_reflect_pad_adjoint_band(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint_band")
+            else:
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_stem(
+                    g.data_ptr(), w_st.data_ptr(), None, base, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0, st),
+                    scope_name=ctx.bscope, detail="dgrad-heads-stem B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_stem dgrad")
+                _lib.check(lib.dwc_bf16_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
         elif ctx.needs_input_grad[0]:        # data gradient: the ordinary P-channel formulation (N = C columns)
             w_dg = _prepped(w4, "dgrad", P, C, 1, ctx.owner, half)
             dx = empty_cl(B, C, H, W, dev, x.dtype)
             pad_bytes = (B * (H + 2 * pad) * (W + 2 * pad) * C * (2 if half else 4) + 255) // 256 * 256
             nws = _fn(lib, "conv2d_bwd_data_ws_bytes", x)(B, H, W, C, P, KH, KW, 1, pad)
             base = workspace(pad_bytes + nws, dev).data_ptr()
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data", x)(
-                g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, P, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
-                st), scope_name=ctx.bscope, detail="dgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_data")
-            _lib.check(_fn(lib, "reflect_pad_adjoint", x)(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+            if DGRAD_FOLD and min(H, W) >= 2 * pad + 2 and C % (8 if half else 4) == 0:
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_fold", x)(
+                    g.data_ptr(), w_dg.data_ptr(), base, dx.data_ptr(), B, H, W, C, P, KH, KW, 1, pad, (base + pad_bytes) if nws else None,
+                    nws, st), scope_name=ctx.bscope, detail="dgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_data_fold")
+            else:
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data", x)(
+                    g.data_ptr(), w_dg.data_ptr(), base, B, H, W, C, P, KH, KW, 1, pad, (base + pad_bytes) if nws else None, nws,
+                    st), scope_name=ctx.bscope, detail="dgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_data")
+                _lib.check(_fn(lib, "reflect_pad_adjoint", x)(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
         if ctx.needs_input_grad[1] and half and NARROW and STEM and P == 8 and C == 64 and KH == 7 and KW == 7:
             dw = torch.empty((P, C, KH, KW), dtype=torch.float32, device=dev)
             ws = workspace(lib.dwc_bf16_conv7_smallk_wgrad_ws_bytes(B, H, W, 1), dev)

@@ -369,6 +369,8 @@ int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W,
  * Conv2dBlock.forward, networks.py:579-585, for the stride-2 layers networks.py:90,94,437 / networks_v2.py:107-111). */
 int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
                                   int KH, int KW, int stride, int pad, void* ws, size_t ws_bytes, void* stream);
+/* the band fold alone (dx already holds the interior of the padded gradient image dxp), for producers with their own epilogue */
+int dwc_bf16_reflect_pad_adjoint_band(const void* dxp, void* dx, int B, int H, int W, int C, int pad, void* stream);
 size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad);
 int dwc_bf16_conv2d_bwd_data_same(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W,
                                   int Cin, int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream);
@@ -435,6 +437,10 @@ int dwc_bf16_conv2d_bwd_data_image_narrow(const void* dy, const void* w_frag, vo
 int dwc_bf16_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act);
 int dwc_bf16_conv2d_stem(const void* x, const void* w_steps, const float* bias, void* y, int B, int IH, int IW, int OH, int OW, int K,
                          int off, int act, int reflect, void* stream);
+/* ... with the interior of the output grid diverted to `inner` ([B][OH-2crop][OW-2crop][64]): the data gradient of the image heads
+ * on the padded grid leaves only its border ring in y (to be folded by dwc_bf16_reflect_pad_adjoint_band). */
+int dwc_bf16_conv2d_stem_crop(const void* x, const void* w_steps, const float* bias, void* y, void* inner, int crop, int B, int IH, int IW,
+                              int OH, int OW, int K, int off, int act, int reflect, void* stream);
 /* weight gradient of the two 7x7 shapes between an NHWC8 image and a 64-channel tensor (pad 3, reflect): heads == 0: stems
  * (img8 = x, t64 = dY, dw [64][planes][7][7]); heads != 0: image heads (img8 = gradient of the pre-activation planes, t64 = x,
  * dw [planes][64][7][7]).  An MFMA row tile is 4 adjacent taps x 8 planes read from the pixel-major patch with the
