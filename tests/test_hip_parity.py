@@ -94,6 +94,41 @@ def test_conv_forward_backward(shape):
     close(bd.grad, br.grad, rel=5e-5, msg="db")
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("switch", ["DGRAD_FOLD", "RES_FUSE", "X3_S2", "S2HALO"])
+def test_alternative_paths_agree(prec, switch):
+    """Every default path that replaced a simpler one this round keeps a switch back to it (DWC_DGRAD_FOLD: reflect-pad adjoint fused
+    into the data-gradient GEMM vs a pass of its own; DWC_RES_FUSE: identity-branch gradient of a ResBlock in the convolution's
+    epilogue vs autograd's add; DWC_X3_S2 / DWC_BF16_S2_HALO: stride-2 layers on the split-product / halo kernels vs the im2col
+    GEMM).  Both settings must give the same gradients up to summation order (fp32) / one bf16 rounding."""
+    from networks.networks import ResBlock, Conv2dBlock
+    ops.set_precision(prec)
+    try:
+        torch.manual_seed(7)
+        blk = torch.nn.Sequential(Conv2dBlock(64, 128, 4, 2, 1, norm="in", activation="relu", pad_type="reflect"),
+                                  ResBlock(128, norm="in", activation="relu", pad_type="reflect")).to(DEV)
+        x0 = torch.randn(3, 64, 64, 64, device=DEV)
+        gy = torch.randn(3, 128, 32, 32, device=DEV)
+        res = {}
+        old = getattr(ops, switch)
+        for val in (1, 0):
+            setattr(ops, switch, val)
+            x = x0.to(ops.act_dtype()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            for p_ in blk.parameters():
+                p_.grad = None
+            y = blk(x)
+            (y.float() * gy).sum().backward()
+            res[val] = [y.detach().float(), x.grad.detach().float()] + [p_.grad.detach().float().clone() for p_ in blk.parameters()
+                                                                        if p_.grad is not None]
+        setattr(ops, switch, old)
+        tol = 2e-5 if prec == "fp32" else 1.6e-2
+        for a, b in zip(res[1], res[0]):
+            scale = b.abs().max().item() + 1e-12
+            assert (a - b).abs().max().item() <= tol * scale, (switch, prec, (a - b).abs().max().item() / scale)
+    finally:
+        ops.set_precision("fp32")
+
+
 # (Cin, Cout, H, k, stride, pad): generic GEMM (stride 2), Winograd forward, split-product 5x5; bf16: halo 3x3, generic
 NONFINITE_SHAPES = [(64, 64, 16, 4, 2, 1), (256, 256, 16, 3, 1, 1), (128, 64, 16, 5, 1, 2)]
 
