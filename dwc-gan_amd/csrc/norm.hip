@@ -15,6 +15,8 @@
 // order (bitwise reproducible; no atomics).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "dwc_common.h"
 
 namespace {
@@ -75,13 +77,63 @@ __device__ __forceinline__ void colsum_groups(float (&a)[V], float (&b)[V], floa
     }
 }
 
+// Last-arriver finalisation (r03): the workgroups of a statistics pass publish their partials with write-through (agent-scope)
+// stores, drain them, and take a ticket per sample; the workgroup that draws the last ticket of a sample reads every partial of
+// that sample back (agent-scope loads: another XCD's L2 may hold none of them) and does what the *_final kernel did -- one launch
+// less per norm pass (a c1 step has 92 of them at ~7 us each).  Nobody waits for anybody, so there is nothing to hang; the
+// summation order is the fixed chunk order, independent of which workgroup arrives last.  Tickets reset themselves.
+typedef __attribute__((address_space(1))) unsigned norm_gu32;
+constexpr int NORM_TICKET_ROWS = 8, NORM_TICKET_COLS = 4096;
+__device__ unsigned g_norm_ticket[NORM_TICKET_ROWS * NORM_TICKET_COLS];
+
+__device__ __forceinline__ void norm_publish(float* p, float v) {
+    __hip_atomic_store((norm_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float norm_read(const float* p) {
+    return __uint_as_float(__hip_atomic_load((norm_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// a += sum_k p[k*C], b += sum_k p[plane + k*C] in chunk order, eight loads of each plane in flight at a time
+__device__ __forceinline__ void norm_sum_partials(const float* p, size_t plane, int C, int chunks, float& a, float& b) {
+    int k = 0;
+    for (; k + 8 <= chunks; k += 8) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            va[u] = norm_read(p + (size_t)(k + u) * C);
+            vb[u] = norm_read(p + plane + (size_t)(k + u) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += va[u], b += vb[u];
+    }
+    for (; k < chunks; ++k) {
+        a += norm_read(p + (size_t)k * C);
+        b += norm_read(p + plane + (size_t)k * C);
+    }
+}
+
+// true in every thread of the workgroup that arrived last at `ticket` (of `expected` workgroups); call after the partial stores
+__device__ __forceinline__ bool norm_last_arriver(unsigned* ticket, unsigned expected) {
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's published partials have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add((norm_gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1 == expected;
+        if (s_last) __hip_atomic_store((norm_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // instance norm
 // ---------------------------------------------------------------------------------------
 // partial[(n*chunks+chunk)*C + c] = sum (x-pivot), second plane = sum (x-pivot)^2
-template <typename T>
+template <typename T, bool FUSED = false>
 __global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                        int rows_per_chunk, size_t plane) {
+                                                        int rows_per_chunk, size_t plane, float* __restrict__ mean = nullptr,
+                                                        float* __restrict__ rstd = nullptr, float eps = 0.f,
+                                                        unsigned* __restrict__ tickets = nullptr) {
     constexpr int V = VecOf<T>::V;
     __shared__ float sm[2 * 256 * V];
     const int cq = C / V;
@@ -125,8 +177,30 @@ __global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x,
     colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
         const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
-        stf<V>(part, o, s1);
-        stf<V>(part + plane, o, s2);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                norm_publish(part + o + k, s1[k]);
+                norm_publish(part + plane + o + k, s2[k]);
+            }
+        } else {
+            stf<V>(part, o, s1);
+            stf<V>(part + plane, o, s2);
+        }
+    }
+    if constexpr (FUSED) {
+        if (!norm_last_arriver(tickets + n, gridDim.x)) return;
+        // what in_stats_final does, for the C channels of sample n
+        const int chunks = gridDim.x;
+        const float inv = 1.f / (float)HW;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, b = 0.f;
+            norm_sum_partials(part + (size_t)n * chunks * C + c, plane, C, chunks, a, b);
+            const float d = a * inv;
+            const float var = fmaxf(b * inv - d * d, 0.f);
+            mean[(size_t)n * C + c] = (float)xs[c] + d;
+            rstd[(size_t)n * C + c] = 1.f / sqrtf(var + eps);
+        }
     }
 }
 
@@ -208,12 +282,14 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
     }
 }
 
-template <typename T>
+template <typename T, bool FUSED = false>
 __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part, int HW, int C, int rows_per_chunk, size_t plane,
-                                                      int relu) {
+                                                      int relu, float* __restrict__ sums = nullptr, float* __restrict__ dgamma = nullptr,
+                                                      float* __restrict__ dbeta = nullptr, int BC = 0,
+                                                      unsigned* __restrict__ tickets = nullptr) {
     constexpr int V = VecOf<T>::V;
     __shared__ float sm[2 * 256 * V];
     const int cq = C / V;
@@ -266,8 +342,30 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, 
     colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
         const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
-        stf<V>(part, o, s1);
-        stf<V>(part + plane, o, s2);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                norm_publish(part + o + k, s1[k]);
+                norm_publish(part + plane + o + k, s2[k]);
+            }
+        } else {
+            stf<V>(part, o, s1);
+            stf<V>(part + plane, o, s2);
+        }
+    }
+    if constexpr (FUSED) {
+        if (!norm_last_arriver(tickets + n, gridDim.x)) return;
+        // what in_bwd_final does, for the C channels of sample n
+        const int chunks = gridDim.x;
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, b = 0.f;
+            norm_sum_partials(part + (size_t)n * chunks * C + c, plane, C, chunks, a, b);
+            const size_t idx = (size_t)n * C + c;
+            sums[idx] = a;
+            sums[BC + idx] = b;
+            if (dgamma) dgamma[idx] = b;
+            if (dbeta) dbeta[idx] = a;
+        }
     }
 }
 
@@ -654,6 +752,20 @@ bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 
 
 namespace {
 
+// A row of self-resetting ticket counters for one statistics launch, or null (B too large / DWC_NORM_FUSED_FINAL=0: the separate
+// *_final kernels run).  Consecutive launches rotate through NORM_TICKET_ROWS rows, so launches overlapping on different streams do
+// not share counters unless more than NORM_TICKET_ROWS of them are in flight at once.
+unsigned* norm_tickets(int B) {
+    static const bool on = !(getenv("DWC_NORM_FUSED_FINAL") && atoi(getenv("DWC_NORM_FUSED_FINAL")) == 0);
+    // (measured r03: worth it at small batches -- c1, B = 16..48: 0.80 -> 0.71 ms and 0.86 -> 0.79 ms of statistics kernels per step plus
+    // 92 launch boundaries; at B >= 128 the per-workgroup publish + ticket costs more than the *_final launch it saves)
+    if (!on || B > 64 || B > NORM_TICKET_COLS) return nullptr;
+    static unsigned* base = nullptr;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_norm_ticket)) != hipSuccess) return nullptr;
+    static std::atomic<unsigned> call{0};
+    return base + (size_t)(call.fetch_add(1u) % NORM_TICKET_ROWS) * NORM_TICKET_COLS;
+}
+
 size_t instnorm_ws_bytes(int B, int HW, int C) {
     const RowSplit rs = plan_rows(B, HW);
     return ((size_t)2 * B * rs.chunks * C + (size_t)2 * B * C) * sizeof(float);
@@ -668,11 +780,17 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
-    hipLaunchKernelGGL(in_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
-    DWC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_stats_final<T>, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
-                       plane, eps);
-    DWC_LAUNCH_CHECK();
+    if (unsigned* tk = norm_tickets(B)) {            // statistics + finalisation in one launch (last-arriver workgroup per sample)
+        hipLaunchKernelGGL((in_stats_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane,
+                           mean, rstd, eps, tk);
+        DWC_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(in_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
+        DWC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(in_stats_final<T>, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
+                           plane, eps);
+        DWC_LAUNCH_CHECK();
+    }
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
                        ra.rows_per_chunk, relu);
@@ -691,12 +809,18 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
     float* sums = part + 2 * plane;
-    hipLaunchKernelGGL(in_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
-                       rs.rows_per_chunk, plane, relu);
-    DWC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(in_bwd_final, dim3((B * C + 255) / 256), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks,
-                       plane);
-    DWC_LAUNCH_CHECK();
+    if (unsigned* tk = norm_tickets(B)) {
+        hipLaunchKernelGGL((in_bwd_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
+                           rs.rows_per_chunk, plane, relu, sums, dgamma, dbeta, B * C, tk);
+        DWC_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(in_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
+                           rs.rows_per_chunk, plane, relu);
+        DWC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(in_bwd_final, dim3((B * C + 255) / 256), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks,
+                           plane);
+        DWC_LAUNCH_CHECK();
+    }
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
                        B * C, ra.rows_per_chunk, relu);
