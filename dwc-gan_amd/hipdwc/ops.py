@@ -447,8 +447,10 @@ class _Conv2d(torch.autograd.Function):
         # (207 vs 220): both decisions therefore follow needs_input_grad alone.)
         w_grad = ctx.needs_input_grad[1]
         use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
+        # (>= 160 workgroups of 256 output pixels x 64 channels: below that the launch leaves most CUs idle -- B=16 32x32 256->256 ran
+        # 200 us on 64 workgroups against 118 us on the native kernel)
         use_x3s2 = bool((not half) and X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1 and cop % 64 == 0
-                        and lib.dwc_x3_conv2d_s2_ok(B, H, W, Cx, cop))
+                        and B * (H // 32) * (W // 32) * (cop // 64) >= 160 and lib.dwc_x3_conv2d_s2_ok(B, H, W, Cx, cop))
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         use_stem = bool(half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
                         and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H, W, KH, act))
