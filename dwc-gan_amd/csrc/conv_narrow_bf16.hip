@@ -533,16 +533,38 @@ __global__ __launch_bounds__(512, 2) void smallk_wgrad_kernel(SmallWgradArgs a) 
 
 // sum the slabs in a fixed order; (g, row) -> filter row g >> 1, column 4*(g & 1) + (row >> 3) (column 7 is the dummy), plane row & 7;
 // dst index = c * sc + plane * sp + kh' * 7 + kw' with (kh', kw') flipped for the heads
-__global__ void smallk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int planes, int sc, int sp,
-                                     int flip) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 14 * 32 * 64) return;
-    const int c = idx & 63, k = idx >> 6;
-    const int g = k >> 5, row = k & 31;
-    const int kh = g >> 1, kw = 4 * (g & 1) + (row >> 3), pl = row & 7;
-    if (kw >= 7 || pl >= planes) return;
+__global__ __launch_bounds__(256) void smallk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int planes,
+                                                            int sc, int sp, int flip) {
+    // up to 512 slabs of 28 672 floats: one thread per element summed them one after the other (141 us per call, 12x what the bytes
+    // cost).  Now a workgroup owns 32 elements: thread (g, e) sums the g-th eighth of the slabs for element e, eight loads in flight,
+    // and the eight partial sums are added in order through LDS -- a fixed order, independent of the launch.
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    const int per = (splits + 7) / 8;
+    const int z0 = g * per, z1 = min(splits, z0 + per);
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * (14 * 32 * 64) + idx];
+    if (idx < 14 * 32 * 64) {
+        const float* p = slab + idx;
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u) * (14 * 32 * 64)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < z1; ++z) s += p[(size_t)z * (14 * 32 * 64)];
+    }
+    part[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= 14 * 32 * 64) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += part[q][e];
+    const int c = idx & 63, k = idx >> 6;
+    const int gg = k >> 5, row = k & 31;
+    const int kh = gg >> 1, kw = 4 * (gg & 1) + (row >> 3), pl = row & 7;
+    if (kw >= 7 || pl >= planes) return;
     const int khd = flip ? 6 - kh : kh, kwd = flip ? 6 - kw : kw;
     dw[(size_t)c * sc + (size_t)pl * sp + khd * 7 + kwd] = s;
 }
@@ -650,7 +672,7 @@ int dwc_bf16_conv7_smallk_wgrad(const void* img8, const void* t64, float* dw, in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(smallk_wgrad_kernel, dim3(splits), dim3(512), 0, st, a);
     DWC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(smallk_reduce_kernel, dim3((14 * 32 * 64 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, splits, planes,
+    hipLaunchKernelGGL(smallk_reduce_kernel, dim3((14 * 32 * 64 + 31) / 32), dim3(256), 0, st, (const float*)ws, dw, splits, planes,
                        heads ? 49 : planes * 49, heads ? 64 * 49 : 49, heads ? 1 : 0);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
