@@ -957,8 +957,9 @@ int wgrad_launch_h(const FwdGeom& f, const bf16* dy, float* dw_oihw, int Cin, in
     }
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)g.K * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel_h, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
-                       cin_real, cout_real);
+    if (!wgrad_reduce_wide(slab, dw_oihw, splits, g.K, Cout, Cin, KHW, cin_real, cout_real, st))
+        hipLaunchKernelGGL(wgrad_reduce_kernel_h, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
+                           cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

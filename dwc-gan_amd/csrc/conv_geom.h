@@ -55,6 +55,54 @@ struct StripSet {
     size_t part_stride;     // elements between the ring buffers of consecutive parts
 };
 
+// Sum of the weight-gradient slabs slab[s][(tap*Cin + ci)][co] over s -> dw[co][ci][tap] for SMALL filters cut into MANY pixel
+// splits (the 7x7 / 4x4 stems on 4-plane images: 12 544 / 4 096 elements, up to a few hundred splits): the element-wise reduce kernels
+// give every element one thread that walks all slabs (89 / 114 us per call on c1, r03 kernel trace).  Here a workgroup owns 32
+// elements, thread (g, e) sums the g-th eighth of the slabs for element e with eight loads in flight, and the eight partial sums are
+// added in order through LDS: a fixed order, independent of the launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int K, int N,
+                                                                int Cin, int KHW, int cin_real, int cout_real) {
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t total = (size_t)K * N;
+    const size_t idx = (size_t)blockIdx.x * 32 + e;
+    const int per = (splits + 7) / 8;
+    const int z0 = g * per, z1 = min(splits, z0 + per);
+    float s = 0.f;
+    if (idx < total) {
+        const float* p = slab + idx;
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u) * total];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < z1; ++z) s += p[(size_t)z * total];
+    }
+    part[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= total) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += part[q][e];
+    const int co = idx % N;
+    const int k = idx / N;
+    const int ci = k % Cin, tap = k / Cin;
+    if (co >= cout_real || ci >= cin_real) return;
+    dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
+}
+
+// (host) true when the wide form was launched: few elements, many splits
+inline bool wgrad_reduce_wide(const float* slab, float* dw, int splits, int K, int N, int Cin, int KHW, int cin_real, int cout_real,
+                              hipStream_t st) {
+    const size_t total = (size_t)K * N;
+    if (splits < 16 || total > 262144) return false;
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, slab, dw, splits, K, N, Cin, KHW,
+                       cin_real, cout_real);
+    return true;
+}
+
 int kw_magic_for(int KW, int max_tap) {
     const int magic = (65536 + KW - 1) / KW;
     for (int tp = 0; tp <= max_tap; ++tp)

@@ -1484,8 +1484,9 @@ static int wgrad_launch(const FwdGeom& f, const float* dy, float* dw_oihw, int C
     }
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)g.K * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
-                       cin_real, cout_real);
+    if (!wgrad_reduce_wide(slab, dw_oihw, splits, g.K, Cout, Cin, KHW, cin_real, cout_real, st))
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin, KHW,
+                           cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1699,8 +1700,9 @@ int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B
     }
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)g.K * Cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin,
-                       KH * KW, cin_real, cout_real);
+    if (!wgrad_reduce_wide(slab, dw_oihw, splits, g.K, Cout, Cin, KH * KW, cin_real, cout_real, st))
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, g.K, Cout, Cin,
+                           KH * KW, cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
