@@ -84,8 +84,17 @@ __global__ __launch_bounds__(1024) void colsum_final(const float* __restrict__ p
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    if (c < C)
-        for (int k = g; k < chunks; k += 16) s += part[(size_t)k * C + c];
+    if (c < C) {
+        int k = g;
+        for (; k + 7 * 16 < chunks; k += 8 * 16) {      // eight loads in flight (the walk over up to 64 partials per thread was all latency)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + 16 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < chunks; k += 16) s += part[(size_t)k * C + c];
+    }
     sm[g][cl] = s;
     __syncthreads();
     if (g == 0 && c < C) {
