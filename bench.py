@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the DWC-GAN training hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4]
+    python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4] [--scaling weak|strong] [--ledger out.json]
 
 N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or
 plainly as ``python bench.py --gpus N``: the parent then starts N rank processes itself BEFORE anything touches a GPU
@@ -16,9 +16,14 @@ HBM.  Workloads (BASELINE.json ``configs``; weak scaling — the per-GPU batch i
     c3  configs[3]  128x128, 64 per GPU, fp32 (global batch 512 on 8 GPUs)
     c4  configs[4]  256x256, 8 per GPU, fp32 (global batch 64 on 8 GPUs)
 
-Rank 0 prints ONE JSON line with the metric, the live roofline figure of the dominant kernel family (HIP events on the
-launch stream around every conv launch of the last timed step) and, for N == 1, the CPU baseline (the oracle timed on
-the host cores by BASELINE.md section 3's protocol).
+``--scaling strong`` fixes the GLOBAL batch at the configuration's 8-GPU value (c1 128, c2 1024, c3 512, c4 64; or
+``--global-batch``) and gives every rank 1/N of it.  With N > 1 the record also carries BASELINE's own multi-GPU
+configurations, c3 (configs[3]) and c4 (configs[4]), as legs under "also" (N == 1: c2).
+
+Rank 0 prints ONE JSON line with the metric, the live roofline figure of the SINGLE kernel that owns the largest share of
+the instrumented step (HIP events on the launch stream around every conv launch of the last timed step; executed flops
+over that kernel's own dense peak) and, for N == 1, the CPU baseline (the oracle timed on the host cores by BASELINE.md
+section 3's protocol).
 """
 import argparse
 import glob
@@ -34,14 +39,14 @@ for _p in (os.path.join(REPO, "dwc-gan_amd"), REPO):
         sys.path.insert(0, _p)
 
 CONFIGS = {
-    "c1": {"image_size": 128, "per_gpu_batch": 16, "precision": "fp32",
+    "c1": {"image_size": 128, "per_gpu_batch": 16, "precision": "fp32", "strong_global_batch": 128,
            "label": "BASELINE configs[1]: CelebA-shaped 128x128, per-GPU batch 16, fp32"},
-    "c2": {"image_size": 128, "per_gpu_batch": 128, "precision": "bf16",
+    "c2": {"image_size": 128, "per_gpu_batch": 128, "precision": "bf16", "strong_global_batch": 1024,
            "label": "BASELINE configs[2]: CelebA-shaped 128x128, per-GPU batch 128, bf16 activations + bf16 MFMA conv path "
                     "(fp32 accumulation, statistics, master weights)"},
-    "c3": {"image_size": 128, "per_gpu_batch": 64, "precision": "fp32",
+    "c3": {"image_size": 128, "per_gpu_batch": 64, "precision": "fp32", "strong_global_batch": 512,
            "label": "BASELINE configs[3]: CelebA-shaped 128x128, per-GPU batch 64 (global 512 on 8 GPUs), fp32"},
-    "c4": {"image_size": 256, "per_gpu_batch": 8, "precision": "fp32",
+    "c4": {"image_size": 256, "per_gpu_batch": 8, "precision": "fp32", "strong_global_batch": 64,
            "label": "BASELINE configs[4]: CelebA-HQ-shaped 256x256, per-GPU batch 8 (global 64 on 8 GPUs), fp32"},
 }
 CONFIGS["c5"] = CONFIGS["c4"]            # SURVEY.md section 8(d) numbers the same workloads C2..C5
@@ -52,6 +57,98 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}   # MI355X_MICROARCH.md: dens
 # flops of the launches actually made (summed over the instrumented step), never from this constant.
 ALGO_GFLOP_PER_IMAGE_128 = 569.6
 DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM family: one span = one conv call
+
+# Launch kind (ops.KernelTimer.ledger: first word of the span detail) -> the kernel the C-ABI call runs, as
+# (label, regex matching its rocprofv3 kernel-stats "Name", matrix pipe).  `{k}` = filter size.  Kinds whose call makes
+# several launches of comparable weight (Winograd: transform + product kernels) are labelled as such and never chosen as
+# "the" roofline kernel; small helper launches inside a call (split-K / slab reduces, folds) are part of its span time.
+KIND_KERNEL = {
+    "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
+    "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
+    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, ", "bf16x3"),
+    "wgrad-x3": ("wgrad_x3_kernel<{k}>", r"wgrad_x3_kernel<{k}, ", "bf16x3"),
+    "fwd-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
+    "dgrad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
+    "fwd-zeropad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
+    "dgrad-zeropad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
+    "fwd-s2halo": ("conv_halo16_kernel<2,S2>", r"conv_halo16_kernel<2, ", "bf16"),
+    "wgrad-halo": ("wgrad_halo_kernel<{k}>", r"wgrad_halo_kernel<{k}, ", "bf16"),
+    "fwd-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),
+    "dgrad-heads-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),
+    "fwd-heads-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
+    "dgrad-image-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
+    "wgrad-stem": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
+    "wgrad-heads-small": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
+    "fwd-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
+    "dgrad-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
+    "wgrad-wino2": ("wino_dy_kernel + conv_wgrad_kernel + wino_wgrad_reduce_kernel (multi-launch call)", r"wino_dy_kernel|wino_wgrad_reduce_kernel", "fp32"),
+    "dgrad-ring": ("conv_gemm_strips_kernel + fold_ring_kernel (multi-launch call)", r"(conv_)?gemm_strips_kernel|fold_ring_kernel", None),
+}
+GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the activation precision
+    "fwd": ("conv_gemm_kernel", "gemm_kernel_h"), "dgrad": ("conv_gemm_kernel", "gemm_kernel_h"),
+    "fwd-heads": ("conv_gemm_kernel", "gemm_kernel_h"), "dgrad-heads": ("conv_gemm_kernel", "gemm_kernel_h"),
+    "dgrad-image": ("conv_gemm_kernel", "gemm_kernel_h"), "fwd-zeropad": ("conv_gemm_kernel", "gemm_kernel_h"),
+    "dgrad-zeropad": ("conv_gemm_kernel", "gemm_kernel_h"),
+    "wgrad": ("conv_wgrad_kernel", "wgrad_kernel_h"), "wgrad-heads": ("conv_wgrad_kernel", "wgrad_kernel_h"),
+}
+PIPE_PEAK = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
+
+
+def kernel_of_kind(kind_key, precision):
+    """(label, csv regex, pipe) of a ledger key such as "fwd-x3/k5"."""
+    kind, _, ksz = kind_key.partition("/")
+    k = ksz[1:] if ksz else ""
+    if kind in KIND_KERNEL:
+        label, rx, pipe = KIND_KERNEL[kind]
+        return label.replace("{k}", k), rx.replace("{k}", k), pipe
+    if kind in GENERIC_KERNEL:
+        name = GENERIC_KERNEL[kind][1 if precision == "bf16" else 0]
+        return name, name + "<", "bf16" if precision == "bf16" else "fp32"
+    return kind, None, None
+
+
+def _shape_bytes(detail, elem):
+    """Algorithmic bytes of one conv launch from its span detail "kind B<b> <h>x<w> <cin>><cout> k<k> [s<s>]": input once +
+    output once + weights once (minimum traffic)."""
+    try:
+        w = detail.split()
+        B = int(w[1][1:])
+        H, W = (int(v) for v in w[2].split("x"))
+        ci, co = (int(v) for v in w[3].split(">"))
+        k = int(w[4][1:])
+        st = int(w[5][1:]) if len(w) > 5 and w[5][0] == "s" else 1
+    except (IndexError, ValueError):
+        return 0
+    return elem * B * H * W * ci + elem * B * (H // st) * (W // st) * co + 4 * ci * co * k * k
+
+
+def kernel_table(ledger, precision):
+    """Ledger kinds folded per kernel: launches, ms, algorithmic / executed GFLOP and algorithmic bytes per launch, and the
+    fraction of the kernel's pipe peak (executed flops / time / peak)."""
+    elem = 2 if precision == "bf16" else 4
+    rows = {}
+    for key, ent in ledger.items():
+        label, rx, pipe = kernel_of_kind(key, precision)
+        r = rows.setdefault(label, {"kernel": label, "csv_regex": rx, "pipe": pipe, "kinds": [], "launches": 0, "ms": 0.0,
+                                    "flops": 0.0, "exec_flops": 0.0, "bytes": 0.0})
+        r["kinds"].append(key)
+        for f in ("launches", "ms", "flops", "exec_flops"):
+            r[f] += ent[f]
+        r["bytes"] += sum(_shape_bytes(d, elem) * n for d, n in ent["shapes"].items())
+    out = []
+    for r in rows.values():
+        n, ms = max(r["launches"], 1), max(r["ms"], 1e-9)
+        peak = PIPE_PEAK.get(r["pipe"])
+        ex_tf = r["exec_flops"] / (ms * 1e-3) / 1e12
+        out.append({"kernel": r["kernel"], "csv_regex": r["csv_regex"], "pipe": r["pipe"], "kinds": sorted(r["kinds"]),
+                    "launches_per_step": r["launches"], "ms_per_step": round(r["ms"], 3), "avg_launch_us": round(ms * 1e3 / n, 2),
+                    "algorithmic_gflop_per_launch": round(r["flops"] / n / 1e9, 3),
+                    "executed_gflop_per_launch": round(r["exec_flops"] / n / 1e9, 3),
+                    "algorithmic_mbytes_per_launch": round(r["bytes"] / n / 1e6, 2),
+                    "algorithmic_tflops": round(r["flops"] / (ms * 1e-3) / 1e12, 2), "executed_tflops": round(ex_tf, 2),
+                    "peak_tflops": peak, "frac": round(ex_tf / peak, 4) if peak else None})
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
 
 
 def run_iteration(trainer, batch, cfg, it):
@@ -82,13 +179,18 @@ def cpu_baseline(gen_sd, dis_sd, cfg, image_size, batch, warmup, timed, thread_c
 
     ncpu = os.cpu_count() or 1
     counts = sorted({min(max(1, t), ncpu) for t in thread_counts})
+    # BASELINE.md section 3 names "N = all physical cores" (hardware threads / 2 on the SMT-2 hosts of this pool).  This graph
+    # gets SLOWER beyond ~16 threads, so the protocol proper runs at the best count; the all-physical-cores figure is
+    # measured by the one-iteration probe and reported beside it (`all_physical_cores_probe`).
+    phys = max(1, ncpu // 2)
+    probe_counts = sorted(set(counts) | {phys})
     probe = {}
-    if len(counts) > 1:
+    if len(probe_counts) > 1:
         small = synth.make_batch(max(1, batch // 4), image_size, seed=98)
         solver = make()
         torch.set_num_threads(counts[len(counts) // 2])
         solver.iteration(small, 0)                               # page everything in once
-        for t in counts:
+        for t in probe_counts:
             torch.set_num_threads(t)
             t0 = time.time()
             solver.iteration(small, 1)
@@ -112,6 +214,8 @@ def cpu_baseline(gen_sd, dis_sd, cfg, image_size, batch, warmup, timed, thread_c
     best = max(results, key=results.get)
     return {"value": round(results[best], 4), "unit": "images/s", "cores": best, "kind": "port",
             "host_cpus": ncpu,
+            "all_physical_cores_probe": ({"threads": phys, "value": round(probe[phys], 4), "unit": "images/s",
+                                          "sample": "one iteration at batch %d" % max(1, batch // 4)} if phys in probe else None),
             "sample": "oracle (torch CPU fp32, as-written reference graph), %dx%d batch %d, %d warm-up + %d timed full iterations "
                       "per thread count, median; thread counts measured %s (one-iteration probe at batch %d: %s)" % (
                           image_size, image_size, batch, warmup, timed,
@@ -139,6 +243,25 @@ def traffic_from_profiles(config, dominant, family="conv_gemm_family"):
     path, d = best
     return int(d[family]["hbm_bytes_per_span_corrected"]), "%s (profiled at commit %s)" % (
         os.path.relpath(path, REPO), d.get("commit", "of round 1, 11e6a6c"))
+
+
+def kernel_traffic_from_profiles(config, kernel_label):
+    """HBM bytes per launch of ONE kernel instantiation (label like "conv_halo_x3_kernel<5>") from the newest committed PMC
+    summary of this workload (`kernels_k` of profiles/rNN_pmc_hbm_traffic_<config>.json, benchmarks/pmc_summary.py)."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic*.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        ent = d.get("kernels_k", {}).get(kernel_label)
+        if d.get("config", "c1") == config and ent:
+            best = (path, d, ent)
+    if best is None:
+        return None, None
+    path, d, ent = best
+    return int(ent["hbm_bytes_per_launch_corrected"]), "%s (profiled at commit %s)" % (os.path.relpath(path, REPO), d.get("commit", "?"))
 
 
 def spawn_ranks(args, timeout_s=3600):
@@ -214,6 +337,11 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
     conf = CONFIGS[config_name]
     image_size, precision = conf["image_size"], conf["precision"]
     per_gpu_batch = args.per_gpu_batch or conf["per_gpu_batch"]
+    if args.scaling == "strong":          # fixed GLOBAL batch (the configuration's 8-GPU value), 1/N of it per rank
+        gb = args.global_batch or conf["strong_global_batch"]
+        if gb % world:
+            raise SystemExit("--scaling strong: global batch %d is not a multiple of %d ranks" % (gb, world))
+        per_gpu_batch = gb // world
     peak = MFMA_PEAK_TFLOPS[precision]
     ops.set_precision(precision)
     cfg = synth.make_config(image_size=image_size)           # shipped config, vgg_w = 0 (weights not obtainable offline)
@@ -311,12 +439,18 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         out["split_bf16x3"] = split
         return out
 
+    ledger = timer.ledger() if timer is not None else {}
+    table = kernel_table(ledger, precision)
+    if getattr(args, "ledger", None):
+        with open(args.ledger if config_name == args.config else args.ledger + "." + config_name, "w") as f:
+            json.dump({"config": config_name, "precision": precision, "per_gpu_batch": per_gpu_batch, "image_size": image_size,
+                       "ledger": ledger, "kernels": table}, f, indent=1)
     dom = total(lambda t: t.endswith(DOMINANT))
     x3 = total(lambda t: t.endswith(X3))
     # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)
     decode_stack = {"forward": stack(lambda t: t.startswith("decode/")),
                     "backward": stack(lambda t: t.startswith("bwd:decode/") and "wgrad" not in t)}
-    roof = None
+    roof = roof_family = None
     if dom and dom["ms"] > 0:
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         executed = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -324,12 +458,29 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         # achieved: ALGORITHMIC flops (the direct convolution's) over the spans' time.  On the fp32 path the
         # 3x3 layers run as Winograd F(2x2,3x3) and issue 2.25x fewer multiply-adds than that, so `executed` (what the
         # matrix cores actually did, transforms' time included in the spans) is the figure to hold against the MFMA roof.
-        roof = {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
-                "traffic": traffic, "traffic_source": traffic_source,
-                "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
-                "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
+        roof_family = {"bound": "mfma", "kernel": DOMINANT + " family (every forward / data-gradient conv call on the native pipe; "
+                                                             "Winograd calls credited with direct-convolution flops in `achieved`)",
+                       "achieved": round(achieved, 2), "peak": peak,
+                       "unit": "TFLOP/s", "frac": round(executed / peak, 4), "algorithmic_frac": round(achieved / peak, 4),
+                       "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
+                       "traffic": traffic, "traffic_source": traffic_source,
+                       "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                       "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
+    # THE roofline record: the single kernel with the largest share of the instrumented step (multi-launch calls such as the
+    # Winograd chain are not "a kernel" and are skipped here; they stay visible in `kernels`).  `achieved` = flops the
+    # matrix cores EXECUTED in that kernel / its span time; `peak` = the dense peak of the pipe it runs on; the
+    # direct-convolution (fp32-equivalent) rate sits under `algorithmic_tflops`.
+    single = [r for r in table if r["pipe"] and "multi-launch" not in r["kernel"] and r["executed_gflop_per_launch"] > 0]
+    if single:
+        r0 = single[0]
+        tr, tr_src = kernel_traffic_from_profiles("c4" if config_name == "c5" else config_name, r0["kernel"])
+        roof = {"bound": "mfma", "kernel": r0["kernel"], "pipe": r0["pipe"], "achieved": r0["executed_tflops"], "peak": r0["peak_tflops"],
+                "unit": "TFLOP/s", "frac": r0["frac"], "algorithmic_tflops": r0["algorithmic_tflops"],
+                "traffic": tr, "traffic_source": tr_src, "algorithmic_bytes_per_launch": int(r0["algorithmic_mbytes_per_launch"] * 1e6),
+                "launches_per_step": r0["launches_per_step"], "avg_launch_us": r0["avg_launch_us"], "ms_per_step": r0["ms_per_step"],
+                "share_of_step": round(r0["ms_per_step"] / (elapsed / steps * 1e3), 4),
+                "algorithmic_gflop_per_launch": r0["algorithmic_gflop_per_launch"],
+                "executed_gflop_per_launch": r0["executed_gflop_per_launch"], "launch_kinds": r0["kinds"]}
     roof_x3 = None
     if x3["ms"] > 0:
         # the fp32 layers that run as split products: six bf16 MFMAs per fp32 MFMA-equivalent (6 of the 9 partial products of
@@ -349,7 +500,7 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
     out = {
         "metric": "CelebA %dx%d training images/sec" % (image_size, image_size), "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
-        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
                        conf["label"], args.vgg_w,
@@ -369,7 +520,9 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         "loss_dis_all": round(float(trainer.loss_dis_all.detach()), 5),
         "loss_gen_total": round(float(trainer.loss_gen_total.detach()), 5),
         "roofline": roof,
+        "roofline_family_native": roof_family,
         "roofline_split_bf16x3": roof_x3,
+        "kernels": [{k: v for k, v in r.items() if k != "csv_regex"} for r in table[:12]],
         "decode_conv_stack": decode_stack,
         "kernel_spans": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                              "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in spans.items()},
@@ -395,8 +548,16 @@ def main():
                          "c3 fp32 128^2 B64; c4 (alias c5) fp32 256^2 B8)")
     ap.add_argument("--also", default=None,
                     help="comma list of further workloads measured after the main one in the same process and reported under "
-                         "\"also\": {name: record} (default: c2 when the main workload is c1 on one GPU, so that the bf16 "
-                         "configuration's images/s and roofline sit in every driver-timed record; 'none' switches it off)")
+                         "\"also\": {name: record} (default when the main workload is c1: c2 on one GPU, so that the bf16 "
+                         "configuration's images/s and roofline sit in every driver-timed record; c3,c4 -- BASELINE's own "
+                         "multi-GPU configurations -- on N > 1; 'none' switches it off)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak (default): fixed per-GPU batch; strong: fixed GLOBAL batch = the configuration's 8-GPU value "
+                         "(c1 128, c2 1024, c3 512, c4 64; --global-batch overrides), split evenly over the ranks")
+    ap.add_argument("--global-batch", type=int, default=None, help="global batch of --scaling strong")
+    ap.add_argument("--ledger", default=None,
+                    help="write the per-kind launch ledger of the instrumented step (launches, ms, algorithmic / executed flops, "
+                         "shapes) and the per-kernel table to this JSON file (input of benchmarks/roofline_table.py)")
     ap.add_argument("--also-steps", type=int, default=10)
     ap.add_argument("--also-warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -460,7 +621,8 @@ def main():
 
     also = args.also
     if also is None:
-        also = "c2" if (args.config == "c1" and world == 1 and not force_dp and args.per_gpu_batch is None) else "none"
+        plain = args.config == "c1" and not force_dp and args.per_gpu_batch is None
+        also = ("c2" if world == 1 else "c3,c4") if plain else "none"
     extra = {}
     for name in [n for n in also.split(",") if n and n != "none"]:
         if name not in CONFIGS:

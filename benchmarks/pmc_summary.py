@@ -19,7 +19,9 @@ import os
 import sys
 
 
-def per_kernel(directory, counter):
+def per_kernel(directory, counter, by_first_arg=False):
+    """Counter totals per kernel name with the template arguments dropped; ``by_first_arg``: per instantiation family, keyed
+    "name<first template argument>" (e.g. "conv_halo_x3_kernel<5>": the filter size), the label bench.py's `roofline.kernel` uses."""
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit("no *counter_collection.csv under %s" % directory)
@@ -30,7 +32,12 @@ def per_kernel(directory, counter):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row["Kernel_Name"]
-                short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+                flat = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+                short = flat.split("<")[0]
+                if by_first_arg:
+                    if "<" not in flat:
+                        continue
+                    short = short + "<" + flat.split("<", 1)[1].split(",")[0].split(">")[0].strip() + ">"
                 if short.startswith("_ZN"):                   # templated kernels may come out mangled: _ZN12_GLOBAL__N_18in_applyI...
                     import re
                     m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", short)
@@ -68,6 +75,15 @@ def main():
         res["kernels"][k] = {"FETCH_SIZE_KiB_avg_per_launch": round(f_avg, 1), "launches": fetch[k][1],
                              "WRITE_SIZE_KiB_avg_per_launch": round(w_avg, 1),
                              "hbm_bytes_per_launch_corrected": int((2 * f_avg + w_avg) * 1024)}
+    # per instantiation family ("name<first template argument>"): what bench.py's single-kernel `roofline.traffic` reads
+    fetch_k, write_k = per_kernel(fetch_dir, "FETCH_SIZE", True), per_kernel(write_dir, "WRITE_SIZE", True)
+    res["kernels_k"] = {}
+    for k in sorted(fetch_k):
+        if k in write_k and k.split("<")[0] in keep:
+            f_avg, w_avg = fetch_k[k][0] / fetch_k[k][1], write_k[k][0] / write_k[k][1]
+            res["kernels_k"][k] = {"FETCH_SIZE_KiB_avg_per_launch": round(f_avg, 1), "launches": fetch_k[k][1],
+                                   "WRITE_SIZE_KiB_avg_per_launch": round(w_avg, 1),
+                                   "hbm_bytes_per_launch_corrected": int((2 * f_avg + w_avg) * 1024)}
     # the forward / data-gradient GEMM family as bench.py's roofline spans see it: one span = one conv call, which for a
     # 3x3 layer is input transform + batched GEMM + output transform (+ ring strips and fold for a data gradient)
     family = ("conv_gemm_kernel", "wino_fused_kernel", "conv_gemm_batched_kernel", "conv_gemm_strips_kernel",

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Machine-readable per-kernel roofline table of one bench run.
+
+    python benchmarks/roofline_table.py <rocprofv3 kernel_stats.csv> <bench.py --ledger json> <iterations profiled> <out.json> [commit]
+
+Joins, per kernel, what rocprofv3 measured (calls, average duration of THAT kernel's launches over the whole run) with what
+the launch ledger of the same run knows (bench.py --ledger: per launch kind -- first word of the span detail + filter size --
+the launches, algorithmic and executed flops, problem shapes of ONE training iteration).  A row:
+
+    kernel, csv_names, pipe, launches_per_iter (rocprof), avg_us (rocprof), ms_per_iter (rocprof),
+    algorithmic_gflop_per_launch, executed_gflop_per_launch, algorithmic_mbytes_per_launch (input + output + weights once),
+    executed_tflops = executed flops per iteration / rocprof time per iteration, peak_tflops (dense peak of the pipe the kernel
+    runs on: fp32 MFMA 157.3, bf16 MFMA 2500; "bf16x3" = fp32 layers as six bf16 products per multiply-add, same bf16 peak),
+    frac = executed_tflops / peak_tflops, algorithmic_tflops (direct-convolution fp32-equivalent rate)
+
+Kernels the ledger does not know (norms, pointwise, reduces, stock torch) are listed with their rocprof time and
+bound "hbm" / null flops, so that the table accounts for the whole iteration.  Multi-launch calls (Winograd) appear once per
+kernel of the chain, each carrying the call's flops only on its product kernel.
+"""
+import csv
+import json
+import re
+import sys
+
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+
+
+def main():
+    stats_csv, ledger_json, iters, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    commit = sys.argv[5] if len(sys.argv) > 5 else "unknown"
+    with open(ledger_json) as f:
+        led = json.load(f)
+    rows_csv = list(csv.DictReader(open(stats_csv)))
+    total_ns = sum(int(r["TotalDurationNs"]) for r in rows_csv)
+    used = set()
+    table = []
+    for k in led["kernels"]:
+        rx = k.get("csv_regex")
+        match = [r for r in rows_csv if rx and re.search(rx, r["Name"])]
+        # a multi-launch call's flops sit on its product kernels only
+        prod = [r for r in match if not re.search(r"wino_(input|output|dy)_kernel|wino_wgrad_reduce|fold_ring|splitk_reduce", r["Name"])] or match
+        ns = sum(int(r["TotalDurationNs"]) for r in match)
+        calls = sum(int(r["Calls"]) for r in prod)
+        used.update(r["Name"] for r in match)
+        ms_iter = ns / 1e6 / iters
+        n_iter = calls / iters
+        peak = k.get("peak_tflops")
+        ex_fl = k["executed_gflop_per_launch"] * k["launches_per_step"] * 1e9
+        al_fl = k["algorithmic_gflop_per_launch"] * k["launches_per_step"] * 1e9
+        ex_tf = ex_fl / (ms_iter * 1e-3) / 1e12 if ms_iter > 0 else None
+        table.append({
+            "kernel": k["kernel"], "csv_names": sorted({r["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+                                                        for r in match}),
+            "pipe": k["pipe"], "launch_kinds": k["kinds"], "launches_per_iter": round(n_iter, 2),
+            "avg_us": round(ns / 1e3 / max(calls, 1), 2), "ms_per_iter": round(ms_iter, 3),
+            "share_of_kernel_time": round(ns / total_ns, 4),
+            "algorithmic_gflop_per_launch": round(al_fl / max(n_iter, 1e-9) / 1e9, 3),
+            "executed_gflop_per_launch": round(ex_fl / max(n_iter, 1e-9) / 1e9, 3),
+            "algorithmic_mbytes_per_launch": k["algorithmic_mbytes_per_launch"],
+            "bound": "mfma" if peak else None, "peak_tflops": peak,
+            "executed_tflops": None if ex_tf is None else round(ex_tf, 2),
+            "algorithmic_tflops": None if ms_iter <= 0 else round(al_fl / (ms_iter * 1e-3) / 1e12, 2),
+            "frac": None if (ex_tf is None or not peak) else round(ex_tf / peak, 4),
+            "span_avg_us_hip_events": k["avg_launch_us"]})
+    rest = {}
+    for r in rows_csv:
+        if r["Name"] in used:
+            continue
+        short = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", short)
+        if m:
+            short = short[len(m.group(0)):len(m.group(0)) + int(m.group(1))]
+        e = rest.setdefault(short, [0, 0])
+        e[0] += int(r["TotalDurationNs"])
+        e[1] += int(r["Calls"])
+    for name, (ns, calls) in sorted(rest.items(), key=lambda kv: -kv[1][0]):
+        if ns / total_ns < 0.002:
+            continue
+        table.append({"kernel": name, "pipe": None, "bound": "hbm/latency", "launches_per_iter": round(calls / iters, 2),
+                      "avg_us": round(ns / 1e3 / calls, 2), "ms_per_iter": round(ns / 1e6 / iters, 3),
+                      "share_of_kernel_time": round(ns / total_ns, 4)})
+    table.sort(key=lambda r: -r["ms_per_iter"])
+    res = {"config": led["config"], "precision": led["precision"], "per_gpu_batch": led["per_gpu_batch"], "image_size": led["image_size"],
+           "commit": commit, "iterations_profiled": iters, "kernel_ms_per_iter": round(total_ns / 1e6 / iters, 3),
+           "peaks_tflops": {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0},
+           "source": {"kernel_stats": stats_csv.split("/")[-1], "ledger": ledger_json.split("/")[-1]}, "kernels": table}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    for r in table[:14]:
+        print("%-58s %8.3f ms/iter %8.1f us  frac %s" % (r["kernel"][:58], r["ms_per_iter"], r["avg_us"], r.get("frac")))
+
+
+if __name__ == "__main__":
+    main()

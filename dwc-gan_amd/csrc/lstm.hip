@@ -247,7 +247,8 @@ __device__ __forceinline__ f32x4 lstm_ld_sc1(const __amdgpu_buffer_rsrc_t rsrc, 
 template <int MT, int NQ>      // NQ: 16-deep contraction blocks per wave (ceil(ceil(H/16)/4))
 __global__ __launch_bounds__(256) void lstm_seq_fwd(const float* __restrict__ xproj, const float* __restrict__ w_hh,
                                                     const int* __restrict__ lens, float* __restrict__ out, float* __restrict__ c,
-                                                    float* __restrict__ gates, unsigned* __restrict__ ws, int T, int B, int H) {
+                                                    float* __restrict__ gates, unsigned* __restrict__ ws, unsigned* __restrict__ status,
+                                                    int T, int B, int H) {
     __shared__ float ex[4][4][MT * 16][17];                  // [wave][gate][batch row][unit]
     __shared__ int s_ok;                                     // (+ dynamic LDS requested by the launcher: > 80 KB in all, one workgroup per CU)
     const int d = blockIdx.y, u0 = blockIdx.x * 16, z = blockIdx.z, b0 = z * (MT * 16);
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd(const float* __restrict__ xp
                         __builtin_amdgcn_s_sleep(2);
                         if (++spins > (1u << 20)) {                        // ~ a second: give up instead of hanging the GPU
                             __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (status) __hip_atomic_fetch_or((lstm_gu32*)status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             ok = false;
                             break;
                         }
@@ -383,6 +385,22 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd(const float* __restrict__ xp
         __syncthreads();
         if (threadIdx.x == 0 && s + 1 < T) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!alive) {
+        // a rendez-vous was missed (a workgroup of the group never became resident): the results are INVALID.  Fail loudly: every
+        // h / c / gate slot this workgroup owns becomes NaN (losses downstream turn NaN) and `status` keeps the sticky flag.
+        const float nan = __uint_as_float(0x7fc00000u);
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int k = 0; k < MT; ++k) {
+                if (!mine[k]) continue;
+                const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+                const size_t row = dTB + (size_t)t * B + b;
+                out[row * H + u] = nan;
+                c[row * H + u] = nan;
+                float* gs = gates + row * 4 * H + u;
+                gs[0] = nan; gs[H] = nan; gs[2 * H] = nan; gs[3 * H] = nan;
+            }
+    }
 }
 
 // Persistent backward: all time steps of both directions in one launch, same hand-off as lstm_seq_fwd.  What crosses
@@ -393,7 +411,7 @@ template <int MT, int NQ>
 __global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_out, const float* __restrict__ d_c,
                                                     const float* __restrict__ w_hh_t, const int* __restrict__ lens,
                                                     const float* __restrict__ c, const float* __restrict__ gates, float* __restrict__ dgates,
-                                                    unsigned* __restrict__ ws, int T, int B, int H) {
+                                                    unsigned* __restrict__ ws, unsigned* __restrict__ status, int T, int B, int H) {
     __shared__ float ex[4][MT * 16][17];
     __shared__ int s_ok;
     const int d = blockIdx.y, u0 = blockIdx.x * 16, z = blockIdx.z, b0 = z * (MT * 16);
@@ -427,6 +445,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_
         len_k[k] = lens[min(b, B - 1)];
         carry[k] = 0.f;
     }
+    bool alive = true;
     for (int s = 0; s < T; ++s) {
         const int t = d == 0 ? T - 1 - s : s;                   // forward direction walks back from the end
         const int tn = d == 0 ? t + 1 : t - 1;                  // the step processed just before
@@ -464,6 +483,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_
                     __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 20)) {
                         __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (status) __hip_atomic_fetch_or((lstm_gu32*)status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = false;
                         break;
                     }
@@ -471,7 +491,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_
                 s_ok = ok ? 1 : 0;
             }
             __syncthreads();
-            if (s_ok == 0) break;
+            if (s_ok == 0) { alive = false; break; }
             const unsigned row_bytes = (unsigned)K * 4u;
             const unsigned base = (unsigned)((dTB + (size_t)tn * B) * K * 4);
             constexpr int CH = 5;
@@ -536,6 +556,36 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd(const float* __restrict__ d_
         __syncthreads();
         if (threadIdx.x == 0 && s + 1 < T) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (!alive) {                                                // missed rendez-vous: poison every gate gradient this workgroup owns
+        const float nan = __uint_as_float(0x7fc00000u);
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int k = 0; k < MT; ++k) {
+                if (!mine[k]) continue;
+                const int p = threadIdx.x + 256 * k, b = b0 + (p >> 4), u = u0 + (p & 15);
+                float* dg = dgates + (dTB + (size_t)t * B + b) * K + u;
+                dg[0] = nan; dg[H] = nan; dg[2 * H] = nan; dg[3 * H] = nan;
+            }
+    }
+}
+
+// Workgroups that can be resident at once for a persistent kernel (CUs x occupancy at its LDS request), per device and
+// kernel variant.  The hand-off inside lstm_seq_* spins on values other workgroups of the launch produce: every workgroup
+// of the grid MUST be resident, so the launchers refuse (DWC_EINVAL -> the caller runs the per-step kernels) any grid above
+// this capacity -- a partitioned device (CPX), a CU mask or a smaller part lowers it.
+template <typename K>
+int lstm_resident_capacity(K kernel, unsigned dyn_lds, int variant) {
+    static int cache[16][16];                                   // [device][variant]; racing writers store the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int* slot = (dev >= 0 && dev < 16 && variant >= 0 && variant < 16) ? &cache[dev][variant] : nullptr;
+    if (slot && *slot > 0) return *slot;
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, dyn_lds) != hipSuccess) return 0;
+    const int cap = cus * occ;
+    if (slot) *slot = cap;
+    return cap;
 }
 
 }  // namespace
@@ -563,51 +613,70 @@ int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* 
 /* All T steps of both directions in one launch (lstm_seq_fwd); same tensors as dwc_lstm_fwd plus ws >= dwc_lstm_seq_ws_bytes
  * (arrival counters + a timeout word: after the launch ws[0] != 0 means a rendez-vous was missed and the results are invalid).
  * Returns DWC_EINVAL for shapes the persistent form does not take (H > 320, more workgroups than CUs): use dwc_lstm_fwd. */
-size_t dwc_lstm_seq_ws_bytes(int B, int dirs) { return (size_t)(16 + dirs * ((B + 63) / 16 + 1)) * sizeof(unsigned) + 64; }
+size_t dwc_lstm_seq_ws_bytes(int B, int dirs) { return ((size_t)(16 + dirs * ((B + 63) / 16 + 1)) * sizeof(unsigned) + 64 + 15) / 16 * 16; }
 
 int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
-                     int dirs, void* ws, size_t ws_bytes, void* stream) {
+                     int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups, void* stream) {
     if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
     const int mt = min(4, (B + 15) / 16);
     const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
     const int nq = (H + 15) / 16, per = (nq + 3) / 4;
-    if (per > 5 || (size_t)grid.x * grid.y * grid.z > 200 || (size_t)dirs * T * B * H * 4 >= 0x80000000ull) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, (dwc_lstm_seq_ws_bytes(B, dirs) + 15) / 16 * 16, st) != hipSuccess) return DWC_ELAUNCH;
-    unsigned* w = (unsigned*)ws;
+    if (per > 5 || (size_t)dirs * T * B * H * 4 >= 0x80000000ull) return DWC_EINVAL;
     // dynamic LDS on top of the exchange buffer so that a workgroup needs > 80 KB: ONE workgroup per CU (the hand-off form used is
     // measured for one workgroup per CU, and the residency argument counts CUs)
     const size_t ex_bytes = (size_t)4 * 4 * mt * 16 * 17 * 4;
     const unsigned dyn = ex_bytes < 84 * 1024 ? (unsigned)(84 * 1024 - ex_bytes) : 0u;
+    int cap = 0;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((lstm_seq_fwd<1, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
-        case 2: hipLaunchKernelGGL((lstm_seq_fwd<2, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
-        case 3: hipLaunchKernelGGL((lstm_seq_fwd<3, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
-        default: hipLaunchKernelGGL((lstm_seq_fwd<4, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, T, B, H); break;
+        case 1: cap = lstm_resident_capacity(lstm_seq_fwd<1, 5>, dyn, 0); break;
+        case 2: cap = lstm_resident_capacity(lstm_seq_fwd<2, 5>, dyn, 1); break;
+        case 3: cap = lstm_resident_capacity(lstm_seq_fwd<3, 5>, dyn, 2); break;
+        default: cap = lstm_resident_capacity(lstm_seq_fwd<4, 5>, dyn, 3); break;
+    }
+    if (max_workgroups > 0) cap = min(cap, max_workgroups);
+    if ((size_t)grid.x * grid.y * grid.z > (size_t)max(cap, 0)) return DWC_EINVAL;      // not all workgroups would be resident
+    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, dwc_lstm_seq_ws_bytes(B, dirs), st) != hipSuccess) return DWC_ELAUNCH;
+    unsigned* w = (unsigned*)ws;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((lstm_seq_fwd<1, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, status, T, B, H); break;
+        case 2: hipLaunchKernelGGL((lstm_seq_fwd<2, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, status, T, B, H); break;
+        case 3: hipLaunchKernelGGL((lstm_seq_fwd<3, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, status, T, B, H); break;
+        default: hipLaunchKernelGGL((lstm_seq_fwd<4, 5>), grid, dim3(256), dyn, st, xproj, w_hh, lens, out, c, gates, w, status, T, B, H); break;
     }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
 int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c, const float* gates,
-                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, void* stream) {
+                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups,
+                     void* stream) {
     if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
     const int mt = min(4, (B + 15) / 16);
     const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
     const int nq = (4 * H + 15) / 16, per = (nq + 3) / 4;
-    if (per > 19 || (size_t)grid.x * grid.y * grid.z > 200 || (size_t)dirs * T * B * 4 * H * 4 >= 0x80000000ull) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, (dwc_lstm_seq_ws_bytes(B, dirs) + 15) / 16 * 16, st) != hipSuccess) return DWC_ELAUNCH;
-    unsigned* w = (unsigned*)ws;
+    if (per > 19 || (size_t)dirs * T * B * 4 * H * 4 >= 0x80000000ull) return DWC_EINVAL;
     const size_t ex_bytes = (size_t)4 * mt * 16 * 17 * 4;
     const unsigned dyn = (unsigned)(84 * 1024 - ex_bytes);
+    int cap = 0;
     switch (mt) {
-        case 1: hipLaunchKernelGGL((lstm_seq_bwd<1, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
-        case 2: hipLaunchKernelGGL((lstm_seq_bwd<2, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
-        case 3: hipLaunchKernelGGL((lstm_seq_bwd<3, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
-        default: hipLaunchKernelGGL((lstm_seq_bwd<4, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, T, B, H); break;
+        case 1: cap = lstm_resident_capacity(lstm_seq_bwd<1, 19>, dyn, 4); break;
+        case 2: cap = lstm_resident_capacity(lstm_seq_bwd<2, 19>, dyn, 5); break;
+        case 3: cap = lstm_resident_capacity(lstm_seq_bwd<3, 19>, dyn, 6); break;
+        default: cap = lstm_resident_capacity(lstm_seq_bwd<4, 19>, dyn, 7); break;
+    }
+    if (max_workgroups > 0) cap = min(cap, max_workgroups);
+    if ((size_t)grid.x * grid.y * grid.z > (size_t)max(cap, 0)) return DWC_EINVAL;
+    if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, dwc_lstm_seq_ws_bytes(B, dirs), st) != hipSuccess) return DWC_ELAUNCH;
+    unsigned* w = (unsigned*)ws;
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((lstm_seq_bwd<1, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, status, T, B, H); break;
+        case 2: hipLaunchKernelGGL((lstm_seq_bwd<2, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, status, T, B, H); break;
+        case 3: hipLaunchKernelGGL((lstm_seq_bwd<3, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, status, T, B, H); break;
+        default: hipLaunchKernelGGL((lstm_seq_bwd<4, 19>), grid, dim3(256), dyn, st, d_out, d_c, w_hh_t, lens, c, gates, dgates, w, status, T, B, H); break;
     }
     DWC_LAUNCH_CHECK();
     return DWC_OK;

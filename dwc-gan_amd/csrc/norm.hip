@@ -82,9 +82,13 @@ __device__ __forceinline__ void colsum_groups(float (&a)[V], float (&b)[V], floa
 // that sample back (agent-scope loads: another XCD's L2 may hold none of them) and does what the *_final kernel did -- one launch
 // less per norm pass (a c1 step has 92 of them at ~7 us each).  Nobody waits for anybody, so there is nothing to hang; the
 // summation order is the fixed chunk order, independent of which workgroup arrives last.  Tickets reset themselves.
+// The tickets are CALLER-OWNED device words (>= B of them, zero before first use; one row per stream that may run norm launches
+// concurrently): the library keeps no mutable state of its own, on any device.  Ordering: the ticket increment is an
+// agent-scope ACQ_REL read-modify-write behind the workgroup barrier that follows every wave's drained write-through stores
+// (release side), and every thread of the last-arriving workgroup passes an agent-scope acquire fence before it reads the
+// other workgroups' partials back (acquire side).
 typedef __attribute__((address_space(1))) unsigned norm_gu32;
-constexpr int NORM_TICKET_ROWS = 8, NORM_TICKET_COLS = 4096;
-__device__ unsigned g_norm_ticket[NORM_TICKET_ROWS * NORM_TICKET_COLS];
+constexpr int NORM_TICKET_MAX_B = 64;     // above this batch the per-workgroup publish + ticket costs more than the *_final launch it saves
 
 __device__ __forceinline__ void norm_publish(float* p, float v) {
     __hip_atomic_store((norm_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -117,11 +121,12 @@ __device__ __forceinline__ bool norm_last_arriver(unsigned* ticket, unsigned exp
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's published partials have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add((norm_gu32*)ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned prev = __hip_atomic_fetch_add((norm_gu32*)ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev + 1 == expected;
-        if (s_last) __hip_atomic_store((norm_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_last) __hip_atomic_store((norm_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-reset for the next launch
     }
     __syncthreads();
+    if (s_last != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // before any thread reads the others' partials
     return s_last != 0;
 }
 
@@ -752,19 +757,10 @@ bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 
 
 namespace {
 
-// A row of self-resetting ticket counters for one statistics launch, or null (B too large / DWC_NORM_FUSED_FINAL=0: the separate
-// *_final kernels run).  Consecutive launches rotate through NORM_TICKET_ROWS rows, so launches overlapping on different streams do
-// not share counters unless more than NORM_TICKET_ROWS of them are in flight at once.
-unsigned* norm_tickets(int B) {
-    static const bool on = !(getenv("DWC_NORM_FUSED_FINAL") && atoi(getenv("DWC_NORM_FUSED_FINAL")) == 0);
-    // (measured r03: worth it at small batches -- c1, B = 16..48: 0.80 -> 0.71 ms and 0.86 -> 0.79 ms of statistics kernels per step plus
-    // 92 launch boundaries; at B >= 128 the per-workgroup publish + ticket costs more than the *_final launch it saves)
-    if (!on || B > 64 || B > NORM_TICKET_COLS) return nullptr;
-    static unsigned* base = nullptr;
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_norm_ticket)) != hipSuccess) return nullptr;
-    static std::atomic<unsigned> call{0};
-    return base + (size_t)(call.fetch_add(1u) % NORM_TICKET_ROWS) * NORM_TICKET_COLS;
-}
+// The caller's ticket row for one statistics launch, or null when the batch is too large for the fused finalisation to pay
+// (measured r03: worth it at small batches -- c1, B = 16..48: 0.80 -> 0.71 ms and 0.86 -> 0.79 ms of statistics kernels per step plus
+// 92 launch boundaries; at B >= 128 the per-workgroup publish + ticket costs more than the *_final launch it saves).
+inline unsigned* norm_tickets(unsigned* tickets, int B) { return (tickets && B <= NORM_TICKET_MAX_B) ? tickets : nullptr; }
 
 size_t instnorm_ws_bytes(int B, int HW, int C) {
     const RowSplit rs = plan_rows(B, HW);
@@ -773,14 +769,14 @@ size_t instnorm_ws_bytes(int B, int HW, int C) {
 
 template <typename T>
 int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y, float* mean,
-                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
-    if (unsigned* tk = norm_tickets(B)) {            // statistics + finalisation in one launch (last-arriver workgroup per sample)
+    if (unsigned* tk = norm_tickets(tickets, B)) {            // statistics + finalisation in one launch (last-arriver workgroup per sample)
         hipLaunchKernelGGL((in_stats_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane,
                            mean, rstd, eps, tk);
         DWC_LAUNCH_CHECK();
@@ -801,7 +797,7 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
 template <typename T>
 int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                     size_t ws_bytes, void* stream) {
+                     size_t ws_bytes, unsigned* tickets, void* stream) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -809,7 +805,7 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
     float* sums = part + 2 * plane;
-    if (unsigned* tk = norm_tickets(B)) {
+    if (unsigned* tk = norm_tickets(tickets, B)) {
         hipLaunchKernelGGL((in_bwd_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
                            rs.rows_per_chunk, plane, relu, sums, dgamma, dbeta, B * C, tk);
         DWC_LAUNCH_CHECK();
@@ -880,16 +876,17 @@ int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv
 extern "C" {
 
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C) { return instnorm_ws_bytes(B, HW, C); }
+size_t dwc_instnorm_ticket_words(void) { return NORM_TICKET_MAX_B; }
 size_t dwc_layernorm_ws_bytes(int B, int HW, int C) { return layernorm_ws_bytes(B, HW, C); }
 
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
-    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, stream);
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, tickets, stream);
 }
 int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                     size_t ws_bytes, void* stream) {
-    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, stream);
+                     size_t ws_bytes, unsigned* tickets, void* stream) {
+    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, tickets, stream);
 }
 int dwc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
                       int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
@@ -903,15 +900,16 @@ int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 
 /* bf16 activations (x, residual, y, dy, dx); statistics, gamma/beta and their gradients stay fp32 */
 int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          void* stream) {
     return instnorm_fwd_t<dwc_bf16>((const dwc_bf16*)x, gamma, beta, (const dwc_bf16*)residual, (dwc_bf16*)y, mean, rstd, B, HW, C,
-                                    eps, relu, ws, ws_bytes, stream);
+                                    eps, relu, ws, ws_bytes, tickets, stream);
 }
 int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, void* stream) {
+                          size_t ws_bytes, unsigned* tickets, void* stream) {
     return instnorm_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (const dwc_bf16*)x, mean, rstd, gamma, beta, (dwc_bf16*)dx, dgamma, dbeta,
-                                    B, HW, C, relu, ws, ws_bytes, stream);
+                                    B, HW, C, relu, ws, ws_bytes, tickets, stream);
 }
 int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
                            int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {

@@ -55,8 +55,9 @@ SIGNATURES = {
     "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "dwc_instnorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
-    "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
-    "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_instnorm_ticket_words": (c_sz, []),
+    "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_fp]),
+    "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_fp]),
     "dwc_layernorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
     "dwc_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
@@ -102,8 +103,8 @@ SIGNATURES = {
     "dwc_bf16_maxpool2_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_bf16_maxpool2_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_lstm_seq_ws_bytes": (c_sz, [c_int, c_int]),
-    "dwc_lstm_seq_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
-    "dwc_lstm_seq_bwd": (c_int, [c_fp] * 7 + [c_int] * 4 + [c_fp, c_sz, c_fp]),
+    "dwc_lstm_seq_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp, c_sz, c_fp, c_int, c_fp]),
+    "dwc_lstm_seq_bwd": (c_int, [c_fp] * 7 + [c_int] * 4 + [c_fp, c_sz, c_fp, c_int, c_fp]),
     "dwc_adv_tail_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_adv_tail_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, AdvSpec, c_fp]),
     "dwc_bf16_conv2d_s2_halo_ok": (c_int, [c_int] * 5),
@@ -134,8 +135,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_bwd_weight_ex_ws_bytes": (c_sz, [c_int] * 11),
     "dwc_bf16_conv2d_bwd_weight_ex": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 13 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
-    "dwc_bf16_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
-    "dwc_bf16_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_fp]),
+    "dwc_bf16_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_fp]),
     "dwc_bf16_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_bf16_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_bf16_upsample2x_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),

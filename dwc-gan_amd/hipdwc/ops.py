@@ -63,9 +63,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """Per-device scratch arena handed to the kernels (grown on demand, never shrunk).
-    Kernels on one stream run in order, so one arena per device is enough."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Scratch arena handed to the kernels (grown on demand, never shrunk): one per (device, stream) -- kernels on one
+    stream run in order and may share it, concurrent streams must not."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -109,6 +109,24 @@ class KernelTimer:
         self.details.append(detail)
         self.executed.append(flops if exec_flops is None else exec_flops)
         return rc
+
+    def ledger(self):
+        """Per launch KIND (first word of the span's detail + filter size, e.g. "fwd-x3/k5"): launches, milliseconds, algorithmic and
+        executed flops, and the problem shapes seen -- what bench.py's `roofline` and benchmarks/roofline_table.py are built from."""
+        torch.cuda.synchronize()
+        out = {}
+        for (tag, flops, a, b), ex, det in zip(self.spans, self.executed, self.details):
+            words = det.split()
+            kind = words[0] if words else tag
+            ksz = next((w for w in words[1:] if w[0] == "k" and w[1:].isdigit()), "")
+            ent = out.setdefault(kind + ("/" + ksz if ksz else ""), {"launches": 0, "ms": 0.0, "flops": 0.0, "exec_flops": 0.0,
+                                                                      "tag": tag.split("/")[-1], "shapes": {}})
+            ent["launches"] += 1
+            ent["ms"] += a.elapsed_time(b)
+            ent["flops"] += flops
+            ent["exec_flops"] += ex
+            ent["shapes"][det] = ent["shapes"].get(det, 0) + 1
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
@@ -325,7 +343,8 @@ def refresh_prepared(params):
         return 0
     lib = _lib.load()
     dev = todo[0][0].device
-    ident = tuple((p.data_ptr(), val[1].data_ptr()) for p, _, _, val, _ in todo)
+    # (the recipe is part of the identity: a lazily rebuilt layout may reuse the address of another layout of the same parameter)
+    ident = tuple((p.data_ptr(), val[1].data_ptr(), tuple(sorted(val[2].items()))) for p, _, _, val, _ in todo)
     table = _REFRESH_TABLES.get(ident)
     if table is None:
         desc = np.zeros(len(todo), dtype=_REFRESH_DT)
@@ -626,13 +645,14 @@ class _Conv2d(torch.autograd.Function):
                 w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
                 ws = workspace(nws, dev)
 
-                def run_x3():
-                    rc = lib.dwc_x3_conv2d_same_add(g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx,
-                                                    KH, 0, 0, st)
-                    return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
-                                                              W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
-                _lib.check(_timed("conv_halo_x3_kernel", flops, run_x3, scope_name=ctx.bscope, exec_flops=6 * flops,
-                                  detail="dgrad-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_same dgrad")
+                shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
+                # (two spans: the interior launch carries the layer's flops, the ring strips + fold are time on top of it)
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add(
+                    g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, st),
+                    scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
+                _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                    scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
             elif wt:
                 # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
@@ -640,25 +660,24 @@ class _Conv2d(torch.autograd.Function):
                 nwino = lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt)
                 ws = workspace(nwino + nws, dev)
 
-                def run():
-                    rc = lib.dwc_conv2d_wino(g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, wt, None,
-                                             ws.data_ptr(), nwino, st)
-                    return rc or lib.dwc_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H,
-                                                              W, Cx, cop, KH, KW, pad, ws.data_ptr() + nwino, nws, st)
-                _lib.check(_timed("conv_gemm_kernel", flops, run, scope_name=ctx.bscope, exec_flops=flops * _WINO_RATIO[wt],
-                                  detail="dgrad-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride)),
-                           "conv2d_wino dgrad")
+                shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
+                    g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, wt, None, ws.data_ptr(), nwino, st),
+                    scope_name=ctx.bscope, exec_flops=flops * _WINO_RATIO[wt], detail="dgrad-wino%d" % wt + shape), "conv2d_wino dgrad")
+                _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad,
+                    ws.data_ptr() + nwino, nws, st), scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
             elif half and HALO and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):
                 # interior on the halo-tiled kernel (zero rule, dgrad weights), the ring stays on the strip GEMMs
                 ws = workspace(nws, dev)
 
-                def run_halo():
-                    rc = lib.dwc_bf16_conv2d_same_halo_add(g.data_ptr(), w_dg.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx,
-                                                           KH, 0, 0, st)
-                    return rc or lib.dwc_bf16_conv2d_bwd_data_ring(g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B,
-                                                                   H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st)
-                _lib.check(_timed("conv_gemm_kernel", flops, run_halo, scope_name=ctx.bscope,
-                                  detail="dgrad-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_same_halo dgrad")
+                shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo_add(
+                    g.data_ptr(), w_dg.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st),
+                    scope_name=ctx.bscope, detail="dgrad-halo" + shape), "conv2d_same_halo dgrad")
+                _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_bf16_conv2d_bwd_data_ring(
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                    scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
             else:
                 ws = workspace(nws, dev)
@@ -960,6 +979,43 @@ def linear(x, w, b, act="none", owner=None):
 # --------------------------------------------------------------------------------------
 # text encoder: one bidirectional LSTM layer over padded sequences with per-sample lengths
 # --------------------------------------------------------------------------------------
+_LSTM_STATUS = {}            # device index -> (persistent int32 device word, pinned host copy, event of the last copy or None)
+LSTM_SEQ_MAX_WORKGROUPS = 0  # > 0: cap on the persistent launches' grid (hipdwc.dp sets it while collectives share the CUs)
+
+
+def _lstm_status(device):
+    """The sticky hand-off status word of the persistent LSTM launches on `device` (dwc_lstm_seq_*: bit 0 forward, bit 1
+    backward timed out).  It is NOT in the scratch arena: no later op overwrites it."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ent = _LSTM_STATUS.get(key)
+    if ent is None:
+        ent = [torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+        _LSTM_STATUS[key] = ent
+    return ent
+
+
+def lstm_status_poll(device, wait=False):
+    """Check the persistent LSTM launches' status word without stalling the stream: each call looks at the copy the PREVIOUS
+    call started (if it has landed, or `wait`) and starts a new one.  Raises when a hand-off between workgroups timed out --
+    the affected results were overwritten with NaN by the kernel, so nothing silently wrong was consumed; the run must stop
+    (DWC_LSTM_SEQ=0 selects the per-step kernels, which have no cross-workgroup hand-off).  Solver calls this once per step."""
+    if not _LSTM_STATUS:
+        return
+    ent = _lstm_status(device)
+    if ent[2] is not None and (wait or ent[2].query()):
+        if wait:
+            ent[2].synchronize()
+        if int(ent[1][0]) != 0:
+            raise _lib.HipKernelError(
+                "persistent LSTM kernel: a workgroup hand-off timed out (status %d: not all workgroups of the launch were resident); "
+                "its results were overwritten with NaN.  Re-run with DWC_LSTM_SEQ=0 (per-step kernels)." % int(ent[1][0]))
+        ent[2] = None
+    if ent[2] is None:
+        ent[1].copy_(ent[0], non_blocking=True)
+        ent[2] = torch.cuda.Event()
+        ent[2].record()
+
+
 class _LSTMBidir(torch.autograd.Function):
     """Both directions of one nn.LSTM layer on a packed batch (reference networks_v2.py:226-233), zero initial state.
     x:[T,B,I]; lens:[B] int32 on the device (sample b is active at steps t < lens[b]); w_ih:[2,4H,I], w_hh:[2,4H,H],
@@ -985,7 +1041,8 @@ class _LSTMBidir(torch.autograd.Function):
             # all T steps in ONE persistent launch (csrc/lstm.hip lstm_seq_fwd); shapes it does not take fall to the step kernels
             ws = workspace(lib.dwc_lstm_seq_ws_bytes(B, 2), dev)
             rc = lib.dwc_lstm_seq_fwd(xproj.data_ptr(), w_hh_c.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(),
-                                      gates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _stream())
+                                      gates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _lstm_status(dev)[0].data_ptr(),
+                                      LSTM_SEQ_MAX_WORKGROUPS, _stream())
             if rc not in (0, _lib.EINVAL):
                 _lib.check(rc, "lstm_seq_fwd")
         if rc != 0:
@@ -1010,7 +1067,8 @@ class _LSTMBidir(torch.autograd.Function):
         if LSTM_SEQ:
             ws = workspace(lib.dwc_lstm_seq_ws_bytes(B, 2), dev)
             rc = lib.dwc_lstm_seq_bwd(_p(d_out), _p(d_c), w_hh_t.data_ptr(), lens.data_ptr(), c.data_ptr(), gates.data_ptr(),
-                                      dgates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _stream())
+                                      dgates.data_ptr(), T, B, H, 2, ws.data_ptr(), ws.numel(), _lstm_status(dev)[0].data_ptr(),
+                                      LSTM_SEQ_MAX_WORKGROUPS, _stream())
             if rc not in (0, _lib.EINVAL):
                 _lib.check(rc, "lstm_seq_bwd")
         if rc != 0:
@@ -1040,6 +1098,23 @@ def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh):
 # --------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------
+NORM_FUSED_FINAL = int(os.environ.get("DWC_NORM_FUSED_FINAL", "1"))   # 0: statistics always finalised by the separate *_final launches
+_NORM_TICKETS = {}           # (device index, stream) -> persistent zero-initialised ticket row (self-resetting, caller-owned)
+
+
+def _norm_tickets(device):
+    """Ticket row of the instance-norm statistics launches for the CURRENT stream of `device` (dwc_instnorm_*: launches on one
+    stream are ordered and share a row, concurrent streams get a row each), or None when the fused finalisation is off."""
+    if not NORM_FUSED_FINAL:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    row = _NORM_TICKETS.get(key)
+    if row is None:
+        row = torch.zeros(int(_lib.load().dwc_instnorm_ticket_words()), dtype=torch.int32, device=device)
+        _NORM_TICKETS[key] = row
+    return row.data_ptr()
+
+
 class _InstNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, relu, eps, token=None):
@@ -1058,8 +1133,8 @@ class _InstNorm(torch.autograd.Function):
         rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
         _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
-                   "instnorm_fwd")
+                                        rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _norm_tickets(dev),
+                                        _stream()), "instnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -1080,7 +1155,7 @@ class _InstNorm(torch.autograd.Function):
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
         _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                         dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
-                                        ws.numel(), _stream()), "instnorm_bwd")
+                                        ws.numel(), _norm_tickets(dev), _stream()), "instnorm_bwd")
         if ctx.token is not None:                 # the first convolution of the block adds it in its data-gradient epilogue
             ctx.token.g = dy
             return dx, dgamma, dbeta, None, None, None, None

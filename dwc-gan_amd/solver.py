@@ -73,8 +73,10 @@ class Solver(nn.Module):
         self._gen_steps = 0            # bumped whenever G's parameters change: validity of the cached content code
         self._content_cache = None
         # D updates per G update (reference train.py:31,105 keeps it in `opts`, out of the solver's sight).  dis_update tapes
-        # enc_content(x_real) for the gen_update that follows ONLY on the iterations that have one; a caller that runs
-        # n_critic > 1 without setting this attribute is detected (a taped content code left unconsumed) and taping stops.
+        # enc_content(x_real) for the gen_update that follows ONLY on the iterations that have one: tell the solver with
+        # set_n_critic(n) (or dis_update(..., tape_content=bool) per call).  A caller that runs n_critic > 1 without doing
+        # either is detected (a taped content code left unconsumed: dropped at once, taping off until the next
+        # set_n_critic / resume / init_network) -- never wrong, only one wasted taped encode.
         self.n_critic = 1
         self._tape_content = True
 
@@ -106,6 +108,10 @@ class Solver(nn.Module):
         self._reducers = {"dis": dp.OverlappedGradReducer(self.dis_opt.param_groups[0]["params"], group, bucket_bytes),
                           "gen": dp.OverlappedGradReducer(self.gen_opt.param_groups[0]["params"], group, bucket_bytes)}
         self.grad_sync = None
+        # the persistent LSTM launches need ALL their workgroups resident while RCCL's all-reduce kernels (launched from inside
+        # backward on a side stream) hold CUs of their own: keep those launches to half of a 256-CU device; larger grids take the
+        # per-step kernels (dwc_lstm_seq_* return DWC_EINVAL above the cap)
+        ops.LSTM_SEQ_MAX_WORKGROUPS = 128
         if os.environ.get("DWC_FORCE_DP") == "1":
             for r in self._reducers.values():
                 r.force = True
@@ -126,6 +132,11 @@ class Solver(nn.Module):
             self.grad_sync((self.dis_opt if which == "dis" else self.gen_opt).param_groups[0]["params"])
 
     # ---- bookkeeping -----------------------------------------------------------------------
+    def set_n_critic(self, n):
+        """D updates per G update of the caller's loop (reference train.py:105 `(iterations + 1) % opts.n_critic == 0`)."""
+        self.n_critic = max(1, int(n))
+        self._tape_content, self._content_cache = True, None
+
     def print_network(self, model, name):
         print("The number of parameters in {}: {}".format(name, sum(p.numel() for p in model.parameters())))
 
@@ -197,12 +208,15 @@ class Solver(nn.Module):
         return self._decode(content, torch.cat(style_txt, dim=1), x4)[:, :3].float()
 
     # ---- D step (reference solver.py:317-353) ---------------------------------------------------
-    def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters):
+    def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters, tape_content=None):
+        """``tape_content`` (not in the reference's signature): True / False = whether a gen_update on this batch follows this
+        call (its enc_content(x_real) is then computed once, here, on the tape); None = decide from set_n_critic()."""
         if configs["gp_w"] > 0.0 or configs["use_r1"]:
             raise NotImplementedError("gradient / R1 penalties need double backward through the HIP ops "
                                       "(off in the shipped config: gp_w 0, use_r1 False)")
         self._zero_grad("dis")
         x4 = ops.pack_image(x_real)
+        ops.lstm_status_poll(x4.device)     # persistent text-encoder kernels: raise if a hand-off of an earlier step timed out
         B = x4.shape[0]
         with torch.no_grad():
             style_real, _ = self.gen.enc_style(x4)              # draw: mapping dropout (same order as gen.encode)
@@ -211,7 +225,10 @@ class Solver(nn.Module):
         # encodes x_real again there, solver.py:155, with identical values).
         if self._content_cache is not None:            # the last taped code was never consumed: no gen_update follows every
             self._tape_content = False                 # dis_update (n_critic > 1, reference train.py:105) -- stop taping
-        if self._tape_content and (iters + 1) % max(1, int(self.n_critic)) == 0:
+            self._content_cache = None                 # ... and release the unconsumed graph now
+        tape = bool(tape_content) if tape_content is not None else (
+            self._tape_content and (iters + 1) % max(1, int(self.n_critic)) == 0)
+        if tape:
             content_taped = self.gen.enc_content(x4)
             self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
         else:
@@ -375,7 +392,7 @@ class Solver(nn.Module):
         out, so a resumed reference run restarts Adam from zero moments); off by default to keep the reference's behaviour."""
         name = self._latest(checkpoint_dir, "gen")
         self.gen.load_state_dict(torch.load(name, map_location="cpu")["a"])
-        self._gen_steps, self._content_cache = self._gen_steps + 1, None
+        self._gen_steps, self._content_cache, self._tape_content = self._gen_steps + 1, None, True
         iterations = int(name[-15:-7]) if "avg" in name else int(name[-11:-3])
         name = self._latest(checkpoint_dir, "dis")
         self.dis.load_state_dict(torch.load(name, map_location="cpu")["b"])
@@ -406,7 +423,7 @@ class Solver(nn.Module):
         sg = self.gen.state_dict()
         sg.update({k: v for k, v in gen_dict.items() if k in sg and "embed_tokens" not in k})
         self.gen.load_state_dict(sg)
-        self._gen_steps, self._content_cache = self._gen_steps + 1, None
+        self._gen_steps, self._content_cache, self._tape_content = self._gen_steps + 1, None, True
         print("Initial model loaded...")
 
     def save(self, snapshot_dir, iterations):

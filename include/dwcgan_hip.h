@@ -157,15 +157,21 @@ int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int r
 /* ---- instance norm / AdaIN (reference networks.py:545 nn.InstanceNorm2d and
  *      networks.py:706-719 AdaptiveInstanceNorm2d; residual add networks.py:518-522) --------- */
 /* y = relu?( (x-mean[n,c])*rstd[n,c]*gamma[n,c] + beta[n,c] ) + residual?
- * gamma/beta: [B*C] or NULL (plain IN).  mean/rstd [B*C] are outputs kept for the backward. */
+ * gamma/beta: [B*C] or NULL (plain IN).  mean/rstd [B*C] are outputs kept for the backward.
+ * tickets: NULL, or a CALLER-OWNED row of dwc_instnorm_ticket_words() device words that are zero before first use and belong
+ * to this stream (launches on one stream may share a row; concurrent streams need a row each).  With a row and a small batch
+ * the statistics launch finalises itself (the last-arriving workgroup of a sample sums the partials; tickets return to zero
+ * when the launch completes) and the separate finalise launch is skipped; results are identical either way (fixed summation
+ * order).  The library keeps no mutable state of its own.  If a launch is aborted, re-zero the row. */
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C);
+size_t dwc_instnorm_ticket_words(void);
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                      float* y, float* mean, float* rstd, int B, int HW, int C, float eps, int relu,
-                     void* ws, size_t ws_bytes, void* stream);
+                     void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
 /* dx (and dgamma/dbeta [B*C] when gamma != NULL) given dy w.r.t. the (pre-residual) output. */
 int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                     int B, int HW, int C, int relu, void* ws, size_t ws_bytes, void* stream);
+                     int B, int HW, int C, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
 
 /* ---- MUNIT LayerNorm (reference networks.py:736-752: per-sample mean, UNBIASED std,
  *      (x-mean)/(std+eps), per-channel gamma/beta) ------------------------------------------ */
@@ -233,14 +239,19 @@ int dwc_lstm_fwd(const float* xproj, const float* w_hh, const int* lens, float* 
  * the caller forms dW_ih, dW_hh, db and dx with three GEMMs.  dc_carry:[dirs][B][H] scratch. */
 /* The same recurrence, ALL T steps of both directions in ONE launch: persistent workgroups, W_hh slices and cell state in
  * registers, h_t handed between workgroups inside the launch (write-through stores + agent-scope arrival counter + sc1 loads;
- * bounded polls).  ws >= dwc_lstm_seq_ws_bytes(B, dirs): [0] timeout word (non-zero after the launch = a rendez-vous was
- * missed, results invalid), then the counters; zeroed by the call.  DWC_EINVAL for shapes it does not take (H > 320, more
- * workgroups than fit the CUs): use dwc_lstm_fwd. */
+ * bounded polls).  ws >= dwc_lstm_seq_ws_bytes(B, dirs) (a multiple of 16 bytes): [0] timeout word, then the counters; zeroed
+ * by the call.  Every workgroup of the launch must be RESIDENT at once: the call queries the device (CU count x occupancy of
+ * the kernel at its LDS request; `max_workgroups` > 0 lowers that capacity further, e.g. to leave CUs to collective kernels
+ * running beside it) and returns DWC_EINVAL -- nothing launched, use dwc_lstm_fwd / dwc_lstm_bwd -- when the grid does not fit
+ * or the shape is not taken (H > 320).  A rendez-vous that is missed all the same (bounded spin, about a second) fails LOUDLY:
+ * the workgroup overwrites every result slot it owns with NaN and ORs 1 (forward) / 2 (backward) into *status, a
+ * caller-owned device word that the library never clears (may be NULL). */
 size_t dwc_lstm_seq_ws_bytes(int B, int dirs);
 int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
-                     int dirs, void* ws, size_t ws_bytes, void* stream);
+                     int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups, void* stream);
 int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c, const float* gates,
-                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, void* stream);
+                     float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups,
+                     void* stream);
 int dwc_lstm_bwd(const float* d_out, const float* d_c, const float* w_hh_t, const int* lens, const float* c,
                  const float* gates, float* dgates, float* dc_carry, int T, int B, int H, int dirs, void* stream);
 
@@ -463,10 +474,11 @@ int dwc_bf16_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw_oihw,
 int dwc_bf16_act_bwd_bias(const void* dy, const void* y, void* g, float* db, int rows, int C, int act, void* ws,
                           size_t ws_bytes, void* stream);
 int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          void* stream);
 int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, void* stream);
+                          size_t ws_bytes, unsigned* tickets, void* stream);
 int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
                            int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
 int dwc_bf16_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* inv, const float* gamma,

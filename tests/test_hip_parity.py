@@ -272,9 +272,10 @@ def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
     par = {n: [dev(getattr(ref, n + "_l0" + suf), True) for suf in ("", "_reverse")] for n in names}
     lens_t = torch.tensor(lens)
     out, cell = ops.lstm_bidir(xd, lens_t.to(torch.int32).to(DEV), *[torch.stack(par[n]) for n in names])
-    if seq:                      # the persistent launch's timeout word (first word of the scratch arena): no rendez-vous was missed
-        torch.cuda.synchronize()
-        assert int(ops.workspace(4, torch.device(DEV))[:4].view(torch.int32)[0]) == 0
+    if seq:                      # the persistent launch's sticky status word (caller-owned, outside the scratch arena): no rendez-vous missed
+        ops.lstm_status_poll(torch.device(DEV))
+        ops.lstm_status_poll(torch.device(DEV), wait=True)
+        assert int(ops._lstm_status(torch.device(DEV))[0].item()) == 0
     last, cols = (lens_t - 1).to(DEV), torch.arange(B, device=DEV)
     mem_d = torch.cat([out[0], out[1]], -1)
     hn_d = torch.stack([out[0][last, cols], out[1][0]])
@@ -287,6 +288,86 @@ def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
     for n in names:
         for k, suf in enumerate(("", "_reverse")):
             close(par[n][k].grad, getattr(ref, n + "_l0" + suf).grad, rel=1e-4, msg=n + suf)
+
+
+def test_lstm_persistent_launch_refuses_grids_that_cannot_be_resident(monkeypatch):
+    """The hand-off inside dwc_lstm_seq_* needs every workgroup of the launch resident.  The launcher derives the capacity from
+    the device (CU count x occupancy) and an optional caller cap: a grid above it is refused with DWC_EINVAL BEFORE anything is
+    launched (ops then runs the per-step kernels, same results), and a failed hand-off is reported through the sticky status
+    word, not through scratch memory."""
+    from hipdwc import _lib
+    lib = _lib.load()
+    T, B, H = 5, 16, 300
+    d = torch.device(DEV)
+    xproj = torch.randn(2, T, B, 4 * H, device=d)
+    w_hh = torch.randn(2, 4 * H, H, device=d) * 0.05
+    lens = torch.full((B,), T, dtype=torch.int32, device=d)
+    out, c, gates = (torch.empty(2, T, B, n, device=d) for n in (H, H, 4 * H))
+    nws = lib.dwc_lstm_seq_ws_bytes(B, 2)
+    assert nws % 16 == 0
+    ws = torch.zeros(nws, dtype=torch.uint8, device=d)          # EXACTLY the size the library asks for
+    status = torch.zeros(1, dtype=torch.int32, device=d)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (xproj.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), out.data_ptr(), c.data_ptr(), gates.data_ptr(), T, B, H, 2,
+            ws.data_ptr(), nws, status.data_ptr())
+    assert lib.dwc_lstm_seq_fwd(*args, 37, st) == _lib.EINVAL     # 19 groups x 2 directions = 38 workgroups > cap 37
+    assert lib.dwc_lstm_seq_fwd(*args, 38, st) == 0
+    ref_out = torch.empty_like(out)
+    _lib.check(lib.dwc_lstm_fwd(xproj.data_ptr(), w_hh.data_ptr(), lens.data_ptr(), ref_out.data_ptr(), c.data_ptr(), gates.data_ptr(),
+                                T, B, H, 2, st), "lstm_fwd")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0 and torch.isfinite(out).all()
+    close(out, ref_out.cpu(), rel=1e-5)
+    # through ops: a cap below the grid silently takes the per-step kernels
+    monkeypatch.setattr(ops, "LSTM_SEQ_MAX_WORKGROUPS", 1)        # 1 group x 2 directions = 2 workgroups > 1
+    x = torch.randn(T, B, 12, device=d)
+    par = [torch.randn(2, 4 * 16, 12, device=d), torch.randn(2, 4 * 16, 16, device=d), torch.randn(2, 64, device=d), torch.randn(2, 64, device=d)]
+    a, _ = ops.lstm_bidir(x, lens, *par)
+    monkeypatch.setattr(ops, "LSTM_SEQ_MAX_WORKGROUPS", 0)
+    b, _ = ops.lstm_bidir(x, lens, *par)
+    close(a, b.cpu(), rel=1e-5)
+
+
+def test_instance_norm_last_arriver_two_streams_stress(monkeypatch):
+    """The statistics launches finalise themselves through caller-owned ticket rows (one per stream, acquire/release ordering,
+    no library-global state).  Two streams run norm forward + backward launches of different shapes
+    concurrently, 200 rounds: every result must equal, BIT FOR BIT (fixed summation order), what the separate *_final launches
+    give for the same input, and every ticket row must be back at zero."""
+    d = torch.device(DEV)
+    shapes = [(16, 256, 32), (48, 64, 16), (5, 128, 8), (32, 256, 32)]
+    g = torch.Generator().manual_seed(5)
+    data = []
+    for (B, C, H) in shapes:
+        x = (torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).to(d).contiguous(memory_format=torch.channels_last)
+        ga, be = (torch.randn(B * C, generator=g) * 0.5 + 1).to(d), torch.randn(B * C, generator=g).to(d)
+        gy = torch.randn(B, C, H, H, generator=g).to(d).contiguous(memory_format=torch.channels_last)
+        data.append((x, ga, be, gy))
+
+    def run(x, ga, be, gy):
+        xr = x.detach().clone().requires_grad_(True)
+        gr, br = ga.detach().clone().requires_grad_(True), be.detach().clone().requires_grad_(True)
+        y = ops.instance_norm(xr, gr, br, relu=True)
+        (y * gy).sum().backward()
+        return [y.detach(), xr.grad, gr.grad, br.grad]
+
+    monkeypatch.setattr(ops, "NORM_FUSED_FINAL", 0)
+    want = [run(*t) for t in data]
+    torch.cuda.synchronize()
+    monkeypatch.setattr(ops, "NORM_FUSED_FINAL", 1)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = {}
+    for rnd in range(200):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                k = (rnd + 2 * si) % len(data)
+                got[(si, k)] = run(*data[k])
+    torch.cuda.synchronize()
+    assert len(ops._NORM_TICKETS) >= 2                       # a row per stream
+    for row in ops._NORM_TICKETS.values():
+        assert int(row.abs().sum().item()) == 0              # self-reset
+    for (si, k), res in got.items():
+        for a, b, name in zip(res, want[k], ("y", "dx", "dgamma", "dbeta")):
+            assert torch.equal(a, b), (si, k, name, (a - b).abs().max().item())
 
 
 @pytest.mark.parametrize("B,C,H", [(2, 256, 16), (3, 64, 32), (1, 128, 8), (2, 8, 6), (2, 512, 2)])
@@ -579,13 +660,16 @@ def test_tiny_three_iterations_vs_reference(tiny):
         host.set_noise(host.DeviceNoise())
 
 
-@pytest.mark.parametrize("S,B,what", [(128, 2, "all"), (256, 1, "all"), (128, 64, "dis"), (256, 8, "dis")])
+@pytest.mark.parametrize("S,B,what", [(128, 2, "all"), (256, 1, "all"), (128, 64, "dis"), (256, 8, "dis"),
+                                      (128, 64, "all"), (256, 8, "all")])
 def test_full_size_iteration_vs_oracle(S, B, what):
     """The shipped network sizes (dim 64, 4 ResBlocks, 5-layer 2-scale D) at 128x128 and at the 256x256 of
     BASELINE configs[4]: one full iteration, every loss scalar against the CPU oracle run from the same
     weights, batch and random stream.  Exercises the real layer shapes (128x128 tiles, split-K tails,
     wide heads) that the tiny configuration cannot.  (128, 64) and (256, 8) are the PER-GPU shapes of BASELINE
-    configs[3] (global batch 512 on 8 GPUs) and configs[4] (global batch 64 on 8 GPUs)."""
+    configs[3] (global batch 512 on 8 GPUs) and configs[4] (global batch 64 on 8 GPUs): the D step alone ("dis") and, since
+    round 4, the WHOLE iteration incl. the G step ("all": all 16 scalars + generator gradients; the oracle's B=64 iteration
+    is ~1 min of host time and ~60 GB of host memory)."""
     from solver import Solver
     if B >= 8:
         torch.set_num_threads(min(32, os.cpu_count() or 1))       # the oracle leg: more threads than that are slower
