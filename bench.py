@@ -94,8 +94,10 @@ GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the 
 PIPE_PEAK = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
 
 
-def kernel_of_kind(kind_key, precision):
-    """(label, csv regex, pipe) of a ledger key such as "fwd-x3/k5"."""
+def kernel_of_kind(kind_key, precision, split_generic=False):
+    """(label, csv regex, pipe) of a ledger key such as "fwd-x3/k5".  The generic im2col kernels serve many layer shapes through
+    several tile instantiations; `split_generic` labels them per launch kind ("conv_gemm_kernel[dgrad/k4]") so that a bag of
+    unrelated small launches is not mistaken for one kernel."""
     kind, _, ksz = kind_key.partition("/")
     k = ksz[1:] if ksz else ""
     if kind in KIND_KERNEL:
@@ -103,7 +105,7 @@ def kernel_of_kind(kind_key, precision):
         return label.replace("{k}", k), rx.replace("{k}", k), pipe
     if kind in GENERIC_KERNEL:
         name = GENERIC_KERNEL[kind][1 if precision == "bf16" else 0]
-        return name, name + "<", "bf16" if precision == "bf16" else "fp32"
+        return (name + "[" + kind_key + "]") if split_generic else name, name + "<", "bf16" if precision == "bf16" else "fp32"
     return kind, None, None
 
 
@@ -122,13 +124,13 @@ def _shape_bytes(detail, elem):
     return elem * B * H * W * ci + elem * B * (H // st) * (W // st) * co + 4 * ci * co * k * k
 
 
-def kernel_table(ledger, precision):
+def kernel_table(ledger, precision, split_generic=False):
     """Ledger kinds folded per kernel: launches, ms, algorithmic / executed GFLOP and algorithmic bytes per launch, and the
     fraction of the kernel's pipe peak (executed flops / time / peak)."""
     elem = 2 if precision == "bf16" else 4
     rows = {}
     for key, ent in ledger.items():
-        label, rx, pipe = kernel_of_kind(key, precision)
+        label, rx, pipe = kernel_of_kind(key, precision, split_generic)
         r = rows.setdefault(label, {"kernel": label, "csv_regex": rx, "pipe": pipe, "kinds": [], "launches": 0, "ms": 0.0,
                                     "flops": 0.0, "exec_flops": 0.0, "bytes": 0.0})
         r["kinds"].append(key)
@@ -440,11 +442,11 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         return out
 
     ledger = timer.ledger() if timer is not None else {}
-    table = kernel_table(ledger, precision)
+    table = kernel_table(ledger, precision, split_generic=True)
     if getattr(args, "ledger", None):
         with open(args.ledger if config_name == args.config else args.ledger + "." + config_name, "w") as f:
             json.dump({"config": config_name, "precision": precision, "per_gpu_batch": per_gpu_batch, "image_size": image_size,
-                       "ledger": ledger, "kernels": table}, f, indent=1)
+                       "ledger": ledger, "kernels": kernel_table(ledger, precision)}, f, indent=1)
     dom = total(lambda t: t.endswith(DOMINANT))
     x3 = total(lambda t: t.endswith(X3))
     # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)

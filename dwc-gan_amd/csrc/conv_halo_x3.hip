@@ -57,6 +57,7 @@ struct X3Args {
     float* y;            // [B][H][W][N] fp32
     int B, H, W, Cin, N, rows, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
+    int stagger = 0;     // two-workgroups-per-CU form: 10 ns ticks the CU's second workgroup sleeps before its first tile (dwc_duo_stagger)
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
+    if constexpr (PB == 1) dwc_duo_stagger(a.stagger, 512);
 
     int bid = blockIdx.x;
     {
@@ -794,8 +796,10 @@ int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* 
     // measured against the best one-workgroup-per-CU tile: 5x5 128->64 +27 %, 5x5 256->128 +5 %, 3x3 256->256 at B=48 +16 %,
     // small launches (<= 256 workgroups) equal.  DWC_X3_DUO=0: the 8-wave tiles below.
     static const int duo = getenv("DWC_X3_DUO") ? atoi(getenv("DWC_X3_DUO")) : 1;
+    static const int stagger = getenv("DWC_X3_STAGGER") ? atoi(getenv("DWC_X3_STAGGER")) : 0;     // development: 10 ns ticks
     if (duo && !force) {
         a.tiles_n = (N + 63) / 64;
+        a.stagger = (long)blocks * a.tiles_n > 512 ? stagger : 0;      // (a launch of one round gains nothing from an offset)
         const dim3 g2(blocks * a.tiles_n);
         if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
         else x3_launch<5, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);

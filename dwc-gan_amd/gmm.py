@@ -8,7 +8,11 @@ import torch
 
 
 def _stack(heads):
-    """list of K tensors [B, D] (or one [B, K*D] tensor is NOT accepted) -> [B, K, D]."""
+    """list of K tensors [B, D] -> [B, K, D].  A networks_v2.HeadList carries the [B, K*D] tensor its entries were cut from:
+    that one is viewed instead of stacking K slices (one autograd edge instead of K)."""
+    flat = getattr(heads, "flat", None)
+    if flat is not None:
+        return flat.reshape(flat.shape[0], len(heads), -1)
     return torch.stack(list(heads), dim=1)
 
 

@@ -15,6 +15,33 @@ from hipdwc import host, ops
 from .networks import ContentEncoder, MLP, Conv2dBlock, ResBlocks, AdaptiveInstanceNorm2d, Decoder  # noqa: F401
 
 
+class HeadList(list):
+    """The reference's per-attribute head list ([mu_0 .. mu_{K-1}], each [B, c_dim]) that also remembers the ONE [B, K*c_dim]
+    tensor its entries are column slices of (``flat``).  Callers inside this package read ``flat`` (``flat_heads``) instead
+    of concatenating / stacking the K slices again: one autograd edge instead of K slice / cat / add nodes per use (the K-way
+    lists cost ~250 of the ~770 stock-torch launches of a training step, r03 kernel trace).  To the reference's callers it is
+    an ordinary list."""
+    flat = None
+
+    @classmethod
+    def of(cls, flat, k):
+        out = cls(flat.reshape(flat.shape[0], k, -1).unbind(1))
+        out.flat = flat
+        return out
+
+    def rows(self, a, b):
+        """The same heads for samples a..b of the batch."""
+        return HeadList.of(self.flat[a:b], len(self))
+
+
+def flat_heads(heads):
+    """[B, K*c_dim] of a head list (its ``flat`` tensor when it has one, else the concatenation the reference writes)."""
+    if torch.is_tensor(heads):
+        return heads
+    flat = getattr(heads, "flat", None)
+    return flat if flat is not None else torch.cat(list(heads), dim=1)
+
+
 class StyleEncoder(nn.Module):
     """Image -> per-attribute (mu, logvar) heads (reference networks_v2.py:98-141): 7x7 stem,
     n_downsample stride-2 convs without norm, global average pool, optional 2-layer mapping
@@ -58,8 +85,7 @@ class StyleEncoder(nn.Module):
         b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
         out = ops.linear(f, w, b)
         k, c = self.num_class, self.c_dim
-        heads = out[:, :2 * k * c].reshape(out.shape[0], 2 * k, c).unbind(1)   # one autograd node instead of 2k slices
-        return list(heads[:k]), list(heads[k:])
+        return HeadList.of(out[:, :k * c], k), HeadList.of(out[:, k * c:2 * k * c], k)
 
 
 def _packed_index(lens_sorted, t_max, bsz, device):
@@ -168,8 +194,7 @@ class TxtEncoder(nn.Module):
         b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
         out = torch.nn.functional.linear(feat, w, b)
         k, c = self.num_class, self.style_dim // self.num_class
-        heads = out.reshape(bsz, 2 * k, c).unbind(1)
-        return list(heads[:k]), list(heads[k:])
+        return HeadList.of(out[:, :k * c], k), HeadList.of(out[:, k * c:2 * k * c], k)
 
 
 class AdaINGen_v2(nn.Module):

@@ -25,7 +25,7 @@ from hipdwc import host, ops
 from hipdwc.host import get_scheduler, moving_average, weights_init
 from hipdwc.optim import FusedAdam, FusedEMA
 from networks.networks import MsImageDis
-from networks.networks_v2 import AdaINGen_v2
+from networks.networks_v2 import AdaINGen_v2, flat_heads
 from tools import dist_sampling_split
 
 from vocab import Vocab
@@ -188,9 +188,7 @@ class Solver(nn.Module):
         return torch.mean((ops.instance_norm(img_fea).float() - ops.instance_norm(target_fea).float()) ** 2)
 
     def criterion_l1(self, a, z):
-        a = torch.cat(a, dim=1) if isinstance(a, (list, tuple)) else a
-        z = torch.cat(z, dim=1) if isinstance(z, (list, tuple)) else z
-        return self.criterionL1(a, z)
+        return self.criterionL1(flat_heads(a), flat_heads(z))
 
     def style_replace(self, c_src, c_trg, z_src, z_trg):
         keep = (c_src == c_trg).repeat_interleave(self.c_dim, dim=1)
@@ -204,8 +202,8 @@ class Solver(nn.Module):
     def forward(self, x_real, txt_src2trg, txt_lens):
         x4 = ops.pack_image(x_real)
         content, style_src, _ = self.gen.encode(x4)
-        style_txt, _ = self.gen.encode_txt(torch.cat(style_src, dim=1), txt_src2trg, txt_lens)
-        return self._decode(content, torch.cat(style_txt, dim=1), x4)[:, :3].float()
+        style_txt, _ = self.gen.encode_txt(flat_heads(style_src), txt_src2trg, txt_lens)
+        return self._decode(content, flat_heads(style_txt), x4)[:, :3].float()
 
     # ---- D step (reference solver.py:317-353) ---------------------------------------------------
     def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters, tape_content=None):
@@ -237,11 +235,11 @@ class Solver(nn.Module):
                 content_taped = self.gen.enc_content(x4)
         with torch.no_grad():
             content = content_taped.detach()
-            style_real = torch.cat(style_real, dim=1)
+            style_real = flat_heads(style_real)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
             # both fakes in ONE decoder pass (AdaIN parameters are per sample)
-            fakes = self._decode(torch.cat([content, content]), torch.cat([torch.cat(style_txt, dim=1), style1]),
+            fakes = self._decode(torch.cat([content, content]), torch.cat([flat_heads(style_txt), style1]),
                                  torch.cat([x4, x4]))
         gw, cw = configs["gan_w"], configs["cls_w"]
         # ONE discriminator pass over [x_fake, x_fake1, x_real]; D(x_real) enters both loss terms as
@@ -277,10 +275,10 @@ class Solver(nn.Module):
                 content_real = cache[3]                                          # taped in dis_update on the same batch and G
             else:
                 content_real = gen.enc_content(x4)
-            s_real = torch.cat(style_real, dim=1)
+            s_real = flat_heads(style_real)
             mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
             style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)   # draws of the text encoder
-            s_txt = torch.cat(style_txt, dim=1)
+            s_txt = flat_heads(style_txt)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             style2 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             mask_rand = gen.draw_encode_mask(B, x4.device)                       # draw of encode(x_fake1)
@@ -296,9 +294,7 @@ class Solver(nn.Module):
             masks = None if mask_rec is None else torch.cat([mask_rec, mask_fake, mask_rand])
             content_all, style_all, _ = gen.encode(x_all, drop_mask=masks)
             content_rec, content_fake, content_rand = torch.split(content_all, B)
-            style_rec = [m[:B] for m in style_all]
-            style_fake = [m[B:2 * B] for m in style_all]
-            style_rand = [m[2 * B:] for m in style_all]
+            style_rec, style_fake, style_rand = torch.split(flat_heads(style_all), B)     # [B, K*c_dim] each
             cyc = cfg["recon_x_cyc_w"] > 0
             if cyc:
                 x_cycle = self._decode(content_fake, s_real, x4)
@@ -359,9 +355,9 @@ class Solver(nn.Module):
         for i in range(x_real.size(0)):
             x4 = ops.pack_image(x_real[i:i + 1])
             content, style_real, _ = self.gen.encode(x4)
-            style_real = torch.cat(style_real, dim=1)
+            style_real = flat_heads(style_real)
             style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg[i:i + 1], txt_lens[i:i + 1])
-            style_txt = torch.cat(style_txt, dim=1)
+            style_txt = flat_heads(style_txt)
             sign = lambda s: torch.where(s.view(1, self.num_cls, self.c_dim).mean(2) < 0, -1.0, 1.0)
             mus_real, mus_txt = sign(style_real), sign(style_txt)
             z = dist_sampling_split(mus_txt, self.c_dim, self.stddev, self.device)
