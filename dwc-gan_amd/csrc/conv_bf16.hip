@@ -271,6 +271,20 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
 
     // accumulator layout: lane l31 = pixel row of tile i, register r = channel (r&3) + 8*(r>>2) + 4*hi of tile n
     const float slope = dwc_act_slope(act);
+    // bias vectors of this lane's columns, loaded ONCE in one batch (r04: inside the per-chunk conditionals of the store loops the
+    // compiler can neither hoist nor batch a load: TM*TN*4 dependent round trips per lane)
+    f32x4 bvec[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) bvec[n][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias && !partial) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                bvec[n][q4] = *reinterpret_cast<const f32x4*>(bias + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, o.N - 4));
+    }
     if constexpr (F32OUT) {
         float* dst = (float*)o.dst + part_offset;
         auto store = [&](auto general) {
@@ -290,7 +304,7 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
                         if (col >= o.N) continue;
                         f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
                         if (!partial) {
-                            if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                            v += bvec[n][q4];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], act, col + k);
@@ -318,7 +332,7 @@ __device__ __forceinline__ void gemm_body_h(const Gather& g, const bf16* __restr
                         const int col = n0 + cl;
                         f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
                         if (col < o.N) {
-                            if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+                            v += bvec[n][q4];
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], act, col + k);
@@ -373,14 +387,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel_h(Gather g, const bf
 }
 
 // the border ring of a stride-1 data gradient: up to four small products in one launch, fp32 strips (see conv_igemm.hip)
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+// (F32OUT = false: whole-K strips rounded to bf16 at their place in a padded bf16 gradient image -- the stride-2 ring)
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool F32OUT = true>
 __global__ __launch_bounds__(256) void gemm_strips_kernel_h(StripSet ss) {
     const Strip& s = ss.s[blockIdx.z];
     if ((int)blockIdx.x >= s.tiles) return;
     const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
-    gemm_body_h<BM, BN, WM, WN, TM, TN, true>(s.g, (const bf16*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0,
-                                              min(s.kt1, kt0 + ss.kt_per_part), blockIdx.y * ss.part_stride, true, 0, 0,
-                                              blockIdx.x, s.tiles);
+    gemm_body_h<BM, BN, WM, WN, TM, TN, F32OUT>(s.g, (const bf16*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0,
+                                                min(s.kt1, kt0 + ss.kt_per_part), blockIdx.y * ss.part_stride, F32OUT, s.oph, s.opw,
+                                                blockIdx.x, s.tiles);
 }
 
 // dst[i] = act(sum_s part[s][i] + bias[i % N]) rounded to bf16, fixed summation order
@@ -1079,6 +1094,25 @@ int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp
     const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C8;
     hipLaunchKernelGGL(fold_band_kernel_h8, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, B, H, W,
                        C8, pad, W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* bf16 twin of dwc_conv2d_bwd_data_s2_ring: ring of the padded gradient image of a 4x4 stride-2 reflect-pad-1 convolution as eight
+ * strips into the bf16 scratch image dxp + band fold onto dx (interior by dwc_bf16_conv2d_s2_halo_bwd_data). */
+int dwc_bf16_conv2d_bwd_data_s2_ring(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
+                                     void* stream) {
+    S2Ring f;
+    if (!dy || !w_dgrad || !dxp || !dx || (Cin & 7) || H > 65535 - 2 || B > 65535 ||
+        !s2_ring_geom(dy, w_dgrad, dxp, 2, B, H, W, Cin, Cout, &f, BK, MIN_LOG_C))
+        return DWC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1, false>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    DWC_LAUNCH_CHECK();
+    const int C8 = Cin / 8;
+    const size_t band_items = (size_t)B * (2 * W + (H - 2) * 2) * C8;
+    hipLaunchKernelGGL(fold_band_kernel_h8, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const bf16*)dxp, (bf16*)dx, B, H, W,
+                       C8, 1, W + 2);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

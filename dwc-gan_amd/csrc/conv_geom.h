@@ -48,9 +48,10 @@ struct Strip {
     Scatter o;
     const void* w;
     int kt0, kt1, tiles, tiles_n;
+    int oph, opw;           // parity class offsets of the scatter (stride-2 gradients: dst pixel = (oh*os + oph, ow*os + opw)), else 0
 };
 struct StripSet {
-    Strip s[4];
+    Strip s[8];             // (the stride-1 ring uses 4, the stride-2 ring 8: gridDim.z of the launch)
     int kt_per_part;        // the K range of every strip is cut into gridDim.y parts (summed by fold_ring_kernel)
     size_t part_stride;     // elements between the ring buffers of consecutive parts
 };
@@ -375,6 +376,7 @@ bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void*
         st.kt1 = ((z & 1) ? pad : KH) * KW * spt;
         st.tiles_n = (Cin + 63) / 64;
         st.tiles = ((st.g.M + 63) / 64) * st.tiles_n;
+        st.oph = st.opw = 0;
         if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
     }
     f->ring_total = (size_t)(p - ring);
@@ -384,6 +386,60 @@ bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void*
     f->parts = range >= 32 ? 4 : (range >= 24 ? 3 : (range >= 16 ? 2 : 1));
     f->ss.kt_per_part = (range + f->parts - 1) / f->parts;
     f->ss.part_stride = f->ring_total;
+    return true;
+}
+
+// Border ring of the PADDED gradient image of a 4x4 stride-2 reflect-pad-1 convolution (reference networks.py:90,94,437,
+// networks_v2.py:107-111), for data gradients whose interior comes from a halo-tiled kernel (dwc_x3_conv2d_s2_bwd_data,
+// dwc_bf16_conv2d_s2_halo_bwd_data): padded pixel (P, Q) = (2 oh + cy, 2 ow + cx) of parity class (cy, cx) is a 2x2-tap
+// zero-padded correlation over dY (src = o - tap, class weight matrix cy*2 + cx of the stride-2 dgrad layout).  The ring --
+// rows P = 0 and P = H+1 (all Q), columns Q = 0 and Q = W+1 (P = 1..H) -- is eight thin strips (2 column / row classes per line),
+// written at their place in the padded scratch image `dxp` ([B][H+2][W+2][Cin]); fold_band_kernel then adds them onto dx.
+struct S2Ring {
+    StripSet ss;
+    int max_tiles;
+};
+
+inline bool s2_ring_geom(const void* dy, const void* w_dgrad, void* dxp, size_t elem_bytes, int B, int H, int W, int Cin, int Cout,
+                         S2Ring* f, int bk = 32, int min_log_c = 2) {
+    if (B <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1) || (Cin & 3) || dwc_ilog2_exact(Cout) < min_log_c) return false;
+    const int H2 = H / 2, W2 = W / 2, Hp = H + 2, Wp = W + 2;
+    const int Kp = (4 * Cout + bk - 1) / bk * bk;
+    const size_t wcs = (size_t)Cin * Kp;                   // elements per class matrix (bwd_geom)
+    const int magic = kw_magic_for(2, 64);
+    f->max_tiles = 0;
+    f->ss.kt_per_part = Kp / bk;
+    f->ss.part_stride = 0;
+    for (int z = 0; z < 8; ++z) {
+        const int line = z >> 1, c = z & 1;                // line: 0 top, 1 bottom, 2 left, 3 right; c: the class along the line
+        const int cy = line == 0 ? 0 : (line == 1 ? 1 : c), cx = line == 2 ? 0 : (line == 3 ? 1 : c);
+        Strip& st = f->ss.s[z];
+        Gather& g = st.g;
+        g.src = dy; g.SH = H2; g.SW = W2; g.SC = Cout; g.logSC = dwc_ilog2_exact(Cout);
+        g.KH = 2; g.KW = 2; g.kw_magic = magic; g.mul_h = g.mul_w = 1; g.kstep = -1; g.reflect = 0; g.tap_t = 0;
+        g.logOW = g.logOHW = -1;
+        g.K = 4 * Cout;
+        size_t shift = 0;                                  // pixels the strip's first row / column lies behind the image origin of dxp
+        if (line < 2) {                                    // rows P = 0 (oh = 0, cy = 0) / P = H+1 (oh = H/2, cy = 1), every column of class cx
+            g.OH = 1; g.OW = W2 + 1; g.off_w = 0;
+            g.off_h = line == 0 ? 0 : H2;
+            shift = line == 0 ? 0 : (size_t)H * Wp;        // 2 * (H/2) rows
+        } else {                                           // columns Q = 0 (ow = 0, cx = 0) / Q = W+1 (ow = W/2, cx = 1), rows P = 1..H of class cy
+            g.OH = H2; g.OW = 1; g.off_h = cy == 0 ? 1 : 0;      // cy = 0: P = 2 oh, oh = 1..H/2; cy = 1: P = 2 oh + 1, oh = 0..H/2-1
+            g.off_w = line == 2 ? 0 : W2;
+            shift = (cy == 0 ? (size_t)2 * Wp : 0) + (line == 2 ? 0 : (size_t)W);
+        }
+        g.M = B * g.OH * g.OW;
+        st.o.dst = dxp ? (void*)((char*)dxp + shift * Cin * elem_bytes) : nullptr;
+        st.o.N = Cin; st.o.OHf = Hp; st.o.OWf = Wp; st.o.os = 2;
+        st.o.crop = 0; st.o.IH = st.o.IW = 0; st.o.inner = nullptr;
+        st.oph = cy; st.opw = cx;
+        st.w = w_dgrad ? (const void*)((const char*)w_dgrad + (size_t)(cy * 2 + cx) * wcs * elem_bytes) : nullptr;
+        st.kt0 = 0; st.kt1 = Kp / bk;
+        st.tiles_n = (Cin + 63) / 64;
+        st.tiles = ((g.M + 63) / 64) * st.tiles_n;
+        if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
+    }
     return true;
 }
 

@@ -262,6 +262,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     __syncthreads();
     bf16* sC = smem;
     const float slope = dwc_act_slope(a.act);
+    f32x4 bvec[TN][4];                                  // bias vectors of this lane's columns: one batch of loads (see conv_halo16_bf16.inc)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            bvec[n][q4] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, a.N - 4))
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
     auto to_lds = [&](auto general) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                     const int col = n0 + cl;
                     f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
                     if (col < a.N) {
-                        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                        v += bvec[n][q4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
@@ -732,6 +739,36 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
         else HALO_LAUNCH(5, 64, 4, 2, 2, 1);
     }
 #undef HALO_LAUNCH
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* INTERIOR of the data gradient of the 4x4, stride-2, reflect-pad-1 convolutions (conv_halo16_bf16.inc, S2 == 2): dy:[B,H/2,W/2,Cout]
+ * bf16 -> the H x W pixels of dx:[B,H,W,Cin] (every pixel written, no accumulation); w_dgrad = dwc_bf16_weight_prepare_dgrad(KH = KW = 4,
+ * stride 2, cout_pad = Cout, cin_pad = Cin): four class matrices [Cin][Kp].  The border ring of the padded gradient image still has to
+ * be folded onto dx: dwc_bf16_conv2d_bwd_data_s2_ring.  H, W multiples of 32, Cout a power of two >= 64, Cin a multiple of 64. */
+int dwc_bf16_conv2d_s2_halo_bwd_data_ok(int B, int H, int W, int Cin, int Cout) {
+    return (B > 0 && H >= 32 && W >= 32 && !(H % 32) && !(W % 32) && Cout >= 64 && dwc_ilog2_exact(Cout) >= 6 && Cin >= 64 && !(Cin % 64) &&
+            (size_t)B * H * W * Cin * 2 < 0x80000000ull && (size_t)B * (H / 2) * (W / 2) * Cout * 2 < 0x80000000ull &&
+            (size_t)4 * Cin * 4 * Cout * 2 < 0x80000000ull) ? 1 : 0;
+}
+
+int dwc_bf16_conv2d_s2_halo_bwd_data(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, void* stream) {
+    if (!dy || !w_dgrad || !dx || !dwc_bf16_conv2d_s2_halo_bwd_data_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
+    HaloArgs a;
+    a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.bias = nullptr; a.add = nullptr; a.y = (bf16*)dx;
+    a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.logCin = dwc_ilog2_exact(Cout); a.N = Cin; a.K = 4;
+    a.Kp = (4 * Cout + BK - 1) / BK * BK; a.act = DWC_ACT_NONE; a.reflect = 0;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B * a.blocks_per_img;
+    if (Cin % 128 == 0) {
+        a.tiles_n = Cin / 128;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 128, 2, 2, 1, 0, 2>), dim3(4 * nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    } else {
+        a.tiles_n = Cin / 64;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 64, 2, 2, 1, 0, 2>), dim3(4 * nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -72,6 +72,13 @@ struct X3Args {
 // parity (dy, dx), 16-channel slab), patch pixel (py, px) of it is input pixel (2 (y0 + py) + dy - 1, 2 (x0 + px) + dx - 1) under
 // the reflect rule, and tap (th, tw) of that slab is filter tap (2 th + dy, 2 tw + dx) of the ordinary K = 4 prepared weights.
 // a.H, a.W are the input dimensions, the output is H/2 x W/2.
+// S2 == 2 (KS == 2): the INTERIOR of the data gradient of those layers.  Output pixel (h, w) of parity (ry, rx) = (h & 1, w & 1)
+// receives dy[i' - 1 + ry + a][j' - 1 + rx + b] . W[.][.][3 - ry - 2a][3 - rx - 2b] over a, b in {0, 1}, (i', j') = (h >> 1, w >> 1):
+// per output parity class a 2x2-tap zero-padded convolution over dY, patch origin (y0 - 1 + ry, x0 - 1 + rx).  The class is
+// the fastest part of the block index (the four classes of a tile read the same dY pixels), a.H x a.W is the dY grid, the
+// result is scattered to (2 i' + ry, 2 j' + rx) of the 2 a.H x 2 a.W tensor.  With the data-gradient weights of
+// dwc_x3_weight_prepare (K = 4, filter rotated) kernel tap (a, b) is prepared tap (ry + 2a, rx + 2b).  The border ring of the
+// padded image (the reflect rule's adjoint) is dwc_conv2d_bwd_data_s2_ring's.
 template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0>
 __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -114,20 +121,26 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
             bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
         }
     }
+    int ry = 0, rx = 0;                                                  // S2 == 2: output parity class of this workgroup
+    if constexpr (S2 == 2) {
+        ry = (bid >> 1) & 1;
+        rx = bid & 1;
+        bid >>= 2;
+    }
     const int tile_n = bid % a.tiles_n, blk = bid / a.tiles_n;
     const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
     const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
     const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
-    const int OH = S2 ? a.H >> 1 : a.H, OW = S2 ? a.W >> 1 : a.W;      // output grid (the blocks tile it)
+    const int OH = S2 == 1 ? a.H >> 1 : a.H, OW = S2 == 1 ? a.W >> 1 : a.W;      // grid the blocks tile (S2 == 2: the dY grid)
     const int ncsr = a.Cin / CS;                                        // 16-channel slabs of the input tensor
-    const int ncs = S2 ? 4 * ncsr : ncsr;                               // slabs walked: x 4 input-pixel parities
+    const int ncs = S2 == 1 ? 4 * ncsr : ncsr;                          // slabs walked: x 4 input-pixel parities
     const int nsteps = ncs * NTAP;
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
-    const float* p_src[S2 ? 1 : PPASS];
+    const float* p_src[S2 == 1 ? 1 : PPASS];
     // S2: element offset of the patch pixel's input pixel for parity (0, 0), and what the odd row / column parity adds to it
     // (kept as base + masked delta: indexing a register array by the parity would send it to scratch)
-    int p_base[S2 ? PPASS : 1], p_drow[S2 ? PPASS : 1], p_dcol[S2 ? PPASS : 1];
+    int p_base[S2 == 1 ? PPASS : 1], p_drow[S2 == 1 ? PPASS : 1], p_dcol[S2 == 1 ? PPASS : 1];
     int p_dst[PPASS];                                   // LDS element offset of (py, px), channels 4*(t&3)..
     unsigned p_ok = 0, p_in = 0;                        // loads are unconditional (the vmcnt arithmetic below counts them)
 #pragma unroll
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
         const int pp = (t >> 2) + PPT * i;
         const int py = pp / PW, px = pp - py * PW;
         bool ok = pp < PPIX;
-        if constexpr (S2) {
+        if constexpr (S2 == 1) {
             const int h0 = min(reflect_idx(2 * (y0 + py) - 1, a.H), a.H - 1), h1 = min(reflect_idx(2 * (y0 + py), a.H), a.H - 1);
             const int w0 = min(reflect_idx(2 * (x0 + px) - 1, a.W), a.W - 1), w1 = min(reflect_idx(2 * (x0 + px), a.W), a.W - 1);
             p_base[i] = ((n_img * a.H + h0) * a.W + w0) * a.Cin;
@@ -143,6 +156,10 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
             p_dcol[i] = (w1 - w0) * a.Cin;
         } else {
             int h = y0 - PAD + py, w = x0 - PAD + px;
+            if constexpr (S2 == 2) {
+                h = y0 - 1 + ry + py;
+                w = x0 - 1 + rx + px;
+            }
             if (a.reflect) {
                 h = reflect_idx(h, a.H);
                 w = reflect_idx(w, a.W);
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     }
     f32x4 pv[PPASS];
     auto load_patch = [&](int cs) {
-        if constexpr (S2) {
+        if constexpr (S2 == 1) {
             const int par = cs / ncsr, csl = cs - par * ncsr;
             const float* base = a.x + csl * CS + (t & 3) * 4;
             const int my = -(par >> 1), mx = -(par & 1);
@@ -199,9 +216,11 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
         const int cs = step / NTAP, tap = step - cs * NTAP;
         bf16* lw = sW + slot * W_SLOT + wave * 512;
         int blk;
-        if constexpr (S2) {
+        if constexpr (S2 == 1) {
             const int par = cs / ncsr, csl = cs - par * ncsr;
             blk = ((2 * (tap >> 1) + (par >> 1)) * 4 + 2 * (tap & 1) + (par & 1)) * ncsr + csl;
+        } else if constexpr (S2 == 2) {
+            blk = ((ry + 2 * (tap >> 1)) * 4 + rx + 2 * (tap & 1)) * ncsr + cs;
         } else {
             blk = tap * ncs + cs;
         }
@@ -361,12 +380,37 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     }
 
     // ---- epilogue: bias + activation, fp32 stores of 4 channels per lane ---------------------------------------------------
+    // (r04: the bias vectors of this lane's columns are loaded ONCE, in one batch, and the `add` operand of a pixel tile in one
+    // batch in front of its stores.  Inside the per-chunk conditionals -- `if (col < N) if (bias) v += bias[col]` -- the compiler
+    // can neither hoist nor batch a load: every chunk paid its own L2 round trip, one after the other.)
     const float slope = dwc_act_slope(a.act);
+    f32x4 bv[TN][4];
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) bv[n][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                bv[n][q4] = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, a.N - 4));
+    }
     auto store = [&](auto general) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int pb = (wm * TM + i) * 32 + l31;
             float* dst = a.y + ((size_t)(n_img * OH + y0 + (pb >> 4)) * OW + x0 + (pb & 15)) * a.N;
+            if constexpr (S2 == 2)
+                dst = a.y + ((size_t)(n_img * 2 * OH + 2 * (y0 + (pb >> 4)) + ry) * (2 * OW) + 2 * (x0 + (pb & 15)) + rx) * a.N;
+            f32x4 adv[TN][4];
+            if (a.add) {
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        adv[n][q4] = *reinterpret_cast<const f32x4*>(a.add + (dst - a.y) + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, a.N - 4));
+            }
 #pragma unroll
             for (int n = 0; n < TN; ++n)
 #pragma unroll
@@ -378,13 +422,13 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
                         const f32x16& c = lo[SPLIT ? i : 0][SPLIT ? n : 0];
                         v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
                     }
-                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                    v += bv[n][q4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
                         else v[k] = dwc_act_simple(v[k], slope);
                     }
-                    if (a.add) v += *reinterpret_cast<const f32x4*>(a.add + (dst - a.y) + col);
+                    if (a.add) v += adv[n][q4];
                     *reinterpret_cast<f32x4*>(dst + col) = v;
                 }
         }
@@ -842,6 +886,27 @@ int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, 
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = (N + 63) / 64;
     x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* INTERIOR of the data gradient of the same layers (conv_halo_x3_kernel, S2 == 2): dy:[B,H/2,W/2,Cout] fp32 -> the H x W pixels
+ * of dx:[B,H,W,N] (N = the convolution's input channels), w_prepared = dwc_x3_weight_prepare(K = 4, dgrad = 1) with `rows` >= N
+ * rows.  Every pixel of dx is written (no accumulation); the border ring of the padded gradient image still has to be folded
+ * onto it: dwc_conv2d_bwd_data_s2_ring.  H, W multiples of 32, Cout a multiple of 16. */
+int dwc_x3_conv2d_s2_bwd_data_ok(int B, int H, int W, int Cin, int Cout) {
+    return (x3_s2_ok(B, H, W, Cout, Cin) && !(Cin % 64) && (size_t)B * H * W * Cin < 0x7fffffffull) ? 1 : 0;
+}
+
+int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx, int B, int H, int W, int Cin, int Cout, int rows,
+                              void* stream) {
+    if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin) return DWC_EINVAL;
+    X3Args a;
+    a.x = dy; a.w = (const bf16*)w_prepared; a.bias = nullptr; a.add = nullptr; a.y = dx;
+    a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    a.tiles_n = Cin / 64;
+    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

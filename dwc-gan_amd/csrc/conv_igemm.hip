@@ -230,6 +230,15 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
 
     float* dst = (float*)o.dst + part_offset;
     const float slope = dwc_act_slope(act);
+    // bias of this lane's TN columns, loaded ONCE in one batch (r04: inside the per-element conditionals of the store loop the
+    // compiler can neither hoist nor batch the load -- TM*16*TN dependent round trips per lane)
+    float bcol[TN];
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bcol[n] = 0.f;
+    if (bias && !partial) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) bcol[n] = bias[min(n0 + (wn * TN + n) * 32 + l31, o.N - 1)];
+    }
     // two loop nests (dwc_common.h, dwc_act_simple): the transcendental activations stay out of the common path's code
     auto store = [&](auto general) {
 #pragma unroll
@@ -255,7 +264,7 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
                     if (col < o.N) {
                         float v = acc[i][n][r];
                         if (!partial) {
-                            if (bias) v += bias[col];
+                            v += bcol[n];
                             if constexpr (decltype(general)::value) v = dwc_act_apply(v, act, col);
                             else v = dwc_act_simple(v, slope);
                         }
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
     if ((int)blockIdx.x >= s.tiles) return;
     const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
     conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, (const float*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
-                                           blockIdx.y * ss.part_stride, false, 0, 0, blockIdx.x, s.tiles);
+                                           blockIdx.y * ss.part_stride, false, s.oph, s.opw, blockIdx.x, s.tiles);
 }
 
 // gridDim.z independent products of one geometry: source, weights and destination advance by a fixed stride per
@@ -902,6 +911,13 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
     }
     const int TW = W >> 1, TH = H >> 1;
     const float slope = dwc_act_slope(act);
+    float bcol[TN];                                       // bias of this lane's columns: one batch of loads (see conv_gemm_body)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bcol[n] = 0.f;
+    if (bias) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n) bcol[n] = bias[min(n0 + (wn * TN + n) * 32 + l31, N - 1)];
+    }
     auto store = [&](auto general) {
         auto fin = [&](float v, int col) {
             if constexpr (decltype(general)::value) return dwc_act_apply(v, act, col);
@@ -922,7 +938,7 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
                 for (int n = 0; n < TN; ++n) {
                     const int col = n0 + (wn * TN + n) * 32 + l31;
                     if (col >= N) continue;
-                    const float bv = bias ? bias[col] : 0.f;
+                    const float bv = bcol[n];
                     base[col] = fin(Y[0][i][n][r] + bv, col);
                     base[(size_t)N + col] = fin(Y[1][i][n][r] + bv, col);
                     base[(size_t)W * N + col] = fin(Y[2][i][n][r] + bv, col);
@@ -1667,6 +1683,26 @@ int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, 
     const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C4;
     hipLaunchKernelGGL(fold_band_kernel, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const float*)dxp, dx, B, H, W, C4, pad,
                        W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* Border ring + fold of the data gradient of a 4x4 stride-2 reflect-pad-1 convolution whose INTERIOR (the H x W pixels of dx)
+ * has been written by a halo-tiled kernel (dwc_x3_conv2d_s2_bwd_data): the ring of the padded gradient image is computed as
+ * eight thin strips into the scratch image dxp ([B][H+2][W+2][Cin], only its ring is touched) and folded onto dx by the
+ * reflect rule (fold_band_kernel).  w_dgrad: the stride-2 data-gradient layout of dwc_weight_prepare_dgrad. */
+int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
+                                void* stream) {
+    S2Ring f;
+    if (!dy || !w_dgrad || !dxp || !dx || H > 65535 - 2 || B > 65535 || !s2_ring_geom(dy, w_dgrad, dxp, sizeof(float), B, H, W, Cin, Cout, &f))
+        return DWC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    DWC_LAUNCH_CHECK();
+    const int C4 = Cin / 4;
+    const size_t band_items = (size_t)B * (2 * W + (H - 2) * 2) * C4;
+    hipLaunchKernelGGL(fold_band_kernel, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, st, (const float*)dxp, dx, B, H, W, C4, 1,
+                       W + 2);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

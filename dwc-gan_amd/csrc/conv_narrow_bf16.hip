@@ -139,6 +139,11 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
 
     // ---- the 8 partial sums meet in LDS, two group tiles per round -----------------------------------------------------------
     const int tile2 = t >> 8, rb = (t >> 6) & 3;        // epilogue thread: tile (of the round), register block, lane
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};                 // this thread's four bias values, loaded once (not per round behind a lane condition)
+    if (a.bias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = a.bias[8 * rb + 4 * hi + k];
+    }
 #pragma unroll
     for (int round = 0; round < MT / 2; ++round) {
         __syncthreads();                                // patch (round 0) / previous round's sums fully read
@@ -162,8 +167,7 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
             const int c0 = 8 * rb + 4 * hi;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (a.bias) v[k] += a.bias[c0 + k];
-                v[k] = dwc_act_apply(v[k], a.act, c0 + k);
+                v[k] = dwc_act_apply(v[k] + bq[k], a.act, c0 + k);
             }
             bf16x4 o;
             o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
@@ -260,6 +264,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
     }
     const int b_off = l31 * 16 + ((hi ^ ((l31 >> 3) & 1)) * 8);
     const float slope = dwc_act_slope(a.act);
+    f32x4 bvs[2][4];                                    // bias vectors of this lane's columns, loaded once for all blocks
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            bvs[c][q4] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c * 32 + 8 * q4 + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int buf = 0;
     for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
                         for (int q4 = 0; q4 < 4; ++q4) {
                             const int col = c * 32 + 8 * q4 + 4 * hi;
                             f32x4 v = {acc[i][c][4 * q4], acc[i][c][4 * q4 + 1], acc[i][c][4 * q4 + 2], acc[i][c][4 * q4 + 3]};
-                            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + col);
+                            v += bvs[c][q4];
                             bf16x4 o;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) o[k] = (bf16)dwc_act_simple(v[k], slope);

@@ -394,6 +394,8 @@ LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM fo
 DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # data gradients through a reflect pad: interior straight into dx + band fold
 X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
+S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
+S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
 
 
 _WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
@@ -685,6 +687,32 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_same")
+        elif (ctx.needs_input_grad[0] and S2DGRAD and stride == 2 and KH == 4 and KW == 4 and pad == 1
+              and 4 * B * (H // 32) * (W // 32) * (Cx // 64) >= S2DGRAD_MIN_WGS
+              and ((half and HALO and lib.dwc_bf16_conv2d_s2_halo_bwd_data_ok(B, H, W, Cx, cop))
+                   or ((not half) and X3 and lib.dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cx, cop)))):
+            # stride-2 4x4 layers: the interior (all H x W pixels of dx) as four output-parity classes of 2x2-tap halo convolutions
+            # over dY, then the border ring of the padded image as eight thin GEMM strips + band fold (reflect-pad adjoint)
+            w_dg = _prepped(w, "dgrad", cop, Cx, 2, owner, half)
+            dx = empty_cl(B, Cx, H, W, dev, dt)
+            flops = 2.0 * rows * Cout * Cin * KH * KW
+            dxp = workspace(B * (H + 2) * (W + 2) * Cx * (2 if half else 4), dev)
+            shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
+            if half:
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_s2_halo_bwd_data(
+                    g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
+                    detail="dgrad-s2halo" + shape), "conv2d_s2_halo_bwd_data")
+                _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_bf16_conv2d_bwd_data_s2_ring(
+                    g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
+                    detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
+            else:
+                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_bwd_data(
+                    g.data_ptr(), w_x3.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope, exec_flops=6 * flops,
+                    detail="dgrad-x3s2" + shape), "x3_conv2d_s2_bwd_data")
+                _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_s2_ring(
+                    g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
+                    detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
         elif ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride, owner, half)
             dx = empty_cl(B, Cx, H, W, dev, dt)

@@ -346,6 +346,17 @@ int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* 
 int dwc_x3_conv2d_s2_ok(int B, int H, int W, int Cin, int Cout);
 int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
                      int act, void* stream);
+/* Data gradient of the same 4x4 stride-2 reflect-pad-1 layers in halo form (r04; reference networks.py:90,94,437,
+ * networks_v2.py:107-111 through autograd).  dwc_x3_conv2d_s2_bwd_data writes the INTERIOR -- all H x W pixels of dx:[B,H,W,Cin]
+ * fp32 from dy:[B,H/2,W/2,Cout] -- as four output-parity classes of 2x2-tap zero-padded split-product convolutions over dY
+ * (w_prepared = dwc_x3_weight_prepare(K = 4, dgrad = 1), rows >= Cin); dwc_conv2d_bwd_data_s2_ring then forms the border ring of
+ * the PADDED gradient image as eight thin fp32 GEMM strips in the scratch image dxp ([B][H+2][W+2][Cin]; only its ring is touched)
+ * and folds it onto dx by the reflect rule (w_dgrad = dwc_weight_prepare_dgrad(4x4, stride 2)).  No further scratch. */
+int dwc_x3_conv2d_s2_bwd_data_ok(int B, int H, int W, int Cin, int Cout);
+int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx, int B, int H, int W, int Cin, int Cout, int rows,
+                              void* stream);
+int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
+                                void* stream);
 /* weight gradient of the same layers as split products: dw (fp32, [cout_real][cin_real][K][K]) from the fp32 NHWC tensors x
  * and dy; both operands are split on the fly (x through LDS, dy in registers); pixel ranges go to fp32 slabs in `ws`, summed in
  * a fixed order.  ws_bytes == 0: shape not handled (K in {3,5}, H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64). */
@@ -421,6 +432,12 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
 int dwc_bf16_conv2d_s2_halo_ok(int B, int H, int W, int Cin, int Cout);
 int dwc_bf16_conv2d_s2_halo(const void* x, const void* w_prepared, const float* bias, void* y, int B, int H, int W, int Cin, int Cout,
                             int act, void* stream);
+/* bf16 twins (conv_halo16_kernel, S2 == 2; w_dgrad = dwc_bf16_weight_prepare_dgrad(4x4, stride 2, cout_pad = Cout, cin_pad = Cin) for
+ * both calls; dxp: bf16 scratch image [B][H+2][W+2][Cin]). */
+int dwc_bf16_conv2d_s2_halo_bwd_data_ok(int B, int H, int W, int Cin, int Cout);
+int dwc_bf16_conv2d_s2_halo_bwd_data(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, void* stream);
+int dwc_bf16_conv2d_bwd_data_s2_ring(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
+                                     void* stream);
 /* Halo form of the weight gradient of the same layers (reflect padding): a workgroup stages the (8+K-1)x(16+K-1) patch of x
  * and the 8x16 block of dY once and forms all 9 taps of a 3x3 / one filter row of a 5x5 from it; pixel ranges are split into
  * fp32 slabs in `ws` that a second kernel sums in a fixed order into dw ([cout_real][cin_real][K][K], fp32).  ws_bytes == 0:

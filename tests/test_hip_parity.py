@@ -23,6 +23,9 @@ T = torch.from_numpy
 DEV = "cuda:0"
 
 
+from hipdwc import _lib as _lib_mod  # noqa: E402
+
+
 def close(a, b, rel=2e-5, atol=1e-6, msg=""):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     assert a.shape == b.shape, (msg, a.shape, b.shape)
@@ -95,7 +98,56 @@ def test_conv_forward_backward(shape):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-@pytest.mark.parametrize("switch", ["DGRAD_FOLD", "RES_FUSE", "X3_S2", "S2HALO"])
+@pytest.mark.parametrize("B,ci,co,H,W", [(3, 64, 128, 32, 32), (2, 128, 256, 64, 32), (1, 64, 64, 32, 96), (2, 256, 512, 32, 32)])
+def test_stride2_data_gradient_halo_form(B, ci, co, H, W, prec, monkeypatch):
+    """Data gradient of the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) in halo
+    form (r04): interior as four output-parity classes of 2x2-tap convolutions over dY (split products in fp32, bf16 MFMA on the
+    bf16 path), border ring of the padded image as eight GEMM strips + band fold.  Against the float64 gradient of the
+    reflect-padded convolution -- every pixel, with the image border (where the ring folds) checked separately --, for square
+    and rectangular images, one and several tiles per image."""
+    monkeypatch.setattr(ops, "S2DGRAD_MIN_WGS", 0)
+    g = torch.Generator().manual_seed(B + ci + co + H + W)
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if prec == "bf16" else (lambda t: t)
+    x = rnd(torch.randn(B, ci, H, W, generator=g))
+    w = rnd(torch.randn(co, ci, 4, 4, generator=g) * (1.0 / (ci * 16) ** 0.5))
+    gy = rnd(torch.randn(B, co, H // 2, W // 2, generator=g))
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(torch.nn.functional.pad(xr, (1, 1, 1, 1), mode="reflect"), w.double(), None, stride=2)
+    (yr * gy.double()).sum().backward()
+    ops.set_precision(prec)
+    try:
+        calls = []
+        lib = _lib_mod.load()
+        name = "dwc_bf16_conv2d_s2_halo_bwd_data" if prec == "bf16" else "dwc_x3_conv2d_s2_bwd_data"
+        real = getattr(lib, name)
+        monkeypatch.setattr(lib, name, lambda *a: (calls.append(1), real(*a))[1])
+        xd = x.to(DEV).to(ops.act_dtype()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(DEV).requires_grad_(True)
+        yd = ops.conv2d(xd, wd, None, 2, 1, "none")
+        (yd.float() * gy.to(DEV)).sum().backward()
+        assert calls, "the halo-form data gradient was not taken"
+        ref = xr.grad.float()
+        got = xd.grad.float().cpu()
+        scale = ref.abs().max().item()
+        tol = 2e-5 if prec == "fp32" else 8e-3
+        err = (got - ref).abs()
+        assert err.max().item() <= tol * scale, ("all pixels", err.max().item() / scale)
+        border = torch.zeros(H, W, dtype=torch.bool)
+        border[[0, 1, 2, H - 3, H - 2, H - 1], :] = True
+        border[:, [0, 1, 2, W - 3, W - 2, W - 1]] = True
+        assert err[:, :, border].max().item() <= tol * scale, ("border band", err[:, :, border].max().item() / scale)
+        # the same gradient through the im2col path
+        monkeypatch.setattr(ops, "S2DGRAD", 0)
+        xd2 = xd.detach().clone().requires_grad_(True)
+        y2 = ops.conv2d(xd2, wd, None, 2, 1, "none")
+        (y2.float() * gy.to(DEV)).sum().backward()
+        close(xd.grad.float(), xd2.grad.float().cpu(), rel=(5e-6 if prec == "fp32" else 1.6e-2), msg="halo form vs im2col form")
+    finally:
+        ops.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("switch", ["DGRAD_FOLD", "RES_FUSE", "X3_S2", "S2HALO", "S2DGRAD"])
 def test_alternative_paths_agree(prec, switch):
     """Every default path that replaced a simpler one this round keeps a switch back to it (DWC_DGRAD_FOLD: reflect-pad adjoint fused
     into the data-gradient GEMM vs a pass of its own; DWC_RES_FUSE: identity-branch gradient of a ResBlock in the convolution's
