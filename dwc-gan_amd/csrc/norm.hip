@@ -757,6 +757,231 @@ bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 
 
 namespace {
 
+// ---------------------------------------------------------------------------------------
+// Resident-plane instance norm (r04): ONE pass over HBM per direction for the small planes (HW = 256 / 1024: every ResBlock
+// norm of the content encoder and the decoder, 17 of the 19 IN / AdaIN layers).  A 512-thread workgroup owns sample n and
+// 128 contiguous bytes of every pixel (32 fp32 / 64 bf16 channels) and keeps its part of the plane in REGISTERS, raw, four
+// channels per lane and pixel (16-byte fp32 / 8-byte bf16 pieces: with eight bf16 channels per lane the per-channel
+// statistics and parameters of the backward pass no longer fit beside the plane): statistics, then normalise / gradient
+// from the same registers -- forward reads x (+ residual) and writes y: 2-3 tensor passes instead of 3-4 (statistics pass +
+// apply pass); backward reads dy, x and writes dx: 3 instead of 5; one launch instead of two or three.  The variance is the
+// exact two-pass form (the data are resident).  Cross-thread sums: xor-shuffles over the row groups of a wave, then the 8
+// wave partials through LDS, summed by every thread in wave order (fixed order: bitwise reproducible).
+// ---------------------------------------------------------------------------------------
+typedef unsigned res_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct Raw4 { typedef f32x4 type; static constexpr int CQ = 8; };        // pieces per pixel and workgroup (128 bytes)
+template <> struct Raw4<dwc_bf16> { typedef res_u32x2 type; static constexpr int CQ = 16; };
+__device__ __forceinline__ void res_unpack(const f32x4& r, float (&o)[4]) { o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; }
+__device__ __forceinline__ void res_unpack(const res_u32x2& r0, float (&o)[4]) {
+    // (the empty asm makes the piece a NEW value at every use: otherwise hipcc converts every resident piece to fp32 once and
+    // keeps the floats -- twice the registers of the raw plane)
+    res_u32x2 r = r0;
+    asm volatile("" : "+v"(r));
+    o[0] = __uint_as_float(r[0] << 16);
+    o[1] = __uint_as_float(r[0] & 0xffff0000u);
+    o[2] = __uint_as_float(r[1] << 16);
+    o[3] = __uint_as_float(r[1] & 0xffff0000u);
+}
+__device__ __forceinline__ void res_pack(const float (&o)[4], f32x4& r) { r = f32x4{o[0], o[1], o[2], o[3]}; }
+__device__ __forceinline__ void res_pack(const float (&o)[4], res_u32x2& r) {
+    typedef dwc_bf16 bf16x2r __attribute__((ext_vector_type(2)));
+    bf16x2r a = {(dwc_bf16)o[0], (dwc_bf16)o[1]}, b = {(dwc_bf16)o[2], (dwc_bf16)o[3]};      // round to nearest even, as every bf16 store here
+    r[0] = __builtin_bit_cast(unsigned, a);
+    r[1] = __builtin_bit_cast(unsigned, b);
+}
+constexpr int RES_THREADS = 512;
+
+// sum of v[0..NV) over the row groups of the workgroup, for this thread's piece column; every thread gets the totals
+template <int CQ, int NV>
+__device__ __forceinline__ void res_reduce(float (&v)[NV], float* sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = threadIdx.x & (CQ - 1);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (CQ <= 8) v[k] += __shfl_xor(v[k], 8);
+        v[k] += __shfl_xor(v[k], 16);
+        v[k] += __shfl_xor(v[k], 32);
+    }
+    __syncthreads();                                       // the previous reduction's partials have been read
+    if (lane < CQ) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sm[(wave * CQ + cq) * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < RES_THREADS / 64; ++w) t += sm[(w * CQ + cq) * NV + k];
+        v[k] = t;
+    }
+}
+
+template <typename T, int HW>
+__global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const T* __restrict__ residual,
+                                                               T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                               int C, float eps, int relu) {
+    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = RES_THREADS / CQ, NP = HW / ROWS;
+    typedef typename Raw4<T>::type Raw;
+    __shared__ float sm[(RES_THREADS / 64) * CQ * 2 * V];
+    const int cqt = C / V;                                                       // 4-channel pieces per pixel of the tensor
+    const int n = blockIdx.y, cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
+    // addressing: workgroup-uniform base (+ a uniform stride per pass) and ONE 32-bit byte offset per thread, so that the 2-3 x NP
+    // loads / stores share a single address register
+    const size_t ubase = ((size_t)n * HW * cqt + blockIdx.x * CQ) * sizeof(Raw);
+    const unsigned toff = (unsigned)((rg * cqt + cq) * sizeof(Raw));
+    const size_t pstride = (size_t)ROWS * cqt * sizeof(Raw);
+    const char* xb = reinterpret_cast<const char*>(x) + ubase;
+    Raw xr[NP], rr[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) xr[p] = *reinterpret_cast<const Raw*>(xb + p * pstride + toff);
+    if (residual) {
+        const char* rb = reinterpret_cast<const char*>(residual) + ubase;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) rr[p] = *reinterpret_cast<const Raw*>(rb + p * pstride + toff);
+    }
+    const size_t sidx = (size_t)n * C + (blockIdx.x * CQ + cq) * V;              // first channel of this thread's piece
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) sc[k] = 1.f, sh[k] = 0.f;
+    if (gamma) ldf<V>(gamma, sidx, sc);
+    if (beta) ldf<V>(beta, sidx, sh);
+    float mu[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) mu[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float v[V];
+        res_unpack(xr[p], v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) mu[k] += v[k];
+    }
+    res_reduce<CQ, V>(mu, sm);
+    const float inv = 1.f / (float)HW;
+    float var[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) mu[k] *= inv, var[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float v[V];
+        res_unpack(xr[p], v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float d = v[k] - mu[k];
+            var[k] += d * d;
+        }
+    }
+    res_reduce<CQ, V>(var, sm);
+    float rs[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) rs[k] = 1.f / sqrtf(var[k] * inv + eps);
+    if (rg == 0) {
+        stf<V>(mean, sidx, mu);
+        stf<V>(rstd, sidx, rs);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) sc[k] *= rs[k];
+    char* yb = reinterpret_cast<char*>(y) + ubase;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float v[V], q[V], o[V];
+        res_unpack(xr[p], v);
+        if (residual) res_unpack(rr[p], q);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float t = (v[k] - mu[k]) * sc[k] + sh[k];
+            if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
+            o[k] = residual ? t + q[k] : t;
+        }
+        Raw out;
+        res_pack(o, out);
+        *reinterpret_cast<Raw*>(yb + p * pstride + toff) = out;
+    }
+}
+
+template <typename T, int HW>
+__global__ __launch_bounds__(RES_THREADS) void in_resident_bwd(const T* __restrict__ dy, const T* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int C, int relu) {
+    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = RES_THREADS / CQ, NP = HW / ROWS;
+    typedef typename Raw4<T>::type Raw;
+    __shared__ float sm[(RES_THREADS / 64) * CQ * 2 * V];
+    const int cqt = C / V;
+    const int n = blockIdx.y, cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
+    const size_t ubase = ((size_t)n * HW * cqt + blockIdx.x * CQ) * sizeof(Raw);
+    const unsigned toff = (unsigned)((rg * cqt + cq) * sizeof(Raw));
+    const size_t pstride = (size_t)ROWS * cqt * sizeof(Raw);
+    const char* xb = reinterpret_cast<const char*>(x) + ubase;
+    const char* gb = reinterpret_cast<const char*>(dy) + ubase;
+    Raw xr[NP], gr[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        xr[p] = *reinterpret_cast<const Raw*>(xb + p * pstride + toff);
+        gr[p] = *reinterpret_cast<const Raw*>(gb + p * pstride + toff);
+    }
+    const size_t sidx = (size_t)n * C + (blockIdx.x * CQ + cq) * V;
+    float mu[V], rs[V], ga[V], be[V];
+    ldf<V>(mean, sidx, mu);
+    ldf<V>(rstd, sidx, rs);
+#pragma unroll
+    for (int k = 0; k < V; ++k) ga[k] = 1.f, be[k] = 0.f;
+    if (gamma) ldf<V>(gamma, sidx, ga);
+    if (beta) ldf<V>(beta, sidx, be);
+    float s[2 * V];
+#pragma unroll
+    for (int k = 0; k < 2 * V; ++k) s[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float xv[V], dv[V];
+        res_unpack(xr[p], xv);
+        res_unpack(gr[p], dv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            float g = dv[k];
+            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            s[k] += g;
+            s[V + k] += g * xh;
+        }
+    }
+    res_reduce<CQ, 2 * V>(s, sm);
+    if (rg == 0 && dgamma) {
+        float a[V], b[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) a[k] = s[k], b[k] = s[V + k];
+        stf<V>(dbeta, sidx, a);
+        stf<V>(dgamma, sidx, b);
+    }
+    const float inv = 1.f / (float)HW;
+    char* ob = reinterpret_cast<char*>(dx) + ubase;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float xv[V], dv[V], o[V];
+        res_unpack(xr[p], xv);
+        res_unpack(gr[p], dv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float xh = (xv[k] - mu[k]) * rs[k];
+            float g = dv[k];
+            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            o[k] = ga[k] * rs[k] * (g - s[k] * inv - xh * (s[V + k] * inv));
+        }
+        Raw out;
+        res_pack(o, out);
+        *reinterpret_cast<Raw*>(ob + p * pstride + toff) = out;
+    }
+}
+
+// plane size when the resident-plane kernels take this shape, else 0
+template <typename T>
+int in_resident_hw(int HW, int C) {
+    static const bool on = !(getenv("DWC_NORM_RESIDENT") && atoi(getenv("DWC_NORM_RESIDENT")) == 0);      // development: 0 = the multi-pass kernels
+    if (!on || C % (Raw4<T>::CQ * 4)) return 0;
+    return (HW == 1024 || HW == 256) ? HW : 0;
+}
+
 // The caller's ticket row for one statistics launch, or null when the batch is too large for the fused finalisation to pay
 // (measured r03: worth it at small batches -- c1, B = 16..48: 0.80 -> 0.71 ms and 0.86 -> 0.79 ms of statistics kernels per step plus
 // 92 launch boundaries; at B >= 128 the per-workgroup publish + ticket costs more than the *_final launch it saves).
@@ -773,6 +998,13 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (const int rhw = in_resident_hw<T>(HW, C)) {          // small planes: one pass, plane resident in registers
+        const dim3 grid(C / (Raw4<T>::CQ * 4), B);
+        if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024>), grid, dim3(RES_THREADS), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu);
+        else hipLaunchKernelGGL((in_resident_fwd<T, 256>), grid, dim3(RES_THREADS), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
@@ -801,6 +1033,13 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (const int rhw = in_resident_hw<T>(HW, C)) {
+        const dim3 grid(C / (Raw4<T>::CQ * 4), B);
+        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024>), grid, dim3(RES_THREADS), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu);
+        else hipLaunchKernelGGL((in_resident_bwd<T, 256>), grid, dim3(RES_THREADS), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu);
+        DWC_LAUNCH_CHECK();
+        return DWC_OK;
+    }
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;

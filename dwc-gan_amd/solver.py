@@ -79,6 +79,15 @@ class Solver(nn.Module):
         # set_n_critic / resume / init_network) -- never wrong, only one wasted taped encode.
         self.n_critic = 1
         self._tape_content = True
+        # The text encoder (embedding, two bi-LSTM layers of ~40 sequential steps, heads) is latency-bound and keeps < 80 of the
+        # 256 CUs busy: DWC_TXT_STREAM=1 runs it on a side stream beside the convolution work that does not depend on it
+        # (enc_content in the D step, the detached x_fake2 decode in the G step; autograd replays its backward on the same
+        # stream).  Random draws are made at CALL time, so their order is unchanged and results are identical.  Measured r04 on
+        # one MI355X: c1 245.4 vs 249.3 images/s, c2 1336.6 vs 1325.6 (on / off) -- nothing beyond run-to-run spread: the
+        # persistent LSTM workgroups want 84 KB of LDS each and wait for the convolution workgroups (2 x 77 KB per CU) to retire
+        # before they become resident, so the two streams mostly take turns.  Off by default.
+        self._txt_stream = None
+        self._txt_async = os.environ.get("DWC_TXT_STREAM", "0") == "1"
 
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
         # torch.optim.Adam subclasses (same param_groups / state_dict / scheduler interface) whose step()
@@ -194,6 +203,25 @@ class Solver(nn.Module):
         keep = (c_src == c_trg).repeat_interleave(self.c_dim, dim=1)
         return torch.where(keep, z_src, z_trg)
 
+    def _encode_txt_side(self, style, txt, lens):
+        """gen.encode_txt on the side stream (see __init__).  Returns (result, join): call ``join()`` on the consuming stream
+        before the result is read.  Falls back to a plain call on CPU tensors / when switched off."""
+        if not (self._txt_async and style.is_cuda):
+            return self.gen.encode_txt(style, txt, lens), (lambda: None)
+        if self._txt_stream is None:
+            self._txt_stream = torch.cuda.Stream(device=style.device)
+        main, side = torch.cuda.current_stream(), self._txt_stream
+        side.wait_stream(main)                               # style (and everything before it) was produced on the main stream
+        with torch.cuda.stream(side):
+            out = self.gen.encode_txt(style, txt, lens)
+        style.record_stream(side)
+        for t in (flat_heads(out[0]), flat_heads(out[1])):
+            t.record_stream(main)
+
+        def join():
+            torch.cuda.current_stream().wait_stream(side)
+        return out, join
+
     def _decode(self, content, style, x_real4):
         """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out."""
         heads = self.gen.decode_nhwc4(content, style, attention_used=self.use_attention)
@@ -226,6 +254,10 @@ class Solver(nn.Module):
             self._content_cache = None                 # ... and release the unconsumed graph now
         tape = bool(tape_content) if tape_content is not None else (
             self._tape_content and (iters + 1) % max(1, int(self.n_critic)) == 0)
+        with torch.no_grad():
+            style_real = flat_heads(style_real)
+            style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)      # (drawn before the text encoder's draws, as in the reference)
+            (style_txt, _), join_txt = self._encode_txt_side(style_real, txt_src2trg, txt_lens)   # side stream, beside enc_content
         if tape:
             content_taped = self.gen.enc_content(x4)
             self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
@@ -235,9 +267,7 @@ class Solver(nn.Module):
                 content_taped = self.gen.enc_content(x4)
         with torch.no_grad():
             content = content_taped.detach()
-            style_real = flat_heads(style_real)
-            style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
-            style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
+            join_txt()
             # both fakes in ONE decoder pass (AdaIN parameters are per sample)
             fakes = self._decode(torch.cat([content, content]), torch.cat([flat_heads(style_txt), style1]),
                                  torch.cat([x4, x4]))
@@ -270,25 +300,27 @@ class Solver(nn.Module):
             # random draws are still made in the reference's order, the masks just get applied later.
             B = x4.shape[0]
             style_real, logvar = gen.enc_style(x4)                               # draw: mapping dropout
+            s_real = flat_heads(style_real)
+            mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
+            # draws of the text encoder; its kernels run on the side stream beside enc_content / the x_fake2 decode below
+            (style_txt, logvar_txt), join_txt = self._encode_txt_side(s_real, txt_src2trg, txt_lens)
             cache, self._content_cache = self._content_cache, None
             if cache is not None and cache[0] is x_real and cache[1] == x_real._version and cache[2] == self._gen_steps:
                 content_real = cache[3]                                          # taped in dis_update on the same batch and G
             else:
                 content_real = gen.enc_content(x4)
-            s_real = flat_heads(style_real)
-            mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
-            style_txt, logvar_txt = gen.encode_txt(s_real, txt_src2trg, txt_lens)   # draws of the text encoder
-            s_txt = flat_heads(style_txt)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             style2 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)
             mask_rand = gen.draw_encode_mask(B, x4.device)                       # draw of encode(x_fake1)
             mask_fake = gen.draw_encode_mask(B, x4.device)                       # draw of encode(x_fake)
 
+            with torch.no_grad():                                                # only ever used detached; independent of the text style
+                x_fake2 = self._decode(content_real, style2, x4)
+            join_txt()
+            s_txt = flat_heads(style_txt)
             # decode [within-domain reconstruction | text-driven fake | random-style fake]
             x_all = self._decode(torch.cat([content_real] * 3), torch.cat([s_real, s_txt, style1]), torch.cat([x4] * 3))
             x_rec, x_fake, x_fake1 = torch.split(x_all, B)
-            with torch.no_grad():                                                # only ever used detached
-                x_fake2 = self._decode(content_real, style2, x4)
             self.loss_ds = ops.l1_mean(x_fake1, x_fake2, image=True)
             self.init_ds_w = max(self.init_ds_w - 1 / 1e5, 0.0)
             masks = None if mask_rec is None else torch.cat([mask_rec, mask_fake, mask_rand])

@@ -133,7 +133,9 @@ def test_bf16_fused_image_heads(B, C, H, W):
 
 
 @pytest.mark.parametrize("B,C,H,adain,relu,res", [(2, 256, 16, True, True, False), (3, 64, 8, False, True, False),
-                                                   (2, 128, 12, True, False, True), (1, 8, 6, False, False, True)])
+                                                   (2, 128, 12, True, False, True), (1, 8, 6, False, False, True),
+                                                   (3, 256, 32, True, True, True), (2, 64, 32, False, True, False),   # resident-plane kernels, HW = 1024
+                                                   (2, 128, 16, True, False, True)])                                 # ... HW = 256 with a residual
 def test_bf16_instance_norm(B, C, H, adain, relu, res):
     g = torch.Generator().manual_seed(B * C + H)
     x = rb(torch.randn(B, C, H, H, generator=g) * 2 + 0.5)

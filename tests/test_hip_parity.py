@@ -428,7 +428,7 @@ def test_instance_norm_last_arriver_two_streams_stress(monkeypatch):
             assert torch.equal(a, b), (si, k, name, (a - b).abs().max().item())
 
 
-@pytest.mark.parametrize("B,C,H", [(2, 256, 16), (3, 64, 32), (1, 128, 8), (2, 8, 6), (2, 512, 2)])
+@pytest.mark.parametrize("B,C,H", [(2, 256, 16), (3, 64, 32), (1, 128, 8), (2, 8, 6), (2, 512, 2), (5, 256, 32)])
 @pytest.mark.parametrize("mode", ["in", "in_relu", "adain_relu", "adain_res"])
 def test_instance_norm(B, C, H, mode):
     g = torch.Generator().manual_seed(B * 1000 + C + H)
