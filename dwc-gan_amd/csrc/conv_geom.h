@@ -384,6 +384,10 @@ bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void*
     // has enough workgroups in flight to hide the load latency of these short K loops
     const int range = pad * KW * spt;
     f->parts = range >= 32 ? 4 : (range >= 24 ? 3 : (range >= 16 ? 2 : 1));
+    // (r04) ... unless the strips alone already fill the machine (large batches): every extra part is another fp32 copy of the
+    // ring to write and to sum in fold_ring_kernel
+    if (4 * f->max_tiles >= 1024) f->parts = 1;
+    else if (4 * f->max_tiles >= 512 && f->parts > 2) f->parts = 2;
     f->ss.kt_per_part = (range + f->parts - 1) / f->parts;
     f->ss.part_stride = f->ring_total;
     return true;

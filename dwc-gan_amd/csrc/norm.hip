@@ -759,8 +759,8 @@ namespace {
 
 // ---------------------------------------------------------------------------------------
 // Resident-plane instance norm (r04): ONE pass over HBM per direction for the small planes (HW = 256 / 1024: every ResBlock
-// norm of the content encoder and the decoder, 17 of the 19 IN / AdaIN layers).  A 512-thread workgroup owns sample n and
-// 128 contiguous bytes of every pixel (32 fp32 / 64 bf16 channels) and keeps its part of the plane in REGISTERS, raw, four
+// norm of the content encoder and the decoder, 17 of the 19 IN / AdaIN layers).  A 256-thread workgroup owns sample n and
+// 64 contiguous bytes of every pixel (16 fp32 / 32 bf16 channels; the two halves of a 128-byte line go to the same XCD, res_block) and keeps its part of the plane in REGISTERS, raw, four
 // channels per lane and pixel (16-byte fp32 / 8-byte bf16 pieces: with eight bf16 channels per lane the per-channel
 // statistics and parameters of the backward pass no longer fit beside the plane): statistics, then normalise / gradient
 // from the same registers -- forward reads x (+ residual) and writes y: 2-3 tensor passes instead of 3-4 (statistics pass +
@@ -769,8 +769,8 @@ namespace {
 // wave partials through LDS, summed by every thread in wave order (fixed order: bitwise reproducible).
 // ---------------------------------------------------------------------------------------
 typedef unsigned res_u32x2 __attribute__((ext_vector_type(2)));
-template <typename T> struct Raw4 { typedef f32x4 type; static constexpr int CQ = 8; };        // pieces per pixel and workgroup (128 bytes)
-template <> struct Raw4<dwc_bf16> { typedef res_u32x2 type; static constexpr int CQ = 16; };
+template <typename T> struct Raw4 { typedef f32x4 type; static constexpr int CQ = 4; };         // pieces per pixel and workgroup (64 bytes)
+template <> struct Raw4<dwc_bf16> { typedef res_u32x2 type; static constexpr int CQ = 8; };
 __device__ __forceinline__ void res_unpack(const f32x4& r, float (&o)[4]) { o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; }
 __device__ __forceinline__ void res_unpack(const res_u32x2& r0, float (&o)[4]) {
     // (the empty asm makes the piece a NEW value at every use: otherwise hipcc converts every resident piece to fp32 once and
@@ -789,14 +789,14 @@ __device__ __forceinline__ void res_pack(const float (&o)[4], res_u32x2& r) {
     r[0] = __builtin_bit_cast(unsigned, a);
     r[1] = __builtin_bit_cast(unsigned, b);
 }
-constexpr int RES_THREADS = 512;
 
 // sum of v[0..NV) over the row groups of the workgroup, for this thread's piece column; every thread gets the totals
-template <int CQ, int NV>
+template <int CQ, int NV, int THREADS>
 __device__ __forceinline__ void res_reduce(float (&v)[NV], float* sm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cq = threadIdx.x & (CQ - 1);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
+        if (CQ <= 4) v[k] += __shfl_xor(v[k], 4);
         if (CQ <= 8) v[k] += __shfl_xor(v[k], 8);
         v[k] += __shfl_xor(v[k], 16);
         v[k] += __shfl_xor(v[k], 32);
@@ -811,36 +811,54 @@ __device__ __forceinline__ void res_reduce(float (&v)[NV], float* sm) {
     for (int k = 0; k < NV; ++k) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < RES_THREADS / 64; ++w) t += sm[(w * CQ + cq) * NV + k];
+        for (int w = 0; w < THREADS / 64; ++w) t += sm[(w * CQ + cq) * NV + k];
         v[k] = t;
     }
 }
 
-template <typename T, int HW>
-__global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
+// Workgroup -> (sample n, 64-byte channel group grp).  Two groups share every 128-byte line of the plane: they are given to
+// workgroups id and id + 8 -- the same XCD (workgroups go round-robin over the 8 XCDs), dispatched together -- so that the line
+// comes from HBM once and is found in that XCD's L2 by the second.  `pairs` = B * groups / 2; the grid has ceil(pairs / 8) * 16
+// workgroups, the surplus ones return false.
+__device__ __forceinline__ bool res_block(int groups, int pairs, int& n, int& grp) {
+    const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+    const int pair = (k >> 1) * 8 + xcd;
+    if (pair >= pairs) return false;
+    const int gp = groups >> 1;
+    n = pair / gp;
+    grp = 2 * (pair - n * gp) + (k & 1);
+    return true;
+}
+
+// THREADS: 256 keeps HW/ROWS = 16 (fp32) / 32 (bf16) pieces per thread and tensor, 512 half of that -- chosen so that a kernel
+// stays near 128 registers (>= 4 waves per SIMD: the load, reduce and store phases of several workgroups overlap on a CU).
+template <typename T, int HW, int THREADS, bool HAS_RES>
+__global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const T* __restrict__ residual,
                                                                T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                               int C, float eps, int relu) {
-    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = RES_THREADS / CQ, NP = HW / ROWS;
+                                                               int C, float eps, int relu, int pairs) {
+    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = THREADS / CQ, NP = HW / ROWS;
     typedef typename Raw4<T>::type Raw;
-    __shared__ float sm[(RES_THREADS / 64) * CQ * 2 * V];
+    __shared__ float sm[(THREADS / 64) * CQ * 2 * V];
     const int cqt = C / V;                                                       // 4-channel pieces per pixel of the tensor
-    const int n = blockIdx.y, cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
+    int n, grp;
+    if (!res_block(C / (CQ * V), pairs, n, grp)) return;
+    const int cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
     // addressing: workgroup-uniform base (+ a uniform stride per pass) and ONE 32-bit byte offset per thread, so that the 2-3 x NP
     // loads / stores share a single address register
-    const size_t ubase = ((size_t)n * HW * cqt + blockIdx.x * CQ) * sizeof(Raw);
+    const size_t ubase = ((size_t)n * HW * cqt + grp * CQ) * sizeof(Raw);
     const unsigned toff = (unsigned)((rg * cqt + cq) * sizeof(Raw));
     const size_t pstride = (size_t)ROWS * cqt * sizeof(Raw);
     const char* xb = reinterpret_cast<const char*>(x) + ubase;
-    Raw xr[NP], rr[NP];
+    Raw xr[NP], rr[HAS_RES ? NP : 1];
 #pragma unroll
     for (int p = 0; p < NP; ++p) xr[p] = *reinterpret_cast<const Raw*>(xb + p * pstride + toff);
-    if (residual) {
+    if constexpr (HAS_RES) {
         const char* rb = reinterpret_cast<const char*>(residual) + ubase;
 #pragma unroll
         for (int p = 0; p < NP; ++p) rr[p] = *reinterpret_cast<const Raw*>(rb + p * pstride + toff);
     }
-    const size_t sidx = (size_t)n * C + (blockIdx.x * CQ + cq) * V;              // first channel of this thread's piece
+    const size_t sidx = (size_t)n * C + (grp * CQ + cq) * V;                     // first channel of this thread's piece
     float sc[V], sh[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) sc[k] = 1.f, sh[k] = 0.f;
@@ -856,7 +874,7 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restri
 #pragma unroll
         for (int k = 0; k < V; ++k) mu[k] += v[k];
     }
-    res_reduce<CQ, V>(mu, sm);
+    res_reduce<CQ, V, THREADS>(mu, sm);
     const float inv = 1.f / (float)HW;
     float var[V];
 #pragma unroll
@@ -871,7 +889,7 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restri
             var[k] += d * d;
         }
     }
-    res_reduce<CQ, V>(var, sm);
+    res_reduce<CQ, V, THREADS>(var, sm);
     float rs[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) rs[k] = 1.f / sqrtf(var[k] * inv + eps);
@@ -886,12 +904,12 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restri
     for (int p = 0; p < NP; ++p) {
         float v[V], q[V], o[V];
         res_unpack(xr[p], v);
-        if (residual) res_unpack(rr[p], q);
+        if constexpr (HAS_RES) res_unpack(rr[HAS_RES ? p : 0], q);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float t = (v[k] - mu[k]) * sc[k] + sh[k];
             if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
-            o[k] = residual ? t + q[k] : t;
+            o[k] = HAS_RES ? t + q[k] : t;
         }
         Raw out;
         res_pack(o, out);
@@ -899,18 +917,20 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_fwd(const T* __restri
     }
 }
 
-template <typename T, int HW>
-__global__ __launch_bounds__(RES_THREADS) void in_resident_bwd(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int HW, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_bwd(const T* __restrict__ dy, const T* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int C, int relu) {
-    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = RES_THREADS / CQ, NP = HW / ROWS;
+                                                               int C, int relu, int pairs) {
+    constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = THREADS / CQ, NP = HW / ROWS;
     typedef typename Raw4<T>::type Raw;
-    __shared__ float sm[(RES_THREADS / 64) * CQ * 2 * V];
+    __shared__ float sm[(THREADS / 64) * CQ * 2 * V];
     const int cqt = C / V;
-    const int n = blockIdx.y, cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
-    const size_t ubase = ((size_t)n * HW * cqt + blockIdx.x * CQ) * sizeof(Raw);
+    int n, grp;
+    if (!res_block(C / (CQ * V), pairs, n, grp)) return;
+    const int cq = threadIdx.x & (CQ - 1), rg = threadIdx.x / CQ;
+    const size_t ubase = ((size_t)n * HW * cqt + grp * CQ) * sizeof(Raw);
     const unsigned toff = (unsigned)((rg * cqt + cq) * sizeof(Raw));
     const size_t pstride = (size_t)ROWS * cqt * sizeof(Raw);
     const char* xb = reinterpret_cast<const char*>(x) + ubase;
@@ -921,7 +941,7 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_bwd(const T* __restri
         xr[p] = *reinterpret_cast<const Raw*>(xb + p * pstride + toff);
         gr[p] = *reinterpret_cast<const Raw*>(gb + p * pstride + toff);
     }
-    const size_t sidx = (size_t)n * C + (blockIdx.x * CQ + cq) * V;
+    const size_t sidx = (size_t)n * C + (grp * CQ + cq) * V;
     float mu[V], rs[V], ga[V], be[V];
     ldf<V>(mean, sidx, mu);
     ldf<V>(rstd, sidx, rs);
@@ -946,7 +966,7 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_bwd(const T* __restri
             s[V + k] += g * xh;
         }
     }
-    res_reduce<CQ, 2 * V>(s, sm);
+    res_reduce<CQ, 2 * V, THREADS>(s, sm);
     if (rg == 0 && dgamma) {
         float a[V], b[V];
 #pragma unroll
@@ -978,7 +998,7 @@ __global__ __launch_bounds__(RES_THREADS) void in_resident_bwd(const T* __restri
 template <typename T>
 int in_resident_hw(int HW, int C) {
     static const bool on = !(getenv("DWC_NORM_RESIDENT") && atoi(getenv("DWC_NORM_RESIDENT")) == 0);      // development: 0 = the multi-pass kernels
-    if (!on || C % (Raw4<T>::CQ * 4)) return 0;
+    if (!on || C % (2 * Raw4<T>::CQ * 4)) return 0;            // an even number of 64-byte groups
     return (HW == 1024 || HW == 256) ? HW : 0;
 }
 
@@ -999,9 +1019,12 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (const int rhw = in_resident_hw<T>(HW, C)) {          // small planes: one pass, plane resident in registers
-        const dim3 grid(C / (Raw4<T>::CQ * 4), B);
-        if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024>), grid, dim3(RES_THREADS), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu);
-        else hipLaunchKernelGGL((in_resident_fwd<T, 256>), grid, dim3(RES_THREADS), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu);
+        const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
+        const dim3 grid((pairs + 7) / 8 * 16);
+        if (rhw == 1024 && residual) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 512, true>), grid, dim3(512), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
+        else if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
+        else if (residual) hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, true>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
+        else hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
@@ -1034,9 +1057,10 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (const int rhw = in_resident_hw<T>(HW, C)) {
-        const dim3 grid(C / (Raw4<T>::CQ * 4), B);
-        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024>), grid, dim3(RES_THREADS), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu);
-        else hipLaunchKernelGGL((in_resident_bwd<T, 256>), grid, dim3(RES_THREADS), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu);
+        const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
+        const dim3 grid((pairs + 7) / 8 * 16);
+        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 512>), grid, dim3(512), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs);
+        else hipLaunchKernelGGL((in_resident_bwd<T, 256, 256>), grid, dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }

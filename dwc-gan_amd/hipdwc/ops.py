@@ -266,8 +266,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         # the P-plane heads (P = w.shape[0]: 4, or 8 on the bf16 path) as px = 32/P pixels x P planes:
         # bank [p*P + co][ci][KH][KW+px-1], copy p shifted right by p taps
         px = 32 // w.shape[0]
-        bank = torch.stack([torch.nn.functional.pad(w.detach(), (p, px - 1 - p)) for p in range(px)]).reshape(
-            32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
+        bank = _shifted_bank(w.detach(), px).reshape(32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
         out = _prepped(bank, "fwd", 32, cin_pad, 1, half=half)
         ent[key] = (stamp, out)
         return out
@@ -278,8 +277,7 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         px = 32 // cin_pad
         wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
         wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
-        bank = torch.stack([torch.nn.functional.pad(wf, (p, px - 1 - p)) for p in range(px)]).reshape(
-            px * cin_pad, cout_pad, kh, kw + px - 1)
+        bank = _shifted_bank(wf, px).reshape(px * cin_pad, cout_pad, kh, kw + px - 1)
         out = _prepped(bank, "fwd", px * cin_pad, cout_pad, 1, half=half)
         ent[key] = (stamp, out)
         return out
@@ -307,6 +305,59 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
                          stride=stride, cout_pad=cout_pad, cin_pad=cin_pad, Kp=n // rows, transpose_hw=int(transposed))
     ent[key] = (stamp, out, recipe)
     return out
+
+
+_PCAT = {}     # id(first parameter) -> (weakref, {key: (stamp, buffer)})
+
+
+class _CatParams(torch.autograd.Function):
+    """torch.cat / torch.stack of PARAMETERS along dim 0, with the concatenated buffer cached until one of them changes (the
+    16 style heads, the 4 x 2 LSTM direction weights: concatenated again on every one of ~20 forward calls per iteration with
+    unchanged values).  Backward hands out views of the incoming gradient (no kernel)."""
+
+    @staticmethod
+    def forward(ctx, stack, *ps):
+        anchor = ps[0]
+        slot = _PCAT.get(id(anchor))
+        if slot is None or slot[0]() is not anchor:
+            aid = id(anchor)
+            slot = (weakref.ref(anchor, lambda _r, aid=aid: _PCAT.pop(aid, None)), {})
+            _PCAT[aid] = slot
+        key = (bool(stack), tuple(id(p) for p in ps))
+        stamp = tuple((p._version, p.data_ptr()) for p in ps)
+        ent = slot[1].get(key)
+        if ent is None or ent[0] != stamp:
+            with torch.no_grad():
+                buf = torch.stack([p.detach() for p in ps]) if stack else torch.cat([p.detach() for p in ps], 0)
+            ent = (stamp, buf)
+            slot[1][key] = ent
+        ctx.stack = bool(stack)
+        ctx.sizes = [p.shape[0] for p in ps]
+        return ent[1].view_as(ent[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        parts = g.unbind(0) if ctx.stack else g.split(ctx.sizes, 0)
+        return (None,) + tuple(parts)
+
+
+def cat_params(params, stack=False):
+    """Concatenation (``stack=True``: stack) along dim 0 of parameters of one module, cached across calls."""
+    params = list(params)
+    if not params[0].is_cuda:
+        return torch.stack(params) if stack else torch.cat(params, 0)
+    return _CatParams.apply(stack, *params)
+
+
+def _shifted_bank(w, px):
+    """[px][*w.shape[:-1]][KW + px - 1]: copy p holds w shifted right by p taps, zeros elsewhere (the "wide" filter banks of the
+    image heads).  One fill + ONE strided copy (the diagonal view's stride along p is the bank's plus one tap) instead of px
+    pad + stack launches."""
+    kw = w.shape[-1]
+    bank = torch.zeros((px,) + tuple(w.shape[:-1]) + (kw + px - 1,), dtype=w.dtype, device=w.device)
+    diag = bank.as_strided((px,) + tuple(w.shape), (bank.stride(0) + 1,) + tuple(bank.stride()[1:]))
+    diag.copy_(w.unsqueeze(0).expand((px,) + tuple(w.shape)))
+    return bank
 
 
 _REFRESH_DT = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n_items", "<u8"), ("kind", "<i4"), ("Cout", "<i4"), ("Cin", "<i4"),
@@ -859,10 +910,8 @@ class _HeadsConvWide(torch.autograd.Function):
                 x.data_ptr(), g.data_ptr(), dwide.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad, C, 32,
                 ws.data_ptr(), ws.numel(), st), scope_name=ctx.bscope,
                 detail="wgrad-heads B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_bwd_weight_ex")
-            dv = dwide.view(px, P, C, KH, KW + px - 1)
-            dw = dv[0, :, :, :, 0:KW].clone()
-            for p in range(1, px):
-                dw += dv[p, :, :, :, p:p + KW]
+            # fold the px shifted copies back onto the real taps: the diagonal view (stride along p = the bank's plus one tap), one sum
+            dw = dwide.as_strided((px, P, C, KH, KW), (dwide.stride(0) * P + 1,) + tuple(dwide.stride())).sum(0)
         return dx, dw, (db if ctx.needs_input_grad[2] else None), None
 
 

@@ -81,9 +81,10 @@ class StyleEncoder(nn.Module):
                 f = f * drop_mask
             f = ops.linear(f, self.mapping[3].weight, self.mapping[3].bias, "relu")
         # the 2*num_class heads share their input: one [2*num_class*c_dim, dim] product
-        w = torch.cat([m.weight for m in self.fcs] + [m.weight for m in self.fcvars], 0)
-        b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
-        out = ops.linear(f, w, b)
+        heads_w = [m.weight for m in self.fcs] + [m.weight for m in self.fcvars]
+        w = ops.cat_params(heads_w)
+        b = ops.cat_params([m.bias for m in self.fcs] + [m.bias for m in self.fcvars])
+        out = ops.linear(f, w, b, owner=tuple(heads_w))     # (prepared-weight cache keyed on the 16 parameters, not on the fresh view)
         k, c = self.num_class, self.c_dim
         return HeadList.of(out[:, :k * c], k), HeadList.of(out[:, k * c:2 * k * c], k)
 
@@ -163,7 +164,7 @@ class TxtEncoder(nn.Module):
             raise NotImplementedError("the HIP text encoder is bidirectional (the reference's only configuration)")
         hs, cs = [], []
         for l in range(self.num_layers):
-            par = {n: torch.stack([getattr(self.lstm, "%s_l%d%s" % (n, l, suf)) for suf in suffixes])
+            par = {n: ops.cat_params([getattr(self.lstm, "%s_l%d%s" % (n, l, suf)) for suf in suffixes], stack=True)
                    for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
             out, cell = ops.lstm_bidir(data, lens_dev, par["weight_ih"], par["weight_hh"], par["bias_ih"], par["bias_hh"])
             # final states: forward direction at each sample's last token, reverse direction at t = 0
@@ -190,8 +191,8 @@ class TxtEncoder(nn.Module):
         # (batch, -1) interleaves samples of the local batch; reproduced, not fixed
         feat = torch.cat([h_n, c_n], dim=1).view(bsz, -1)
         # the 2*num_class heads read the same feature row: one [2*num_class*c_dim, feat] product
-        w = torch.cat([m.weight for m in self.fcs] + [m.weight for m in self.fcvars], 0)
-        b = torch.cat([m.bias for m in self.fcs] + [m.bias for m in self.fcvars], 0)
+        w = ops.cat_params([m.weight for m in self.fcs] + [m.weight for m in self.fcvars])
+        b = ops.cat_params([m.bias for m in self.fcs] + [m.bias for m in self.fcvars])
         out = torch.nn.functional.linear(feat, w, b)
         k, c = self.num_class, self.style_dim // self.num_class
         return HeadList.of(out[:, :k * c], k), HeadList.of(out[:, k * c:2 * k * c], k)

@@ -17,7 +17,8 @@
  *  - pointers are borrowed device pointers; the library never allocates, frees or synchronises;
  *    scratch is passed in by the caller (`ws`, `ws_bytes`); `stream` is a hipStream_t
  *  - return value: 0 on success, a negative DWC_E* code otherwise; nothing throws
- *  - thread-safe per stream (no global mutable state)
+ *  - thread-safe per stream: no device-side state of the library's own (scratch, instance-norm tickets and the LSTM status word
+ *    are caller memory, one set per concurrently used stream); host side only write-once caches of switches / occupancy queries
  */
 #ifndef DWCGAN_HIP_H
 #define DWCGAN_HIP_H
