@@ -498,7 +498,7 @@ class _Conv2d(torch.autograd.Function):
     ``owner``: the parameter(s) ``w`` is derived from when ``w`` is a fresh tensor on every call (prepared-weight cache)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True, owner=None, token=None):
+    def forward(ctx, x, w, b, stride, pad, act, bias_grad=True, owner=None, token=None, nograd=False):
         _require_device(x)
         lib = _lib.load()
         x = cl(x)
@@ -517,7 +517,10 @@ class _Conv2d(torch.autograd.Function):
         # those forwards -- 48 3x3 layers per step -- as gradient-free and sending them to the split-product kernel costs 4 ms per
         # step (206 vs 218 images/s), and so does merely dropping their v_keep buffer so that V lands in the shared scratch arena
         # (207 vs 220): both decisions therefore follow needs_input_grad alone.)
-        w_grad = ctx.needs_input_grad[1]
+        # r04: the split-product 3x3 forward is now ahead of Winograd at every batch (B=16: 121 vs 135 us, B=48: 265 vs 312), so
+        # the forwards made under torch.no_grad() -- the caller tells, grad mode is always off in here -- take it; forwards on
+        # the tape keep Winograd, whose transformed input the weight gradient reuses.
+        w_grad = ctx.needs_input_grad[1] and not nograd
         use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
         # (>= 160 workgroups of 256 output pixels x 64 channels: below that the launch leaves most CUs idle -- B=16 32x32 256->256 ran
         # 200 us on 64 workgroups against 118 us on the native kernel)
@@ -788,7 +791,7 @@ class _Conv2d(torch.autograd.Function):
                     _lib.check(_fn(lib, "reflect_pad_adjoint", x)(target, dx.data_ptr(), B, H, W, Cx, pad, st), "reflect_pad_adjoint")
         if g_res is not None and dx is not None:               # no fused form on this path: the plain sum
             dx = dx + g_res.to(dx.dtype)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None, token=None):
@@ -796,7 +799,7 @@ def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None, token=N
     slice of the 4-aligned buffer when Cout is not a multiple of 4).  ``bias_grad=False``: the caller feeds the
     result to an instance norm, whose mean subtraction makes the bias gradient identically zero -- it is returned
     as zeros instead of being reduced from dY."""
-    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner, token)
+    y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner, token, not torch.is_grad_enabled())
     return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
 
 
