@@ -83,7 +83,7 @@ KIND_KERNEL = {
     "wgrad-heads-small": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
     "fwd-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
     "dgrad-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
-    "wgrad-wino2": ("wino_dy_kernel + conv_wgrad_kernel + wino_wgrad_reduce_kernel (multi-launch call)", r"wino_dy_kernel|wino_wgrad_reduce_kernel", "fp32"),
+    "wgrad-wino2": ("wino_dy_kernel + conv_wgrad_kernel + wino_wgrad_reduce_kernel (multi-launch call)", r"wino_dy_kernel|wino_wgrad_reduce_kernel|conv_wgrad_kernel<", "fp32"),
     "dgrad-ring": ("conv_gemm_strips_kernel + fold_ring_kernel (multi-launch call)", r"(conv_)?gemm_strips_kernel|fold_ring_kernel", None),
 }
 GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the activation precision

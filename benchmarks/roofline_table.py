@@ -34,9 +34,32 @@ def main():
     total_ns = sum(int(r["TotalDurationNs"]) for r in rows_csv)
     used = set()
     table = []
+    # ledger rows whose kernels overlap in the csv (the Winograd weight gradient runs its products on conv_wgrad_kernel, which the
+    # generic weight gradients use too) are merged into one row: a kernel's time is never attributed twice
+    merged = []
     for k in led["kernels"]:
         rx = k.get("csv_regex")
-        match = [r for r in rows_csv if rx and re.search(rx, r["Name"])]
+        names = {r["Name"] for r in rows_csv if rx and re.search(rx, r["Name"])}
+        for m in merged:
+            if names & m["_names"]:
+                m["_names"] |= names
+                m["kernel"] += " + " + k["kernel"]
+                m["csv_regex"] = "(%s)|(%s)" % (m["csv_regex"], rx)
+                m["kinds"] = sorted(set(m["kinds"]) | set(k["kinds"]))
+                n0, n1 = m["launches_per_step"], k["launches_per_step"]
+                for f in ("algorithmic_gflop_per_launch", "executed_gflop_per_launch", "algorithmic_mbytes_per_launch", "avg_launch_us"):
+                    m[f] = (m[f] * n0 + k[f] * n1) / max(n0 + n1, 1)
+                m["launches_per_step"] = n0 + n1
+                if m.get("pipe") != k.get("pipe"):
+                    m["pipe"], m["peak_tflops"] = m.get("pipe") or k.get("pipe"), m.get("peak_tflops") or k.get("peak_tflops")
+                break
+        else:
+            e = dict(k)
+            e["_names"] = names
+            merged.append(e)
+    for k in merged:
+        rx = k.get("csv_regex")
+        match = [r for r in rows_csv if r["Name"] in k["_names"]]
         # a multi-launch call's flops sit on its product kernels only
         prod = [r for r in match if not re.search(r"wino_(input|output|dy)_kernel|wino_wgrad_reduce|fold_ring|splitk_reduce", r["Name"])] or match
         ns = sum(int(r["TotalDurationNs"]) for r in match)

@@ -22,6 +22,8 @@
 // partial images that a small epilogue kernel sums (+bias, +activation) in a fixed order.
 #include <type_traits>
 
+#include <atomic>
+
 #include "conv_geom.h"
 
 namespace {
@@ -68,7 +70,40 @@ __device__ __forceinline__ void lds_dma_barrier() {
 
 // One output tile (or, when part_stride != 0, its contribution from K-slabs [kt0, kt1_in)).  `bid`/`nb`: this
 // workgroup's linear tile index and the number of tiles of the launch; (oph, opw): parity class of a stride-2 gradient.
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+// X3 (r04): the SAME kernel -- staging, geometry, prepared fp32 weights, epilogue -- with the inner product taken as exact
+// three-way bf16 split products on the bf16 matrix cores (conv_halo_x3.hip explains the arithmetic: a = a0 + a1 + a2 with 8
+// significand bits each, six of the nine partial products, the rest below one fp32 rounding; leading product and corrections
+// in separate accumulators).  The fp32 fragments are read from the unchanged LDS image and split in registers in front of the
+// MFMAs: ~44 vector-ALU instructions per 32x16 fragment, which two workgroups per CU hide behind each other's 48 bf16 MFMAs
+// per slab.  For the layers the halo form cannot take (small discriminator layers, 7x7 image layers, ring strips, 1x1).
+typedef __bf16 gx3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gx3_u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 fp32 (two 16-byte chunks of a row) -> three bf16x8 planes, exact: v = p0 + p1 + p2 (truncate, subtract, truncate, subtract)
+__device__ __forceinline__ void gx3_split8(const f32x4& a, const f32x4& b, gx3_bf16x8& p0, gx3_bf16x8& p1, gx3_bf16x8& p2) {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? a[k] : b[k - 4];
+        const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+        const float r = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
+        const float q = r - __uint_as_float(mb);
+        h[k] = hb; m[k] = mb; l[k] = __float_as_uint(q);
+    }
+    gx3_u32x4 u0, u1, u2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // bytes 2,3 of the even element below bytes 2,3 of the odd one
+        u0[k] = __builtin_amdgcn_perm(h[2 * k + 1], h[2 * k], 0x07060302u);
+        u1[k] = __builtin_amdgcn_perm(m[2 * k + 1], m[2 * k], 0x07060302u);
+        u2[k] = __builtin_amdgcn_perm(l[2 * k + 1], l[2 * k], 0x07060302u);
+    }
+    p0 = __builtin_bit_cast(gx3_bf16x8, u0);
+    p1 = __builtin_bit_cast(gx3_bf16x8, u1);
+    p2 = __builtin_bit_cast(gx3_bf16x8, u2);
+}
+
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __restrict__ wmat, const Scatter& o,
                                                const float* __restrict__ bias, int act, int tiles_n, int kt0, int kt1_in,
                                                size_t part_offset, bool partial, int oph, int opw, int bid, int nb) {
@@ -207,7 +242,67 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][j], fb[set][n][j], acc[i][n], 0, 0, 0);
     };
 
-    if (kt0 < kt1) {
+    if constexpr (X3) {
+        static_assert(TM * TN <= 2, "split accumulators: at most two 32x32 tiles per wave");
+        f32x16 lo[TM][TN];                               // the five correction products, merged once at the end
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lo[i][j][r] = 0.f;
+        // k-step s (16 deep) of a slab: lane half hi takes k = 16 s + 8 hi .. + 7 = logical chunks 4 s + 2 hi, + 1 of its row
+        int xoff[2][2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) xoff[ss][e] = ((4 * ss + 2 * hi + e) ^ fsw) * 4;
+        gx3_bf16x8 pa[3][TM], pb[3][TN];
+        auto frags_x3 = [&](int buf, int ss) {
+            const float* a = sA + buf * A_TILE + a_row;
+            const float* b = sB + buf * B_TILE + b_row;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                gx3_split8(*reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][0]),
+                           *reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][1]), pa[0][i], pa[1][i], pa[2][i]);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                gx3_split8(*reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][0]),
+                           *reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][1]), pb[0][n], pb[1][n], pb[2][n]);
+        };
+        auto mfma_x3 = [&]() {
+            constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        if (term == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], acc[i][n], 0, 0, 0);
+                        else lo[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], lo[i][n], 0, 0, 0);
+                    }
+        };
+        if (kt0 < kt1) {
+            stage_slab(kt0, 0);
+            lds_dma_barrier();
+            int buf = 0;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                if (kt + 1 < kt1) stage_slab(kt + 1, buf ^ 1);   // other buffer: fully read before the last barrier
+                frags_x3(buf, 0);
+                mfma_x3();
+                frags_x3(buf, 1);
+                lds_dma_barrier();                            // direct loads landed (vmcnt), this buffer fully read
+                mfma_x3();
+                buf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += lo[i][j][r];
+    } else if (kt0 < kt1) {
         stage_slab(kt0, 0);
         lds_dma_barrier();
         int buf = 0;
@@ -278,23 +373,23 @@ __device__ __forceinline__ void conv_gemm_body(const Gather& g, const float* __r
     else store(std::true_type{});
 }
 
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
                                                              Scatter o, const float* __restrict__ bias, int act, int tiles_n,
                                                              int kt_per_split, size_t part_stride) {
     DWC_PROBE();
     const int cls = blockIdx.z, split = blockIdx.y;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
+    conv_gemm_body<BM, BN, WM, WN, TM, TN, X3>(g, wmat + (size_t)cls * w_class_stride, o, bias, act, tiles_n, split * kt_per_split,
                                            (split + 1) * kt_per_split, (size_t)split * part_stride, part_stride != 0, cls >> 1,
                                            cls & 1, blockIdx.x, gridDim.x);
 }
 
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
     const Strip& s = ss.s[blockIdx.z];
     if ((int)blockIdx.x >= s.tiles) return;
     const int kt0 = s.kt0 + blockIdx.y * ss.kt_per_part;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN>(s.g, (const float*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
+    conv_gemm_body<BM, BN, WM, WN, TM, TN, X3>(s.g, (const float*)s.w, s.o, nullptr, DWC_ACT_NONE, s.tiles_n, kt0, min(s.kt1, kt0 + ss.kt_per_part),
                                            blockIdx.y * ss.part_stride, false, s.oph, s.opw, blockIdx.x, s.tiles);
 }
 
@@ -457,7 +552,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // weight gradient: dW[k][n] = sum_m A[m][k] * dY[m][n], split over m ("split-K") into slabs
 // ------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int TM, int TN>
+// X3: the contraction over pixels as exact bf16 split products (see conv_gemm_body): both operands are read from the unchanged
+// fp32 LDS tiles -- eight pixels of one k / n column per lane and 16-deep step, the same ds_read_b32 count as the fp32 MFMA path --
+// and split in registers.
+template <int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* __restrict__ dy, int N, float* __restrict__ slab,
                                                          int m_chunk, int splits_per_class = 0, size_t src_class_stride = 0,
                                                          size_t dy_class_stride = 0) {
@@ -571,7 +669,62 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(Gather g, const float* 
                 for (int n = 0; n < TN; ++n)
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][s][i], bv[set][s][n], acc[i][n], 0, 0, 0);
     };
-    if (m_begin < m_end) {
+    if constexpr (X3) {
+        f32x16 lo[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lo[i][j][r] = 0.f;
+        gx3_bf16x8 pa[3][TM], pb[3][TN];
+        auto ops_x3 = [&](int buf, int ss) {              // 16-pixel step ss of the slab: lane half hi takes pixels 16 ss + 8 hi .. + 7
+            const float* a = sA + buf * A_TILE + (wm * TM) * 32 + l31 + (16 * ss + 8 * hi) * 128;
+            const float* b = sB + buf * B_TILE + (wn * TN) * 32 + l31 + (16 * ss + 8 * hi) * BN;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                gx3_split8(f32x4{a[i * 32], a[128 + i * 32], a[2 * 128 + i * 32], a[3 * 128 + i * 32]},
+                           f32x4{a[4 * 128 + i * 32], a[5 * 128 + i * 32], a[6 * 128 + i * 32], a[7 * 128 + i * 32]}, pa[0][i], pa[1][i],
+                           pa[2][i]);
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                gx3_split8(f32x4{b[n * 32], b[BN + n * 32], b[2 * BN + n * 32], b[3 * BN + n * 32]},
+                           f32x4{b[4 * BN + n * 32], b[5 * BN + n * 32], b[6 * BN + n * 32], b[7 * BN + n * 32]}, pb[0][n], pb[1][n],
+                           pb[2][n]);
+        };
+        auto mfma_x3 = [&]() {
+            constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n) {
+                        if (term == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], acc[i][n], 0, 0, 0);
+                        else lo[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], lo[i][n], 0, 0, 0);
+                    }
+        };
+        if (m_begin < m_end) {
+            stage_slab(m_begin, 0);
+            lds_dma_barrier();
+            int buf = 0;
+            for (int mb = m_begin; mb < m_end; mb += 32) {
+                if (mb + 32 < m_end) stage_slab(mb + 32, buf ^ 1);
+                ops_x3(buf, 0);
+                mfma_x3();
+                ops_x3(buf, 1);
+                lds_dma_barrier();
+                mfma_x3();
+                buf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += lo[i][j][r];
+    } else if (m_begin < m_end) {
         stage_slab(m_begin, 0);
         lds_dma_barrier();
         int buf = 0;
@@ -737,13 +890,32 @@ __global__ void weight_prepare_dgrad_kernel(const float* __restrict__ w, float* 
 
 
 
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 void launch_variant(const Gather& g, const float* w, size_t wcs, int classes, const Scatter& o, const float* bias, int act,
                     const Plan& p, size_t part_stride, hipStream_t st) {
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (o.N + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, TM, TN>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0, st,
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, TM, TN, X3>), dim3(tiles_m * tiles_n, p.splits, classes), dim3(256), 0, st,
                        g, w, wcs, o, bias, act, tiles_n, p.kt_per_split, part_stride);
 }
+
+// 1: the im2col GEMM takes its inner product as split products on the bf16 matrix cores (conv_gemm_body<..., X3>): default for every
+// product with K >= 128 (below that the launch is latency, not arithmetic).  DWC_X3_GEMM=0: the native fp32 MFMA everywhere.
+// Process-wide switch of the split-product inner products: bit 0 the forward / data-gradient GEMM, bit 1 the weight-gradient
+// kernel.  Initialised from DWC_X3_GEMM / DWC_X3_WGRAD (default on); dwc_x3_gemm_mode() reads / sets it at run time (tests use it
+// to obtain the native fp32 MFMA result as a yardstick).
+static std::atomic<int> g_x3_mode{-1};
+static int x3_mode() {
+    int m = g_x3_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const int a = getenv("DWC_X3_GEMM") ? atoi(getenv("DWC_X3_GEMM")) : 1;
+        const int b = getenv("DWC_X3_WGRAD") ? atoi(getenv("DWC_X3_WGRAD")) : 1;
+        m = (a ? 1 : 0) | (b ? 2 : 0);
+        g_x3_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+static bool wgrad_x3_on() { return (x3_mode() & 2) != 0; }
+static bool gemm_x3_on(int K) { return (x3_mode() & 1) != 0 && K >= 128; }
 
 int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int classes, Scatter o, const float* bias, int act,
                 size_t dst_elems, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -759,7 +931,12 @@ int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int clas
             part_stride = dst_elems;
         }
     }
-    if (p.bm == 128 && p.bn == 128) launch_variant<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+    if (gemm_x3_on(g.K)) {
+        // (split accumulators need the registers of two tiles: the 128x128 plan runs as 128x64 with twice the column tiles)
+        if (p.bm == 128 && p.bn >= 64) launch_variant<128, 64, 2, 2, 2, 1, true>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+        else if (p.bm == 64 && p.bn == 64) launch_variant<64, 64, 2, 2, 1, 1, true>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+        else launch_variant<128, 32, 4, 1, 1, 1, true>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
+    } else if (p.bm == 128 && p.bn == 128) launch_variant<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
     else if (p.bm == 128 && p.bn == 64) launch_variant<128, 64, 2, 2, 2, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
     else if (p.bm == 64 && p.bn == 64) launch_variant<64, 64, 2, 2, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
     else launch_variant<128, 32, 4, 1, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, st);
@@ -954,6 +1131,14 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
 extern "C" {
 
 int dwc_version(void) { return 2; }
+
+/* mode >= 0: set the split-product switch of the im2col kernels (bit 0: forward / data-gradient GEMM, bit 1: weight gradient;
+ * 0 = native fp32 MFMA everywhere); returns the previous value.  mode < 0: query only. */
+int dwc_x3_gemm_mode(int mode) {
+    const int prev = x3_mode();
+    if (mode >= 0) g_x3_mode.store(mode & 3, std::memory_order_relaxed);
+    return prev;
+}
 
 size_t dwc_weight_prepared_elems(int Cout, int Cin, int KH, int KW, int stride, int cout_pad, int cin_pad, int for_dgrad) {
     if (!for_dgrad) return (size_t)cout_pad * ((KH * KW * cin_pad + BK - 1) / BK * BK);
@@ -1430,9 +1615,15 @@ int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float
     g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = g.off_w = 0; g.reflect = 1; g.M = T; g.K = Cin;
     const int tk = (Cin + 127) / 128;
     const size_t sv = (size_t)T * Cin, sz = (size_t)T * Cout;
-    if (Cout > 64) {
+    if (Cout > 64 && wgrad_x3_on()) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2, true>), dim3(tk, (Cout + 127) / 128, NC * splits), dim3(256), 0, st, g, Z,
+                           Cout, slab, chunk, splits, sv, sz);
+    } else if (Cout > 64) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, NC * splits), dim3(256), 0, st, g, Z,
                            Cout, slab, chunk, splits, sv, sz);
+    } else if (wgrad_x3_on()) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1, true>), dim3(tk, 1, NC * splits), dim3(256), 0, st, g, Z, Cout, slab, chunk,
+                           splits, sv, sz);
     } else {
         hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1>), dim3(tk, 1, NC * splits), dim3(256), 0, st, g, Z, Cout, slab, chunk,
                            splits, sv, sz);
@@ -1490,7 +1681,15 @@ static int wgrad_launch(const FwdGeom& f, const float* dy, float* dw_oihw, int C
     if (!ws || ws_bytes < (size_t)splits * g.K * Cout * sizeof(float)) return DWC_EWORKSPACE;
     float* slab = (float*)ws;
     const int tk = (g.K + 127) / 128;
-    if (Cout > 64) {
+    if (wgrad_x3_on()) {
+        if (Cout > 64)
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2, true>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy,
+                               Cout, slab, chunk);
+        else if (Cout > 32)
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1, true>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1, 1, 1, true>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    } else if (Cout > 64) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy,
                            Cout, slab, chunk);
     } else if (Cout > 32) {
@@ -1624,7 +1823,10 @@ static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_
                              ws_bytes - ring_bytes, st);
         if (rc != DWC_OK) return rc;
     }
-    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    if (gemm_x3_on(f.ss.s[0].g.K))
+        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    else
+        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
     hipLaunchKernelGGL(fold_ring_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dx, (const float*)ws, f.ring_elems[0],
@@ -1697,7 +1899,10 @@ int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dx
     if (!dy || !w_dgrad || !dxp || !dx || H > 65535 - 2 || B > 65535 || !s2_ring_geom(dy, w_dgrad, dxp, sizeof(float), B, H, W, Cin, Cout, &f))
         return DWC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    if (gemm_x3_on(f.ss.s[0].g.K))
+        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    else
+        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const int C4 = Cin / 4;
     const size_t band_items = (size_t)B * (2 * W + (H - 2) * 2) * C4;
@@ -1726,7 +1931,15 @@ int dwc_conv2d_bwd_weight(const float* x, const float* dy, float* dw_oihw, int B
     wgrad_plan(g.M, g.K, Cout, &splits, &chunk);
     float* slab = (float*)ws;
     const int tk = (g.K + 127) / 128;
-    if (Cout > 64) {
+    if (wgrad_x3_on()) {
+        if (Cout > 64)
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2, true>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy,
+                               Cout, slab, chunk);
+        else if (Cout > 32)
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1, true>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+        else
+            hipLaunchKernelGGL((conv_wgrad_kernel<32, 4, 1, 1, 1, true>), dim3(tk, 1, splits), dim3(256), 0, st, g, dy, Cout, slab, chunk);
+    } else if (Cout > 64) {
         hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, splits), dim3(256), 0, st, g, dy,
                            Cout, slab, chunk);
     } else if (Cout > 32) {

@@ -22,6 +22,7 @@ class AdvSpec(ctypes.Structure):               # struct dwc_adv_spec (passed by 
 # name -> (restype, argtypes): mirrors include/dwcgan_hip.h one to one
 SIGNATURES = {
     "dwc_version": (c_int, []),
+    "dwc_x3_gemm_mode": (c_int, [c_int]),
     "dwc_weight_prepared_elems": (c_sz, [c_int] * 8),
     "dwc_weight_prepare_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_weight_prepare_dgrad": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),

@@ -46,6 +46,12 @@ extern "C" {
 #define DWC_ACT_HEADS8 6   /* the same heads on an 8-plane (NHWC8, bf16) image: planes 0..2 tanh, 3 sigmoid, 4..7 zero */
 
 int dwc_version(void);
+/* The fp32 im2col kernels (dwc_conv2d_fwd / _bwd_data* / _bwd_weight*, ring strips) take their inner products as exact three-way
+ * bf16 split products on the bf16 matrix cores by default (r04; fp32 operands, results and accumulation -- see
+ * csrc/conv_halo_x3.hip for the arithmetic).  dwc_x3_gemm_mode(mode >= 0) sets the process-wide switch (bit 0: forward /
+ * data-gradient GEMM, bit 1: weight gradient; 0 = native fp32 MFMA) and returns the previous value; mode < 0 only queries.
+ * Environment at first use: DWC_X3_GEMM, DWC_X3_WGRAD (0 / 1). */
+int dwc_x3_gemm_mode(int mode);
 
 /* ---- weight re-layout --------------------------------------------------------------------
  * The GEMM kernels stream weights as one row per GEMM column with K contiguous and

@@ -76,11 +76,13 @@ def test_x3_forward_matches_float64(shape):
     err_32 = (ref32 - ref).abs().max().item() / scale
     old = ops.X3
     ops.X3 = 0
+    old_mode = _lib.load().dwc_x3_gemm_mode(0)           # the yardstick is the NATIVE fp32 MFMA product
     try:
         with torch.no_grad():
             yn = ops.conv2d(xd.permute(0, 3, 1, 2), wd, bd, 1, pad, act)
     finally:
         ops.X3 = old
+        _lib.load().dwc_x3_gemm_mode(old_mode)
     err_native = (yn[:, :Cout].double().cpu() - ref).abs().max().item() / scale
     print("%s max err / scale vs float64: split-bf16 %.2e | native fp32 MFMA path %.2e | fp32 CPU conv %.2e" % (
         "x".join(str(v) for v in shape), err_x3, err_native, err_32))
@@ -114,11 +116,13 @@ def test_x3_stride2_forward_matches_float64(shape):
     err_x3 = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
     old = ops.X3_S2
     ops.X3_S2 = 0
+    old_mode = _lib.load().dwc_x3_gemm_mode(0)
     try:
         with torch.no_grad():
             yn = ops.conv2d(xd, wd, bd, 2, 1, act)
     finally:
         ops.X3_S2 = old
+        _lib.load().dwc_x3_gemm_mode(old_mode)
     err_native = (yn[:, :Cout].double() - ref).abs().max().item() / scale
     err_32 = (ref32 - ref.cpu()).abs().max().item() / scale if ref32 is not None else 0.0
     print("s2 %s max err / scale vs float64: split-bf16 %.2e | native fp32 MFMA path %.2e | fp32 CPU conv %.2e" % (
