@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
 
 // gridDim.z independent products of one geometry: source, weights and destination advance by a fixed stride per
 // class (the 16 transform-domain products of a Winograd convolution).
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_gemm_batched_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
                                                                 size_t src_class_stride, Scatter o, size_t dst_class_stride,
                                                                 int tiles_n, int nk) {
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void conv_gemm_batched_kernel(Gather g, const 
     const int cls = blockIdx.z;
     g.src = (const float*)g.src + (size_t)cls * src_class_stride;
     o.dst = (float*)o.dst + (size_t)cls * dst_class_stride;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN>(g, wmat + (size_t)cls * w_class_stride, o, nullptr, DWC_ACT_NONE, tiles_n, 0, nk, 0, false,
-                                           0, 0, blockIdx.x, gridDim.x);
+    conv_gemm_body<BM, BN, WM, WN, TM, TN, X3>(g, wmat + (size_t)cls * w_class_stride, o, nullptr, DWC_ACT_NONE, tiles_n, 0, nk, 0, false,
+                                               0, 0, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -961,7 +961,7 @@ int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int clas
 // four output pixels of the tile, Y[a][b] += A^T[a][xi] * A^T[b][nu] * M_e (coefficients 0, +-1), and cleared; the
 // epilogue adds the bias, applies the activation and scatters the 2x2 pixels.
 //   V:[16][T][Cin] (wino_input_kernel), U:[16][N][Cin], y:[B][H][W][N]
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
 __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict__ V, const float* __restrict__ U,
                                                          const float* __restrict__ bias, float* __restrict__ y, int T, int Cin,
                                                          int N, int H, int W, int act, int tiles_n) {
@@ -1046,22 +1046,71 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
                 for (int n = 0; n < TN; ++n)
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][j], fb[set][n][j], acc[i][n], 0, 0, 0);
     };
+    // X3 (r04): the 16 transform-domain products as exact bf16 split products (conv_gemm_body explains): Winograd's 2.25x fewer
+    // multiply-adds AND the bf16 matrix cores -- 6 / 2.25 bf16 MFMA-equivalents per multiply-add of the direct convolution.
+    f32x16 lo[X3 ? TM : 1][X3 ? TN : 1];
+    int xoff[2][2];
+    gx3_bf16x8 pa[3][TM], pb[3][TN];
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lo[i][j][r] = 0.f;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xoff[ss][q] = ((4 * ss + 2 * hi + q) ^ fsw) * 4;
+    }
+    auto frags_x3 = [&](int buf_, int ss) {
+        const float* a = sA + buf_ * A_TILE + a_row;
+        const float* b = sB + buf_ * B_TILE + b_row;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            gx3_split8(*reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][0]),
+                       *reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][1]), pa[0][i], pa[1][i], pa[2][i]);
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+            gx3_split8(*reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][0]),
+                       *reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][1]), pb[0][n], pb[1][n], pb[2][n]);
+    };
+    auto mfma_x3 = [&]() {
+        constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    if (term == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], acc[i][n], 0, 0, 0);
+                    else lo[X3 ? i : 0][X3 ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], lo[X3 ? i : 0][X3 ? n : 0], 0, 0, 0);
+                }
+    };
     stage_slab(0, 0);
     lds_dma_barrier();
     int buf = 0, kt = 0, e = 0;
-    load_frags(0, 0, 0);
+    if constexpr (!X3) load_frags(0, 0, 0);
     for (int s = 0; s < total; ++s) {
         const bool more = s + 1 < total;
         if (more) stage_slab(s + 1, buf ^ 1);
-        load_frags(1, buf, 1);
-        mfma_group(0);
-        load_frags(0, buf, 2);
-        mfma_group(1);
-        load_frags(1, buf, 3);
-        mfma_group(0);
-        lds_dma_barrier();
-        if (more) load_frags(0, buf ^ 1, 0);
-        mfma_group(1);
+        if constexpr (X3) {
+            frags_x3(buf, 0);
+            mfma_x3();
+            frags_x3(buf, 1);
+            lds_dma_barrier();
+            mfma_x3();
+        } else {
+            load_frags(1, buf, 1);
+            mfma_group(0);
+            load_frags(0, buf, 2);
+            mfma_group(1);
+            load_frags(1, buf, 3);
+            mfma_group(0);
+            lds_dma_barrier();
+            if (more) load_frags(0, buf ^ 1, 0);
+            mfma_group(1);
+        }
         buf ^= 1;
         if (++kt == nk) {                                    // product e = (xi, nu) complete: fold into the 2x2 outputs
             kt = 0;
@@ -1076,7 +1125,11 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
                 for (int n = 0; n < TN; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float m = acc[i][n][r];
+                        float m = acc[i][n][r];
+                        if constexpr (X3) {
+                            m += lo[X3 ? i : 0][X3 ? n : 0][r];
+                            lo[X3 ? i : 0][X3 ? n : 0][r] = 0.f;
+                        }
                         Y[0][i][n][r] += c00 * m;
                         Y[1][i][n][r] += c01 * m;
                         Y[2][i][n][r] += c10 * m;
@@ -1518,8 +1571,12 @@ int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y,
     const long fused_wgs = (long)((T + 63) / 64) * ((Cout + 63) / 64);
     if (tile == 2 && !unfused && fused_wgs >= 2 * NUM_CU) {
         const int tn = (Cout + 63) / 64;
-        hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T, Cin,
-                           Cout, H, W, act, tn);
+        if (gemm_x3_on(Cin))
+            hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1, true>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T,
+                               Cin, Cout, H, W, act, tn);
+        else
+            hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T, Cin,
+                               Cout, H, W, act, tn);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
@@ -1534,14 +1591,18 @@ int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y,
     const Plan p = plan_gemm(T, Cout, Cin, NC);
     const int nk = (Cin + BK - 1) / BK;
     const size_t ws_w = (size_t)Cout * Cin, ws_s = (size_t)T * Cin, ws_d = (size_t)T * Cout;
-#define WINO_LAUNCH(BM, BN, WM, WN, TM, TN)                                                                                       \
-    hipLaunchKernelGGL((conv_gemm_batched_kernel<BM, BN, WM, WN, TM, TN>),                                                        \
+#define WINO_LAUNCH(BM, BN, WM, WN, TM, TN, X3)                                                                                   \
+    hipLaunchKernelGGL((conv_gemm_batched_kernel<BM, BN, WM, WN, TM, TN, X3>),                                                    \
                        dim3(((T + BM - 1) / BM) * ((Cout + BN - 1) / BN), 1, NC), dim3(256), 0, st, g, U, ws_w, ws_s, o, ws_d,    \
                        (Cout + BN - 1) / BN, nk)
-    if (p.bm == 128 && p.bn == 128) WINO_LAUNCH(128, 128, 2, 2, 2, 2);
-    else if (p.bm == 128 && p.bn == 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1);
-    else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1);
-    else WINO_LAUNCH(128, 32, 4, 1, 1, 1);
+    if (gemm_x3_on(Cin)) {
+        if (p.bm == 128 && p.bn >= 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1, true);
+        else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1, true);
+        else WINO_LAUNCH(128, 32, 4, 1, 1, 1, true);
+    } else if (p.bm == 128 && p.bn == 128) WINO_LAUNCH(128, 128, 2, 2, 2, 2, false);
+    else if (p.bm == 128 && p.bn == 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1, false);
+    else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1, false);
+    else WINO_LAUNCH(128, 32, 4, 1, 1, 1, false);
 #undef WINO_LAUNCH
     DWC_LAUNCH_CHECK();
     if (tile == 2) {
