@@ -508,10 +508,12 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
                        conf["label"], args.vgg_w,
-                       (", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
-                           ", 5x5 convs and 3x3 data gradients as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 "
-                           "operands, results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)"
-                           if ops.X3 else "")) if precision == "fp32" else ""),
+                       ((", every convolution / linear product as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 operands, "
+                         "results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)" if ops.X3 >= 2 else
+                         ", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
+                             ", 5x5 convs and 3x3 data gradients as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 "
+                             "operands, results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)"
+                             if ops.X3 else ""))) if precision == "fp32" else ""),
                    "name": config_name, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
                    "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
         # algorithmic (direct-convolution, fp32-equivalent) flops of the launches this step actually made (conv + linear

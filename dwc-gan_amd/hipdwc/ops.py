@@ -436,7 +436,10 @@ WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 # bf16 path: halo-tiled kernel for the stride-1 "same" 3x3 / 5x5 layers (0: im2col GEMM everywhere; development knob)
 # fp32 stride-1 "same" 5x5 (and with DWC_X3=2 also 3x3) convolutions as exact three-way bf16 splits on the bf16 MFMA
 # (csrc/conv_halo_x3.hip): 0 = native fp32 MFMA kernels only
-X3 = int(os.environ.get("DWC_X3", "1"))
+# (r04: 2 is the default -- every stride-1 3x3 / 5x5 layer as split products, forward, data gradient and weight gradient; same-box
+# A/B on c1, interleaved: 256.7 / 252.2 images/s against 249.4 / 247.2 with Winograd (1) for the taped 3x3 forwards and their
+# weight gradients.  Winograd F(2x2,3x3) / F(4x4,3x3) stay available behind DWC_X3=1 (+ DWC_WINOGRAD).)
+X3 = int(os.environ.get("DWC_X3", "2"))
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))

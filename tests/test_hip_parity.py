@@ -63,6 +63,7 @@ CONV_SHAPES = [
 
 @pytest.fixture(params=[2, 4], ids=["wino2", "wino4"])
 def winograd_tile(request, monkeypatch):
+    monkeypatch.setattr(ops, "X3", 1)              # (r04: split products are the default for the 3x3 layers; Winograd is opt-in)
     monkeypatch.setattr(ops, "WINOGRAD_TILE", request.param)
     return request.param
 

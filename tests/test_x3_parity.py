@@ -249,7 +249,7 @@ def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
     fn = {"none": lambda v: v, "relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[act]
 
     def cpu(dtype):
-        xr, wr, br = x.to(dtype).requires_grad_(True), w.to(dtype).requires_grad_(True), b.to(dtype).requires_grad_(True)
+        xr, wr, br = (t.detach().clone().to(dtype).requires_grad_(True) for t in (x, w, b))    # (.to(float32) alone would alias x)
         xp = F.pad(xr, (pad,) * 4, mode="reflect") if pad else xr
         y = fn(F.conv2d(xp, wr, br, stride=stride))
         (y * gy.to(dtype)).sum().backward()
@@ -261,8 +261,8 @@ def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
     def gpu(mode):
         old = lib.dwc_x3_gemm_mode(mode)
         try:
-            xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
-            wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+            xd = x.detach().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
             y = ops.conv2d(xd, wd, bd, stride, pad, act)
             (y * gy.cuda()).sum().backward()
             torch.cuda.synchronize()
