@@ -86,6 +86,17 @@ KIND_KERNEL = {
     "wgrad-wino2": ("wino_dy_kernel + conv_wgrad_kernel + wino_wgrad_reduce_kernel (multi-launch call)", r"wino_dy_kernel|wino_wgrad_reduce_kernel|conv_wgrad_kernel<", "fp32"),
     "dgrad-ring": ("conv_gemm_strips_kernel + fold_ring_kernel (multi-launch call)", r"(conv_)?gemm_strips_kernel|fold_ring_kernel", None),
 }
+# the fp32 im2col / Winograd kernels with split-product inner products (ops._timed appends -g3 to the kind)
+for _k, _lab, _rx in (("fwd", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("dgrad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
+                      ("dgrad-image", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("fwd-heads", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
+                      ("dgrad-heads", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("fwd-zeropad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
+                      ("dgrad-zeropad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
+                      ("wgrad", "conv_wgrad_kernel<X3>", r"conv_wgrad_kernel<.*true>\("), ("wgrad-heads", "conv_wgrad_kernel<X3>", r"conv_wgrad_kernel<.*true>\("),
+                      ("fwd-wino2", "wino_input_kernel + wino_fused_kernel<X3> (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel"),
+                      ("dgrad-wino2", "wino_input_kernel + wino_fused_kernel<X3> (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel"),
+                      ("wgrad-wino2", "wino_dy_kernel + conv_wgrad_kernel<X3> + wino_wgrad_reduce_kernel (multi-launch call)",
+                       r"wino_dy_kernel|wino_wgrad_reduce_kernel|conv_wgrad_kernel<.*true>\(")):
+    KIND_KERNEL[_k + "-g3"] = (_lab, _rx, "bf16x3")
 GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the activation precision
     "fwd": ("conv_gemm_kernel", "gemm_kernel_h"), "dgrad": ("conv_gemm_kernel", "gemm_kernel_h"),
     "fwd-heads": ("conv_gemm_kernel", "gemm_kernel_h"), "dgrad-heads": ("conv_gemm_kernel", "gemm_kernel_h"),
@@ -104,6 +115,8 @@ def kernel_of_kind(kind_key, precision, split_generic=False):
     k = ksz[1:] if ksz else ""
     if kind in KIND_KERNEL:
         label, rx, pipe = KIND_KERNEL[kind]
+        if split_generic and kind.endswith("-g3") and "multi-launch" not in label:
+            label = label + "[" + kind_key + "]"
         return label.replace("{k}", k), rx.replace("{k}", k), pipe
     if kind in GENERIC_KERNEL:
         name = GENERIC_KERNEL[kind][1 if precision == "bf16" else 0]

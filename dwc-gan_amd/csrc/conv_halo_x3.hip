@@ -846,7 +846,7 @@ int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* 
         a.stagger = (long)blocks * a.tiles_n > 512 ? stagger : 0;      // (a launch of one round gains nothing from an offset)
         // r04: launches that would leave half of the 512 two-per-CU slots empty (3x3 256->256 at batch 16: 256 workgroups, one per
         // CU, nothing to overlap with) run 32-channel tiles instead: twice the workgroups, two per CU again
-        static const int bn32 = getenv("DWC_X3_BN32") ? atoi(getenv("DWC_X3_BN32")) : 1;
+        static const int bn32 = getenv("DWC_X3_BN32") ? atoi(getenv("DWC_X3_BN32")) : 0;      // (lab: B=16 121.6 -> 117.0 us; no gain visible in the step: opt-in)
         if (bn32 && K == 3 && (long)blocks * a.tiles_n <= 256 && N % 32 == 0) {
             a.tiles_n = N / 32;
             x3_launch<3, 32, 4, 1, 2, 1, 0, 1>(a, dim3(blocks * a.tiles_n), (hipStream_t)stream);

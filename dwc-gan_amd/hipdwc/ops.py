@@ -159,10 +159,31 @@ class scope:
         SCOPE = self.prev
 
 
+# launch kinds of the fp32 im2col / Winograd kernels whose inner products run as split products when dwc_x3_gemm_mode says so (r04)
+_G3_GEMM = {"fwd", "dgrad", "dgrad-image", "fwd-heads", "dgrad-heads", "fwd-zeropad", "dgrad-zeropad", "fwd-wino2", "dgrad-wino2",
+            "fwd-wino4", "dgrad-wino4", "fwd-zeropad-wino2", "dgrad-zeropad-wino2", "fwd-zeropad-wino4", "dgrad-zeropad-wino4"}
+_G3_WGRAD = {"wgrad", "wgrad-heads", "wgrad-wino2", "wgrad-wino4"}
+
+
 def _timed(tag, flops, fn, scope_name=None, detail="", exec_flops=None):
     if TIMER is None:
         return fn()
     s = SCOPE if scope_name is None else scope_name
+    words = detail.split()
+    if PRECISION == "fp32" and words and (words[0] in _G3_GEMM or words[0] in _G3_WGRAD):
+        # bookkeeping only: which matrix pipe the span's multiply-adds ran on (kind suffix -g3, split-product family, 6 bf16
+        # multiply-adds per executed fp32 one)
+        mode = _lib.load().dwc_x3_gemm_mode(-1)
+        try:
+            ci = int(words[3].split(">")[0])
+            k = int(next(w for w in words[4:] if w[0] == "k")[1:])
+        except (IndexError, ValueError, StopIteration):
+            ci, k = 0, 0
+        on = (mode & 2) if words[0] in _G3_WGRAD else ((mode & 1) and k * k * ci >= 128)
+        if on:
+            detail = words[0] + "-g3 " + " ".join(words[1:])
+            exec_flops = 6.0 * (flops if exec_flops is None else exec_flops)
+            tag = "wgrad_x3_kernel+reduce" if words[0] in _G3_WGRAD else "conv_halo_x3_kernel"
     return TIMER.run((s + "/" + tag) if s else tag, flops, fn, detail, exec_flops)
 
 
