@@ -470,6 +470,7 @@ DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # data gradients throu
 X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
+X3_WGRAD_HALO3 = int(os.environ.get("DWC_X3_WGRAD_HALO3", "1"))   # 0: 3x3 weight gradients on the im2col kernel (split-product inner product)
 S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
 
 
@@ -672,6 +673,7 @@ class _Conv2d(torch.autograd.Function):
                     scope_name=ctx.bscope, detail="wgrad-stem" + detail[5:]), "conv7_smallk_wgrad")
             elif ((not half) and (_x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
                                   or (X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1))
+                  and (KH != 3 or X3_WGRAD_HALO3)
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
                 _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
