@@ -1103,11 +1103,13 @@ int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp
 int dwc_bf16_conv2d_bwd_data_s2_ring(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
                                      void* stream) {
     S2Ring f;
+    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1);
     if (!dy || !w_dgrad || !dxp || !dx || (Cin & 7) || H > 65535 - 2 || B > 65535 ||
-        !s2_ring_geom(dy, w_dgrad, dxp, 2, B, H, W, Cin, Cout, &f, BK, MIN_LOG_C))
+        !s2_ring_geom(dy, w_dgrad, dxp, 2, B, H, W, Cin, Cout, &f, BK, MIN_LOG_C, bm))
         return DWC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1, false>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    if (bm == 128) hipLaunchKernelGGL((gemm_strips_kernel_h<128, 64, 2, 2, 2, 1, false>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    else hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1, false>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const int C8 = Cin / 8;
     const size_t band_items = (size_t)B * (2 * W + (H - 2) * 2) * C8;
@@ -1147,7 +1149,8 @@ int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W,
 
 size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
-    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return 0;
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, BK, bm)) return 0;
     const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     return ring + gemm_ws_bytes_h(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
@@ -1155,7 +1158,8 @@ size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int 
 static int same_dgrad_run_h(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W, int Cin,
                             int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
-    if ((Cin & 7) || !same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, BK)) return DWC_EINVAL;
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    if ((Cin & 7) || !same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, BK, bm)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1164,7 +1168,8 @@ static int same_dgrad_run_h(const void* dy, const void* w_dgrad, const void* w_d
                                ws_bytes - ring_bytes, st);
         if (rc != DWC_OK) return rc;
     }
-    hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    if (bm == 128) hipLaunchKernelGGL((gemm_strips_kernel_h<128, 64, 2, 2, 2, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    else hipLaunchKernelGGL((gemm_strips_kernel_h<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
     hipLaunchKernelGGL(fold_ring_kernel_h, dim3((total + 255) / 256), dim3(256), 0, st, (bf16*)dx, (const float*)ws, f.ring_elems[0],

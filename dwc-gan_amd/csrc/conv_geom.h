@@ -336,7 +336,7 @@ struct SameDgrad {
 };
 
 bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void* dx, float* ring, int B, int H, int W,
-                     int Cin, int Cout, int KH, int KW, int pad, SameDgrad* f, int bk = 32) {
+                     int Cin, int Cout, int KH, int KW, int pad, SameDgrad* f, int bk = 32, int bm = 64) {
     if (!conv_args_ok(B, H, W, Cout, Cin, KH, KW, 1, pad)) return false;
     if (Cout < bk || dwc_ilog2_exact(Cout) < 5 || (Cin & 3) || pad <= 0 || KH != KW || 2 * pad != KH - 1) return false;
     if (H < 2 * pad + 2 || W < 2 * pad + 2) return false;    // the two border bands of an axis must not overlap
@@ -375,7 +375,7 @@ bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void*
         st.kt0 = first * KW * spt;
         st.kt1 = ((z & 1) ? pad : KH) * KW * spt;
         st.tiles_n = (Cin + 63) / 64;
-        st.tiles = ((st.g.M + 63) / 64) * st.tiles_n;
+        st.tiles = ((st.g.M + bm - 1) / bm) * st.tiles_n;      // bm x 64 tiles (strip_bm)
         st.oph = st.opw = 0;
         if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
     }
@@ -386,8 +386,8 @@ bool same_dgrad_geom(const void* dy, const void* w_dg, const void* w_dg_t, void*
     f->parts = range >= 32 ? 4 : (range >= 24 ? 3 : (range >= 16 ? 2 : 1));
     // (r04) ... unless the strips alone already fill the machine (large batches): every extra part is another fp32 copy of the
     // ring to write and to sum in fold_ring_kernel
-    if (4 * f->max_tiles >= 1024) f->parts = 1;
-    else if (4 * f->max_tiles >= 512 && f->parts > 2) f->parts = 2;
+    if (4 * f->max_tiles * (bm / 64) >= 1024) f->parts = 1;
+    else if (4 * f->max_tiles * (bm / 64) >= 512 && f->parts > 2) f->parts = 2;
     f->ss.kt_per_part = (range + f->parts - 1) / f->parts;
     f->ss.part_stride = f->ring_total;
     return true;
@@ -405,7 +405,7 @@ struct S2Ring {
 };
 
 inline bool s2_ring_geom(const void* dy, const void* w_dgrad, void* dxp, size_t elem_bytes, int B, int H, int W, int Cin, int Cout,
-                         S2Ring* f, int bk = 32, int min_log_c = 2) {
+                         S2Ring* f, int bk = 32, int min_log_c = 2, int bm = 64) {
     if (B <= 0 || H < 4 || W < 4 || (H & 1) || (W & 1) || (Cin & 3) || dwc_ilog2_exact(Cout) < min_log_c) return false;
     const int H2 = H / 2, W2 = W / 2, Hp = H + 2, Wp = W + 2;
     const int Kp = (4 * Cout + bk - 1) / bk * bk;
@@ -441,10 +441,19 @@ inline bool s2_ring_geom(const void* dy, const void* w_dgrad, void* dxp, size_t 
         st.w = w_dgrad ? (const void*)((const char*)w_dgrad + (size_t)(cy * 2 + cx) * wcs * elem_bytes) : nullptr;
         st.kt0 = 0; st.kt1 = Kp / bk;
         st.tiles_n = (Cin + 63) / 64;
-        st.tiles = ((g.M + 63) / 64) * st.tiles_n;
+        st.tiles = ((g.M + bm - 1) / bm) * st.tiles_n;
         if (st.tiles > f->max_tiles) f->max_tiles = st.tiles;
     }
     return true;
+}
+
+// Row-tile height of the ring-strip launches (64-column tiles either way): 128 rows per workgroup -- two 32x32 accumulators per wave
+// sharing every weight fragment -- once the strips hold enough rows to fill the chip with tiles of that size, 64 below that.
+// `rows` = GEMM rows of the longest strip, `strips` x `tiles_n` x `parts` workgroups per row tile.  DWC_STRIP_BM=64|128 pins it.
+inline int strip_bm(long rows, int tiles_n, int strips, int parts) {
+    static const int force = getenv("DWC_STRIP_BM") ? atoi(getenv("DWC_STRIP_BM")) : 0;
+    if (force == 64 || force == 128) return force;
+    return ((rows + 127) / 128) * tiles_n * strips * parts >= 2 * NUM_CU ? 128 : 64;
 }
 
 // Data gradient w.r.t. an NHWC4 IMAGE (stem convolutions, Cin = 4): N = 4 would fill 1/8 of a 32-wide MFMA tile, so

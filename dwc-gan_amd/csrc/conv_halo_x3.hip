@@ -33,20 +33,21 @@ constexpr int TB = 16;                 // block edge: 16x16 output pixels
 constexpr int CS = 16;                 // channels per slab = one MFMA k-step
 
 // fp32 x4 -> three planes of 4 bf16 (packed two per dword), exact: v = p0 + p1 + p2
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-    unsigned h[4], m[4], l[4];
+    // (pairs: the two subtractions compile to v_pk_add_f32; the high halves of v and of r = v - hi are the hi / mid planes as they are)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned hb = __float_as_uint(v[k]) & 0xffff0000u;
-        const float r = v[k] - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r) & 0xffff0000u;
-        const float q = r - __uint_as_float(mb);
-        h[k] = hb; m[k] = mb; l[k] = __float_as_uint(q);
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const f32x2 hb = {__uint_as_float(__float_as_uint(x[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(x[1]) & 0xffff0000u)};
+        const f32x2 r = x - hb;
+        const f32x2 mb = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
+        const f32x2 l = r - mb;
+        // bytes 2,3 of the even element below bytes 2,3 of the odd one
+        p0[k] = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);
+        p1[k] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+        p2[k] = __builtin_amdgcn_perm(__float_as_uint(l[1]), __float_as_uint(l[0]), 0x07060302u);
     }
-    // bytes 2,3 of the even element below bytes 2,3 of the odd one
-    p0 = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
-    p1 = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
-    p2 = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
 }
 
 struct X3Args {
@@ -497,7 +498,7 @@ struct X3WgradArgs {
 
 // CIW = 64: 8 waves, one workgroup per CU.  CIW = 32: 4 waves, <= 74 KB of LDS, TWO independent workgroups per CU (see
 // conv_halo_x3_kernel: they drift out of phase and overlap each other's MFMA and load phases).
-template <int KS, int BN, int CIW = 64>
+template <int KS, int BN, int CIW = 64, int AHEAD = 2>
 __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgrad_x3_kernel(X3WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert((BN == 128 || BN == 64) && (CIW == 64 || CIW == 32), "tile shape");
@@ -541,28 +542,50 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     const int l31 = lane & 31, hi = lane >> 5;
     const int OH = S2 ? a.H >> 1 : a.H, OW = S2 ? a.W >> 1 : a.W;     // the dY grid (units tile it)
 
-    // ---- x patch: thread = (pixel t / QPP [+32 per pass], channel quad t % QPP) ----------------------------------------------
+    // ---- unit walk ---------------------------------------------------------------------------------------------------------
+    // (r04) Position (image, unit row, unit column) of the current and the next unit, advanced incrementally: wave-uniform, scalar
+    // ALU only.  The gathers are buffer loads -- a 32-bit per-lane offset that is constant over the kernel (dY) or needs one
+    // multiply-add per pass (x) plus a scalar offset for everything that moves with the unit.  Before that every dY row paid two
+    // integer divisions and eight 64-bit address chains, every fragment read its swizzle: 4.7 vector instructions per MFMA.
+    const int units_y = a.units_per_img / a.units_x;
+    struct UnitPos { int n, uy, ux; };
+    auto unit_pos = [&](int u) {
+        UnitPos q;
+        q.n = u / a.units_per_img;
+        const int ur = u - q.n * a.units_per_img;
+        q.uy = ur / a.units_x;
+        q.ux = ur - q.uy * a.units_x;
+        return q;
+    };
+    auto unit_next = [&](UnitPos q) {
+        if (++q.ux == a.units_x) {
+            q.ux = 0;
+            if (++q.uy == units_y) q.uy = 0, ++q.n;
+        }
+        return q;
+    };
+
+    // ---- x patch: thread = (pixel t / QPP [+32 per pass], channel quad t % QPP); pass p covers patch rows 2p, 2p+1 ------------
     const int quad = t % QPP;
     // chunk swizzle of the transposing read: 128-byte rows need it, 64-byte rows (CIW 32) place 4 consecutive pixels on the
     // four quarters of the 256-byte bank window by themselves
     auto p_swz = [](int pp) { return CIW == 64 ? 4 * ((pp >> 1) & 1) : 0; };
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (unsigned)((size_t)a.B * a.H * a.W * a.Cin * 4), 0x00020000);
+    const int prow = (t / QPP) >> 4, pcol = (t / QPP) & 15;
+    const unsigned x_lane = (unsigned)(cs * CIW + quad * 4) * 4u;
+    const unsigned img_bytes = (unsigned)a.H * a.W * a.Cin * 4u;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     f32x4 pv[2];
-    auto unit_origin = [&](int u, int& n, int& y0, int& x0) {
-        n = u / a.units_per_img;
-        const int ur = u - n * a.units_per_img;
-        const int uy = ur / a.units_x;
-        y0 = uy * UH;
-        x0 = (ur - uy * a.units_x) * UW;
-    };
-    auto load_patch = [&](int u, int first) {          // passes first, first+1 of unit u into pv[]
-        int n, y0, x0;
-        unit_origin(u, n, y0, x0);
+    auto load_patch = [&](UnitPos q, int first) {      // passes first, first+1 of the unit at q into pv[]
+        const int y0 = q.uy * UH, x0 = q.ux * UW;
+        const int w = min(reflect_idx(S2 ? 2 * (x0 + pcol) + kw - 1 : x0 - PAD + kw + pcol, a.W), a.W - 1);
+        const unsigned img = (unsigned)q.n * img_bytes;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int pp = min(t / QPP + 32 * (first + j), PPIX - 1);
-            const int h = min(reflect_idx(S2 ? 2 * y0 - 1 + (pp >> 4) : y0 - PAD + (pp >> 4), a.H), a.H - 1);
-            const int w = min(reflect_idx(S2 ? 2 * (x0 + (pp & 15)) + kw - 1 : x0 - PAD + kw + (pp & 15), a.W), a.W - 1);
-            pv[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.Cin + cs * CIW + quad * 4);
+            const int h = min(reflect_idx((S2 ? 2 * y0 - 1 : y0 - PAD) + prow + 2 * (first + j), a.H), a.H - 1);
+            const unsigned off = (unsigned)((h * a.W + w) * a.Cin) * 4u + x_lane;
+            pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, img, 0));
         }
     };
     auto write_patch = [&](int buf, int first) {
@@ -579,32 +602,32 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         }
     };
 
-    // ---- dY fragments straight from global memory: lane (co = l31, pixels 8*hi .. 8*hi+7 of the row) ----------------------
-    float raw[8];
-    auto load_dy = [&](int u, int row) {
-        int n, y0, x0;
-        unit_origin(u, n, y0, x0);
-        const float* src = a.dy + ((size_t)(n * OH + y0 + row) * OW + x0 + 8 * hi) * a.N + tn * BN + co_tile * 32 + l31;
+    // ---- dY fragments straight from global memory: lane (co = l31, pixels 8*hi .. 8*hi+7 of the row), AHEAD rows in flight ----
+    const __amdgpu_buffer_rsrc_t rsrc_dy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)((size_t)a.B * OH * OW * a.N * 4), 0x00020000);
+    const unsigned n4 = (unsigned)a.N * 4u;
+    const unsigned dy_lane = (unsigned)(8 * hi * a.N + tn * BN + co_tile * 32 + l31) * 4u;
+    float raw[AHEAD][8];
+    auto load_dy = [&](auto slot, UnitPos q, int row) {
+        const unsigned base = (unsigned)((q.n * OH + q.uy * UH + row) * OW + q.ux * UW) * n4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = src[(size_t)j * a.N];
+        for (int j = 0; j < 8; ++j)
+            raw[decltype(slot)::value][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_dy, dy_lane, base + j * n4, 0));
     };
     bf16x8 fb[3];
-    auto split_dy = [&]() {
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned hb = __float_as_uint(raw[k]) & 0xffff0000u;
-            const float r = raw[k] - __uint_as_float(hb);
-            const unsigned mb = __float_as_uint(r) & 0xffff0000u;
-            h[k] = hb; m[k] = mb; l[k] = __float_as_uint(r - __uint_as_float(mb));
-        }
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto split_dy = [&](auto slot) {
+        // two values per instruction where the ISA has one: v_pk_add_f32 for the two subtractions (36 instead of 44 per row)
         u32x4 q0, q1, q2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            q0[k] = __builtin_amdgcn_perm(h[2 * k + 1], h[2 * k], 0x07060302u);
-            q1[k] = __builtin_amdgcn_perm(m[2 * k + 1], m[2 * k], 0x07060302u);
-            q2[k] = __builtin_amdgcn_perm(l[2 * k + 1], l[2 * k], 0x07060302u);
+            const f32x2 v = {raw[decltype(slot)::value][2 * k], raw[decltype(slot)::value][2 * k + 1]};
+            const f32x2 hb = {__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
+            const f32x2 r = v - hb;
+            const f32x2 mb = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
+            const f32x2 l = r - mb;
+            q0[k] = __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);      // high halves: v's = hb's
+            q1[k] = __builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u);
+            q2[k] = __builtin_amdgcn_perm(__float_as_uint(l[1]), __float_as_uint(l[0]), 0x07060302u);
         }
         fb[0] = __builtin_bit_cast(bf16x8, q0);
         fb[1] = __builtin_bit_cast(bf16x8, q1);
@@ -612,20 +635,18 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     };
 
     // ---- x fragments: transposing reads, lane 4q+p of a 16-lane group addresses pixel q, channels 4p..4p+3 ------------------
+    // (the chunk swizzle of pixel r*16 + pxl + 4*hf depends on bit 1 of pxl only: one lane offset, the rest are immediates)
     const int li = lane & 15, gam = (lane >> 4) & 1;
     const int tq = li >> 2, tp = li & 3;
     const int pxl = 8 * hi + tq;
     const int a_col = ci_tile * 32 + 16 * gam + 4 * tp;
+    const int a_lane = pxl * CIW + (((a_col >> 3) ^ p_swz(pxl)) << 3) + (a_col & 7);
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) bf16x4* lds4;
-    auto a_frag = [&](const bf16* plane, int r) {
+    auto a_frag = [&](const bf16* plane_lane, int r) {   // plane_lane = plane + a_lane
         bf16x4 v[2];
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const int pp = r * UW + pxl + 4 * hf;
-            v[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (lds4)(plane + pp * CIW + (((a_col >> 3) ^ p_swz(pp)) << 3) + (a_col & 7)));
-        }
+        for (int hf = 0; hf < 2; ++hf) v[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)(plane_lane + (r * UW + 4 * hf) * CIW));
         return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
@@ -635,18 +656,23 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f, lo[j][r] = 0.f;
 
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, AHEAD - 1> S1;
+    static_assert(AHEAD == 1 || (AHEAD == 2 && ROWS % 2 == 0), "dY rows in flight");
     if (u0 < u1) {
+        UnitPos cur = unit_pos(u0), nxt = unit_next(cur);
         // first unit's patch
         for (int f = 0; f < PPASS; f += 2) {
-            load_patch(u0, f);
+            load_patch(cur, f);
             write_patch(0, f);
         }
-        load_dy(u0, half_id * ROWS);
+        load_dy(S0{}, cur, half_id * ROWS);
+        if constexpr (AHEAD == 2) load_dy(S1{}, cur, half_id * ROWS + 1);
         __syncthreads();
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
             const bool next = u + 1 < u1;
-            const bf16* p = smem + buf * 3 * P_PLANE;
+            const bf16* p = smem + buf * 3 * P_PLANE + a_lane;
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) {
                 const int ks = half_id * ROWS + rr;
@@ -655,11 +681,16 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
                 constexpr int STEP = ROWS >= 2 * GROUPS + 2 ? 2 : 1;
                 if (next) {
                     if (rr >= STEP && (rr - STEP) % STEP == 0 && (rr - STEP) / STEP < GROUPS) write_patch(buf ^ 1, 2 * ((rr - STEP) / STEP));
-                    if (rr % STEP == 0 && rr / STEP < GROUPS) load_patch(u + 1, 2 * (rr / STEP));
+                    if (rr % STEP == 0 && rr / STEP < GROUPS) load_patch(nxt, 2 * (rr / STEP));
                 }
-                split_dy();
-                if (rr + 1 < ROWS) load_dy(u, ks + 1);
-                else if (next) load_dy(u + 1, half_id * ROWS);
+                // this row's dY: split, then its registers take the row AHEAD rows further on (of the next unit at the end)
+                auto refill = [&](auto slot) {
+                    split_dy(slot);
+                    if (rr + AHEAD < ROWS) load_dy(slot, cur, ks + AHEAD);
+                    else if (next) load_dy(slot, nxt, half_id * ROWS + rr + AHEAD - ROWS);
+                };
+                if ((rr & (AHEAD - 1)) == 0) refill(S0{});
+                else refill(S1{});
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh) {
                     bf16x8 fa[3];
@@ -680,13 +711,15 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
                 constexpr int DONE_L = (ROWS - 1) / STEP + 1;                                 // groups loaded inside the loop
 #pragma unroll
                 for (int gq = (DONE_W < GROUPS ? DONE_W : GROUPS); gq < GROUPS; ++gq) {
-                    if (gq >= (DONE_L < GROUPS ? DONE_L : GROUPS)) load_patch(u + 1, 2 * gq);
+                    if (gq >= (DONE_L < GROUPS ? DONE_L : GROUPS)) load_patch(nxt, 2 * gq);
                     write_patch(buf ^ 1, 2 * gq);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // patch writes done; raw barrier: the next unit's first dY
-            __builtin_amdgcn_s_barrier();                                // row stays in flight (no vmcnt drain as in __syncthreads)
+            __builtin_amdgcn_s_barrier();                                // rows stay in flight (no vmcnt drain as in __syncthreads)
             buf ^= 1;
+            cur = nxt;
+            nxt = unit_next(nxt);
         }
     }
     // slab[split * HALVES + half][(tap*Cin + ci)][co]
@@ -730,6 +763,8 @@ int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
     if (K == 4) {
         if (B <= 0 || H < 8 || W < 32 || (H % 8) || (W % 32) || Cin < 64 || (Cin % 64)) return 0;
     } else if (B <= 0 || (K != 3 && K != 5) || H < 8 || W < 16 || (H % 8) || (W % 16) || Cin < 64 || (Cin % 64)) return 0;
+    // (the kernel addresses x and dY through 32-bit buffer offsets)
+    if ((size_t)B * H * W * Cin * 4 >= 0xffffffffull || (size_t)B * H * W * Cout * 4 >= 0xffffffffull) return 0;
     if (Cout >= 128 && !(Cout % 128)) return 128;
     return (Cout >= 64 && !(Cout % 64)) ? 64 : 0;
 }

@@ -1853,7 +1853,8 @@ __global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict
 
 size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
-    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f)) return 0;
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, 32, bm)) return 0;
     const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
 }
@@ -1875,7 +1876,8 @@ int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float*
 static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W, int Cin,
                           int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
-    if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f)) return DWC_EINVAL;
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, 32, bm)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1884,10 +1886,14 @@ static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_
                              ws_bytes - ring_bytes, st);
         if (rc != DWC_OK) return rc;
     }
-    if (gemm_x3_on(f.ss.s[0].g.K))
-        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
-    else
-        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, f.parts, 4), dim3(256), 0, st, f.ss);
+    const dim3 sgrid(f.max_tiles, f.parts, 4);
+    if (gemm_x3_on(f.ss.s[0].g.K)) {
+        if (bm == 128) hipLaunchKernelGGL((conv_gemm_strips_kernel<128, 64, 2, 2, 2, 1, true>), sgrid, dim3(256), 0, st, f.ss);
+        else hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), sgrid, dim3(256), 0, st, f.ss);
+    } else {
+        if (bm == 128) hipLaunchKernelGGL((conv_gemm_strips_kernel<128, 64, 2, 2, 2, 1>), sgrid, dim3(256), 0, st, f.ss);
+        else hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), sgrid, dim3(256), 0, st, f.ss);
+    }
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)B * 2 * pad * (W + H) * (Cin / 4);
     hipLaunchKernelGGL(fold_ring_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dx, (const float*)ws, f.ring_elems[0],
@@ -1957,13 +1963,19 @@ int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, 
 int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
                                 void* stream) {
     S2Ring f;
-    if (!dy || !w_dgrad || !dxp || !dx || H > 65535 - 2 || B > 65535 || !s2_ring_geom(dy, w_dgrad, dxp, sizeof(float), B, H, W, Cin, Cout, &f))
+    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1);
+    if (!dy || !w_dgrad || !dxp || !dx || H > 65535 - 2 || B > 65535 ||
+        !s2_ring_geom(dy, w_dgrad, dxp, sizeof(float), B, H, W, Cin, Cout, &f, 32, 2, bm))
         return DWC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (gemm_x3_on(f.ss.s[0].g.K))
-        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
-    else
-        hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), dim3(f.max_tiles, 1, 8), dim3(256), 0, st, f.ss);
+    const dim3 sgrid(f.max_tiles, 1, 8);
+    if (gemm_x3_on(f.ss.s[0].g.K)) {
+        if (bm == 128) hipLaunchKernelGGL((conv_gemm_strips_kernel<128, 64, 2, 2, 2, 1, true>), sgrid, dim3(256), 0, st, f.ss);
+        else hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1, true>), sgrid, dim3(256), 0, st, f.ss);
+    } else {
+        if (bm == 128) hipLaunchKernelGGL((conv_gemm_strips_kernel<128, 64, 2, 2, 2, 1>), sgrid, dim3(256), 0, st, f.ss);
+        else hipLaunchKernelGGL((conv_gemm_strips_kernel<64, 64, 2, 2, 1, 1>), sgrid, dim3(256), 0, st, f.ss);
+    }
     DWC_LAUNCH_CHECK();
     const int C4 = Cin / 4;
     const size_t band_items = (size_t)B * (2 * W + (H - 2) * 2) * C4;

@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdwcgan_hip.so")
+# DWC_HIP_LIB: another build of the SAME library (benchmarks: A/B runs of two builds inside one gpurun call); it must export every
+# symbol of SIGNATURES like the default one, and a missing file is an error, never a fallback
+LIB_PATH = os.environ.get("DWC_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libdwcgan_hip.so")
 
 c_fp = ctypes.c_void_p   # device pointers travel as void*
 c_int = ctypes.c_int
