@@ -42,12 +42,16 @@ def main():
             _lib.check(lib.dwc_x3_weight_prepare(w.data_ptr(), wp.data_ptr(), co, ci, k, co, 0, st), "prep")
             y = torch.empty(B, Ho, Ho, co, device=dev)
             flops = 2.0 * B * Ho * Ho * co * ci * k * k
+            # scratch of the contraction split of small launches (<= 256 tiles; DWC_X3_KSPLIT=0: off)
+            need = lib.dwc_x3_conv2d_ksplit_ws_bytes(B, H, H, ci, co, k, s)
+            ksw = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            kst = torch.zeros(lib.dwc_x3_conv2d_ksplit_ticket_words(), dtype=torch.int32, device=dev)
             if s == 1:
-                tf = med(lambda: _lib.check(lib.dwc_x3_conv2d_same(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci, co,
-                                                                   co, k, 1, 1, st), "x3"))
+                tf = med(lambda: _lib.check(lib.dwc_x3_conv2d_same_add_ws(x.data_ptr(), wp.data_ptr(), b.data_ptr(), None, y.data_ptr(), B, H, H,
+                                                                          ci, co, co, k, 1, 1, ksw.data_ptr(), need, kst.data_ptr(), st), "x3"))
             else:
-                tf = med(lambda: _lib.check(lib.dwc_x3_conv2d_s2(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci, co, co,
-                                                                 1, st), "x3s2"))
+                tf = med(lambda: _lib.check(lib.dwc_x3_conv2d_s2_ws(x.data_ptr(), wp.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci, co, co,
+                                                                    1, ksw.data_ptr(), need, kst.data_ptr(), st), "x3s2"))
             nws = lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, H, ci, co, k)
             tw = float("nan")
             if nws:
@@ -55,8 +59,8 @@ def main():
                 dw = torch.empty(co, ci, k, k, device=dev)
                 tw = med(lambda: _lib.check(lib.dwc_x3_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, H, ci, co, k, ci, co,
                                                                     wsb.data_ptr(), nws, st), "x3 wgrad"))
-            print("  B%-3d %-18s fwd %8.1f us  %.3f of 2.5PF | wgrad+reduce %8.1f us  %.3f of 2.5PF   checksum %.6e" % (
-                B, name, tf * 1e6, 6 * flops / tf / 2.5e15, tw * 1e6, 6 * flops / tw / 2.5e15, float(y.double().sum())))
+            print("  B%-3d %-18s%s fwd %8.1f us  %.3f of 2.5PF | wgrad+reduce %8.1f us  %.3f of 2.5PF   checksum %.6e" % (
+                B, name, " (split)" if need else "        ", tf * 1e6, 6 * flops / tf / 2.5e15, tw * 1e6, 6 * flops / tw / 2.5e15, float(y.double().sum())))
 
 
 if __name__ == "__main__":

@@ -1103,7 +1103,7 @@ int dwc_bf16_conv2d_bwd_data_fold(const void* dy, const void* w_dgrad, void* dxp
 int dwc_bf16_conv2d_bwd_data_s2_ring(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
                                      void* stream) {
     S2Ring f;
-    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1);
+    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1, true);
     if (!dy || !w_dgrad || !dxp || !dx || (Cin & 7) || H > 65535 - 2 || B > 65535 ||
         !s2_ring_geom(dy, w_dgrad, dxp, 2, B, H, W, Cin, Cout, &f, BK, MIN_LOG_C, bm))
         return DWC_EINVAL;
@@ -1149,7 +1149,7 @@ int dwc_bf16_reflect_pad_adjoint(const void* dxp, void* dx, int B, int H, int W,
 
 size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
-    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1, true);
     if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, BK, bm)) return 0;
     const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     return ring + gemm_ws_bytes_h(f.g.M, Cin, f.g.K, 1, f.dst_elems);
@@ -1158,7 +1158,7 @@ size_t dwc_bf16_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int 
 static int same_dgrad_run_h(const void* dy, const void* w_dgrad, const void* w_dgrad_t, void* dx, int B, int H, int W, int Cin,
                             int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
-    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1, true);
     if ((Cin & 7) || !same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, BK, bm)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;

@@ -447,12 +447,15 @@ inline bool s2_ring_geom(const void* dy, const void* w_dgrad, void* dxp, size_t 
     return true;
 }
 
-// Row-tile height of the ring-strip launches (64-column tiles either way): 128 rows per workgroup -- two 32x32 accumulators per wave
-// sharing every weight fragment -- once the strips hold enough rows to fill the chip with tiles of that size, 64 below that.
-// `rows` = GEMM rows of the longest strip, `strips` x `tiles_n` x `parts` workgroups per row tile.  DWC_STRIP_BM=64|128 pins it.
-inline int strip_bm(long rows, int tiles_n, int strips, int parts) {
+// Row-tile height of the ring-strip launches (64-column tiles either way).  bf16: 128 rows per workgroup -- two 32x32 accumulators
+// per wave sharing every weight fragment -- once the strips hold enough rows to fill the chip with tiles of that size (measured,
+// benchmarks/ring_bench.py: -10..15 % at batch 128, equal at 384), 64 below that.  fp32 (split products): always 64 -- the
+// 128-row form has to halve its accumulator tile per MFMA group and lost 10..30 % at every batch.  DWC_STRIP_BM=64|128 pins it.
+// `rows` = GEMM rows of the longest strip, `strips` x `tiles_n` x `parts` workgroups per row tile.
+inline int strip_bm(long rows, int tiles_n, int strips, int parts, bool half) {
     static const int force = getenv("DWC_STRIP_BM") ? atoi(getenv("DWC_STRIP_BM")) : 0;
     if (force == 64 || force == 128) return force;
+    if (!half) return 64;
     return ((rows + 127) / 128) * tiles_n * strips * parts >= 2 * NUM_CU ? 128 : 64;
 }
 

@@ -59,6 +59,8 @@ struct X3Args {
     int B, H, W, Cin, N, rows, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
     int stagger = 0;     // two-workgroups-per-CU form: 10 ns ticks the CU's second workgroup sleeps before its first tile (dwc_duo_stagger)
+    float* part = nullptr;          // KSP == 2: [tiles][256 pixels x 64 channels] fp32, the first arriver's half sum
+    unsigned* tickets = nullptr;    // KSP == 2: [tiles], zero between launches (caller-owned, self-resetting)
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
@@ -80,7 +82,12 @@ struct X3Args {
 // result is scattered to (2 i' + ry, 2 j' + rx) of the 2 a.H x 2 a.W tensor.  With the data-gradient weights of
 // dwc_x3_weight_prepare (K = 4, filter rotated) kernel tap (a, b) is prepared tap (ry + 2a, rx + 2b).  The border ring of the
 // padded image (the reflect rule's adjoint) is dwc_conv2d_bwd_data_s2_ring's.
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0>
+// KSP == 2: launches of at most 256 tiles (3x3 256->256 at batch 16: one 4-wave workgroup per CU, nothing beside it to overlap
+// with, 0.39 of the MFMA peak against 0.52 at two per CU) are cut along the CONTRACTION instead: two workgroups per tile, each
+// walks half of the channel slabs.  Whichever of the two takes the tile's ticket first publishes its half sum in `part` and
+// leaves; the other waits for that (the first is running and waits for nobody), adds it to its own -- a + b = b + a, so the
+// result does not depend on the order of arrival -- and runs the epilogue.  The ticket is back at zero when the tile is done.
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
 __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
     static_assert(!S2 || (KS == 2 && PB == 1), "stride-2 form: 2x2 taps per parity, single patch buffer");
+    static_assert(KSP == 1 || (KSP == 2 && S2 != 2 && PB == 1 && TM * TN <= 4), "contraction split: the two-per-CU tile only");
     constexpr int PW = TB + KS - 1;                    // patch edge
     constexpr int PPIX = PW * PW;                      // patch pixels
     constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
@@ -115,7 +123,15 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     if constexpr (PB == 1) dwc_duo_stagger(a.stagger, 512);
 
     int bid = blockIdx.x;
-    {
+    int khalf = 0;                                                       // KSP == 2: which half of the channel slabs
+    if constexpr (KSP == 2) {
+        // hardware workgroups h and h + 8 run on the same XCD (h % 8): they are the two halves of a tile, so that the half sum
+        // travels through THAT XCD's L2 and nothing wider (gridDim.x = 2 x tiles, tiles a multiple of 8); XCD x owns the tiles
+        // x * tiles/8 .. as in the plain remap below
+        const int x = bid & 7, slot = bid >> 3;
+        khalf = slot & 1;
+        bid = x * (int)(gridDim.x >> 4) + (slot >> 1);
+    } else {
         const int nb = gridDim.x;
         if (nb >= 16) {     // XCD-aware remap (neighbouring blocks share halo pixels and the weight slabs in one L2)
             const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
@@ -128,13 +144,15 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
         rx = bid & 1;
         bid >>= 2;
     }
+    const int tile_id = bid;
     const int tile_n = bid % a.tiles_n, blk = bid / a.tiles_n;
     const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
     const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
     const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
     const int OH = S2 == 1 ? a.H >> 1 : a.H, OW = S2 == 1 ? a.W >> 1 : a.W;      // grid the blocks tile (S2 == 2: the dY grid)
     const int ncsr = a.Cin / CS;                                        // 16-channel slabs of the input tensor
-    const int ncs = S2 == 1 ? 4 * ncsr : ncsr;                          // slabs walked: x 4 input-pixel parities
+    const int ncs_all = S2 == 1 ? 4 * ncsr : ncsr;                      // slabs of the contraction: x 4 input-pixel parities
+    const int ncs = ncs_all / KSP, cs0 = khalf * ncs;                   // slabs this workgroup walks: cs0 .. cs0 + ncs - 1
     const int nsteps = ncs * NTAP;
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
@@ -176,7 +194,8 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
         p_in |= pp < PPIX ? 1u << i : 0u;
     }
     f32x4 pv[PPASS];
-    auto load_patch = [&](int cs) {
+    auto load_patch = [&](int cs_local) {
+        const int cs = cs0 + cs_local;
         if constexpr (S2 == 1) {
             const int par = cs / ncsr, csl = cs - par * ncsr;
             const float* base = a.x + csl * CS + (t & 3) * 4;
@@ -214,7 +233,8 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     }
     const int w_step_bytes = 3 * a.rows * CS * 2;                         // one (tap, slab) block of the prepared tensor
     auto stage_w = [&](int step, int slot) {                              // step = cs * NTAP + tap -> block tap * ncs + cs
-        const int cs = step / NTAP, tap = step - cs * NTAP;
+        const int csl_ = step / NTAP, tap = step - csl_ * NTAP;
+        const int cs = cs0 + csl_;
         bf16* lw = sW + slot * W_SLOT + wave * 512;
         int blk;
         if constexpr (S2 == 1) {
@@ -223,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
         } else if constexpr (S2 == 2) {
             blk = ((ry + 2 * (tap >> 1)) * 4 + rx + 2 * (tap & 1)) * ncsr + cs;
         } else {
-            blk = tap * ncs + cs;
+            blk = tap * ncs_all + cs;
         }
         const int soff = __builtin_amdgcn_readfirstlane(blk * w_step_bytes);
 #pragma unroll
@@ -384,6 +404,73 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     // (r04: the bias vectors of this lane's columns are loaded ONCE, in one batch, and the `add` operand of a pixel tile in one
     // batch in front of its stores.  Inside the per-chunk conditionals -- `if (col < N) if (bias) v += bias[col]` -- the compiler
     // can neither hoist nor batch a load: every chunk paid its own L2 round trip, one after the other.)
+    if constexpr (KSP == 2) {
+        // ---- the two halves of the contraction meet (see the template comment) ------------------------------------------------
+        __shared__ unsigned s_role;
+        if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0];
+        }
+        // Both workgroups sit on one XCD: its L2 is the meeting point.  The first arriver's stores are complete (acknowledged by the
+        // L2) before it raises the ticket, the second reads the ticket and the half sum past its L1 (sc1) -- no L2 write-back or
+        // invalidate, which an agent-scope release / acquire pair would cost every workgroup (measured: 145 against 117 us).
+        unsigned* ticket = a.tickets + tile_id;
+        if (t == 0) s_role = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned role = s_role;
+        // [tile][i][n][q4][thread] f32x4: 16 bytes per lane, consecutive lanes consecutive
+        constexpr unsigned TILE_B = TM * TN * 4 * THREADS * 16;
+        const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<char*>(a.part) + (size_t)tile_id * TILE_B, 0, TILE_B, 0x00020000);
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        if (role == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(u32x4_t, f32x4{acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]}),
+                            rsrc_p, (unsigned)(((i * TN + n) * 4 + q4) * THREADS + t) * 16u, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) __hip_atomic_fetch_add(ticket, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // second arriver: the ticket reads 1 (first) + 1 (this one) + 2 (first done) once the other half is published.  The
+        // wait is bounded (an aborted earlier launch may have left the ticket dirty): on expiry the tile is poisoned with NaN.
+        __shared__ unsigned s_ok;
+        if (t == 0) {
+            unsigned ok = 0;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ok = ok;
+        }
+        __syncthreads();
+        const float poison = s_ok ? 0.f : __builtin_nanf("");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f32x4 ov[TN][4];
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)       // aux 16 = sc1: served by the L2, never by this CU's L1
+                    ov[n][q4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                              rsrc_p, (unsigned)(((i * TN + n) * 4 + q4) * THREADS + t) * 16u, 0, 16));
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][n][4 * q4 + k] += ov[n][q4][k] + poison;
+        }
+    }
     const float slope = dwc_act_slope(a.act);
     f32x4 bv[TN][4];
 #pragma unroll
@@ -419,7 +506,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
                     const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
                     if (col >= a.N) continue;
                     f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                    if (SPLIT) {
+                    if (SPLIT && KSP == 1) {
                         const f32x16& c = lo[SPLIT ? i : 0][SPLIT ? n : 0];
                         v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
                     }
@@ -791,9 +878,18 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2, KSP>), grid, dim3(64 * WM * WN), 0, st, a);
+}
+
+// Contraction split of the two-per-CU tile (conv_halo_x3_kernel, KSP == 2): launches of at most X3_KSPLIT_TILES tiles whose slab
+// count is even and long enough to be worth halving.  DWC_X3_KSPLIT=0 switches it off.
+constexpr int X3_KSPLIT_TILES = 256;
+constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
+bool x3_ksplit_on(long tiles, int slabs) {
+    static const int on = getenv("DWC_X3_KSPLIT") ? atoi(getenv("DWC_X3_KSPLIT")) : 1;
+    return on && tiles <= X3_KSPLIT_TILES && !(tiles & 7) && slabs >= 8 && !(slabs & 1);      // (tiles % 8: pairs share an XCD)
 }
 
 bool x3_s2_ok(int B, int H, int W, int Cin, int N) {
@@ -829,6 +925,9 @@ int dwc_x3_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int
  * weights, to be followed by dwc_conv2d_bwd_data_ring). */
 int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
                            int Cin, int N, int rows, int K, int act, int reflect, void* stream);
+int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                              int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,
+                              void* stream);
 int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N,
                        int rows, int K, int act, int reflect, void* stream) {
     return dwc_x3_conv2d_same_add(x, w_prepared, bias, nullptr, y, B, H, W, Cin, N, rows, K, act, reflect, stream);
@@ -838,6 +937,29 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
  * dwc_bf16_conv2d_same_halo_add: the identity-branch gradient of a ResBlock rides on the data gradient of its first convolution). */
 int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
                            int Cin, int N, int rows, int K, int act, int reflect, void* stream) {
+    return dwc_x3_conv2d_same_add_ws(x, w_prepared, bias, add, y, B, H, W, Cin, N, rows, K, act, reflect, nullptr, 0, nullptr, stream);
+}
+
+/* Scratch for the contraction split of small launches (see conv_halo_x3_kernel, KSP == 2): bytes of `ws` that
+ * dwc_x3_conv2d_same_add_ws / dwc_x3_conv2d_s2_ws want for this shape (0: the launch is not split), and the number of 32-bit
+ * ticket words the caller keeps per stream -- zero before the first call, left at zero by every call. */
+size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K, int stride) {
+    if (stride == 2) {
+        if (!x3_s2_ok(B, H, W, Cin, N)) return 0;
+        const long tiles = (long)B * ((H / 2) / TB) * ((W / 2) / TB) * ((N + 63) / 64);
+        return x3_ksplit_on(tiles, 4 * (Cin / CS)) ? (size_t)tiles * X3_KSPLIT_TILE_BYTES : 0;
+    }
+    if (!x3_ok(B, H, W, Cin, N, K)) return 0;
+    const long tiles = (long)B * (H / TB) * (W / TB) * ((N + 63) / 64);
+    return x3_ksplit_on(tiles, Cin / CS) ? (size_t)tiles * X3_KSPLIT_TILE_BYTES : 0;
+}
+int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TILES; }
+
+/* dwc_x3_conv2d_same_add with the scratch of the contraction split: ws / tickets may be NULL (or ws_bytes too small), the launch
+ * then runs unsplit.  Results do not depend on which form ran beyond fp32 summation order (two half sums instead of one). */
+int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                              int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,
+                              void* stream) {
     if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N) return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
@@ -889,7 +1011,14 @@ int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* 
             return DWC_OK;
         }
         const dim3 g2(blocks * a.tiles_n);
-        if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
+        const size_t need = dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, K, 1);
+        if (need && ws && tickets && ws_bytes >= need) {
+            a.part = (float*)ws;
+            a.tickets = tickets;
+            const dim3 g4(2 * g2.x);
+            if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
+            else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
+        } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
         else x3_launch<5, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
@@ -921,15 +1050,30 @@ int dwc_x3_conv2d_s2_ok(int B, int H, int W, int Cin, int Cout) { return x3_s2_o
 /* y = act(conv4x4_stride2(reflect_pad1(x)) + bias) for fp32 NHWC tensors as split products (see conv_halo_x3_kernel, S2):
  * x:[B,H,W,Cin], y:[B,H/2,W/2,N], H and W multiples of 32, Cin a multiple of 16; w_prepared = dwc_x3_weight_prepare(K = 4, forward)
  * with `rows` >= N rows. */
+int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                        int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
 int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
                      int act, void* stream) {
+    return dwc_x3_conv2d_s2_ws(x, w_prepared, bias, y, B, H, W, Cin, N, rows, act, nullptr, 0, nullptr, stream);
+}
+
+/* dwc_x3_conv2d_s2 with the scratch of the contraction split (see dwc_x3_conv2d_same_add_ws). */
+int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                        int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
     if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N) return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = 1;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = (N + 63) / 64;
-    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    const size_t need = dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, 4, 2);
+    if (need && ws && tickets && ws_bytes >= need) {
+        a.part = (float*)ws;
+        a.tickets = tickets;
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    } else {
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

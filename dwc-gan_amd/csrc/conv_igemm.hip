@@ -1853,7 +1853,7 @@ __global__ void fold_ring_kernel(float* __restrict__ dx, const float* __restrict
 
 size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
     SameDgrad f;
-    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1, false);
     if (!same_dgrad_geom(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Cin, Cout, KH, KW, pad, &f, 32, bm)) return 0;
     const size_t ring = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     return ring + gemm_ws_bytes(f.g.M, Cin, f.g.K, 1, f.dst_elems);
@@ -1876,7 +1876,7 @@ int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float*
 static int same_dgrad_run(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx, int B, int H, int W, int Cin,
                           int Cout, int KH, int KW, int pad, void* ws, size_t ws_bytes, void* stream, bool ring_only) {
     SameDgrad f;
-    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1);
+    const int bm = strip_bm((long)B * pad * max(W + 2 * pad, H), (Cin + 63) / 64, 4, 1, false);
     if (!same_dgrad_geom(dy, w_dgrad, w_dgrad_t, dx, (float*)ws, B, H, W, Cin, Cout, KH, KW, pad, &f, 32, bm)) return DWC_EINVAL;
     const size_t ring_bytes = (f.ring_total * f.parts * sizeof(float) + 255) / 256 * 256;
     if (!ws || ws_bytes < ring_bytes) return DWC_EWORKSPACE;
@@ -1963,7 +1963,7 @@ int dwc_conv2d_bwd_data_fold(const float* dy, const float* w_dgrad, float* dxp, 
 int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
                                 void* stream) {
     S2Ring f;
-    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1);
+    const int bm = strip_bm((long)B * max(W / 2 + 1, H / 2), (Cin + 63) / 64, 8, 1, false);
     if (!dy || !w_dgrad || !dxp || !dx || H > 65535 - 2 || B > 65535 ||
         !s2_ring_geom(dy, w_dgrad, dxp, sizeof(float), B, H, W, Cin, Cout, &f, 32, 2, bm))
         return DWC_EINVAL;

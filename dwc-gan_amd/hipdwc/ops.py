@@ -518,6 +518,26 @@ def res_token(x):
     return ResGradToken() if RES_FUSE and torch.is_grad_enabled() and x.requires_grad else None
 
 
+_X3_TICKETS = {}
+
+
+def _x3_ksplit(lib, dev, B, H, W, Cx, cop, K, stride, at_least=0):
+    """(scratch arena, its size, ticket row) for the contraction split of small split-product launches
+    (dwc_x3_conv2d_same_add_ws / dwc_x3_conv2d_s2_ws), the arena at least ``at_least`` bytes; ticket row None: shape not split.
+    One ticket row per (device, stream), zeroed once -- every launch leaves it at zero."""
+    need = lib.dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cx, cop, K, stride)
+    if not need:
+        ws = workspace(at_least, dev) if at_least else None
+        return ws, at_least, None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    row = _X3_TICKETS.get(key)
+    if row is None:
+        row = torch.zeros(int(lib.dwc_x3_conv2d_ksplit_ticket_words()), dtype=torch.int32, device=dev)
+        _X3_TICKETS[key] = row
+    n = max(int(need), int(at_least))
+    return workspace(n, dev), n, row.data_ptr()
+
+
 class _Conv2d(torch.autograd.Function):
     """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4 (fp32) / 8 (bf16); its dtype is x's.
     ``owner``: the parameter(s) ``w`` is derived from when ``w`` is a fresh tensor on every call (prepared-weight cache)."""
@@ -576,14 +596,16 @@ class _Conv2d(torch.autograd.Function):
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
         elif use_x3:
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
-            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same(
-                x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, st),
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
+                x.data_ptr(), w_x3.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, _p(ks_ws), ks_n, ks_t, st),
                 detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
         elif use_x3s2:
             # stride-2 4x4 layers, fp32: split products, 2x2 taps per input-pixel parity, space-to-depth in the patch gather
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
-            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2(
-                x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, st),
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 2)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_ws(
+                x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, _p(ks_ws), ks_n, ks_t, st),
                 detail="fwd-x3s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_s2")
         elif use_stem:
             # 7x7 stem on an NHWC8 image: filter resident in LDS, persistent workgroups (csrc/conv_narrow_bf16.hip)
@@ -725,13 +747,14 @@ class _Conv2d(torch.autograd.Function):
             if x3:
                 # interior = zero-padded convolution of dY with the rotated filter on the split-bf16 kernel; ring direct
                 w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
-                ws = workspace(nws, dev)
+                # (one arena: the interior's half sums -- small launches, contraction split -- are dead when the ring strips start)
+                ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1, at_least=nws)
 
                 shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
                 # (two spans: the interior launch carries the layer's flops, the ring strips + fold are time on top of it)
-                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add(
-                    g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, st),
-                    scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
+                    g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, ws.data_ptr(), ks_n, ks_t,
+                    st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
                 _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
                     g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")

@@ -347,6 +347,20 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
  * ResBlock (reference networks.py:521) rides on the data gradient of its first convolution instead of costing a pass. */
 int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
                            int Cin, int N, int rows, int K, int act, int reflect, void* stream);
+/* Small launches (r04): when a shape yields at most 256 tiles of 256 pixels x 64 channels (3x3 256->256 on 32x32 at batch 16) the
+ * two-workgroups-per-CU kernel would run one workgroup per CU; the _ws forms cut such launches along the CONTRACTION instead --
+ * two workgroups per tile, each half of the channel slabs; the first to finish leaves its half sum in `ws`, the second adds it to
+ * its own (a + b = b + a: no dependence on arrival order) and applies bias / activation / add.  dwc_x3_conv2d_ksplit_ws_bytes:
+ * bytes of `ws` wanted for a shape (stride 1: K in {3,5}; stride 2: the 4x4 layers, K ignored; 0 = the launch is not split);
+ * `tickets`: dwc_x3_conv2d_ksplit_ticket_words() 32-bit words owned by the caller PER STREAM, zero before the first call and
+ * left at zero by every call.  ws / tickets NULL or ws_bytes too small: the plain launch.  DWC_X3_KSPLIT=0 disables the split. */
+size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K, int stride);
+int dwc_x3_conv2d_ksplit_ticket_words(void);
+int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                              int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,
+                              void* stream);
+int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                        int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
 /* The 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) on the same kernel: 2x2 taps
  * per input-pixel parity over the space-to-depth image, the space-to-depth done by the patch gather.  x:[B,H,W,Cin] ->
  * y:[B,H/2,W/2,N]; H, W multiples of 32, Cin a multiple of 16; w_prepared = dwc_x3_weight_prepare(K = 4, forward). */

@@ -278,3 +278,64 @@ def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
         e, en, e32 = ((t - r).abs().max().item() / scale for t in (a, n_, c32))
         print("%s %s: split %.2e native %.2e cpu-fp32 %.2e" % ("x".join(str(v) for v in shape), name, e, en, e32))
         assert e <= (1e-5 if wino else 5e-6) and e <= 2 * max(en, e32) + 2e-7, (name, e, en, e32)
+
+
+@pytest.mark.parametrize("shape", [(16, 256, 256, 32, 32, 3, 1, "relu", True), (4, 128, 256, 32, 32, 3, 1, "none", False),
+                                   (2, 256, 128, 32, 32, 5, 1, "lrelu", True), (16, 128, 256, 64, 64, 4, 2, "lrelu", False),
+                                   (4, 64, 128, 32, 64, 4, 2, "none", False)], ids=lambda s: "x".join(str(v) for v in s))
+def test_x3_contraction_split_of_small_launches(shape):
+    """Launches of at most 256 tiles run two workgroups per tile, each half of the channel slabs; whichever arrives second adds the
+    other's half sum (conv_halo_x3_kernel, KSP == 2; dwc_x3_conv2d_same_add_ws / dwc_x3_conv2d_s2_ws).  Against float64 at fp32
+    accuracy like the unsplit launch, bit-identical from run to run (the sum of two halves does not depend on who arrives first),
+    tickets back at zero, and the second arriver really waited for the first: repeated 20 times on a busy device."""
+    B, Cin, Cout, H, W, K, stride, act, with_add = shape
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    need = lib.dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, Cout, K, stride)
+    assert need > 0, "shape is meant to be split"
+    g = torch.Generator().manual_seed(sum(shape[:7]))
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.rand(1, Cin, 1, 1, generator=g) * 3
+    w = torch.randn(Cout, Cin, K, K, generator=g) * (1.0 / (Cin * K * K) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.1
+    Ho, Wo = H // stride, W // stride
+    add = torch.randn(B, Cout, Ho, Wo, generator=g) if with_add else None
+    fn = {"none": lambda v: v, "relu": torch.relu, "lrelu": lambda v: F.leaky_relu(v, 0.1)}[act]
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    pad = 1 if stride == 2 else K // 2
+    ref = fn(F.conv2d(F.pad(xd.double(), (pad,) * 4, mode="reflect"), wd.double(), bd.double(), stride=stride))
+    if add is not None:
+        ref = ref + add.to(DEV).double()
+    xn = xd.permute(0, 2, 3, 1).contiguous()
+    addn = add.to(DEV).permute(0, 2, 3, 1).contiguous() if add is not None else None
+    wp = _prep(lib, wd, Cout, False)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    tickets = torch.zeros(lib.dwc_x3_conv2d_ksplit_ticket_words(), dtype=torch.int32, device=DEV)
+
+    def run(ws_t, tk):
+        y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.float32, device=DEV)
+        wsp, wsn, tkp = (ws_t.data_ptr(), ws_t.numel(), tk.data_ptr()) if ws_t is not None else (None, 0, None)
+        if stride == 1:
+            _lib.check(lib.dwc_x3_conv2d_same_add_ws(xn.data_ptr(), wp.data_ptr(), bd.data_ptr(), addn.data_ptr() if addn is not None else None,
+                                                     y.data_ptr(), B, H, W, Cin, Cout, Cout, K, ACT[act], 1, wsp, wsn, tkp, st), "same_add_ws")
+        else:
+            _lib.check(lib.dwc_x3_conv2d_s2_ws(xn.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, Cout, ACT[act],
+                                               wsp, wsn, tkp, st), "s2_ws")
+        return y
+
+    plain = run(None, None)
+    first = run(ws, tickets)
+    torch.cuda.synchronize()
+    assert int(tickets.abs().sum()) == 0
+    scale = ref.abs().max().item()
+    err_split = (first.permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
+    err_plain = (plain.permute(0, 3, 1, 2).double() - ref).abs().max().item() / scale
+    print("%s max err / scale vs float64: split launch %.2e | plain launch %.2e" % ("x".join(str(v) for v in shape), err_split, err_plain))
+    assert err_split <= 5e-6 and err_split <= 2 * err_plain + 2e-7
+    filler = torch.randn(4096, 4096, device=DEV)
+    for it in range(20):
+        if it % 2:
+            filler = filler @ filler * 1e-4        # other kernels in flight on the device while the pairs meet
+        again = run(ws, tickets)
+        assert torch.equal(again, first), "run %d differs" % it
+    torch.cuda.synchronize()
+    assert int(tickets.abs().sum()) == 0
