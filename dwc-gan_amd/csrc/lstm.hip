@@ -588,6 +588,12 @@ int lstm_resident_capacity(K kernel, unsigned dyn_lds, int variant) {
     return cap;
 }
 
+// first chunk size (in 16-row tiles) the persistent launchers try; DWC_LSTM_MT_MIN=4: the r03 choice min(4, ceil(B / 16)) (A/B runs)
+int lstm_mt_first(int B) {
+    static const int lo = getenv("DWC_LSTM_MT_MIN") ? atoi(getenv("DWC_LSTM_MT_MIN")) : 1;
+    return max(1, min(min(lo, 4), (B + 15) / 16));
+}
+
 }  // namespace
 
 extern "C" {
@@ -618,23 +624,31 @@ size_t dwc_lstm_seq_ws_bytes(int B, int dirs) { return ((size_t)(16 + dirs * ((B
 int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, float* out, float* c, float* gates, int T, int B, int H,
                      int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups, void* stream) {
     if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
-    const int mt = min(4, (B + 15) / 16);
-    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
     const int nq = (H + 15) / 16, per = (nq + 3) / 4;
     if (per > 5 || (size_t)dirs * T * B * H * 4 >= 0x80000000ull) return DWC_EINVAL;
-    // dynamic LDS on top of the exchange buffer so that a workgroup needs > 80 KB: ONE workgroup per CU (the hand-off form used is
-    // measured for one workgroup per CU, and the residency argument counts CUs)
-    const size_t ex_bytes = (size_t)4 * 4 * mt * 16 * 17 * 4;
-    const unsigned dyn = ex_bytes < 84 * 1024 ? (unsigned)(84 * 1024 - ex_bytes) : 0u;
-    int cap = 0;
-    switch (mt) {
-        case 1: cap = lstm_resident_capacity(lstm_seq_fwd<1, 5>, dyn, 0); break;
-        case 2: cap = lstm_resident_capacity(lstm_seq_fwd<2, 5>, dyn, 1); break;
-        case 3: cap = lstm_resident_capacity(lstm_seq_fwd<3, 5>, dyn, 2); break;
-        default: cap = lstm_resident_capacity(lstm_seq_fwd<4, 5>, dyn, 3); break;
+    // Batch rows per workgroup (16 * mt): the SMALLEST chunk whose grid is still resident at once -- a step is a chain of MFMAs over
+    // the chunk's rows (320 fp32 MFMAs per wave at 64 rows: 5 of the 11 us of a step at B = 128), so more, smaller chunks on the
+    // idle CUs shorten every step (r04: B = 128 runs 152 workgroups of 32 rows instead of 76 of 64).
+    int mt = 0;
+    unsigned dyn = 0;
+    dim3 grid;
+    for (int m = lstm_mt_first(B); m <= 4 && !mt; ++m) {
+        // dynamic LDS on top of the exchange buffer so that a workgroup needs > 80 KB: ONE workgroup per CU (the hand-off form used
+        // is measured for one workgroup per CU, and the residency argument counts CUs)
+        const size_t ex_bytes = (size_t)4 * 4 * m * 16 * 17 * 4;
+        const unsigned dy = ex_bytes < 84 * 1024 ? (unsigned)(84 * 1024 - ex_bytes) : 0u;
+        int cp = 0;
+        switch (m) {
+            case 1: cp = lstm_resident_capacity(lstm_seq_fwd<1, 5>, dy, 0); break;
+            case 2: cp = lstm_resident_capacity(lstm_seq_fwd<2, 5>, dy, 1); break;
+            case 3: cp = lstm_resident_capacity(lstm_seq_fwd<3, 5>, dy, 2); break;
+            default: cp = lstm_resident_capacity(lstm_seq_fwd<4, 5>, dy, 3); break;
+        }
+        if (max_workgroups > 0) cp = min(cp, max_workgroups);
+        const dim3 g((H + 15) / 16, dirs, (B + 16 * m - 1) / (16 * m));
+        if ((size_t)g.x * g.y * g.z <= (size_t)max(cp, 0)) mt = m, dyn = dy, grid = g;
     }
-    if (max_workgroups > 0) cap = min(cap, max_workgroups);
-    if ((size_t)grid.x * grid.y * grid.z > (size_t)max(cap, 0)) return DWC_EINVAL;      // not all workgroups would be resident
+    if (!mt) return DWC_EINVAL;                                  // not all workgroups would be resident at any chunk size
     if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws, 0, dwc_lstm_seq_ws_bytes(B, dirs), st) != hipSuccess) return DWC_ELAUNCH;
@@ -653,21 +667,26 @@ int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, 
                      float* dgates, int T, int B, int H, int dirs, void* ws, size_t ws_bytes, unsigned* status, int max_workgroups,
                      void* stream) {
     if (T <= 0 || B <= 0 || H <= 0 || (H & 3) || dirs < 1 || dirs > 2) return DWC_EINVAL;
-    const int mt = min(4, (B + 15) / 16);
-    const dim3 grid((H + 15) / 16, dirs, (B + 16 * mt - 1) / (16 * mt));
     const int nq = (4 * H + 15) / 16, per = (nq + 3) / 4;
     if (per > 19 || (size_t)dirs * T * B * 4 * H * 4 >= 0x80000000ull) return DWC_EINVAL;
-    const size_t ex_bytes = (size_t)4 * mt * 16 * 17 * 4;
-    const unsigned dyn = (unsigned)(84 * 1024 - ex_bytes);
-    int cap = 0;
-    switch (mt) {
-        case 1: cap = lstm_resident_capacity(lstm_seq_bwd<1, 19>, dyn, 4); break;
-        case 2: cap = lstm_resident_capacity(lstm_seq_bwd<2, 19>, dyn, 5); break;
-        case 3: cap = lstm_resident_capacity(lstm_seq_bwd<3, 19>, dyn, 6); break;
-        default: cap = lstm_resident_capacity(lstm_seq_bwd<4, 19>, dyn, 7); break;
+    int mt = 0;                                                  // smallest resident chunk, see dwc_lstm_seq_fwd
+    unsigned dyn = 0;
+    dim3 grid;
+    for (int m = lstm_mt_first(B); m <= 4 && !mt; ++m) {
+        const size_t ex_bytes = (size_t)4 * m * 16 * 17 * 4;
+        const unsigned dy = (unsigned)(84 * 1024 - ex_bytes);
+        int cp = 0;
+        switch (m) {
+            case 1: cp = lstm_resident_capacity(lstm_seq_bwd<1, 19>, dy, 4); break;
+            case 2: cp = lstm_resident_capacity(lstm_seq_bwd<2, 19>, dy, 5); break;
+            case 3: cp = lstm_resident_capacity(lstm_seq_bwd<3, 19>, dy, 6); break;
+            default: cp = lstm_resident_capacity(lstm_seq_bwd<4, 19>, dy, 7); break;
+        }
+        if (max_workgroups > 0) cp = min(cp, max_workgroups);
+        const dim3 g((H + 15) / 16, dirs, (B + 16 * m - 1) / (16 * m));
+        if ((size_t)g.x * g.y * g.z <= (size_t)max(cp, 0)) mt = m, dyn = dy, grid = g;
     }
-    if (max_workgroups > 0) cap = min(cap, max_workgroups);
-    if ((size_t)grid.x * grid.y * grid.z > (size_t)max(cap, 0)) return DWC_EINVAL;
+    if (!mt) return DWC_EINVAL;
     if (!ws || ws_bytes < dwc_lstm_seq_ws_bytes(B, dirs)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(ws, 0, dwc_lstm_seq_ws_bytes(B, dirs), st) != hipSuccess) return DWC_ELAUNCH;
