@@ -88,7 +88,7 @@ struct X3Args {
 // leaves; the other waits for that (the first is running and waits for nobody), adds it to its own -- a + b = b + a, so the
 // result does not depend on the order of arrival -- and runs the epilogue.  The ticket is back at zero when the tile is done.
 template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
-__global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
     // SIMD with up to 512 registers -- 4x2 tiles, a second fragment set, all latency hiding inside the wave's own instruction
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     constexpr int NW = WM * WN, THREADS = 64 * NW;
     constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
-    static_assert(!S2 || (KS == 2 && PB == 1), "stride-2 form: 2x2 taps per parity, single patch buffer");
-    static_assert(KSP == 1 || (KSP == 2 && S2 != 2 && PB == 1 && TM * TN <= 4), "contraction split: the two-per-CU tile only");
+    static_assert(!S2 || KS == 2, "stride-2 form: 2x2 taps per parity");
+    static_assert(KSP == 1 || (KSP == 2 && S2 != 2 && NW == 4 && TM * TN <= 4), "contraction split: the two-per-CU tile only");
     constexpr int PW = TB + KS - 1;                    // patch edge
     constexpr int PPIX = PW * PW;                      // patch pixels
     constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN, PB == 1 ? 2 : 1) void conv_halo_x3_ke
     // the last third of the MFMAs runs while they arrive; the patch conversion (VALU + ds_write) is placed between MFMA groups
     // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
     // eight waves of the one resident workgroup reach every phase together.)
-    constexpr bool PIPE = PB == 2 && (NW == 4 || TM * TN <= 2);
+    constexpr bool PIPE = PB == 2 && TM * TN <= 2;
     bf16x8 fa[PIPE ? 2 : 1][3][TM], fb[PIPE ? 2 : 1][3][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
@@ -892,6 +892,14 @@ bool x3_ksplit_on(long tiles, int slabs) {
     return on && tiles <= X3_KSPLIT_TILES && !(tiles & 7) && slabs >= 8 && !(slabs & 1);      // (tiles % 8: pairs share an XCD)
 }
 
+// patch buffers of the stride-2 forms (two-per-CU tile).  DWC_X3_S2_PB=2: the next slab's patch is converted beside the taps of the
+// current one (a slab is only 4 taps there; 81.7 KB of LDS, still two per CU) -- measured equal to the conversion at the slab
+// boundary (B = 48: 261.2 / 264.2 against 260.1 / 265.6 us), so the smaller footprint stays the default
+int x3_s2_pb() {
+    static const int pb = getenv("DWC_X3_S2_PB") ? atoi(getenv("DWC_X3_S2_PB")) : 1;
+    return pb == 2 ? 2 : 1;
+}
+
 bool x3_s2_ok(int B, int H, int W, int Cin, int N) {
     return B > 0 && H >= 2 * TB && W >= 2 * TB && !(H % (2 * TB)) && !(W % (2 * TB)) && Cin >= CS && !(Cin % CS) && N >= 32 && !(N % 4) &&
            (size_t)B * H * W * Cin < 0x7fffffffull;
@@ -1071,6 +1079,8 @@ int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bia
         a.part = (float*)ws;
         a.tickets = tickets;
         x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    } else if (x3_s2_pb() == 2) {
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 2, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     } else {
         x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     }
@@ -1094,7 +1104,8 @@ int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx
     a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = Cin / 64;
-    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    if (x3_s2_pb() == 2) x3_launch<2, 64, 4, 1, 2, 2, 0, 2, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    else x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
