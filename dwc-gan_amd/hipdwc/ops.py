@@ -120,12 +120,14 @@ class KernelTimer:
             kind = words[0] if words else tag
             ksz = next((w for w in words[1:] if w[0] == "k" and w[1:].isdigit()), "")
             ent = out.setdefault(kind + ("/" + ksz if ksz else ""), {"launches": 0, "ms": 0.0, "flops": 0.0, "exec_flops": 0.0,
-                                                                      "tag": tag.split("/")[-1], "shapes": {}})
+                                                                      "tag": tag.split("/")[-1], "shapes": {}, "shape_ms": {}})
+            ms = a.elapsed_time(b)
             ent["launches"] += 1
-            ent["ms"] += a.elapsed_time(b)
+            ent["ms"] += ms
             ent["flops"] += flops
             ent["exec_flops"] += ex
             ent["shapes"][det] = ent["shapes"].get(det, 0) + 1
+            ent["shape_ms"][det] = round(ent["shape_ms"].get(det, 0.0) + ms, 4)
         return out
 
     def summary(self):
@@ -1106,8 +1108,113 @@ def linear(x, w, b, act="none", owner=None):
 
 
 # --------------------------------------------------------------------------------------
+# Dense products with widths that are not powers of two (the text encoder: 364 / 600 / 1200 / 2400) on the im2col GEMM kernels.
+# A row of K = taps * c values (c = the largest power of two <= 32 dividing K, >= 4) is read as an NHWC image of `taps` pixels
+# x c channels and contracted by ONE filter of `taps` taps: the kernels' gather wants a power-of-two channel count, not a
+# power-of-two K.  No copy of the activations; the weight views are re-laid-out once per optimiser step (prepared-weight cache).
+# fp32 in / out, inner products as exact split products on the bf16 matrix cores like every other fp32 layer (dwc_x3_gemm_mode).
+# --------------------------------------------------------------------------------------
+def _pow2_div(k, cap=32):
+    c = 1
+    while c < cap and k % (2 * c) == 0:
+        c *= 2
+    return c
+
+
+def gemm_ok(K, N):
+    """Shapes `_gemm_nt` / `_gemm_nn` / `_gemm_tn` take: both widths multiples of 4 whose tap counts the gather can enumerate."""
+    return K % 4 == 0 and N % 4 == 0 and K // _pow2_div(K) <= 256 and N // _pow2_div(N) <= 256
+
+
+def _gemm_nt(x, w, bias, owner):
+    """x:[M,K] @ w:[N,K]^T (+ bias:[N]) -> [M,N].  `owner`: the parameter(s) `w` derives from (prepared-layout cache key)."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = w.shape[0]
+    c = _pow2_div(K)
+    taps = K // c
+    w4 = w.detach().reshape(N, taps, c).permute(0, 2, 1).unsqueeze(2)                 # OIHW [N, c, 1, taps]
+    wp = _prepped(w4, "fwd", N, c, 1, owner)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    nws = lib.dwc_conv2d_fwd_ws_bytes(M, 1, taps, c, N, 1, taps, 1, 0)
+    wsp = workspace(nws, x.device).data_ptr() if nws else None
+    flops = 2.0 * M * N * K
+    _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
+        x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), M, 1, taps, c, N, 1, taps, 1, 0, 0, wsp, nws, _stream()),
+        detail="fwd B%d 1x%d %d>%d k%d s1" % (M, taps, c, N, taps)), "gemm_nt")
+    return y
+
+
+def _gemm_nn(dy, w, owner):
+    """dy:[M,N] @ w:[N,K] -> [M,K] (the input gradient of `_gemm_nt`): the same kernel over dy's row with w^T as the filter."""
+    lib = _lib.load()
+    M, N = dy.shape
+    K = w.shape[1]
+    c = _pow2_div(N)
+    taps = N // c
+    # taps along the filter's HEIGHT here: the cache entry can never collide with the forward layout of a square weight
+    wt4 = w.detach().t().reshape(K, taps, c).permute(0, 2, 1).unsqueeze(3)              # OIHW [K, c, taps, 1]
+    wp = _prepped(wt4, "fwd", K, c, 1, owner)
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    nws = lib.dwc_conv2d_fwd_ws_bytes(M, taps, 1, c, K, taps, 1, 1, 0)
+    wsp = workspace(nws, dy.device).data_ptr() if nws else None
+    flops = 2.0 * M * N * K
+    _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_fwd(
+        dy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), M, taps, 1, c, K, taps, 1, 1, 0, 0, wsp, nws, _stream()),
+        detail="dgrad B%d %dx1 %d>%d k%d s1" % (M, taps, c, K, taps)), "gemm_nn")
+    return dx
+
+
+def _gemm_tn(dy, x):
+    """dy:[M,N]^T @ x:[M,K] -> [N,K] (the weight gradient of `_gemm_nt`): the weight-gradient kernel of the same one-filter layer."""
+    lib = _lib.load()
+    M, N = dy.shape
+    K = x.shape[1]
+    c = _pow2_div(K)
+    taps = K // c
+    dw4 = torch.empty((N, c, 1, taps), dtype=torch.float32, device=x.device)
+    nws = lib.dwc_conv2d_bwd_weight_ws_bytes(M, 1, taps, c, N, 1, taps, 1, 0)
+    ws = workspace(nws, x.device)
+    flops = 2.0 * M * N * K
+    _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
+        x.data_ptr(), dy.data_ptr(), dw4.data_ptr(), M, 1, taps, c, N, 1, taps, 1, 0, c, N, ws.data_ptr(), ws.numel(), _stream()),
+        detail="wgrad B%d 1x%d %d>%d k%d s1" % (M, taps, c, N, taps)), "gemm_tn")
+    return dw4.squeeze(2).permute(0, 2, 1).reshape(N, K)
+
+
+class _LinearAny(torch.autograd.Function):
+    """nn.Linear for fp32 x:[M,K], w:[N,K] with K and N multiples of 4, no power-of-two requirement (reference
+    networks_v2.py:204-205: the 2 x num_class text heads read a 2400-wide feature row)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, owner):
+        _require_device(x)
+        if x.dtype != torch.float32 or not gemm_ok(x.shape[1], w.shape[0]):
+            raise ValueError("linear_any: fp32, widths multiples of 4 (got %s x %s)" % (tuple(x.shape), tuple(w.shape)))
+        x = x.contiguous()
+        ctx.owner = owner if owner is not None else w
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return _gemm_nt(x, w, None if b is None else b.detach().contiguous(), ctx.owner)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _gemm_nn(dy, w, ctx.owner) if ctx.needs_input_grad[0] else None
+        dw = _gemm_tn(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+def linear_any(x, w, b, owner=None):
+    return _LinearAny.apply(x, w, b, owner)
+
+
+# --------------------------------------------------------------------------------------
 # text encoder: one bidirectional LSTM layer over padded sequences with per-sample lengths
 # --------------------------------------------------------------------------------------
+LSTM_GEMM = int(os.environ.get("DWC_LSTM_GEMM", "1"))     # 0: the layer's dense products through torch (rocBLAS / hipBLASLt)
 _LSTM_STATUS = {}            # device index -> (persistent int32 device word, pinned host copy, event of the last copy or None)
 LSTM_SEQ_MAX_WORKGROUPS = 0  # > 0: cap on the persistent launches' grid (hipdwc.dp sets it while collectives share the CUs)
 
@@ -1153,14 +1260,23 @@ class _LSTMBidir(torch.autograd.Function):
     steps run in dwc_lstm_fwd / dwc_lstm_bwd."""
 
     @staticmethod
-    def forward(ctx, x, lens, w_ih, w_hh, b_ih, b_hh):
+    def forward(ctx, x, lens, w_ih, w_hh, b_ih, b_hh, owners=None):
         _require_device(x)
         lib = _lib.load()
         T, B, I = x.shape
         H = w_hh.shape[2]
         dev = x.device
         X = x.reshape(T * B, I)
-        xproj = torch.baddbmm((b_ih + b_hh).unsqueeze(1), X.unsqueeze(0).expand(2, -1, -1), w_ih.transpose(1, 2))   # [2,TB,4H]
+        # owners: the two direction parameters weight_ih is stacked from (cache key of the prepared layouts; without them the
+        # dense products stay with torch: the stacked tensor is a cached buffer whose address may be reused)
+        ctx.hip_gemm = bool(LSTM_GEMM and owners is not None and gemm_ok(I, 4 * H) and gemm_ok(H, 4 * H))
+        ctx.owners = owners
+        if ctx.hip_gemm:
+            bsum = b_ih + b_hh
+            X = X.contiguous()
+            xproj = torch.stack([_gemm_nt(X, w_ih[d], bsum[d], owners[d]) for d in range(2)])                     # [2,TB,4H]
+        else:
+            xproj = torch.baddbmm((b_ih + b_hh).unsqueeze(1), X.unsqueeze(0).expand(2, -1, -1), w_ih.transpose(1, 2))   # [2,TB,4H]
         w_hh_c = w_hh.contiguous()
         out = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
         c = torch.empty((2, T, B, H), dtype=torch.float32, device=dev)
@@ -1205,7 +1321,10 @@ class _LSTMBidir(torch.autograd.Function):
                                         dgates.data_ptr(), carry.data_ptr(), T, B, H, 2, _stream()), "lstm_bwd")
         dG = dgates.view(2, T * B, 4 * H)
         dGt = dG.transpose(1, 2)
-        dw_ih = torch.matmul(dGt, X) if ctx.needs_input_grad[2] else None                       # [2,4H,I]
+        hip = ctx.hip_gemm
+        dw_ih = None
+        if ctx.needs_input_grad[2]:                                                             # [2,4H,I]
+            dw_ih = torch.stack([_gemm_tn(dG[d], X) for d in range(2)]) if hip else torch.matmul(dGt, X)
         db = dG.sum(1) if (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]) else None
         dw_hh = None
         if ctx.needs_input_grad[3]:
@@ -1213,15 +1332,21 @@ class _LSTMBidir(torch.autograd.Function):
             hprev = torch.zeros((2, T, B, H), dtype=torch.float32, device=dev)
             hprev[0, 1:] = out[0, :-1]
             hprev[1, :-1] = out[1, 1:]
-            dw_hh = torch.bmm(dGt, hprev.view(2, T * B, H))                                     # [2,4H,H]
+            hp = hprev.view(2, T * B, H)
+            dw_hh = torch.stack([_gemm_tn(dG[d], hp[d]) for d in range(2)]) if hip else torch.bmm(dGt, hp)   # [2,4H,H]
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.bmm(dG, w_ih).sum(0).view(T, B, I)
-        return dx, None, dw_ih, dw_hh, db, db
+            if hip:
+                dx = (_gemm_nn(dG[0], w_ih[0], ctx.owners[0]) + _gemm_nn(dG[1], w_ih[1], ctx.owners[1])).view(T, B, I)
+            else:
+                dx = torch.bmm(dG, w_ih).sum(0).view(T, B, I)
+        return dx, None, dw_ih, dw_hh, db, db, None
 
 
-def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh):
-    return _LSTMBidir.apply(x.contiguous(), lens, w_ih, w_hh, b_ih, b_hh)
+def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh, owners=None):
+    """``owners``: (weight_ih of direction 0, of direction 1) -- the parameters ``w_ih`` was stacked from; given, the layer's
+    dense products (input projection, its input and weight gradients, the recurrent weight gradient) run on the HIP GEMM kernels."""
+    return _LSTMBidir.apply(x.contiguous(), lens, w_ih, w_hh, b_ih, b_hh, owners)
 
 
 # --------------------------------------------------------------------------------------

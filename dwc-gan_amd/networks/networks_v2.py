@@ -166,7 +166,8 @@ class TxtEncoder(nn.Module):
         for l in range(self.num_layers):
             par = {n: ops.cat_params([getattr(self.lstm, "%s_l%d%s" % (n, l, suf)) for suf in suffixes], stack=True)
                    for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")}
-            out, cell = ops.lstm_bidir(data, lens_dev, par["weight_ih"], par["weight_hh"], par["bias_ih"], par["bias_hh"])
+            out, cell = ops.lstm_bidir(data, lens_dev, par["weight_ih"], par["weight_hh"], par["bias_ih"], par["bias_hh"],
+                                       owners=tuple(getattr(self.lstm, "weight_ih_l%d%s" % (l, suf)) for suf in suffixes))
             # final states: forward direction at each sample's last token, reverse direction at t = 0
             hs += [out[0][last, cols], out[1][0]]
             cs += [cell[0][last, cols], cell[1][0]]
@@ -193,7 +194,10 @@ class TxtEncoder(nn.Module):
         # the 2*num_class heads read the same feature row: one [2*num_class*c_dim, feat] product
         w = ops.cat_params([m.weight for m in self.fcs] + [m.weight for m in self.fcvars])
         b = ops.cat_params([m.bias for m in self.fcs] + [m.bias for m in self.fcvars])
-        out = torch.nn.functional.linear(feat, w, b)
+        if feat.is_cuda and ops.LSTM_GEMM and ops.gemm_ok(feat.shape[1], w.shape[0]):
+            out = ops.linear_any(feat, w, b, owner=tuple(m.weight for m in self.fcs) + tuple(m.weight for m in self.fcvars))
+        else:
+            out = torch.nn.functional.linear(feat, w, b)
         k, c = self.num_class, self.style_dim // self.num_class
         return HeadList.of(out[:, :k * c], k), HeadList.of(out[:, k * c:2 * k * c], k)
 

@@ -302,11 +302,16 @@ def test_conv_no_bias_and_cout_not_multiple_of_4():
     (6, 70, 12, 20, None),                            # more than 64 sequences (row chunks), H not a multiple of 16
 ])
 @pytest.mark.parametrize("seq", [1, 0], ids=["persistent", "per-step"])
-def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
+@pytest.mark.parametrize("hip_gemm", [1, 0], ids=["hip-gemm", "torch-gemm"])
+def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, hip_gemm, monkeypatch):
     """One bidirectional layer on padded input + lengths against torch's nn.LSTM on the PackedSequence (what the
     reference runs, networks_v2.py:226-233): outputs, final states, and every gradient -- with the forward recurrence as ONE
-    persistent launch (workgroups hand h_t to each other inside the launch) and as one launch per time step."""
+    persistent launch (workgroups hand h_t to each other inside the launch) and as one launch per time step; the layer's dense
+    products (input projection, its input / weight gradients, the recurrent weight gradient) on the HIP GEMM kernels
+    (ops._gemm_nt / _gemm_nn / _gemm_tn: widths 364, 600, 1200 -- no powers of two) and through torch."""
     monkeypatch.setattr(ops, "LSTM_SEQ", seq)
+    if hip_gemm and not (ops.gemm_ok(I, 4 * H) and ops.gemm_ok(H, 4 * H)):
+        pytest.skip("widths the HIP GEMM path does not take (ops falls back to torch by itself)")
     g = torch.Generator().manual_seed(T * 1000 + B + H)
     if lens is None:
         lens = sorted((int(v) for v in torch.randint(1, T + 1, (B,), generator=g)), reverse=True)
@@ -327,7 +332,8 @@ def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
     names = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
     par = {n: [dev(getattr(ref, n + "_l0" + suf), True) for suf in ("", "_reverse")] for n in names}
     lens_t = torch.tensor(lens)
-    out, cell = ops.lstm_bidir(xd, lens_t.to(torch.int32).to(DEV), *[torch.stack(par[n]) for n in names])
+    out, cell = ops.lstm_bidir(xd, lens_t.to(torch.int32).to(DEV), *[torch.stack(par[n]) for n in names],
+                               owners=tuple(par["weight_ih"]) if hip_gemm else None)
     if seq:                      # the persistent launch's sticky status word (caller-owned, outside the scratch arena): no rendez-vous missed
         ops.lstm_status_poll(torch.device(DEV))
         ops.lstm_status_poll(torch.device(DEV), wait=True)
@@ -344,6 +350,32 @@ def test_lstm_bidir_matches_packed_nn_lstm(T, B, I, H, lens, seq, monkeypatch):
     for n in names:
         for k, suf in enumerate(("", "_reverse")):
             close(par[n][k].grad, getattr(ref, n + "_l0" + suf).grad, rel=1e-4, msg=n + suf)
+
+
+@pytest.mark.parametrize("M,K,N", [(16, 2400, 128), (640, 364, 1200), (37, 600, 1200), (5, 12, 8), (3000, 1200, 364)])
+def test_linear_any_matches_float64(M, K, N):
+    """nn.Linear with widths that are no powers of two on the im2col GEMM kernels (a K-wide row read as K/c pixels of c channels;
+    ops.linear_any: the 2 x num_class text heads, reference networks_v2.py:204-205, and the LSTM's dense products): y, dx, dw, db
+    against float64 at fp32 accuracy."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * (1.0 / K ** 0.5), torch.randn(N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    (yr * gy.double()).sum().backward()
+    xd, wd, bd = dev(x, True), dev(w, True), dev(b, True)
+    y = ops.linear_any(xd, wd, bd)
+    (y * gy.to(DEV)).sum().backward()
+    for name, got, ref in (("y", y, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        scale = ref.abs().max().item()
+        err = (got.detach().double().cpu() - ref.detach()).abs().max().item() / scale
+        assert err <= 2e-5, "%s: %.3e of scale" % (name, err)
+    # the prepared layouts follow the parameter: an in-place update must not be served from the cache
+    with torch.no_grad():
+        wd.mul_(2.0)
+    y2 = ops.linear_any(xd.detach(), wd, bd)
+    ref2 = torch.nn.functional.linear(x.double(), 2.0 * w.double(), b.double())
+    assert (y2.detach().double().cpu() - ref2).abs().max().item() / ref2.abs().max().item() <= 2e-5
 
 
 def test_lstm_persistent_launch_refuses_grids_that_cannot_be_resident(monkeypatch):
