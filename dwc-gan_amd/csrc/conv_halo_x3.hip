@@ -61,6 +61,7 @@ struct X3Args {
     int stagger = 0;     // two-workgroups-per-CU form: 10 ns ticks the CU's second workgroup sleeps before its first tile (dwc_duo_stagger)
     float* part = nullptr;          // KSP == 2: [tiles][256 pixels x 64 channels] fp32, the first arriver's half sum
     unsigned* tickets = nullptr;    // KSP == 2: [tiles], zero between launches (caller-owned, self-resetting)
+    int split_from = 0;             // KSP == 2: tiles [0, split_from) run whole (one workgroup), [split_from, tiles) as two halves
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
@@ -87,6 +88,8 @@ struct X3Args {
 // walks half of the channel slabs.  Whichever of the two takes the tile's ticket first publishes its half sum in `part` and
 // leaves; the other waits for that (the first is running and waits for nobody), adds it to its own -- a + b = b + a, so the
 // result does not depend on the order of arrival -- and runs the epilogue.  The ticket is back at zero when the tile is done.
+// The same instantiation serves launches whose LAST round of workgroups would be at most half full (768 tiles on 512 slots: the
+// 256 stragglers run one per CU): tiles [0, split_from) run whole and are dispatched first, only the tail is split.
 template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -124,13 +127,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 
     int bid = blockIdx.x;
     int khalf = 0;                                                       // KSP == 2: which half of the channel slabs
+    bool halved = false;                                                 // KSP == 2: this workgroup is one half of a split tile
     if constexpr (KSP == 2) {
         // hardware workgroups h and h + 8 run on the same XCD (h % 8): they are the two halves of a tile, so that the half sum
-        // travels through THAT XCD's L2 and nothing wider (gridDim.x = 2 x tiles, tiles a multiple of 8); XCD x owns the tiles
-        // x * tiles/8 .. as in the plain remap below
-        const int x = bid & 7, slot = bid >> 3;
-        khalf = slot & 1;
-        bid = x * (int)(gridDim.x >> 4) + (slot >> 1);
+        // travels through THAT XCD's L2 and nothing wider (split_from and the number of split tiles are multiples of 8); XCD x
+        // owns a contiguous range of the whole tiles and one of the split tiles, as in the plain remap below
+        const int x = bid & 7;
+        if (bid < a.split_from) {
+            bid = x * (a.split_from >> 3) + (bid >> 3);
+        } else {
+            const int slot = (bid - a.split_from) >> 3;
+            khalf = slot & 1;
+            halved = true;
+            bid = a.split_from + x * (int)((gridDim.x - a.split_from) >> 4) + (slot >> 1);
+        }
     } else {
         const int nb = gridDim.x;
         if (nb >= 16) {     // XCD-aware remap (neighbouring blocks share halo pixels and the weight slabs in one L2)
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     const int OH = S2 == 1 ? a.H >> 1 : a.H, OW = S2 == 1 ? a.W >> 1 : a.W;      // grid the blocks tile (S2 == 2: the dY grid)
     const int ncsr = a.Cin / CS;                                        // 16-channel slabs of the input tensor
     const int ncs_all = S2 == 1 ? 4 * ncsr : ncsr;                      // slabs of the contraction: x 4 input-pixel parities
-    const int ncs = ncs_all / KSP, cs0 = khalf * ncs;                   // slabs this workgroup walks: cs0 .. cs0 + ncs - 1
+    const int ncs = halved ? ncs_all >> 1 : ncs_all, cs0 = khalf * ncs; // slabs this workgroup walks: cs0 .. cs0 + ncs - 1
     const int nsteps = ncs * NTAP;
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // batch in front of its stores.  Inside the per-chunk conditionals -- `if (col < N) if (bias) v += bias[col]` -- the compiler
     // can neither hoist nor batch a load: every chunk paid its own L2 round trip, one after the other.)
     if constexpr (KSP == 2) {
-        // ---- the two halves of the contraction meet (see the template comment) ------------------------------------------------
+        // (whole tiles of a mixed launch skip the exchange; the correction accumulators are merged here either way)
         __shared__ unsigned s_role;
         if (SPLIT) {
 #pragma unroll
@@ -416,14 +426,16 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         // Both workgroups sit on one XCD: its L2 is the meeting point.  The first arriver's stores are complete (acknowledged by the
         // L2) before it raises the ticket, the second reads the ticket and the half sum past its L1 (sc1) -- no L2 write-back or
         // invalidate, which an agent-scope release / acquire pair would cost every workgroup (measured: 145 against 117 us).
-        unsigned* ticket = a.tickets + tile_id;
+      if (halved) {
+        // ---- the two halves of the contraction meet (see the template comment) ------------------------------------------------
+        unsigned* ticket = a.tickets + (tile_id - a.split_from);
         if (t == 0) s_role = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned role = s_role;
         // [tile][i][n][q4][thread] f32x4: 16 bytes per lane, consecutive lanes consecutive
         constexpr unsigned TILE_B = TM * TN * 4 * THREADS * 16;
         const __amdgpu_buffer_rsrc_t rsrc_p = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<char*>(a.part) + (size_t)tile_id * TILE_B, 0, TILE_B, 0x00020000);
+            reinterpret_cast<char*>(a.part) + (size_t)(tile_id - a.split_from) * TILE_B, 0, TILE_B, 0x00020000);
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
         if (role == 0) {
 #pragma unroll
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
                     for (int k = 0; k < 4; ++k) acc[i][n][4 * q4 + k] += ov[n][q4][k] + poison;
         }
+      }
     }
     const float slope = dwc_act_slope(a.act);
     f32x4 bv[TN][4];
@@ -887,9 +900,21 @@ void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
 // count is even and long enough to be worth halving.  DWC_X3_KSPLIT=0 switches it off.
 constexpr int X3_KSPLIT_TILES = 256;
 constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
-bool x3_ksplit_on(long tiles, int slabs) {
+// Number of tiles that run whole (a multiple of 8; the remaining tiles - split_from <= 256 are split), or -1: the launch is not
+// split.  512 = the workgroups resident at once (two per CU): a last round of at most 256 tiles is the one worth halving.
+// DWC_X3_KSPLIT: 0 off, 1 (default) launches of <= 256 tiles only, 2 also the tail of larger launches (measured: no gain -- 3x3
+// 256->256 at batch 48, 768 tiles: 330.6 against 323.8 us; workgroups are dispatched as slots free up, there is no "last round").
+long x3_ksplit_from(long tiles, int slabs) {
     static const int on = getenv("DWC_X3_KSPLIT") ? atoi(getenv("DWC_X3_KSPLIT")) : 1;
-    return on && tiles <= X3_KSPLIT_TILES && !(tiles & 7) && slabs >= 8 && !(slabs & 1);      // (tiles % 8: pairs share an XCD)
+    if (!on || slabs < 8 || (slabs & 1) || (tiles & 7)) return -1;                              // (tiles % 8: pairs share an XCD)
+    const long tail = tiles % 512;
+    if (tail == 0 || tail > X3_KSPLIT_TILES || (tiles > X3_KSPLIT_TILES && on < 2)) return -1;
+    return tiles - tail;
+}
+bool x3_ksplit_on(long tiles, int slabs) { return x3_ksplit_from(tiles, slabs) >= 0; }
+size_t x3_ksplit_bytes(long tiles, int slabs) {
+    const long from = x3_ksplit_from(tiles, slabs);
+    return from < 0 ? 0 : (size_t)(tiles - from) * X3_KSPLIT_TILE_BYTES;
 }
 
 // patch buffers of the stride-2 forms (two-per-CU tile).  DWC_X3_S2_PB=2: the next slab's patch is converted beside the taps of the
@@ -955,11 +980,11 @@ size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K,
     if (stride == 2) {
         if (!x3_s2_ok(B, H, W, Cin, N)) return 0;
         const long tiles = (long)B * ((H / 2) / TB) * ((W / 2) / TB) * ((N + 63) / 64);
-        return x3_ksplit_on(tiles, 4 * (Cin / CS)) ? (size_t)tiles * X3_KSPLIT_TILE_BYTES : 0;
+        return x3_ksplit_bytes(tiles, 4 * (Cin / CS));
     }
     if (!x3_ok(B, H, W, Cin, N, K)) return 0;
     const long tiles = (long)B * (H / TB) * (W / TB) * ((N + 63) / 64);
-    return x3_ksplit_on(tiles, Cin / CS) ? (size_t)tiles * X3_KSPLIT_TILE_BYTES : 0;
+    return x3_ksplit_bytes(tiles, Cin / CS);
 }
 int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TILES; }
 
@@ -1023,7 +1048,8 @@ int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const floa
         if (need && ws && tickets && ws_bytes >= need) {
             a.part = (float*)ws;
             a.tickets = tickets;
-            const dim3 g4(2 * g2.x);
+            a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
+            const dim3 g4(2 * g2.x - a.split_from);
             if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
             else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
         } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
@@ -1078,7 +1104,9 @@ int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bia
     if (need && ws && tickets && ws_bytes >= need) {
         a.part = (float*)ws;
         a.tickets = tickets;
-        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+        const int tiles = B * a.blocks_per_img * a.tiles_n;
+        a.split_from = (int)x3_ksplit_from(tiles, 4 * (Cin / CS));
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * tiles - a.split_from), (hipStream_t)stream);
     } else if (x3_s2_pb() == 2) {
         x3_launch<2, 64, 4, 1, 2, 2, 0, 2, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     } else {

@@ -282,16 +282,21 @@ def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(16, 256, 256, 32, 32, 3, 1, "relu", True), (4, 128, 256, 32, 32, 3, 1, "none", False),
                                    (2, 256, 128, 32, 32, 5, 1, "lrelu", True), (16, 128, 256, 64, 64, 4, 2, "lrelu", False),
-                                   (4, 64, 128, 32, 64, 4, 2, "none", False)], ids=lambda s: "x".join(str(v) for v in s))
+                                   (4, 64, 128, 32, 64, 4, 2, "none", False),
+                                   (36, 128, 256, 32, 32, 3, 1, "lrelu", True),        # 576 tiles: mixed mode = 512 whole + a split tail of 64
+                                   (48, 128, 256, 64, 64, 4, 2, "relu", False)],       # stride 2, 768 tiles: 512 whole + 256 split
+                         ids=lambda s: "x".join(str(v) for v in s))
 def test_x3_contraction_split_of_small_launches(shape):
-    """Launches of at most 256 tiles run two workgroups per tile, each half of the channel slabs; whichever arrives second adds the
-    other's half sum (conv_halo_x3_kernel, KSP == 2; dwc_x3_conv2d_same_add_ws / dwc_x3_conv2d_s2_ws).  Against float64 at fp32
+    """Launches of at most 256 tiles -- and the tail of launches whose last round of 512 resident workgroups would be at most half
+    full -- run two workgroups per tile, each half of the channel slabs; whichever arrives second adds the other's half sum (conv_halo_x3_kernel, KSP == 2; dwc_x3_conv2d_same_add_ws / dwc_x3_conv2d_s2_ws).  Against float64 at fp32
     accuracy like the unsplit launch, bit-identical from run to run (the sum of two halves does not depend on who arrives first),
     tickets back at zero, and the second arriver really waited for the first: repeated 20 times on a busy device."""
     B, Cin, Cout, H, W, K, stride, act, with_add = shape
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     need = lib.dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, Cout, K, stride)
+    if B >= 36 and need == 0:
+        pytest.skip("tail split of larger launches is opt-in (DWC_X3_KSPLIT=2)")
     assert need > 0, "shape is meant to be split"
     g = torch.Generator().manual_seed(sum(shape[:7]))
     x = torch.randn(B, Cin, H, W, generator=g) * torch.rand(1, Cin, 1, 1, generator=g) * 3
