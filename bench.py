@@ -65,8 +65,9 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 KIND_KERNEL = {
     "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
     "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
-    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1>\(", "bf16x3"),
-    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2>\(", "bf16x3"),
+    # (template arguments: ..., PB, S2, KSP -- S2 is the last but one: 1 = stride-2 forward, 2 = its data gradient)
+    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12]>\(", "bf16x3"),
+    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1>\(", "bf16x3"),
     "dgrad-s2halo": ("conv_halo16_kernel<2,S2-dgrad>", r"conv_halo16_kernel<2, .*, 2>\(", "bf16"),
     "wgrad-x3": ("wgrad_x3_kernel<{k}>", r"wgrad_x3_kernel<{k}, ", "bf16x3"),
     "fwd-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),

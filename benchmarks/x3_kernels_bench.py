@@ -57,8 +57,11 @@ def main():
             if nws:
                 wsb = torch.empty(nws, dtype=torch.uint8, device=dev)
                 dw = torch.empty(co, ci, k, k, device=dev)
-                tw = med(lambda: _lib.check(lib.dwc_x3_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, H, ci, co, k, ci, co,
-                                                                    wsb.data_ptr(), nws, st), "x3 wgrad"))
+                try:
+                    tw = med(lambda: _lib.check(lib.dwc_x3_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, H, ci, co, k, ci, co,
+                                                                        wsb.data_ptr(), nws, st), "x3 wgrad"))
+                except _lib.HipKernelError:          # (a knob selected a variant this shape has no instantiation of)
+                    pass
             print("  B%-3d %-18s%s fwd %8.1f us  %.3f of 2.5PF | wgrad+reduce %8.1f us  %.3f of 2.5PF   checksum %.6e" % (
                 B, name, " (split)" if need else "        ", tf * 1e6, 6 * flops / tf / 2.5e15, tw * 1e6, 6 * flops / tw / 2.5e15, float(y.double().sum())))
 
