@@ -65,6 +65,8 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 KIND_KERNEL = {
     "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
     "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
+    "fwd-heads-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
+    "dgrad-image-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     # (template arguments: ..., PB, S2, KSP -- S2 is the last but one: 1 = stride-2 forward, 2 = its data gradient)
     "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12]>\(", "bf16x3"),
     "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1>\(", "bf16x3"),

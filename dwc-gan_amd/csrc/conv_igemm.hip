@@ -1800,6 +1800,17 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
     return DWC_OK;
 }
 
+/* The same for a padded gradient image whose rows are `pitch` >= W + 2*pad pixels apart (the 8-pixel-group grid of
+ * dwc_x3_conv2d_narrow's image gradient). */
+int dwc_reflect_pad_adjoint_pitch(const float* dxp, float* dx, int B, int H, int W, int C, int pad, int pitch, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || pad < 0 || pad >= H || pad >= W || pitch < W + 2 * pad) return DWC_EINVAL;
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(fold_reflect_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dxp, dx, B, H, W, C / 4,
+                       pad, pitch);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 // dx += the border ring of the padded gradient image, folded back by the reflect rule.  dx already holds the interior;
 // the ring lives in four strips: top/bottom [B][pad][Wp][C], left/right [B][H][pad][C], `parts` copies `part_stride`
 // apart (partial sums over K, added in order).  Only the bands of dx that receive something are visited: per image

@@ -285,6 +285,32 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         out = base.view(32, taps, ch // 16, 2, 8).permute(1, 2, 3, 0, 4).contiguous()
         ent[key] = (stamp, out)
         return out
+    if kind in ("heads_narrow_x3", "dgrad_image_narrow_x3"):
+        # csrc/conv_narrow_x3.hip: the fp32 wide bank [32][64][KH][KW+7] (8 pixels x 4 planes; copy p = the filter shifted right by
+        # p taps) as three exact bf16 planes (v = hi + mid + lo: truncate, subtract, truncate, subtract) in MFMA-fragment order
+        # [slab q of 16 channels][tap][plane][lane = half*32 + bank row][8 channels 16q + 8*half ..]
+        if kind == "heads_narrow_x3":
+            px = 32 // w.shape[0]
+            bank = _shifted_bank(w.detach().float(), px).reshape(32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
+        else:
+            co, ci, kh, kw = w.shape
+            px = 32 // cin_pad
+            wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
+            wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
+            bank = _shifted_bank(wf, px).reshape(px * cin_pad, cout_pad, kh, kw + px - 1)
+        rows_, ch, kh, kww = bank.shape
+        assert rows_ == 32 and ch == 64
+        v = bank.permute(2, 3, 1, 0).reshape(kh * kww, 4, 2, 8, 32).permute(1, 0, 2, 4, 3).contiguous()    # [q][tap][half][row][8]
+        hi_ = (v.view(torch.int32) & -65536).view(torch.float32)
+        r_ = v - hi_
+        mid_ = (r_.view(torch.int32) & -65536).view(torch.float32)
+        lo_ = r_ - mid_
+        out = torch.stack([hi_, mid_, lo_], 2).to(BF16)                                                     # [q][tap][plane][half][row][8]
+        ntp = (kh * kww + 7) // 8 * 8                                                                       # taps padded with zeros: 13 per wave
+        out = torch.nn.functional.pad(out.reshape(4, kh * kww, 3 * 64 * 8), (0, 0, 0, ntp - kh * kww)).reshape(-1).contiguous()
+        assert out.numel() == lib.dwc_x3_conv2d_narrow_weight_elems(kh, kww)
+        ent[key] = (stamp, out)
+        return out
     if kind == "heads_wide":
         # the P-plane heads (P = w.shape[0]: 4, or 8 on the bf16 path) as px = 32/P pixels x P planes:
         # bank [p*P + co][ci][KH][KW+px-1], copy p shifted right by p taps
@@ -467,6 +493,7 @@ HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
+NARROW_X3 = int(os.environ.get("DWC_X3_NARROW", "1"))     # fp32: 64 -> 4-plane 7x7 convolutions on csrc/conv_narrow_x3.hip (split products)
 LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM forward: all time steps in one persistent launch
 DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # data gradients through a reflect pad: interior straight into dx + band fold
 X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
@@ -731,6 +758,17 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_frag.data_ptr(), dx.data_ptr(), B, H, W, cop, KH, KW, pad, ws.data_ptr(), ws.numel(), st),
                     scope_name=ctx.bscope, detail="dgrad-image-narrow B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_image_narrow")
+            elif ((not half) and X3 and NARROW_X3 and Cx == 4 and cop == 64
+                  and lib.dwc_x3_conv2d_narrow_ok(B, H, W, cop, H + 2 * pad, (W + 2 * pad + 7) // 8, KH, KW + 7)):
+                # fp32: the padded gradient image on the split-product narrow kernel (zero rule), folded by the reflect adjoint
+                wg8 = (W + 2 * pad + 7) // 8
+                w_frag = _prepped(w, "dgrad_image_narrow_x3", cop, Cx, 1, owner)
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_narrow(
+                    g.data_ptr(), w_frag.data_ptr(), None, ws.data_ptr(), B, H, W, cop, H + 2 * pad, wg8, KH, KW + 7, -(KH - 1), -(KW - 1),
+                    0, 0, st), scope_name=ctx.bscope, exec_flops=6 * flops,
+                    detail="dgrad-image-nx3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "x3_conv2d_narrow dgrad")
+                _lib.check(lib.dwc_reflect_pad_adjoint_pitch(ws.data_ptr(), dx.data_ptr(), B, H, W, Cx, pad, 8 * wg8, st),
+                           "reflect_pad_adjoint_pitch")
             else:
                 w_img = _prepped(w, "dgrad_image", cop, Cx, 1, owner, half)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_image", x)(
@@ -887,6 +925,14 @@ class _HeadsConvWide(torch.autograd.Function):
                 x.data_ptr(), _prepped(w4, "heads_narrow", 32, C, 1, owner, True).data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W,
                 C, H, W // px, KH, KW + px - 1, -pad, -pad, ACT["heads8"], 1, st),
                 detail="fwd-heads-narrow B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_narrow")
+        elif ((not half) and X3 and NARROW_X3 and P == 4
+              and lib.dwc_x3_conv2d_narrow_ok(B, H, W, C, H, W // px, KH, KW + px - 1)):
+            # fp32: the same form as split products (csrc/conv_narrow_x3.hip): patch split once per 16-channel slab, taps dealt to the waves
+            w_frag = _prepped(w4, "heads_narrow_x3", 32, C, 1, owner)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_narrow(
+                x.data_ptr(), w_frag.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, H, W // px, KH, KW + px - 1, -pad, -pad,
+                ACT["heads"], 1, st), detail="fwd-heads-nx3 B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH), exec_flops=6 * flops),
+                "x3_conv2d_narrow")
         else:
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd_ex", x)(
                 x.data_ptr(), w_prep.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad,

@@ -347,6 +347,19 @@ int dwc_x3_conv2d_same(const float* x, const void* w_prepared, const float* bias
  * ResBlock (reference networks.py:521) rides on the data gradient of its first convolution instead of costing a pass. */
 int dwc_x3_conv2d_same_add(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
                            int Cin, int N, int rows, int K, int act, int reflect, void* stream);
+/* fp32 7x7 convolutions from 64 channels to the 4 planes of an NHWC4 image as split products (conv_narrow_x3.hip, r04): the fused
+ * image heads of the decoder (reference networks.py:218-246) and the image gradient of the 7x7 stems (networks.py:579-585
+ * backward).  y[B][OH][OWg][32] (8 pixels x 4 planes per group) = act(sum over the KH x KWW wide taps and 64 channels + bias32), the
+ * input window of (oy, gx) starting at (oy + off_h, 8*gx + off_w) of x[B][IH][IW][64].  w_frag: the [32][64][KH][KWW] wide bank
+ * (copy p of the filter shifted right by p taps) as three exact bf16 planes in MFMA-fragment order
+ * [slab q of 16 channels][tap kh*KWW+u][plane][lane = half*32 + bank row][8 channels 16q + 8*half ..]
+ * (dwc_x3_conv2d_narrow_weight_elems bf16 elements).  reflect != 0: reflect rule (forward), else zero rule (image gradient on the
+ * padded grid, folded by dwc_reflect_pad_adjoint_pitch with pitch = 8 * OWg).  KH = 7, KWW = 14, Cin = 64 only (_ok). */
+int dwc_x3_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW);
+size_t dwc_x3_conv2d_narrow_weight_elems(int KH, int KWW);
+int dwc_x3_conv2d_narrow(const float* x, const void* w_frag, const float* bias32, float* y, int B, int IH, int IW, int Cin, int OH,
+                         int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
+int dwc_reflect_pad_adjoint_pitch(const float* dxp, float* dx, int B, int H, int W, int C, int pad, int pitch, void* stream);
 /* Small launches (r04): when a shape yields at most 256 tiles of 256 pixels x 64 channels (3x3 256->256 on 32x32 at batch 16) the
  * two-workgroups-per-CU kernel would run one workgroup per CU; the _ws forms cut such launches along the CONTRACTION instead --
  * two workgroups per tile, each half of the channel slabs; the first to finish leaves its half sum in `ws`, the second adds it to
