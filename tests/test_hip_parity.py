@@ -258,9 +258,10 @@ def test_conv_nonfinite_values_propagate(shape, act, prec):
         ops.set_precision("fp32")
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 32), (1, 16, 9, 24), (2, 8, 6, 12)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 16, 32), (1, 16, 9, 24), (2, 8, 6, 12), (3, 64, 21, 72), (1, 64, 128, 128)])
 def test_fused_image_heads(B, C, H, W):
-    """tanh x3 + sigmoid heads as one conv; W % 8 == 0 takes the 'wide' 32-column formulation."""
+    """tanh x3 + sigmoid heads as one conv; W % 8 == 0 takes the 'wide' 32-column formulation -- with 64 input channels on the
+    dedicated split-product kernel (csrc/conv_narrow_x3.hip; 21 rows / 9 pixel groups: blocks hanging over both image edges)."""
     g = torch.Generator().manual_seed(B + C + H + W)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(4, C, 7, 7, generator=g) * (1.0 / (C * 49) ** 0.5)
