@@ -1172,8 +1172,9 @@ def gemm_ok(K, N):
     return K % 4 == 0 and N % 4 == 0 and K // _pow2_div(K) <= 256 and N // _pow2_div(N) <= 256
 
 
-def _gemm_nt(x, w, bias, owner):
-    """x:[M,K] @ w:[N,K]^T (+ bias:[N]) -> [M,N].  `owner`: the parameter(s) `w` derives from (prepared-layout cache key)."""
+def _gemm_nt(x, w, bias, owner, out=None):
+    """x:[M,K] @ w:[N,K]^T (+ bias:[N]) -> [M,N] (into `out` when given).  `owner`: the parameter(s) `w` derives from
+    (prepared-layout cache key)."""
     lib = _lib.load()
     M, K = x.shape
     N = w.shape[0]
@@ -1181,7 +1182,8 @@ def _gemm_nt(x, w, bias, owner):
     taps = K // c
     w4 = w.detach().reshape(N, taps, c).permute(0, 2, 1).unsqueeze(2)                 # OIHW [N, c, 1, taps]
     wp = _prepped(w4, "fwd", N, c, 1, owner)
-    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device) if out is None else out
+    assert y.shape == (M, N) and y.is_contiguous() and y.dtype == torch.float32
     nws = lib.dwc_conv2d_fwd_ws_bytes(M, 1, taps, c, N, 1, taps, 1, 0)
     wsp = workspace(nws, x.device).data_ptr() if nws else None
     flops = 2.0 * M * N * K
@@ -1211,8 +1213,9 @@ def _gemm_nn(dy, w, owner):
     return dx
 
 
-def _gemm_tn(dy, x):
-    """dy:[M,N]^T @ x:[M,K] -> [N,K] (the weight gradient of `_gemm_nt`): the weight-gradient kernel of the same one-filter layer."""
+def _gemm_tn(dy, x, out=None):
+    """dy:[M,N]^T @ x:[M,K] -> [N,K] (the weight gradient of `_gemm_nt`; into `out` when given): the weight-gradient kernel of the
+    same one-filter layer."""
     lib = _lib.load()
     M, N = dy.shape
     K = x.shape[1]
@@ -1225,7 +1228,10 @@ def _gemm_tn(dy, x):
     _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_bwd_weight(
         x.data_ptr(), dy.data_ptr(), dw4.data_ptr(), M, 1, taps, c, N, 1, taps, 1, 0, c, N, ws.data_ptr(), ws.numel(), _stream()),
         detail="wgrad B%d 1x%d %d>%d k%d s1" % (M, taps, c, N, taps)), "gemm_tn")
-    return dw4.squeeze(2).permute(0, 2, 1).reshape(N, K)
+    if out is None:
+        return dw4.squeeze(2).permute(0, 2, 1).reshape(N, K)
+    out.view(N, taps, c).copy_(dw4.squeeze(2).permute(0, 2, 1))
+    return out
 
 
 class _LinearAny(torch.autograd.Function):
@@ -1320,7 +1326,9 @@ class _LSTMBidir(torch.autograd.Function):
         if ctx.hip_gemm:
             bsum = b_ih + b_hh
             X = X.contiguous()
-            xproj = torch.stack([_gemm_nt(X, w_ih[d], bsum[d], owners[d]) for d in range(2)])                     # [2,TB,4H]
+            xproj = torch.empty((2, T * B, 4 * H), dtype=torch.float32, device=dev)                               # [2,TB,4H]
+            for d in range(2):
+                _gemm_nt(X, w_ih[d], bsum[d], owners[d], out=xproj[d])
         else:
             xproj = torch.baddbmm((b_ih + b_hh).unsqueeze(1), X.unsqueeze(0).expand(2, -1, -1), w_ih.transpose(1, 2))   # [2,TB,4H]
         w_hh_c = w_hh.contiguous()
@@ -1370,7 +1378,12 @@ class _LSTMBidir(torch.autograd.Function):
         hip = ctx.hip_gemm
         dw_ih = None
         if ctx.needs_input_grad[2]:                                                             # [2,4H,I]
-            dw_ih = torch.stack([_gemm_tn(dG[d], X) for d in range(2)]) if hip else torch.matmul(dGt, X)
+            if hip:
+                dw_ih = torch.empty((2, 4 * H, I), dtype=torch.float32, device=dev)
+                for d in range(2):
+                    _gemm_tn(dG[d], X, out=dw_ih[d])
+            else:
+                dw_ih = torch.matmul(dGt, X)
         db = dG.sum(1) if (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]) else None
         dw_hh = None
         if ctx.needs_input_grad[3]:
@@ -1379,7 +1392,12 @@ class _LSTMBidir(torch.autograd.Function):
             hprev[0, 1:] = out[0, :-1]
             hprev[1, :-1] = out[1, 1:]
             hp = hprev.view(2, T * B, H)
-            dw_hh = torch.stack([_gemm_tn(dG[d], hp[d]) for d in range(2)]) if hip else torch.bmm(dGt, hp)   # [2,4H,H]
+            if hip:
+                dw_hh = torch.empty((2, 4 * H, H), dtype=torch.float32, device=dev)
+                for d in range(2):
+                    _gemm_tn(dG[d], hp[d], out=dw_hh[d])
+            else:
+                dw_hh = torch.bmm(dGt, hp)                                                                     # [2,4H,H]
         dx = None
         if ctx.needs_input_grad[0]:
             if hip:
