@@ -65,6 +65,8 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 KIND_KERNEL = {
     "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
     "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
+    "fwd-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
+    "dgrad-heads-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
     "fwd-heads-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     "dgrad-image-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     # (template arguments: ..., PB, S2, KSP -- S2 is the last but one: 1 = stride-2 forward, 2 = its data gradient)

@@ -1800,6 +1800,18 @@ int dwc_reflect_pad_adjoint(const float* dxp, float* dx, int B, int H, int W, in
     return DWC_OK;
 }
 
+/* dx (already holding the interior of the padded gradient image dxp [B][H+2pad][W+2pad][C]) += the border ring of dxp folded back by
+ * the reflect rule; only the band of dx a ring pixel folds onto is visited (fp32 twin of dwc_bf16_reflect_pad_adjoint_band). */
+int dwc_reflect_pad_adjoint_band(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream) {
+    if (!dxp || !dx || B <= 0 || C <= 0 || (C & 3) || pad <= 0 || H < 2 * pad + 2 || W < 2 * pad + 2) return DWC_EINVAL;
+    const int C4 = C / 4;
+    const size_t band_items = (size_t)B * (2 * pad * W + (H - 2 * pad) * 2 * pad) * C4;
+    hipLaunchKernelGGL(fold_band_kernel, dim3((unsigned)((band_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dxp, dx, B, H, W, C4, pad,
+                       W + 2 * pad);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 /* The same for a padded gradient image whose rows are `pitch` >= W + 2*pad pixels apart (the 8-pixel-group grid of
  * dwc_x3_conv2d_narrow's image gradient). */
 int dwc_reflect_pad_adjoint_pitch(const float* dxp, float* dx, int B, int H, int W, int C, int pad, int pitch, void* stream) {

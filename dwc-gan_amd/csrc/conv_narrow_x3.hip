@@ -228,6 +228,180 @@ __global__ __launch_bounds__(512, MT == 1 ? 2 : 1) void conv_narrow_x3_kernel(Na
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// The opposite shape, fp32: 7x7 convolutions from the 4 planes of an NHWC4 image to 64 channels as split products -- the stems
+// (forward, reference networks.py:163-166 / :60-66) and the data gradient of the image heads.  The fp32 twin of conv_stem_kernel
+// (conv_narrow_bf16.hip).  K = 49 taps x 4 planes: one MFMA k-step is FOUR taps (lane half hi takes taps 4j+2hi, 4j+2hi+1: two
+// 8-byte pixels of a patch plane), 13 steps.  The whole filter as three bf16 planes (3 x 13 x 64 x 32 bytes = 78 KB, halves of a
+// row swapped by (row>>3)&1 as in conv_halo_x3.hip) stays in LDS while the workgroup walks over 16x16-pixel blocks (persistent);
+// the 22x22 patch is gathered from the fp32 image (one pixel per thread), split in registers and stored as three planes of 8-byte
+// pixels.  8 waves, one 32-pixel tile x both 32-channel tiles each; six products per tile pair, leading product and corrections
+// in separate accumulators; fp32 results stored straight from registers (a lane owns a pixel and 4 consecutive channels).
+// ------------------------------------------------------------------------------------------
+struct StemX3Args {
+    const float* x;      // [B][IH][IW][4]
+    const bf16* w;       // [3 planes][13][64][16]: k-step j, channel co, (tap 4j + 2h + t, plane p) at ((h ^ ((co>>3)&1))*8 + 4t + p)
+    const float* bias;   // [64] or null
+    float* y;            // [B][OH][OW][64]
+    int B, IH, IW, OH, OW, off, act, reflect;
+    int blocks_x, blocks_y, nblocks;
+    // crop > 0 (data gradient of the image heads: y is the gradient of the PADDED tensor): an output pixel whose cropped coordinate
+    // lies inside CH x CW goes straight to `inner` ([B][CH][CW][64]), only the border ring to y; a band fold follows
+    int crop, CH, CW;
+    float* inner;
+};
+
+__global__ __launch_bounds__(512, 1) void conv_stem_x3_kernel(StemX3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = 7, PW = 16 + KS - 1, PPIX = PW * PW, NKS = 13;
+    constexpr int W_PLANE = NKS * 64 * 16;              // elements of one weight plane
+    constexpr int P_PLANE = 512 * 4;                    // one patch plane: 484 pixels x 4 planes (one pixel per thread)
+    __shared__ __attribute__((aligned(16))) bf16 smem[3 * W_PLANE + 3 * P_PLANE];
+    bf16* sW = smem;
+    bf16* sP = smem + 3 * W_PLANE;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // ---- the filter, once -------------------------------------------------------------------------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, 3 * W_PLANE * 2u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < (3 * W_PLANE * 2 + 8191) / 8192; ++i) {   // 512 lanes x 16 bytes per instruction
+            const unsigned off = (unsigned)(i * 8192 + t * 16);
+            if (off < 3 * W_PLANE * 2u)                 // (masked lanes write nothing: the tail must not spill zeros over the patch)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(sW + i * 4096 + wave * 512),
+                                                         16, off, 0, 0, 0);
+        }
+    }
+    const unsigned x_bytes = (unsigned)((size_t)a.B * a.IH * a.IW * 16u);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    auto load_patch = [&](int blk) -> f32x4 {           // this thread's patch pixel of block blk (zero past the patch / image)
+        int bid = blk;
+        const int bx = bid % a.blocks_x;
+        bid /= a.blocks_x;
+        const int by = bid % a.blocks_y, n = bid / a.blocks_y;
+        const int pr = t / PW, pc = t - pr * PW;
+        int h = by * 16 + pr + a.off, w = bx * 16 + pc + a.off;
+        bool ok = t < PPIX;
+        if (a.reflect) {
+            h = reflect_idx(h, a.IH);
+            w = reflect_idx(w, a.IW);
+        } else {
+            ok = ok && (unsigned)h < (unsigned)a.IH && (unsigned)w < (unsigned)a.IW;
+        }
+        h = min(max(h, 0), a.IH - 1);
+        w = min(max(w, 0), a.IW - 1);
+        const unsigned off = (unsigned)((n * a.IH + h) * a.IW + w) * 16u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? off : 0x80000000u, 0, 0));
+    };
+    // fragment addressing: this wave's pixel tile: block pixel pb = wave*32 + l31 -> patch pixel (pb>>4)*PW + (pb&15)
+    const int pb = wave * 32 + l31;
+    const int pp0 = (pb >> 4) * PW + (pb & 15);
+    const int b_off = l31 * 16 + ((hi ^ ((l31 >> 3) & 1)) * 8);
+    const float slope = dwc_act_slope(a.act);
+    f32x4 bvs[2][4];                                    // bias vectors of this lane's columns, loaded once for all blocks
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+            bvs[c][q4] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c * 32 + 8 * q4 + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 pv = load_patch(blockIdx.x < (unsigned)a.nblocks ? blockIdx.x : 0);
+    for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
+        int bid = blk;
+        const int bx = bid % a.blocks_x;
+        bid /= a.blocks_x;
+        const int by = bid % a.blocks_y, n = bid / a.blocks_y;
+        const int oy0 = by * 16, ox0 = bx * 16;
+        __syncthreads();                                              // every wave is past the previous block's reads
+        {
+            u32x2 p0, p1, p2;
+            nx_split3(pv, p0, p1, p2);
+            *reinterpret_cast<u32x2*>(sP + t * 4) = p0;
+            *reinterpret_cast<u32x2*>(sP + P_PLANE + t * 4) = p1;
+            *reinterpret_cast<u32x2*>(sP + 2 * P_PLANE + t * 4) = p2;
+        }
+        if (blk + (int)gridDim.x < a.nblocks) pv = load_patch(blk + gridDim.x);      // in flight during this block's products
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (blk == (int)blockIdx.x) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the filter (first block only; also drains pv)
+        __syncthreads();
+
+        f32x16 acc[2], lo[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f, lo[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            const int ta = min(4 * j + 2 * hi, KS * KS - 1), tb = min(4 * j + 2 * hi + 1, KS * KS - 1);   // (taps >= 49: zero weights)
+            const int da = (ta / KS) * PW + ta % KS, db = (tb / KS) * PW + tb % KS;
+            bf16x8 fa[3], fb[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const u32x2 va = *reinterpret_cast<const u32x2*>(sP + pl * P_PLANE + (pp0 + da) * 4);
+                const u32x2 vb = *reinterpret_cast<const u32x2*>(sP + pl * P_PLANE + (pp0 + db) * 4);
+                fa[pl] = __builtin_bit_cast(bf16x8, u32x4{va[0], va[1], vb[0], vb[1]});
+#pragma unroll
+                for (int c = 0; c < 2; ++c) fb[pl][c] = *reinterpret_cast<const bf16x8*>(sW + pl * W_PLANE + (j * 64 + c * 32) * 16 + b_off);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][c], fa[0], acc[c], 0, 0, 0);
+                lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][c], fa[1], lo[c], 0, 0, 0);
+                lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][c], fa[0], lo[c], 0, 0, 0);
+                lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][c], fa[2], lo[c], 0, 0, 0);
+                lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][c], fa[1], lo[c], 0, 0, 0);
+                lo[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[2][c], fa[0], lo[c], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: D[channel][pixel]: lane = pixel, 4 consecutive channels per register quad: 16-byte fp32 stores ----------
+        const int yy = oy0 + (pb >> 4), xx = ox0 + (pb & 15);
+        if (yy < a.OH && xx < a.OW) {
+            float* d = a.y + ((size_t)(n * a.OH + yy) * a.OW + xx) * 64;
+            if (a.crop) {
+                const int cy = yy - a.crop, cx = xx - a.crop;
+                if ((unsigned)cy < (unsigned)a.CH && (unsigned)cx < (unsigned)a.CW) d = a.inner + ((size_t)(n * a.CH + cy) * a.CW + cx) * 64;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v = {acc[c][4 * q4] + lo[c][4 * q4], acc[c][4 * q4 + 1] + lo[c][4 * q4 + 1], acc[c][4 * q4 + 2] + lo[c][4 * q4 + 2],
+                               acc[c][4 * q4 + 3] + lo[c][4 * q4 + 3]};
+                    v += bvs[c][q4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = dwc_act_simple(v[k], slope);
+                    *reinterpret_cast<f32x4*>(d + c * 32 + 8 * q4 + 4 * hi) = v;
+                }
+        }
+    }
+#endif
+}
+
+// out[p][i] = plane p of the exact three-way bf16 split of (idx[i] < 0 ? 0 : src[idx[i]]): the prepared filter banks of the two
+// kernels above are a fixed permutation (+ zero padding) of the OIHW filter -- one launch per optimiser step instead of a dozen
+// torch ops (hipdwc.ops._prepped builds the index table once per layout)
+__global__ __launch_bounds__(256) void x3_gather_split_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                              unsigned short* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = idx[i];
+    const float v = k < 0 ? 0.f : src[k];
+    const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+    const float r1 = v - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    out[i] = (unsigned short)(hb >> 16);
+    out[(size_t)n + i] = (unsigned short)(mb >> 16);
+    out[2 * (size_t)n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+bool stem_x3_ok(int B, int IH, int IW, int OH, int OW, int K, int act) {
+    return B > 0 && K == 7 && IH >= 7 && IW >= 7 && OH > 0 && OW > 0 && act <= DWC_ACT_LRELU &&
+           (size_t)B * IH * IW * 16 < 0x80000000ull;
+}
+
 bool narrow_x3_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW) {
     return B > 0 && IH > 0 && IW > 0 && Cin == NX_CH && OH > 0 && OWg > 0 && KH == 7 && KWW == 14 &&
            (size_t)B * IH * IW * NX_CH * 4 < 0x7fffffffull;
@@ -273,6 +447,46 @@ int dwc_x3_conv2d_narrow(const float* x, const void* w_frag, const float* bias32
     else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+/* out (bf16, [3][n]) = the three planes of the exact split of src[idx[i]] (idx[i] < 0: zero), i < n: filter-bank preparation of
+ * dwc_x3_conv2d_narrow / dwc_x3_conv2d_stem from an index table (a fixed permutation + padding of the OIHW filter). */
+int dwc_x3_gather_split(const float* src, const int* idx, void* out, int n, void* stream) {
+    if (!src || !idx || !out || n <= 0) return DWC_EINVAL;
+    hipLaunchKernelGGL(x3_gather_split_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, (unsigned short*)out, n);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_x3_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act) { return stem_x3_ok(B, IH, IW, OH, OW, K, act) ? 1 : 0; }
+
+/* bf16 elements of the split filter of dwc_x3_conv2d_stem: [3 planes][13 k-steps][64 channels][16] */
+size_t dwc_x3_conv2d_stem_weight_elems(void) { return (size_t)3 * 13 * 64 * 16; }
+
+/* y[B][OH][OW][64] (fp32) = act(conv7x7(x[B][IH][IW][4 planes] fp32) + bias) as split products, window of output (oy, ox) starting
+ * at (oy + off, ox + off); reflect != 0: reflect rule (stems forward, off = -3), else zero rule (data gradient of the image heads on
+ * the padded grid, off = -6).  act: none / relu / lrelu.  w_steps: the OIHW filter [64][4][7][7] as three exact bf16 planes
+ * [plane][13][64][16]: element (k-step j, channel co, tap 4j + 2h + t, image plane p) at ((h ^ ((co>>3)&1))*8 + 4t + p), taps
+ * beyond 48 zero (built by the caller).  crop > 0: output pixels whose cropped coordinate lies inside (OH - 2 crop) x (OW - 2 crop)
+ * go to `inner` ([B][OH-2crop][OW-2crop][64]) instead of y (see dwc_bf16_conv2d_stem_crop). */
+int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bias, float* y, float* inner, int crop, int B, int IH, int IW,
+                            int OH, int OW, int K, int off, int act, int reflect, void* stream) {
+    if (!x || !w_steps || !y || !stem_x3_ok(B, IH, IW, OH, OW, K, act) || crop < 0 || (crop > 0 && (!inner || OH <= 2 * crop || OW <= 2 * crop)))
+        return DWC_EINVAL;
+    StemX3Args a;
+    a.x = x; a.w = (const bf16*)w_steps; a.bias = bias; a.y = y;
+    a.crop = crop; a.CH = OH - 2 * crop; a.CW = OW - 2 * crop; a.inner = inner;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.off = off; a.act = act; a.reflect = reflect;
+    a.blocks_x = (OW + 15) / 16; a.blocks_y = (OH + 15) / 16; a.nblocks = a.blocks_x * a.blocks_y * B;
+    const int grid = a.nblocks < 256 ? a.nblocks : 256;              // one persistent workgroup per CU (the filter alone is 78 KB)
+    hipLaunchKernelGGL(conv_stem_x3_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, float* y, int B, int IH, int IW, int OH, int OW, int K,
+                       int off, int act, int reflect, void* stream) {
+    return dwc_x3_conv2d_stem_crop(x, w_steps, bias, y, nullptr, 0, B, IH, IW, OH, OW, K, off, act, reflect, stream);
 }
 
 }  // extern "C"

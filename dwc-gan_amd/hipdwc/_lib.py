@@ -121,6 +121,12 @@ SIGNATURES = {
     "dwc_x3_conv2d_narrow_weight_elems": (c_sz, [c_int] * 2),
     "dwc_x3_conv2d_narrow": (c_int, [c_fp] * 4 + [c_int] * 12 + [c_fp]),
     "dwc_reflect_pad_adjoint_pitch": (c_int, [c_fp, c_fp] + [c_int] * 6 + [c_fp]),
+    "dwc_x3_gather_split": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
+    "dwc_x3_conv2d_stem_ok": (c_int, [c_int] * 7),
+    "dwc_x3_conv2d_stem_weight_elems": (c_sz, []),
+    "dwc_x3_conv2d_stem": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
+    "dwc_x3_conv2d_stem_crop": (c_int, [c_fp] * 5 + [c_int] * 10 + [c_fp]),
+    "dwc_reflect_pad_adjoint_band": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_x3_conv2d_ksplit_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_x3_conv2d_ksplit_ticket_words": (c_int, []),
     "dwc_x3_conv2d_same_add_ws": (c_int, [c_fp] * 5 + [c_int] * 9 + [c_fp, c_sz, c_fp, c_fp]),

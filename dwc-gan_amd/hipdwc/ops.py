@@ -204,6 +204,43 @@ def _padc(n, dtype):
 _WCACHE = {}   # id(tensor) -> (weakref to it, {layout key: (version, prepared tensor)})
 
 
+_X3_BANK_IDX = {}      # (kind, filter shape, pads, device) -> int32 gather table of a split filter bank (see _prepped)
+
+
+def _x3_bank_recipe(kind, w, cout_pad, cin_pad):
+    """fp32 filter (or its element numbers) -> the UNSPLIT bank of csrc/conv_narrow_x3.hip in the kernels' element order.
+    stem_steps*: [13 k-steps][64 channels][(h ^ ((co>>3)&1))*8 + 4t + p] with tap = 4j + 2h + t (stem_steps_x3: w is the stem
+    filter [64][P<=4][7][7]; stem_steps_dgrad_x3: the heads filter [P<=4][64][7][7], rotated and transposed).
+    heads_narrow_x3 / dgrad_image_narrow_x3: the wide bank [32][64][7][14] (8 pixels x 4 planes, copy p = the filter shifted right
+    by p taps) as [slab q of 16 channels][tap, 98 padded to 104 with zeros][lane = half*32 + bank row][8 channels 16q + 8*half ..]."""
+    if kind in ("stem_steps_x3", "stem_steps_dgrad_x3"):
+        wf = w.float()
+        if kind == "stem_steps_dgrad_x3":
+            wf = wf.flip(2, 3).permute(1, 0, 2, 3)                      # [64][P][7][7]
+        co, pl, kh, kw = wf.shape
+        assert co == 64 and pl <= 4 and kh == 7 and kw == 7
+        bank = torch.zeros((64, 52, 4), dtype=torch.float32, device=w.device)      # [co][tap (49 + 3 zero)][plane]
+        bank[:, :49, :pl] = wf.permute(0, 2, 3, 1).reshape(64, 49, pl)
+        steps = bank.view(64, 13, 2, 8).permute(1, 0, 2, 3).contiguous()           # [j][co][h][t*4 + p]
+        swap = ((torch.arange(64, device=w.device) >> 3) & 1).bool()
+        steps[:, swap] = steps[:, swap].flip(2)
+        return steps.reshape(13, 64, 16)
+    if kind == "heads_narrow_x3":
+        px = 32 // w.shape[0]
+        bank = _shifted_bank(w.float(), px).reshape(32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
+    else:
+        co, ci, kh, kw = w.shape
+        px = 32 // cin_pad
+        wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
+        wf[:ci, :co] = w.float().flip(2, 3).permute(1, 0, 2, 3)
+        bank = _shifted_bank(wf, px).reshape(px * cin_pad, cout_pad, kh, kw + px - 1)
+    rows_, ch, kh, kww = bank.shape
+    assert rows_ == 32 and ch == 64
+    v = bank.permute(2, 3, 1, 0).reshape(kh * kww, 4, 2, 8, 32).permute(1, 0, 2, 4, 3)                  # [q][tap][half][row][8]
+    ntp = (kh * kww + 7) // 8 * 8
+    return torch.nn.functional.pad(v.reshape(4, kh * kww, 512), (0, 0, 0, ntp - kh * kww))
+
+
 def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
     """Re-laid-out copy of an OIHW weight; recomputed only when the parameter changed
     (optimizer steps bump ``_version``).  ``owner``: the parameter(s) ``w`` was derived from when ``w`` itself is a
@@ -277,38 +314,37 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         out = steps.reshape(25, 64, 16).to(BF16).contiguous()
         ent[key] = (stamp, out)
         return out
+    if kind in ("stem_steps_x3", "stem_steps_dgrad_x3", "heads_narrow_x3", "dgrad_image_narrow_x3"):
+        # Split filter banks of csrc/conv_narrow_x3.hip: a fixed permutation (+ zero padding) of the OIHW filter, split into three
+        # exact bf16 planes.  The permutation is built ONCE per layout as an index table (the torch recipe below applied to the
+        # element numbers); every later refresh is one launch (dwc_x3_gather_split).
+        ikey = (kind, tuple(w.shape), cout_pad, cin_pad, str(w.device))
+        idx = _X3_BANK_IDX.get(ikey)
+        if idx is None:
+            num = (torch.arange(w.numel(), dtype=torch.float32, device=w.device) + 1.0).view(w.shape)      # 0 = "zero element"
+            idx = (_x3_bank_recipe(kind, num, cout_pad, cin_pad).reshape(-1).round().to(torch.int32) - 1).contiguous()
+            _X3_BANK_IDX[ikey] = idx
+        n = idx.numel()
+        src = w.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        out = torch.empty(3 * n, dtype=BF16, device=w.device)
+        _lib.check(lib.dwc_x3_gather_split(src.data_ptr(), idx.data_ptr(), out.data_ptr(), n, _stream()), "x3_gather_split")
+        if kind.startswith("stem_steps"):
+            assert out.numel() == lib.dwc_x3_conv2d_stem_weight_elems()             # [plane][13][64][16]
+        else:
+            # [plane][q][tap][lane][8] -> the kernel's [q][tap][plane][lane][8]
+            ntp = n // (4 * 512)
+            out = out.view(3, 4, ntp, 512).permute(1, 2, 0, 3).contiguous().view(-1)
+            assert out.numel() == lib.dwc_x3_conv2d_narrow_weight_elems(7, 14)
+        ent[key] = (stamp, out)
+        return out
     if kind in ("heads_narrow", "dgrad_image_narrow"):
         # the wide bank ([32][taps*64] prepared rows) in MFMA-fragment order [tap][q][hi][row][8] for csrc/conv_narrow_bf16.hip
         base = _prepped(w, "heads_wide" if kind == "heads_narrow" else "dgrad_image", cout_pad, cin_pad, stride, owner, True)
         ch = cout_pad if kind == "dgrad_image_narrow" else cin_pad          # contraction channels (64)
         taps = base.numel() // (32 * ch)
         out = base.view(32, taps, ch // 16, 2, 8).permute(1, 2, 3, 0, 4).contiguous()
-        ent[key] = (stamp, out)
-        return out
-    if kind in ("heads_narrow_x3", "dgrad_image_narrow_x3"):
-        # csrc/conv_narrow_x3.hip: the fp32 wide bank [32][64][KH][KW+7] (8 pixels x 4 planes; copy p = the filter shifted right by
-        # p taps) as three exact bf16 planes (v = hi + mid + lo: truncate, subtract, truncate, subtract) in MFMA-fragment order
-        # [slab q of 16 channels][tap][plane][lane = half*32 + bank row][8 channels 16q + 8*half ..]
-        if kind == "heads_narrow_x3":
-            px = 32 // w.shape[0]
-            bank = _shifted_bank(w.detach().float(), px).reshape(32, w.shape[1], w.shape[2], w.shape[3] + px - 1)
-        else:
-            co, ci, kh, kw = w.shape
-            px = 32 // cin_pad
-            wf = torch.zeros((cin_pad, cout_pad, kh, kw), dtype=torch.float32, device=w.device)
-            wf[:ci, :co] = w.detach().flip(2, 3).permute(1, 0, 2, 3)
-            bank = _shifted_bank(wf, px).reshape(px * cin_pad, cout_pad, kh, kw + px - 1)
-        rows_, ch, kh, kww = bank.shape
-        assert rows_ == 32 and ch == 64
-        v = bank.permute(2, 3, 1, 0).reshape(kh * kww, 4, 2, 8, 32).permute(1, 0, 2, 4, 3).contiguous()    # [q][tap][half][row][8]
-        hi_ = (v.view(torch.int32) & -65536).view(torch.float32)
-        r_ = v - hi_
-        mid_ = (r_.view(torch.int32) & -65536).view(torch.float32)
-        lo_ = r_ - mid_
-        out = torch.stack([hi_, mid_, lo_], 2).to(BF16)                                                     # [q][tap][plane][half][row][8]
-        ntp = (kh * kww + 7) // 8 * 8                                                                       # taps padded with zeros: 13 per wave
-        out = torch.nn.functional.pad(out.reshape(4, kh * kww, 3 * 64 * 8), (0, 0, 0, ntp - kh * kww)).reshape(-1).contiguous()
-        assert out.numel() == lib.dwc_x3_conv2d_narrow_weight_elems(kh, kww)
         ent[key] = (stamp, out)
         return out
     if kind == "heads_wide":
@@ -603,7 +639,9 @@ class _Conv2d(torch.autograd.Function):
         use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         use_stem = bool(half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
                         and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H, W, KH, act))
-        w_hwio = None if use_wino or use_x3 or use_x3s2 or use_stem else _prepped(w, "fwd", cop, Cx, stride, owner, half)
+        use_stem_x3 = bool((not half) and X3 and NARROW_X3 and Cx == 4 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
+                           and lib.dwc_x3_conv2d_stem_ok(B, H, W, H, W, KH, act))
+        w_hwio = None if use_wino or use_x3 or use_x3s2 or use_stem or use_stem_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -636,6 +674,12 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_ws(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, _p(ks_ws), ks_n, ks_t, st),
                 detail="fwd-x3s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_s2")
+        elif use_stem_x3:
+            # fp32 7x7 stem on an NHWC4 image as split products: filter planes resident in LDS, persistent workgroups (csrc/conv_narrow_x3.hip)
+            w_st = _prepped(w, "stem_steps_x3", cop, Cx, 1, owner)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_stem(
+                x.data_ptr(), w_st.data_ptr(), _p(bias), y.data_ptr(), B, H, W, H, W, KH, -pad, act, 1, st),
+                detail="fwd-stem-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_stem")
         elif use_stem:
             # 7x7 stem on an NHWC8 image: filter resident in LDS, persistent workgroups (csrc/conv_narrow_bf16.hip)
             w_st = _prepped(w, "stem_steps", cop, Cx, 1, owner, True)
@@ -981,6 +1025,18 @@ class _HeadsConvWide(torch.autograd.Function):
                     g.data_ptr(), w_st.data_ptr(), None, base, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0, st),
                     scope_name=ctx.bscope, detail="dgrad-heads-stem B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv2d_stem dgrad")
                 _lib.check(lib.dwc_bf16_reflect_pad_adjoint(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint")
+        elif (ctx.needs_input_grad[0] and (not half) and X3 and NARROW_X3 and P == 4 and C == 64 and KH == 7 and KW == 7
+              and DGRAD_FOLD and min(H, W) >= 2 * pad + 2 and lib.dwc_x3_conv2d_stem_ok(B, H, W, H + 2 * pad, W + 2 * pad, KH, 0)):
+            # fp32: the same as split products (conv_stem_x3_kernel): interior of the padded gradient image straight into dx, its
+            # border ring through the scratch image + band fold
+            w_st = _prepped(w4, "stem_steps_dgrad_x3", 64, P, 1, ctx.owner)
+            dx = empty_cl(B, C, H, W, dev, x.dtype)
+            base = workspace(B * (H + 2 * pad) * (W + 2 * pad) * C * 4, dev).data_ptr()
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_stem_crop(
+                g.data_ptr(), w_st.data_ptr(), None, base, dx.data_ptr(), pad, B, H, W, H + 2 * pad, W + 2 * pad, KH, -(KH - 1), 0, 0,
+                st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-heads-stem-x3 B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)),
+                "x3_conv2d_stem dgrad")
+            _lib.check(lib.dwc_reflect_pad_adjoint_band(base, dx.data_ptr(), B, H, W, C, pad, st), "reflect_pad_adjoint_band")
         elif ctx.needs_input_grad[0]:        # data gradient: the ordinary P-channel formulation (N = C columns)
             w_dg = _prepped(w4, "dgrad", P, C, 1, ctx.owner, half)
             dx = empty_cl(B, C, H, W, dev, x.dtype)

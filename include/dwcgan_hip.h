@@ -360,6 +360,20 @@ size_t dwc_x3_conv2d_narrow_weight_elems(int KH, int KWW);
 int dwc_x3_conv2d_narrow(const float* x, const void* w_frag, const float* bias32, float* y, int B, int IH, int IW, int Cin, int OH,
                          int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
 int dwc_reflect_pad_adjoint_pitch(const float* dxp, float* dx, int B, int H, int W, int C, int pad, int pitch, void* stream);
+/* fp32 7x7 convolutions from the 4 planes of an NHWC4 image to 64 channels as split products (conv_narrow_x3.hip, r04; the fp32 twin
+ * of dwc_bf16_conv2d_stem): the stems forward (reference networks.py:163-166 / :60-66; reflect rule, off = -3) and the data
+ * gradient of the image heads (zero rule on the padded grid, off = -6; with crop = pad the interior goes straight to `inner` and
+ * only the border ring to y, folded by dwc_reflect_pad_adjoint_band).  w_steps: the OIHW filter [64][4][7][7] as three exact bf16
+ * planes [plane][13 k-steps][64][16], element (k-step j, channel co, tap 4j + 2h + t, image plane p) at
+ * ((h ^ ((co>>3)&1))*8 + 4t + p), taps beyond 48 zero.  act: none / relu / lrelu. */
+int dwc_x3_gather_split(const float* src, const int* idx, void* out_3planes, int n, void* stream);   /* out[p][i] = plane p of src[idx[i]] (idx < 0: 0) */
+int dwc_x3_conv2d_stem_ok(int B, int IH, int IW, int OH, int OW, int K, int act);
+size_t dwc_x3_conv2d_stem_weight_elems(void);
+int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, float* y, int B, int IH, int IW, int OH, int OW, int K,
+                       int off, int act, int reflect, void* stream);
+int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bias, float* y, float* inner, int crop, int B, int IH, int IW,
+                            int OH, int OW, int K, int off, int act, int reflect, void* stream);
+int dwc_reflect_pad_adjoint_band(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream);
 /* Small launches (r04): when a shape yields at most 256 tiles of 256 pixels x 64 channels (3x3 256->256 on 32x32 at batch 16) the
  * two-workgroups-per-CU kernel would run one workgroup per CU; the _ws forms cut such launches along the CONTRACTION instead --
  * two workgroups per tile, each half of the channel slabs; the first to finish leaves its half sum in `ws`, the second adds it to
