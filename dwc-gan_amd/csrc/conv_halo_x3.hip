@@ -911,7 +911,7 @@ void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
 
 // Contraction split of the two-per-CU tile (conv_halo_x3_kernel, KSP == 2): launches of at most X3_KSPLIT_TILES tiles whose slab
 // count is even and long enough to be worth halving.  DWC_X3_KSPLIT=0 switches it off.
-constexpr int X3_KSPLIT_TILES = 256;
+constexpr int X3_KSPLIT_TILES = 256, X3_KSPLIT_TICKETS = 512;
 constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
 // Number of tiles that run whole (a multiple of 8; the remaining tiles - split_from <= 256 are split), or -1: the launch is not
 // split.  512 = the workgroups resident at once (two per CU): a last round of at most 256 tiles is the one worth halving.
@@ -920,8 +920,11 @@ constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
 long x3_ksplit_from(long tiles, int slabs) {
     static const int on = getenv("DWC_X3_KSPLIT") ? atoi(getenv("DWC_X3_KSPLIT")) : 1;
     if (!on || slabs < 8 || (slabs & 1) || (tiles & 7)) return -1;                              // (tiles % 8: pairs share an XCD)
+    // (DWC_X3_KSPLIT_TILES: the largest launch that is split whole; 256 = launches that would run one workgroup per CU)
+    static const int whole = getenv("DWC_X3_KSPLIT_TILES") ? atoi(getenv("DWC_X3_KSPLIT_TILES")) : X3_KSPLIT_TILES;
+    if (tiles <= whole && tiles <= X3_KSPLIT_TICKETS) return 0;
     const long tail = tiles % 512;
-    if (tail == 0 || tail > X3_KSPLIT_TILES || (tiles > X3_KSPLIT_TILES && on < 2)) return -1;
+    if (tail == 0 || tail > X3_KSPLIT_TILES || on < 2) return -1;
     return tiles - tail;
 }
 bool x3_ksplit_on(long tiles, int slabs) { return x3_ksplit_from(tiles, slabs) >= 0; }
@@ -999,7 +1002,7 @@ size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K,
     const long tiles = (long)B * (H / TB) * (W / TB) * ((N + 63) / 64);
     return x3_ksplit_bytes(tiles, Cin / CS);
 }
-int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TILES; }
+int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS; }
 
 /* dwc_x3_conv2d_same_add with the scratch of the contraction split: ws / tickets may be NULL (or ws_bytes too small), the launch
  * then runs unsplit.  Results do not depend on which form ran beyond fp32 summation order (two half sums instead of one). */
