@@ -57,11 +57,11 @@ struct NarrowX3Args {
     int blocks_x, blocks_y;
 };
 
-// MT: 32-group tiles per workgroup (8 rows each).  1: 70 KB of LDS, <= 128 registers, two workgroups per CU.  2: 16 rows, 110 KB,
-// one workgroup per CU -- every weight fragment (1 KB per wave, tap, slab and plane, streamed from L2: 1.2 MB per block) feeds two
-// tiles: the MT = 1 form is bound by exactly that stream (2.4 MB per CU and ~20 us: ~12 TB/s over the chip).
-template <int KH, int KWW, int MT>
-__global__ __launch_bounds__(512, MT == 1 ? 2 : 1) void conv_narrow_x3_kernel(NarrowX3Args a) {
+// MT: 32-group tiles per workgroup (8 rows each).  1: 70 KB of LDS, <= 128 registers (PF = 1), two workgroups per CU.  2: 16 rows,
+// 110 KB, one workgroup per CU -- every weight fragment (1 KB per wave, tap, slab and plane, streamed from L2: 1.2 MB per block)
+// feeds two tiles.  Measured equal within 2 % once the weight loads are really in flight ahead of their use (see load_item).
+template <int KH, int KWW, int MT, int PF>      // PF: weight fragment sets in flight ahead of the one being multiplied (1 or 2)
+__global__ __launch_bounds__(512, MT == 1 && PF == 1 ? 2 : 1) void conv_narrow_x3_kernel(NarrowX3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NX_ROWS = 8 * MT, NX_CS = 16;
     constexpr int PR = NX_ROWS + KH - 1, PC = 8 * NX_GROUPS + KWW - 1, PPIX = PR * PC;
@@ -149,16 +149,37 @@ __global__ __launch_bounds__(512, MT == 1 ? 2 : 1) void conv_narrow_x3_kernel(Na
     // (taps >= KH*KWW carry zero weights) and the 4 x 13 steps are unrolled, so the set of a step is a compile-time index.  (The
     // first version rotated by copying; the copy of the set loaded in the SAME iteration drained vmcnt to 0 at every tap.)
     constexpr int NT_W = (NTAP + 7) / 8, NTAP_P = 8 * NT_W, N_ITEMS = NSLAB * NT_W;
-    bf16x8 wset[3][3];
+    bf16x8 wset[PF + 1][3];
+    // The weight loads are asm statements with hand-counted waits tied to the fragment registers (wait_item): as plain loads hipcc
+    // sinks every one of them to just in front of its first use (the kernel is at 124 registers), and a step then waits out a whole
+    // L2 round trip -- 52 of them in a row per block, ~49 us per pair of resident blocks whatever the tile size or the prefetch
+    // distance written in the source.  Invisible to the compiler's own vmcnt bookkeeping (the patch gather), they can only make ITS
+    // waits longer, never shorter.
     auto load_item = [&](int j, bf16x8 (&dst)[3]) {     // item j = (slab j / NT_W, tap wave + 8 * (j % NT_W))
         const int qq = j / NT_W;
         const bf16* src = wlane + ((size_t)(qq * NTAP_P + wave + 8 * (j - qq * NT_W)) * 3) * 512;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const bf16x8*>(src + pl * 512);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(src));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(dst[1]) : "v"(src));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(dst[2]) : "v"(src));
+    };
+    // vm operations issued AFTER the loads of the item about to be used: the two items ahead (3 loads each) and, for the first two
+    // steps of a slab, the PPASS gather loads of the next slab's patch issued at the slab's top
+    auto wait_item = [&](bf16x8 (&cur)[3], int younger) {
+#define DWC_NX_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]))
+        static_assert(PPASS <= 10, "vmcnt immediates below");
+        switch (younger) {
+            case 0: DWC_NX_WAIT(0); break;
+            case 3: DWC_NX_WAIT(3); break;
+            case 6: DWC_NX_WAIT(6); break;
+            case 3 + PPASS: if (PPASS == 5) DWC_NX_WAIT(8); else DWC_NX_WAIT(3); break;
+            case 6 + PPASS: if (PPASS == 5) DWC_NX_WAIT(11); else DWC_NX_WAIT(6); break;
+            default: DWC_NX_WAIT(0); break;
+        }
+#undef DWC_NX_WAIT
     };
     load_patch(0);
     load_item(0, wset[0]);
-    load_item(1, wset[1]);
+    if (PF == 2) load_item(1, wset[PF == 2 ? 1 : 0]);
     write_patch();
 #pragma unroll
     for (int q = 0; q < NSLAB; ++q) {
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(512, MT == 1 ? 2 : 1) void conv_narrow_x3_kernel(Na
             constexpr int dummy = 0;
             (void)dummy;
             const int item = q * NT_W + j;
-            if (item + 2 < N_ITEMS) load_item(item + 2, wset[(item + 2) % 3]);
+            if (item + PF < N_ITEMS) load_item(item + PF, wset[(item + PF) % (PF + 1)]);
             const int tp = wave + 8 * j;
             int kh = tp / KWW, u = tp - kh * KWW;
             if (tp >= NTAP) kh = 0, u = 0;              // padding tap: zero weights, any patch pixel
@@ -181,7 +202,8 @@ __global__ __launch_bounds__(512, MT == 1 ? 2 : 1) void conv_narrow_x3_kernel(Na
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) fa[m][pl] = *reinterpret_cast<const bf16x8*>(p + m * 8 * PITCH_S * 8 + pl * P_PLANE);
             // D[column][group]: planes (weight, patch); the leading product apart from the five corrections (conv_halo_x3.hip)
-            bf16x8 (&cur)[3] = wset[item % 3];
+            bf16x8 (&cur)[3] = wset[item % (PF + 1)];
+            wait_item(cur, (item + 1 < N_ITEMS ? 3 : 0) + (PF == 2 && item + 2 < N_ITEMS ? 3 : 0) + ((j < PF && q + 1 < NSLAB) ? PPASS : 0));
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], fa[m][0], acc[m], 0, 0, 0);
@@ -443,8 +465,16 @@ int dwc_x3_conv2d_narrow(const float* x, const void* w_frag, const float* bias32
     a.blocks_y = (OH + rows - 1) / rows;
     const dim3 grid(a.blocks_x * a.blocks_y * B);
     (void)blocks16;
-    if (rows == 16) hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    // weight fragment sets ahead: 1 (120 registers: two 8-row workgroups per CU; measured per c1 step, heads forward + image gradient:
+    // 8 rows 1.17 ms at one set ahead, 1.26 at two; 16 rows 1.16 / 1.17) -- DWC_X3_NARROW_PF=2 selects two
+    static const int pf = getenv("DWC_X3_NARROW_PF") ? atoi(getenv("DWC_X3_NARROW_PF")) : 1;
+    if (rows == 16) {
+        if (pf == 1) hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 2, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 2, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    } else {
+        if (pf == 1) hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
+    }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
