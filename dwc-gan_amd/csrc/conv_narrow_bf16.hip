@@ -30,7 +30,8 @@ constexpr int NB_GROUPS = 8, NCH = 64;
 
 struct NarrowArgs {
     const bf16* x;       // [B][IH][IW][64]
-    const bf16* w;       // [tap][q][lane][8]: MFMA-fragment order of the wide bank (one contiguous 1 KB read per wave and k-step)
+    const bf16* w;       // [tap, padded to a multiple of 8 with zeros][q][lane][8]: MFMA-fragment order of the wide bank (one contiguous
+                         // 1 KB read per wave and k-step)
     const float* bias;   // [32] or null
     bf16* y;             // [B][OH][OWg][32]
     int B, IH, IW, OH, OWg, off_h, off_w, act, reflect;
@@ -107,18 +108,32 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
     // (read in the prepared [32][Kp] layout a load instruction touched 64 different cache lines -- 17 us per block, all of it
     // address traffic; fragment order makes it one contiguous kilobyte)
     const bf16* wlane = a.w + lane * 8;
-    bf16x8 fb[4], fbn[4];
-    auto load_w = [&](int tp, bf16x8* dst) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const bf16x8*>(wlane + (tp * 4 + q) * 512);
+    // Weight fragments one tap ahead, two fragment sets rotating by NAME: the tap list is padded to NT_W taps per wave (taps >= NTAP
+    // carry zero weights) and the NT_W steps are unrolled, so the set of a step is a compile-time index; the loads are asm statements
+    // with hand-counted waits tied to the fragment registers.  (r04.  The first form copied the prefetched set into the working one at
+    // the end of every tap -- which drains vmcnt to 0 in front of the copy -- and as plain loads hipcc sinks them to their first use
+    // anyway: every tap waited out an L2 round trip, see conv_narrow_x3.hip.)
+    constexpr int NT_W = (NTAP + 7) / 8;
+    bf16x8 wset[2][4];
+    auto load_item = [&](int j, bf16x8 (&dst)[4]) {
+        const bf16* src = wlane + (size_t)(wave + 8 * j) * 4 * 512;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(src));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(dst[1]) : "v"(src));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(dst[2]) : "v"(src));
+        asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(dst[3]) : "v"(src));
     };
-    if (wave < NTAP) load_w(wave, fb);
+    load_item(0, wset[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                    // patch landed (every wave's share)
-    for (int tp = wave; tp < NTAP; tp += 8) {
-        const bool more = tp + 8 < NTAP;
-        if (more) load_w(tp + 8, fbn);
-        const int kh = tp / KWW, u = tp - kh * KWW;
+#pragma unroll
+    for (int j = 0; j < NT_W; ++j) {
+        if (j + 1 < NT_W) load_item(j + 1, wset[(j + 1) & 1]);
+        bf16x8 (&fb)[4] = wset[j & 1];
+        if (j + 1 < NT_W) asm volatile("s_waitcnt vmcnt(4)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+        const int tp = wave + 8 * j;
+        int kh = tp / KWW, u = tp - kh * KWW;
+        if (tp >= NTAP) kh = 0, u = 0;                  // padding tap: zero weights, any patch pixel
         const int d = kh * PC + u;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -130,10 +145,6 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
                 const bf16x8 fa = *reinterpret_cast<const bf16x8*>(p + (((2 * q + hi) ^ sw) << 3));
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[q], fa, acc[m], 0, 0, 0);      // D[column][group]
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fb[q] = fbn[q];
         }
     }
 
@@ -604,8 +615,8 @@ int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, i
 
 /* y[B][OH][OWg][32] (bf16; 4 pixels x 8 planes per group) = act(sum over the KH x KWW wide taps and 64 channels + bias32) with
  * the input window of (oy, gx) starting at (oy + off_h, 4*gx + off_w) of x[B][IH][IW][64].  w_frag = the [32][KH][KWW][64]
- * wide bank in MFMA-fragment order [tap][q][hi][row][8] (tap = kh*KWW + u, q = 16-channel step, hi = 8-channel half):
- * dwc_bf16_weight_prepare_fwd's [32][Kp] layout permuted.  reflect != 0: reflect rule (forward heads), else zero rule (image
+ * wide bank in MFMA-fragment order [tap][q][hi][row][8] (tap = kh*KWW + u, q = 16-channel step, hi = 8-channel half), the tap
+ * count rounded up to a multiple of 8 with ZERO taps (r04): dwc_bf16_weight_prepare_fwd's [32][Kp] layout permuted + padded.  reflect != 0: reflect rule (forward heads), else zero rule (image
  * gradient on the padded grid). */
 int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream) {

@@ -344,7 +344,8 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         base = _prepped(w, "heads_wide" if kind == "heads_narrow" else "dgrad_image", cout_pad, cin_pad, stride, owner, True)
         ch = cout_pad if kind == "dgrad_image_narrow" else cin_pad          # contraction channels (64)
         taps = base.numel() // (32 * ch)
-        out = base.view(32, taps, ch // 16, 2, 8).permute(1, 2, 3, 0, 4).contiguous()
+        out = base.view(32, taps, ch // 16, 2, 8).permute(1, 2, 3, 0, 4).reshape(taps, -1)
+        out = torch.nn.functional.pad(out, (0, 0, 0, (taps + 7) // 8 * 8 - taps)).contiguous()      # zero taps: every wave walks the same count
         ent[key] = (stamp, out)
         return out
     if kind == "heads_wide":

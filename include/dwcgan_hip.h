@@ -499,7 +499,8 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
  * reflect rule, DWC_ACT_HEADS8) and the gradient of a 7x7 stem w.r.t. its input image on the padded grid (off = -6, zero
  * rule; dwc_bf16_conv2d_bwd_data_image_narrow = that + the reflect fold).  Patch staged once per 16x32-pixel block, taps dealt
  * to the waves, weight fragments straight from L2 in fragment order w_frag[tap][q][hi][row][8] (the [32][Kp] layout of
- * dwc_bf16_weight_prepare_fwd permuted by the caller).  y: [B][OH][OWg][32] bf16. */
+ * dwc_bf16_weight_prepare_fwd permuted by the caller; r04: the tap count rounded up to a multiple of 8 with ZERO taps, 72 for
+ * KH x KWW = 7 x 10, so that every wave walks the same number of taps).  y: [B][OH][OWg][32] bf16. */
 int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW);
 int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
