@@ -920,9 +920,8 @@ constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
 long x3_ksplit_from(long tiles, int slabs) {
     static const int on = getenv("DWC_X3_KSPLIT") ? atoi(getenv("DWC_X3_KSPLIT")) : 1;
     if (!on || slabs < 8 || (slabs & 1) || (tiles & 7)) return -1;                              // (tiles % 8: pairs share an XCD)
-    // (DWC_X3_KSPLIT_TILES: the largest launch that is split whole; 256 = launches that would run one workgroup per CU)
-    static const int whole = getenv("DWC_X3_KSPLIT_TILES") ? atoi(getenv("DWC_X3_KSPLIT_TILES")) : X3_KSPLIT_TILES;
-    if (tiles <= whole && tiles <= X3_KSPLIT_TICKETS) return 0;
+    // (launches of up to 512 tiles split whole were measured too: no gain at 5x5 batch 16, worse at 3x3 batch 32 and stride 2)
+    if (tiles <= X3_KSPLIT_TILES) return 0;
     const long tail = tiles % 512;
     if (tail == 0 || tail > X3_KSPLIT_TILES || on < 2) return -1;
     return tiles - tail;
@@ -933,14 +932,8 @@ size_t x3_ksplit_bytes(long tiles, int slabs) {
     return from < 0 ? 0 : (size_t)(tiles - from) * X3_KSPLIT_TILE_BYTES;
 }
 
-// patch buffers of the stride-2 forms (two-per-CU tile).  DWC_X3_S2_PB=2: the next slab's patch is converted beside the taps of the
-// current one (a slab is only 4 taps there; 81.7 KB of LDS, still two per CU) -- measured equal to the conversion at the slab
-// boundary (B = 48: 261.2 / 264.2 against 260.1 / 265.6 us), so the smaller footprint stays the default
-int x3_s2_pb() {
-    static const int pb = getenv("DWC_X3_S2_PB") ? atoi(getenv("DWC_X3_S2_PB")) : 1;
-    return pb == 2 ? 2 : 1;
-}
-
+// (A second patch buffer in the stride-2 forms -- PB = 2 with the two-per-CU tile: 81.7 KB of LDS, still two per CU -- was measured
+// equal to the conversion at the slab boundary, B = 48: 261.2 / 264.2 against 260.1 / 265.6 us; not instantiated.)
 bool x3_s2_ok(int B, int H, int W, int Cin, int N) {
     return B > 0 && H >= 2 * TB && W >= 2 * TB && !(H % (2 * TB)) && !(W % (2 * TB)) && Cin >= CS && !(Cin % CS) && N >= 32 && !(N % 4) &&
            (size_t)B * H * W * Cin < 0x7fffffffull;
@@ -1123,8 +1116,6 @@ int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bia
         const int tiles = B * a.blocks_per_img * a.tiles_n;
         a.split_from = (int)x3_ksplit_from(tiles, 4 * (Cin / CS));
         x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * tiles - a.split_from), (hipStream_t)stream);
-    } else if (x3_s2_pb() == 2) {
-        x3_launch<2, 64, 4, 1, 2, 2, 0, 2, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     } else {
         x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     }
@@ -1148,8 +1139,7 @@ int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx
     a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = Cin / 64;
-    if (x3_s2_pb() == 2) x3_launch<2, 64, 4, 1, 2, 2, 0, 2, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
-    else x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

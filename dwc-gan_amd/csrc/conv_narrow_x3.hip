@@ -454,27 +454,11 @@ int dwc_x3_conv2d_narrow(const float* x, const void* w_frag, const float* bias32
     a.x = x; a.w = (const bf16*)w_frag; a.bias = bias32; a.y = y;
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg;
     a.off_h = off_h; a.off_w = off_w; a.act = act; a.reflect = reflect;
-    // rows per workgroup: 16 (every weight fragment feeds two tiles: the kernel is bound by that stream) unless the launch would then
-    // leave CUs idle; DWC_X3_NARROW_ROWS=8|16 pins it
-    static const int force = getenv("DWC_X3_NARROW_ROWS") ? atoi(getenv("DWC_X3_NARROW_ROWS")) : 0;
+    // 8 rows per workgroup, weight fragments one set ahead (120 registers: two workgroups per CU).  Measured per c1 step, heads forward +
+    // image gradient: 1.17 ms; two sets ahead (132 registers, one workgroup per CU) 1.26; 16 rows 1.16 / 1.17 -- not instantiated.
     a.blocks_x = (OWg + NX_GROUPS - 1) / NX_GROUPS;
-    const long blocks16 = (long)a.blocks_x * ((OH + 15) / 16) * B;
-    // (measured, c1: 16 rows 105 / 304 us against 97 / 294 us at batch 16 / 48 -- one workgroup per CU loses what the halved weight
-    // stream gains; 8 rows stay the default)
-    const int rows = force == 16 ? 16 : 8;
-    a.blocks_y = (OH + rows - 1) / rows;
-    const dim3 grid(a.blocks_x * a.blocks_y * B);
-    (void)blocks16;
-    // weight fragment sets ahead: 1 (120 registers: two 8-row workgroups per CU; measured per c1 step, heads forward + image gradient:
-    // 8 rows 1.17 ms at one set ahead, 1.26 at two; 16 rows 1.16 / 1.17) -- DWC_X3_NARROW_PF=2 selects two
-    static const int pf = getenv("DWC_X3_NARROW_PF") ? atoi(getenv("DWC_X3_NARROW_PF")) : 1;
-    if (rows == 16) {
-        if (pf == 1) hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 2, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 2, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    } else {
-        if (pf == 1) hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1, 2>), grid, dim3(512), 0, (hipStream_t)stream, a);
-    }
+    a.blocks_y = (OH + 7) / 8;
+    hipLaunchKernelGGL((conv_narrow_x3_kernel<7, 14, 1, 1>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -588,12 +588,6 @@ int lstm_resident_capacity(K kernel, unsigned dyn_lds, int variant) {
     return cap;
 }
 
-// first chunk size (in 16-row tiles) the persistent launchers try; DWC_LSTM_MT_MIN=4: the r03 choice min(4, ceil(B / 16)) (A/B runs)
-int lstm_mt_first(int B) {
-    static const int lo = getenv("DWC_LSTM_MT_MIN") ? atoi(getenv("DWC_LSTM_MT_MIN")) : 1;
-    return max(1, min(min(lo, 4), (B + 15) / 16));
-}
-
 }  // namespace
 
 extern "C" {
@@ -632,7 +626,7 @@ int dwc_lstm_seq_fwd(const float* xproj, const float* w_hh, const int* lens, flo
     int mt = 0;
     unsigned dyn = 0;
     dim3 grid;
-    for (int m = lstm_mt_first(B); m <= 4 && !mt; ++m) {
+    for (int m = 1; m <= 4 && !mt; ++m) {
         // dynamic LDS on top of the exchange buffer so that a workgroup needs > 80 KB: ONE workgroup per CU (the hand-off form used
         // is measured for one workgroup per CU, and the residency argument counts CUs)
         const size_t ex_bytes = (size_t)4 * 4 * m * 16 * 17 * 4;
@@ -672,7 +666,7 @@ int dwc_lstm_seq_bwd(const float* d_out, const float* d_c, const float* w_hh_t, 
     int mt = 0;                                                  // smallest resident chunk, see dwc_lstm_seq_fwd
     unsigned dyn = 0;
     dim3 grid;
-    for (int m = lstm_mt_first(B); m <= 4 && !mt; ++m) {
+    for (int m = 1; m <= 4 && !mt; ++m) {
         const size_t ex_bytes = (size_t)4 * m * 16 * 17 * 4;
         const unsigned dy = (unsigned)(84 * 1024 - ex_bytes);
         int cp = 0;
