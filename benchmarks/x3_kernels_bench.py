@@ -64,6 +64,28 @@ def main():
                     pass
             print("  B%-3d %-18s%s fwd %8.1f us  %.3f of 2.5PF | wgrad+reduce %8.1f us  %.3f of 2.5PF   checksum %.6e" % (
                 B, name, " (split)" if need else "        ", tf * 1e6, 6 * flops / tf / 2.5e15, tw * 1e6, 6 * flops / tw / 2.5e15, float(y.double().sum())))
+            # the same layer as two-plane f16 split products (three MFMAs per fp32 MFMA-equivalent), absmax passes timed apart
+            from hipdwc import ops
+            hp = torch.empty(lib.dwc_h2_weight_prepared_elems(co, ci, k), dtype=torch.float16, device=dev)
+            wsl, wep = ops.amax_slot(dev)
+            _lib.check(lib.dwc_absmax(w.data_ptr(), w.numel(), wsl, wep, st), "absmax w")
+            _lib.check(lib.dwc_h2_weight_prepare(w.data_ptr(), hp.data_ptr(), co, ci, k, co, 0, wsl, wep, st), "h2 prep")
+            xsl, xep = ops.amax_slot(dev)
+            dsl, dep = ops.amax_slot(dev)
+            ta = med(lambda: _lib.check(lib.dwc_absmax(x.data_ptr(), x.numel(), xsl, xep, st), "absmax x"))
+            _lib.check(lib.dwc_absmax(dy.data_ptr(), dy.numel(), dsl, dep, st), "absmax dy")
+            if s == 1:
+                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_same_add_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), None, y.data_ptr(),
+                                                                           B, H, H, ci, co, co, k, 1, 1, ksw.data_ptr(), need, kst.data_ptr(), st), "h2"))
+            else:
+                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_s2_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci,
+                                                                     co, co, 1, ksw.data_ptr(), need, kst.data_ptr(), st), "h2s2"))
+            tw2 = float("nan")
+            if nws:
+                tw2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_wgrad(x.data_ptr(), xsl, xep, dy.data_ptr(), dsl, dep, dw.data_ptr(), B, H, H, ci, co,
+                                                                     k, ci, co, wsb.data_ptr(), nws, st), "h2 wgrad"))
+            print("       %-18s  h2 fwd %8.1f us  %.3f of 2.5PF (%.2fx) | wgrad+reduce %8.1f us  %.3f of 2.5PF (%.2fx) | absmax(x) %6.1f us  checksum %.6e" % (
+                "", tf2 * 1e6, 3 * flops / tf2 / 2.5e15, tf / tf2, tw2 * 1e6, 3 * flops / tw2 / 2.5e15, tw / tw2, ta * 1e6, float(y.double().sum())))
 
 
 if __name__ == "__main__":

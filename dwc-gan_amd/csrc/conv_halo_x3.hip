@@ -50,9 +50,47 @@ __device__ __forceinline__ void split3(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2)
     }
 }
 
+// ---- two-plane f16 split ("h2", r05) ------------------------------------------------------------------------------------------
+// s*a = hi + lo * 2^-11 with hi = f16(s*a) and lo = f16((s*a - hi) * 2^11), both ROUNDED TO NEAREST (v_cvt_pk_f16_f32): hi holds 11
+// significand bits, the residual (exact in fp32) is at most half an ulp of hi and lo holds 11 of its bits -- |s*a - hi - lo 2^-11| <=
+// 2^-24 |s*a|, the size of an fp32 rounding.  a*b = [hi*hi + 2^-11 (hi*lo + lo*hi)] / (sa sb) up to lo*lo <= 2^-24 |ab|: THREE f16
+// MFMAs per fp32 MFMA-equivalent instead of the six of the three-plane bf16 split (f16 products are 22 bits: exact in the fp32
+// accumulator).  f16 has 5 exponent bits, so every operand TENSOR is brought to a working range by a power of two s (exact): its
+// largest magnitude lands in [2^13, 2^14), values down to 2^-27 of it keep all bits, smaller ones lose them gradually (f16
+// subnormals, which the MFMA honours: benchmarks/split2_lab.hip) with an absolute error of 2^-49 of the largest magnitude.
+// The largest magnitude comes from a caller-owned 64-bit slot: (epoch << 32) | bits of max |a|, raised by atomic max from the
+// kernel that produced the tensor or from dwc_absmax; a slot whose epoch is not the one the caller names poisons the result
+// with NaN (a stale or never-written slot must not pass for a small tensor).  Non-finite input: the slot reads inf / NaN, s = 1,
+// and the NaN of inf - inf in the lo plane reaches every output the value touches.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// fp32 x4 (already scaled) -> two planes of 4 f16
+__device__ __forceinline__ void split2h(f32x4 v, u32x2& p0, u32x2& p1) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const f32x2 x = {v[2 * k], v[2 * k + 1]};
+        const f16x2 h = __builtin_convertvector(x, f16x2);
+        const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * 2048.f;
+        const f16x2 l = __builtin_convertvector(r, f16x2);
+        p0[k] = __builtin_bit_cast(unsigned, h);
+        p1[k] = __builtin_bit_cast(unsigned, l);
+    }
+}
+template <int NPL> struct Planes { u32x2 p[NPL]; };
+template <int NPL> __device__ __forceinline__ Planes<NPL> split_planes(f32x4 v, float s) {
+    Planes<NPL> r;
+    if constexpr (NPL == 3) split3(v, r.p[0], r.p[1], r.p[2]);
+    else split2h(v * s, r.p[0], r.p[1]);
+    return r;
+}
+template <int NPL> __device__ __forceinline__ f32x16 x3_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (NPL == 3) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
 struct X3Args {
     const float* x;      // [B][H][W][Cin] fp32
-    const bf16* w;       // [K*K][Cin/16][3][rows][16]   (dwc_x3_weight_prepare)
+    const bf16* w;       // [K*K][Cin/16][NPL][rows][16]   (dwc_x3_weight_prepare / dwc_h2_weight_prepare: + {s, 1/s} behind it)
     const float* bias;   // [N] or null
     const float* add;    // [B][H][W][N] or null: added behind bias + activation (a second gradient w.r.t. the same tensor)
     float* y;            // [B][H][W][N] fp32
@@ -62,6 +100,9 @@ struct X3Args {
     float* part = nullptr;          // KSP == 2: [tiles][256 pixels x 64 channels] fp32, the first arriver's half sum
     unsigned* tickets = nullptr;    // KSP == 2: [tiles], zero between launches (caller-owned, self-resetting)
     int split_from = 0;             // KSP == 2: tiles [0, split_from) run whole (one workgroup), [split_from, tiles) as two halves
+    const unsigned long long* xs = nullptr;      // NPL == 2: absmax slot of x and the epoch it must carry
+    unsigned xs_epoch = 0;
+    size_t w_elems = 0;             // NPL == 2: 16-bit elements of the prepared planes; {s_w, 1 / s_w} (fp32) sit behind them
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
@@ -90,7 +131,9 @@ struct X3Args {
 // result does not depend on the order of arrival -- and runs the epilogue.  The ticket is back at zero when the tile is done.
 // The same instantiation serves launches whose LAST round of workgroups would be at most half full (768 tiles on 512 slots: the
 // 256 stragglers run one per CU): tiles [0, split_from) run whole and are dispatched first, only the tail is split.
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
+// NPL: planes per operand -- 3: exact bf16 split, six products; 2: f16 hi / lo split with per-tensor power-of-two scales, three
+// products (see h2_scale above).
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
@@ -110,20 +153,28 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // the same eight 16-byte bank slots (every fragment read 2-way conflicted); with the half-slot offset all 16 differ.
     constexpr int PITCH = PW * CS + 8;
     constexpr int P_PLANE = PW * PITCH;                // elements per plane of a patch buffer
-    constexpr int W_CHUNKS = 3 * BN * 2;               // 16-byte chunks of one tap's weight slab (3 planes x BN rows x 32 B)
+    static_assert(NPL == 3 || (NPL == 2 && TM * TN <= 4), "two planes: separate correction accumulators only");
+    constexpr int W_CHUNKS = NPL * BN * 2;             // 16-byte chunks of one tap's weight slab (NPL planes x BN rows x 32 B)
     constexpr int W_INSTR = (W_CHUNKS + THREADS - 1) / THREADS;    // LDS-DMA instructions per thread and tap
     constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
     constexpr int NTAP = KS * KS;
     constexpr int PAD = (KS - 1) / 2;
-    __shared__ __attribute__((aligned(16))) bf16 smem[PB * 3 * P_PLANE + 3 * W_SLOT];
-    bf16* sP = smem;                                   // [PB buffers][3 planes][pixel][16]
-    bf16* sW = smem + PB * 3 * P_PLANE;                // [3 slots][3 planes][BN][16]
+    __shared__ __attribute__((aligned(16))) bf16 smem[PB * NPL * P_PLANE + 3 * W_SLOT];
+    bf16* sP = smem;                                   // [PB buffers][NPL planes][pixel][16]
+    bf16* sW = smem + PB * NPL * P_PLANE;              // [3 slots][NPL planes][BN][16]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     if constexpr (PB == 1) dwc_duo_stagger(a.stagger, 512);
+    H2Scale sx = {1.f, 1.f}, sw = {1.f, 1.f};
+    if constexpr (NPL == 2) {
+        sx = h2_scale(a.xs, a.xs_epoch);
+        const float* wt = reinterpret_cast<const float*>(a.w + a.w_elems);
+        sw.s = wt[0];
+        sw.inv = wt[1];
+    }
 
     int bid = blockIdx.x;
     int khalf = 0;                                                       // KSP == 2: which half of the channel slabs
@@ -218,20 +269,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         }
     };
     auto write_patch = [&](int buf) {
-        bf16* dst = sP + buf * 3 * P_PLANE;
+        bf16* dst = sP + buf * NPL * P_PLANE;
 #pragma unroll
         for (int i = 0; i < PPASS; ++i) {
             if (!((p_in >> i) & 1)) continue;                             // slot past the patch
-            u32x2 p0, p1, p2;
-            split3((p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f}, p0, p1, p2);
-            *reinterpret_cast<u32x2*>(dst + p_dst[i]) = p0;
-            *reinterpret_cast<u32x2*>(dst + P_PLANE + p_dst[i]) = p1;
-            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE + p_dst[i]) = p2;
+            const Planes<NPL> q = split_planes<NPL>((p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f}, sx.s);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * P_PLANE + p_dst[i]) = q.p[pl];
         }
     };
 
     // ---- weight ring: chunk g = t + 512*p of the slab [plane][row][half] ----------------------------------------------------
-    const unsigned w_bytes = (unsigned)(S2 ? 16 : NTAP) * ncsr * 3u * a.rows * CS * 2u;
+    const unsigned w_bytes = (unsigned)(S2 ? 16 : NTAP) * ncsr * (unsigned)NPL * a.rows * CS * 2u;
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, w_bytes, 0x00020000);
     unsigned w_off[W_INSTR];
 #pragma unroll
@@ -241,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         const int row = min(n0 + (rem >> 1), a.rows - 1);
         w_off[p] = g < W_CHUNKS ? (unsigned)(((plane * a.rows + row) * CS + (rem & 1) * 8) * 2) : 0x80000000u;
     }
-    const int w_step_bytes = 3 * a.rows * CS * 2;                         // one (tap, slab) block of the prepared tensor
+    const int w_step_bytes = NPL * a.rows * CS * 2;                       // one (tap, slab) block of the prepared tensor
     auto stage_w = [&](int step, int slot) {                              // step = cs * NTAP + tap -> block tap * ncs + cs
         const int csl_ = step / NTAP, tap = step - csl_ * NTAP;
         const int cs = cs0 + csl_;
@@ -306,14 +355,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
     // eight waves of the one resident workgroup reach every phase together.)
     constexpr bool PIPE = PB == 2 && TM * TN <= 2;
-    bf16x8 fa[PIPE ? 2 : 1][3][TM], fb[PIPE ? 2 : 1][3][TN];
+    bf16x8 fa[PIPE ? 2 : 1][NPL][TM], fb[PIPE ? 2 : 1][NPL][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
         const int d = (tap_ / KS) * PITCH + (tap_ % KS) * CS;
-        const bf16* p = sP + pbuf_ * 3 * P_PLANE + d;
+        const bf16* p = sP + pbuf_ * NPL * P_PLANE + d;
         const bf16* w = sW + slot_ * W_SLOT + b_row;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
             for (int n = 0; n < TN; ++n) {
                 if (DBG & 2) { for (int e = 0; e < 8; ++e) fb[set][pl][n][e] = (bf16)(float)(lane + tap_ + pl); }
@@ -331,8 +380,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // not wait for the last reads.  One accumulator (4x2 tiles): smallest terms first.
     auto mfma_terms = [&](auto setc, auto t0c, auto t1c) {
         constexpr int set = decltype(setc)::value, t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        constexpr int TA[6] = {SPLIT ? 0 : 2, 1, 0, SPLIT ? 2 : 1, SPLIT ? 1 : 0, 0};
-        constexpr int TBp[6] = {0, SPLIT ? 0 : 1, SPLIT ? 1 : 2, 0, 1, SPLIT ? 2 : 0};
+        // (two planes: hi*hi, then lo*hi and hi*lo into the correction accumulator)
+        constexpr int TA[6] = {NPL == 2 ? 0 : (SPLIT ? 0 : 2), 1, 0, SPLIT ? 2 : 1, SPLIT ? 1 : 0, 0};
+        constexpr int TBp[6] = {0, NPL == 2 ? 0 : (SPLIT ? 0 : 1), NPL == 2 ? 1 : (SPLIT ? 1 : 2), 0, 1, SPLIT ? 2 : 0};
 #pragma unroll
         for (int term = t0; term < t1; ++term)
 #pragma unroll
@@ -344,18 +394,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                         continue;
                     }
                     if (SPLIT && (TA[term] | TBp[term]) != 0)
-                        lo[SPLIT ? i : 0][SPLIT ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            fb[set][TBp[term]][n], fa[set][TA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0], 0, 0, 0);
+                        lo[SPLIT ? i : 0][SPLIT ? n : 0] =
+                            x3_mfma<NPL>(fb[set][TBp[term]][n], fa[set][TA[term]][i], lo[SPLIT ? i : 0][SPLIT ? n : 0]);
                     else
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][TBp[term]][n], fa[set][TA[term]][i], acc[i][n], 0, 0,
-                                                                            0);
+                        acc[i][n] = x3_mfma<NPL>(fb[set][TBp[term]][n], fa[set][TA[term]][i], acc[i][n]);
                 }
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
-    typedef std::integral_constant<int, 2> I2;
-    typedef std::integral_constant<int, 4> I4;
-    typedef std::integral_constant<int, 6> I6;
+    // the products of a step in three groups (six products: 2 + 2 + 2, three: 1 + 1 + 1)
+    typedef std::integral_constant<int, NPL == 3 ? 2 : 1> I2;
+    typedef std::integral_constant<int, NPL == 3 ? 4 : 2> I4;
+    typedef std::integral_constant<int, NPL == 3 ? 6 : 3> I6;
+    constexpr float LO_W = NPL == 2 ? 1.f / 2048.f : 1.f;                // weight of the correction accumulator
 
     int pbuf = 0, tap = 0, cs = 0, slot = 0;
     auto step = [&](auto curc, auto nxtc, int s) {
@@ -421,7 +472,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int n = 0; n < TN; ++n) acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0];
+                for (int n = 0; n < TN; ++n) acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0] * LO_W;
         }
         // Both workgroups sit on one XCD: its L2 is the meeting point.  The first arriver's stores are complete (acknowledged by the
         // L2) before it raises the ticket, the second reads the ticket and the half sum past its L1 (sc1) -- no L2 write-back or
@@ -429,6 +480,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
       if (halved) {
         // ---- the two halves of the contraction meet (see the template comment) ------------------------------------------------
         unsigned* ticket = a.tickets + (tile_id - a.split_from);
+        // The hand-off below is only coherent inside ONE XCD's L2.  That the two halves share one rests on the dispatcher placing
+        // hardware workgroup h on XCD h % 8; each half therefore reads the XCD it really runs on (XCC_ID), the first arriver
+        // publishes its id in bits 8.. of the ticket and the second poisons the tile when the ids differ (a CU mask, another
+        // partition mode or a dispatch change must not turn into a silently stale half sum).
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xfu;
         if (t == 0) s_role = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned role = s_role;
@@ -449,16 +507,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                             rsrc_p, (unsigned)(((i * TN + n) * 4 + q4) * THREADS + t) * 16u, 0, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t == 0) __hip_atomic_fetch_add(ticket, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) __hip_atomic_fetch_add(ticket, 2u + ((xcc + 1u) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
-        // second arriver: the ticket reads 1 (first) + 1 (this one) + 2 (first done) once the other half is published.  The
+        // second arriver: the low byte of the ticket reads 1 (first) + 1 (this one) + 2 (first done) once the other half is published.  The
         // wait is bounded (an aborted earlier launch may have left the ticket dirty): on expiry the tile is poisoned with NaN.
         __shared__ unsigned s_ok;
         if (t == 0) {
             unsigned ok = 0;
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) { ok = 1; break; }
+                const unsigned tv = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((tv & 0xffu) >= 4u) { ok = (tv >> 8) == xcc + 1u; break; }      // published -- by a workgroup of THIS XCD, or the tile is poisoned
                 __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -521,8 +580,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                     f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
                     if (SPLIT && KSP == 1) {
                         const f32x16& c = lo[SPLIT ? i : 0][SPLIT ? n : 0];
-                        v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]};
+                        v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]} * LO_W;
                     }
+                    if constexpr (NPL == 2) v = v * sx.inv * sw.inv;      // (two exact multiplications: the product of the two could underflow)
                     v += bv[n][q4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -573,6 +633,66 @@ __global__ void x3_weight_prepare_kernel(const float* __restrict__ w, bf16* __re
     o[base + 2 * (size_t)rows * CS] = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
+// Two-plane form of the same layout: out[((tap*ncs + cs)*2 + plane)*rows + row][16] f16 planes of s_w * w, s_w from the weight's
+// absmax slot; {s_w, 1 / s_w} as two floats behind the planes (the convolution kernels read them from there).
+__global__ void h2_weight_prepare_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout, int Cin, int K,
+                                         int rows, int kdim, int dgrad, const unsigned long long* slot, unsigned epoch) {
+    const int ncs = (kdim + CS - 1) / CS;
+    const size_t total = (size_t)K * K * ncs * rows * CS;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const H2Scale sw = h2_scale(slot, epoch);
+    if (idx == 0) {
+        float* tail = reinterpret_cast<float*>(out + 2 * total);
+        tail[0] = sw.s;
+        tail[1] = sw.inv;
+    }
+    if (idx >= total) return;
+    const int j = idx % CS;
+    size_t r = idx / CS;
+    const int row = r % rows;
+    r /= rows;
+    const int cs = r % ncs, tap = r / ncs;
+    const int kh = tap / K, kw = tap - kh * K;
+    const int kc = cs * CS + j;
+    float v = 0.f;
+    if (!dgrad) {
+        if (row < Cout && kc < Cin) v = w[(((size_t)row * Cin + kc) * K + kh) * K + kw];
+    } else {
+        if (row < Cin && kc < Cout) v = w[(((size_t)kc * Cin + row) * K + (K - 1 - kh)) * K + (K - 1 - kw)];
+    }
+    v *= sw.s;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+    const size_t base = ((size_t)(tap * ncs + cs) * 2 * rows + row) * CS + (j ^ (((row >> 3) & 1) << 3));
+    out[base] = __builtin_bit_cast(unsigned short, h);
+    out[base + (size_t)rows * CS] = __builtin_bit_cast(unsigned short, l);
+}
+
+// max |x| over n floats -> slot (see dwc_amax_publish)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, unsigned long long* slot, unsigned epoch) {
+    const size_t n4 = n >> 2;
+    unsigned m = 0;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {      // four 16-byte loads in flight per thread
+        const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = max(max(m, dwc_abs_bits(a[k])), max(dwc_abs_bits(b[k]), max(dwc_abs_bits(c[k]), dwc_abs_bits(d[k]))));
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 a = x4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = max(m, dwc_abs_bits(a[k]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = max(m, dwc_abs_bits(x[(n4 << 2) + threadIdx.x]));
+    m = dwc_wave_max_u32(m);
+    __shared__ unsigned sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) dwc_amax_publish(slot, epoch, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+}
+
 // ------------------------------------------------------------------------------------------
 // Weight gradient of the same layers as split products.  dW[kh][kw][ci][co] = sum_pixels x[pixel + tap][ci] * dY[pixel][co]:
 // both operands are activations, so both are split on the fly.  A workgroup owns 64 channels of x, BN channels of dY and ONE
@@ -594,11 +714,13 @@ struct X3WgradArgs {
     int B, H, W, Cin, N;
     int units_x, units_per_img, total_units, units_per_split;
     int n_tiles, roles;
+    const unsigned long long *xs = nullptr, *dys = nullptr;      // NPL == 2: absmax slots of x and dy and the epochs they must carry
+    unsigned xs_epoch = 0, dys_epoch = 0;
 };
 
 // CIW = 64: 8 waves, one workgroup per CU.  CIW = 32: 4 waves, <= 74 KB of LDS, TWO independent workgroups per CU (see
 // conv_halo_x3_kernel: they drift out of phase and overlap each other's MFMA and load phases).
-template <int KS, int BN, int CIW = 64, int AHEAD = 2>
+template <int KS, int BN, int CIW = 64, int AHEAD = 2, int NPL = 3>
 __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgrad_x3_kernel(X3WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert((BN == 128 || BN == 64) && (CIW == 64 || CIW == 32), "tile shape");
@@ -615,7 +737,12 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
     constexpr int P_PLANE = PPASS * 32 * CIW;          // elements per plane
     constexpr int PAD = (KS - 1) / 2;
     constexpr int ROWS = UH / HALVES;                  // dY rows of a unit per wave
-    __shared__ __attribute__((aligned(16))) bf16 smem[2 * 3 * P_PLANE];
+    __shared__ __attribute__((aligned(16))) bf16 smem[2 * NPL * P_PLANE];
+    H2Scale sx = {1.f, 1.f}, sdy = {1.f, 1.f};
+    if constexpr (NPL == 2) {
+        sx = h2_scale(a.xs, a.xs_epoch);
+        sdy = h2_scale(a.dys, a.dys_epoch);
+    }
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -693,12 +820,10 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         for (int j = 0; j < 2; ++j) {
             const int pp = t / QPP + 32 * (first + j);
             if (first + j >= PPASS) continue;
-            u32x2 p0, p1, p2;
-            split3(pv[j], p0, p1, p2);
-            bf16* dst = smem + buf * 3 * P_PLANE + pp * CIW + (((quad >> 1) ^ p_swz(pp)) << 3) + (quad & 1) * 4;
-            *reinterpret_cast<u32x2*>(dst) = p0;
-            *reinterpret_cast<u32x2*>(dst + P_PLANE) = p1;
-            *reinterpret_cast<u32x2*>(dst + 2 * P_PLANE) = p2;
+            const Planes<NPL> q = split_planes<NPL>(pv[j], sx.s);
+            bf16* dst = smem + buf * NPL * P_PLANE + pp * CIW + (((quad >> 1) ^ p_swz(pp)) << 3) + (quad & 1) * 4;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * P_PLANE) = q.p[pl];
         }
     };
 
@@ -714,8 +839,22 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         for (int j = 0; j < 8; ++j)
             raw[decltype(slot)::value][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_dy, dy_lane, base + j * n4, 0));
     };
-    bf16x8 fb[3];
+    bf16x8 fb[NPL];
     auto split_dy = [&](auto slot) {
+        if constexpr (NPL == 2) {
+            u32x4 q0, q1;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                u32x2 p0, p1;
+                split2h(f32x4{raw[decltype(slot)::value][4 * k], raw[decltype(slot)::value][4 * k + 1], raw[decltype(slot)::value][4 * k + 2],
+                              raw[decltype(slot)::value][4 * k + 3]} * sdy.s, p0, p1);
+                q0[2 * k] = p0[0]; q0[2 * k + 1] = p0[1];
+                q1[2 * k] = p1[0]; q1[2 * k + 1] = p1[1];
+            }
+            fb[0] = __builtin_bit_cast(bf16x8, q0);
+            fb[1] = __builtin_bit_cast(bf16x8, q1);
+            return;
+        } else {
         // two values per instruction where the ISA has one: v_pk_add_f32 for the two subtractions (36 instead of 44 per row)
         u32x4 q0, q1, q2;
 #pragma unroll
@@ -731,7 +870,8 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         }
         fb[0] = __builtin_bit_cast(bf16x8, q0);
         fb[1] = __builtin_bit_cast(bf16x8, q1);
-        fb[2] = __builtin_bit_cast(bf16x8, q2);
+        fb[NPL - 1] = __builtin_bit_cast(bf16x8, q2);
+        }
     };
 
     // ---- x fragments: transposing reads, lane 4q+p of a 16-lane group addresses pixel q, channels 4p..4p+3 ------------------
@@ -772,7 +912,7 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         int buf = 0;
         for (int u = u0; u < u1; ++u) {
             const bool next = u + 1 < u1;
-            const bf16* p = smem + buf * 3 * P_PLANE + a_lane;
+            const bf16* p = smem + buf * NPL * P_PLANE + a_lane;
 #pragma unroll
             for (int rr = 0; rr < ROWS; ++rr) {
                 const int ks = half_id * ROWS + rr;
@@ -793,15 +933,21 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
                 else refill(S1{});
 #pragma unroll
                 for (int kh = 0; kh < KS; ++kh) {
-                    bf16x8 fa[3];
+                    bf16x8 fa[NPL];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) fa[pl] = a_frag(p + pl * P_PLANE, S2 ? 2 * ks + kh : ks + kh);
-                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], lo[kh], 0, 0, 0);
-                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], lo[kh], 0, 0, 0);
-                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], lo[kh], 0, 0, 0);
-                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], lo[kh], 0, 0, 0);
-                    lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], lo[kh], 0, 0, 0);
-                    acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kh], 0, 0, 0);
+                    for (int pl = 0; pl < NPL; ++pl) fa[pl] = a_frag(p + pl * P_PLANE, S2 ? 2 * ks + kh : ks + kh);
+                    if constexpr (NPL == 3) {
+                        lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], lo[kh], 0, 0, 0);
+                        lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], lo[kh], 0, 0, 0);
+                        lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[NPL - 1], lo[kh], 0, 0, 0);
+                        lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], lo[kh], 0, 0, 0);
+                        lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], lo[kh], 0, 0, 0);
+                        acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kh], 0, 0, 0);
+                    } else {
+                        acc[kh] = x3_mfma<2>(fa[0], fb[0], acc[kh]);
+                        lo[kh] = x3_mfma<2>(fa[1], fb[0], lo[kh]);
+                        lo[kh] = x3_mfma<2>(fa[0], fb[1], lo[kh]);
+                    }
                 }
             }
             if (next) {                                 // gather groups the row loop had no room for
@@ -831,7 +977,8 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[kh][r] + lo[kh][r];
+            if constexpr (NPL == 2) out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = (acc[kh][r] + lo[kh][r] * (1.f / 2048.f)) * sx.inv * sdy.inv;
+            else out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[kh][r] + lo[kh][r];
         }
     }
 #endif
@@ -904,10 +1051,12 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2, KSP>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2, KSP, NPL>), grid, dim3(64 * WM * WN), 0, st, a);
 }
+// 16-bit elements of the two-plane prepared filter ({s_w, 1 / s_w} follow as two floats: + 4 elements)
+size_t h2_w_elems(int rows, int kdim, int K) { return (size_t)K * K * ((kdim + CS - 1) / CS) * 2 * rows * CS; }
 
 // Contraction split of the two-per-CU tile (conv_halo_x3_kernel, KSP == 2): launches of at most X3_KSPLIT_TILES tiles whose slab
 // count is even and long enough to be worth halving.  DWC_X3_KSPLIT=0 switches it off.
@@ -999,12 +1148,16 @@ int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS; }
 
 /* dwc_x3_conv2d_same_add with the scratch of the contraction split: ws / tickets may be NULL (or ws_bytes too small), the launch
  * then runs unsplit.  Results do not depend on which form ran beyond fp32 summation order (two half sums instead of one). */
-int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
-                              int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,
-                              void* stream) {
-    if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N) return DWC_EINVAL;
+}  // extern "C"
+
+template <int NPL>
+static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, const float* add,
+                               float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect, void* ws,
+                               size_t ws_bytes, unsigned* tickets, void* stream) {
+    if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N || (NPL == 2 && !xs)) return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
+    a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, K);
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     const int blocks = B * a.blocks_per_img;
@@ -1040,17 +1193,19 @@ int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const floa
     // small launches (<= 256 workgroups) equal.  DWC_X3_DUO=0: the 8-wave tiles below.
     static const int duo = getenv("DWC_X3_DUO") ? atoi(getenv("DWC_X3_DUO")) : 1;
     static const int stagger = getenv("DWC_X3_STAGGER") ? atoi(getenv("DWC_X3_STAGGER")) : 0;     // development: 10 ns ticks
-    if (duo && !force) {
+    if (NPL == 2 || (duo && !force)) {
         a.tiles_n = (N + 63) / 64;
         a.stagger = (long)blocks * a.tiles_n > 512 ? stagger : 0;      // (a launch of one round gains nothing from an offset)
         // r04: launches that would leave half of the 512 two-per-CU slots empty (3x3 256->256 at batch 16: 256 workgroups, one per
         // CU, nothing to overlap with) run 32-channel tiles instead: twice the workgroups, two per CU again
         static const int bn32 = getenv("DWC_X3_BN32") ? atoi(getenv("DWC_X3_BN32")) : 0;      // (lab: B=16 121.6 -> 117.0 us; no gain visible in the step: opt-in)
-        if (bn32 && K == 3 && (long)blocks * a.tiles_n <= 256 && N % 32 == 0) {
-            a.tiles_n = N / 32;
-            x3_launch<3, 32, 4, 1, 2, 1, 0, 1>(a, dim3(blocks * a.tiles_n), (hipStream_t)stream);
-            DWC_LAUNCH_CHECK();
-            return DWC_OK;
+        if constexpr (NPL == 3) {
+            if (bn32 && K == 3 && (long)blocks * a.tiles_n <= 256 && N % 32 == 0) {
+                a.tiles_n = N / 32;
+                x3_launch<3, 32, 4, 1, 2, 1, 0, 1>(a, dim3(blocks * a.tiles_n), (hipStream_t)stream);
+                DWC_LAUNCH_CHECK();
+                return DWC_OK;
+            }
         }
         const dim3 g2(blocks * a.tiles_n);
         const size_t need = dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, K, 1);
@@ -1059,13 +1214,14 @@ int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const floa
             a.tickets = tickets;
             a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
             const dim3 g4(2 * g2.x - a.split_from);
-            if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
-            else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2>(a, g4, (hipStream_t)stream);
-        } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
-        else x3_launch<5, 64, 4, 1, 2, 2, 0, 1>(a, g2, (hipStream_t)stream);
+            if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
+            else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
+        } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
+        else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
+    if constexpr (NPL == 3) {
     a.tiles_n = (N + bn - 1) / bn;
     const dim3 grid(blocks * a.tiles_n);
     hipStream_t st = (hipStream_t)stream;
@@ -1085,6 +1241,52 @@ int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const floa
         else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
     }
     DWC_LAUNCH_CHECK();
+    }
+    return DWC_OK;
+}
+
+extern "C" {
+
+int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
+                              int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,
+                              void* stream) {
+    return x3_same_add_ws_impl<3>(x, nullptr, 0, w_prepared, bias, add, y, B, H, W, Cin, N, rows, K, act, reflect, ws, ws_bytes, tickets, stream);
+}
+
+/* ---- the same layers as TWO-plane f16 split products (r05; see split2h / h2_scale): x_amax = the absmax slot of x (dwc_absmax or a
+ * producing kernel) carrying `x_epoch`, w_prepared = dwc_h2_weight_prepare.  Same tiles, scratch and tickets as the three-plane form. */
+int dwc_h2_conv2d_same_add_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias,
+                              const float* add, float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect,
+                              void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+    return x3_same_add_ws_impl<2>(x, x_amax, x_epoch, w_prepared, bias, add, y, B, H, W, Cin, N, rows, K, act, reflect, ws, ws_bytes, tickets,
+                                  stream);
+}
+
+size_t dwc_h2_weight_prepared_elems(int rows, int kdim, int K) { return h2_w_elems(rows, kdim, K) + 8; }
+
+/* w (fp32 OIHW) -> two f16 planes of s_w * w per (tap, 16-channel slab) + {s_w, 1 / s_w}; w_amax: absmax slot of w carrying w_epoch
+ * (dwc_absmax over the Cout*Cin*K*K floats).  Geometry arguments as dwc_x3_weight_prepare. */
+int dwc_h2_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, const void* w_amax,
+                          unsigned w_epoch, void* stream) {
+    if (!w_oihw || !out || !w_amax || Cout <= 0 || Cin <= 0 || K <= 0 || rows < (dgrad ? Cin : Cout)) return DWC_EINVAL;
+    const int kdim = dgrad ? Cout : Cin;
+    const size_t total = h2_w_elems(rows, kdim, K) / 2;
+    hipLaunchKernelGGL(h2_weight_prepare_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, (unsigned short*)out,
+                       Cout, Cin, K, rows, kdim, dgrad, (const unsigned long long*)w_amax, w_epoch);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+/* slot = max(slot, (epoch << 32) | bits of max |x[0..n)|): the largest-magnitude slot the two-plane kernels scale a tensor by.
+ * x 16-byte aligned.  Slots are 8 bytes of caller memory, zero before their first use; epochs handed to one slot must not decrease. */
+int dwc_absmax(const float* x, size_t n, void* slot, unsigned epoch, void* stream) {
+    if (!x || !slot || ((uintptr_t)x & 15)) return DWC_EINVAL;
+    if (n == 0) return DWC_OK;
+    const size_t per_block = 256 * 4 * 4;      // floats one block covers per round of four loads
+    size_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, (unsigned long long*)slot, epoch);
+    DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
 
@@ -1100,12 +1302,15 @@ int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, 
     return dwc_x3_conv2d_s2_ws(x, w_prepared, bias, y, B, H, W, Cin, N, rows, act, nullptr, 0, nullptr, stream);
 }
 
-/* dwc_x3_conv2d_s2 with the scratch of the contraction split (see dwc_x3_conv2d_same_add_ws). */
-int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
-                        int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
-    if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N) return DWC_EINVAL;
+}  // extern "C"
+
+template <int NPL>
+static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, float* y, int B, int H,
+                         int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+    if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N || (NPL == 2 && !xs)) return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = y;
+    a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, 4);
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = 1;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = (N + 63) / 64;
@@ -1115,12 +1320,40 @@ int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bia
         a.tickets = tickets;
         const int tiles = B * a.blocks_per_img * a.tiles_n;
         a.split_from = (int)x3_ksplit_from(tiles, 4 * (Cin / CS));
-        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2>(a, dim3(2 * tiles - a.split_from), (hipStream_t)stream);
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2, NPL>(a, dim3(2 * tiles - a.split_from), (hipStream_t)stream);
     } else {
-        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 1, NPL>(a, dim3(B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
     }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+template <int NPL>
+static int x3_s2_bwd_data_impl(const float* dy, const void* ds, unsigned ds_epoch, const void* w_prepared, float* dx, int B, int H, int W,
+                               int Cin, int Cout, int rows, void* stream) {
+    if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin || (NPL == 2 && !ds)) return DWC_EINVAL;
+    X3Args a;
+    a.x = dy; a.w = (const bf16*)w_prepared; a.bias = nullptr; a.add = nullptr; a.y = dx;
+    a.xs = (const unsigned long long*)ds; a.xs_epoch = ds_epoch; a.w_elems = h2_w_elems(rows, Cout, 4);
+    a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    a.tiles_n = Cin / 64;
+    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2, 1, NPL>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
+extern "C" {
+
+/* dwc_x3_conv2d_s2 with the scratch of the contraction split (see dwc_x3_conv2d_same_add_ws). */
+int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bias, float* y, int B, int H, int W, int Cin, int N, int rows,
+                        int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+    return x3_s2_ws_impl<3>(x, nullptr, 0, w_prepared, bias, y, B, H, W, Cin, N, rows, act, ws, ws_bytes, tickets, stream);
+}
+/* two-plane f16 form (see dwc_h2_conv2d_same_add_ws); w_prepared = dwc_h2_weight_prepare(K = 4) */
+int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y, int B,
+                        int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+    return x3_s2_ws_impl<2>(x, x_amax, x_epoch, w_prepared, bias, y, B, H, W, Cin, N, rows, act, ws, ws_bytes, tickets, stream);
 }
 
 /* INTERIOR of the data gradient of the same layers (conv_halo_x3_kernel, S2 == 2): dy:[B,H/2,W/2,Cout] fp32 -> the H x W pixels
@@ -1133,15 +1366,12 @@ int dwc_x3_conv2d_s2_bwd_data_ok(int B, int H, int W, int Cin, int Cout) {
 
 int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx, int B, int H, int W, int Cin, int Cout, int rows,
                               void* stream) {
-    if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin) return DWC_EINVAL;
-    X3Args a;
-    a.x = dy; a.w = (const bf16*)w_prepared; a.bias = nullptr; a.add = nullptr; a.y = dx;
-    a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
-    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
-    a.tiles_n = Cin / 64;
-    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
-    DWC_LAUNCH_CHECK();
-    return DWC_OK;
+    return x3_s2_bwd_data_impl<3>(dy, nullptr, 0, w_prepared, dx, B, H, W, Cin, Cout, rows, stream);
+}
+/* two-plane f16 form; w_prepared = dwc_h2_weight_prepare(K = 4, dgrad = 1), dy_amax = absmax slot of dy */
+int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H, int W,
+                              int Cin, int Cout, int rows, void* stream) {
+    return x3_s2_bwd_data_impl<2>(dy, dy_amax, dy_epoch, w_prepared, dx, B, H, W, Cin, Cout, rows, stream);
 }
 
 size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {
@@ -1156,16 +1386,20 @@ size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int 
  * tensors x:[B,H,W,Cin] and dy:[B,H,W,Cout], or of the 4x4 stride-2 reflect-pad-1 convolution (K = 4, dy:[B,H/2,W/2,Cout]), split
  * products (see wgrad_x3_kernel).  ws_bytes == 0: shape not handled (K in {3,5}: H % 8 == 0, W % 16 == 0; K = 4: H % 8 == 0,
  * W % 32 == 0; Cin and Cout multiples of 64) - use dwc_conv2d_bwd_weight. */
-int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real,
-                        int cout_real, void* ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+
+template <int NPL>
+static int x3_wgrad_impl(const float* x, const void* xs, unsigned xs_epoch, const float* dy, const void* dys, unsigned dys_epoch, float* dw_oihw,
+                         int B, int H, int W, int Cin, int Cout, int K, int cin_real, int cout_real, void* ws, size_t ws_bytes, void* stream) {
     const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
-    if (!x || !dy || !dw_oihw || !bn || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
+    if (!x || !dy || !dw_oihw || !bn || cin_real > Cin || cout_real > Cout || (NPL == 2 && (!xs || !dys))) return DWC_EINVAL;
     int splits, ups;
     x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
     const int halves = bn == 128 ? 1 : 2;
     if (!ws || ws_bytes < (size_t)splits * halves * K * K * Cin * Cout * sizeof(float)) return DWC_EWORKSPACE;
     X3WgradArgs a;
     a.x = x; a.dy = dy; a.slab = (float*)ws;
+    a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.dys = (const unsigned long long*)dys; a.dys_epoch = dys_epoch;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = Cout;
     if (K == 4) {
         a.units_x = W / 32; a.units_per_img = (H / 8) * (W / 32);      // 4x16-pixel units of the H/2 x W/2 dY grid
@@ -1180,23 +1414,40 @@ int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, 
     const dim3 grid(a.roles * splits);
     if (K == 4) {
         if (ciw != 64) return DWC_EINVAL;      // (DWC_X3_WDUO has no stride-2 instantiation)
-        if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<4, 128>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_x3_kernel<4, 64>), grid, dim3(512), 0, st, a);
+        if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<4, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_x3_kernel<4, 64, 64, 2, NPL>), grid, dim3(512), 0, st, a);
     } else if (ciw == 32) {
-        if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 32>), grid, dim3(256), 0, st, a);
-        else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 32>), grid, dim3(256), 0, st, a);
-        else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 32>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64, 32>), grid, dim3(256), 0, st, a);
-    } else if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128>), grid, dim3(512), 0, st, a);
-    else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64>), grid, dim3(512), 0, st, a);
-    else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64>), grid, dim3(512), 0, st, a);
+        if constexpr (NPL == 3) {
+            if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 32>), grid, dim3(256), 0, st, a);
+            else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 32>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 32>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64, 32>), grid, dim3(256), 0, st, a);
+        } else {
+            return DWC_EINVAL;
+        }
+    } else if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);
+    else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 64, 2, NPL>), grid, dim3(512), 0, st, a);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64, 64, 2, NPL>), grid, dim3(512), 0, st, a);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)K * K * Cin * Cout;
     hipLaunchKernelGGL(x3_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)ws, dw_oihw, splits * halves,
                        K * K * Cin, Cout, Cin, K * K, cin_real, cout_real);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
+}
+
+extern "C" {
+
+int dwc_x3_conv2d_wgrad(const float* x, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real,
+                        int cout_real, void* ws, size_t ws_bytes, void* stream) {
+    return x3_wgrad_impl<3>(x, nullptr, 0, dy, nullptr, 0, dw_oihw, B, H, W, Cin, Cout, K, cin_real, cout_real, ws, ws_bytes, stream);
+}
+/* two-plane f16 form: both operands scaled by their absmax slots (same scratch as dwc_x3_conv2d_wgrad) */
+int dwc_h2_conv2d_wgrad(const float* x, const void* x_amax, unsigned x_epoch, const float* dy, const void* dy_amax, unsigned dy_epoch,
+                        float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real, int cout_real, void* ws, size_t ws_bytes,
+                        void* stream) {
+    return x3_wgrad_impl<2>(x, x_amax, x_epoch, dy, dy_amax, dy_epoch, dw_oihw, B, H, W, Cin, Cout, K, cin_real, cout_real, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -67,6 +67,37 @@ __device__ __forceinline__ void stf(float* p, size_t e, const float (&o)[V]) {
 
 #endif
 
+#ifdef __HIPCC__
+// ---- largest-magnitude slots of the two-plane f16 split kernels (csrc/conv_halo_x3.hip, "h2") ------------------------------------
+// A slot is 64 bits of caller memory: (epoch << 32) | bits of max |a| over a tensor.  Producers raise it with an atomic max -- a
+// newer epoch beats any older content, so a slot is never zeroed -- and consumers derive the tensor's power-of-two working scale
+// from it (h2_scale).  NaN bits compare above inf bits above every finite magnitude: a non-finite tensor reads as such.
+__device__ __forceinline__ void dwc_amax_publish(unsigned long long* slot, unsigned epoch, unsigned abs_bits) {
+    atomicMax(slot, ((unsigned long long)epoch << 32) | abs_bits);
+}
+__device__ __forceinline__ unsigned dwc_abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned dwc_wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
+    return v;
+}
+struct H2Scale { float s, inv; };
+__device__ __forceinline__ H2Scale h2_scale(const unsigned long long* slot, unsigned epoch) {
+    const unsigned long long v = *slot;
+    unsigned e = ((unsigned)v >> 23) & 0xffu;
+    H2Scale r;
+    if (e == 0xffu) {
+        r.s = r.inv = 1.f;
+    } else {
+        e = min(max(e, 27u), 254u);
+        r.s = __uint_as_float((267u - e) << 23);      // 2^(140 - e): max|a| in [2^(e-127), 2^(e-126)) -> [2^13, 2^14)
+        r.inv = __uint_as_float((e - 13u) << 23);
+    }
+    if ((unsigned)(v >> 32) != epoch) r.s = r.inv = __builtin_nanf("");
+    return r;
+}
+#endif
+
 #define DWC_LAUNCH_CHECK()                                   \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return DWC_ELAUNCH; \

@@ -15,6 +15,7 @@ c_fp = ctypes.c_void_p   # device pointers travel as void*
 c_int = ctypes.c_int
 c_sz = ctypes.c_size_t
 c_f = ctypes.c_float
+c_u = ctypes.c_uint
 
 
 class AdvSpec(ctypes.Structure):               # struct dwc_adv_spec (passed by value)
@@ -141,6 +142,13 @@ SIGNATURES = {
     "dwc_bf16_conv2d_bwd_data_s2_ring": (c_int, [c_fp] * 4 + [c_int] * 5 + [c_fp]),
     "dwc_x3_conv2d_wgrad_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_x3_conv2d_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
+    "dwc_absmax": (c_int, [c_fp, c_sz, c_fp, c_u, c_fp]),
+    "dwc_h2_weight_prepared_elems": (c_sz, [c_int] * 3),
+    "dwc_h2_weight_prepare": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp, c_u, c_fp]),
+    "dwc_h2_conv2d_same_add_ws": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 4 + [c_int] * 9 + [c_fp, c_sz, c_fp, c_fp]),
+    "dwc_h2_conv2d_s2_ws": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 3 + [c_int] * 7 + [c_fp, c_sz, c_fp, c_fp]),
+    "dwc_h2_conv2d_s2_bwd_data": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp] + [c_int] * 6 + [c_fp]),
+    "dwc_h2_conv2d_wgrad": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp, c_u, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_wgrad_halo_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_bf16_conv2d_wgrad_halo": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv7_smallk_wgrad_ws_bytes": (c_sz, [c_int] * 4),

@@ -297,6 +297,24 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
                              KH=kh, KW=kw, rows=rows, kdim=kdim)
         ent[key] = (stamp, out, recipe)
         return out
+    if kind in ("h2_fwd", "h2_dgrad"):
+        # two f16 planes of s_w * w per (tap, 16-channel slab) + {s_w, 1 / s_w} (dwc_h2_weight_prepare), s_w from the filter's largest
+        # magnitude (dwc_absmax: padding zeros do not change it)
+        co, ci, kh, kw = w.shape
+        wz = w.detach()
+        if co != cout_pad or ci != cin_pad:
+            wz = torch.zeros((cout_pad, cin_pad, kh, kw), dtype=torch.float32, device=w.device)
+            wz[:co, :ci] = w.detach()
+        wz = wz.contiguous()
+        dg = kind == "h2_dgrad"
+        rows, kdim = (cin_pad, cout_pad) if dg else (cout_pad, cin_pad)
+        out = torch.empty(lib.dwc_h2_weight_prepared_elems(rows, kdim, kh), dtype=torch.float16, device=w.device)
+        slot, ep = amax_slot(w.device)
+        _lib.check(lib.dwc_absmax(wz.data_ptr(), wz.numel(), slot, ep, _stream()), "absmax(weight)")
+        _lib.check(lib.dwc_h2_weight_prepare(wz.data_ptr(), out.data_ptr(), cout_pad, cin_pad, kh, rows, int(dg), slot, ep, _stream()),
+                   "h2_weight_prepare")
+        ent[key] = (stamp, out, None)
+        return out
     if kind in ("stem_steps", "stem_steps_dgrad"):
         # csrc/conv_narrow_bf16.hip conv_stem_kernel: [25 k-steps][64 channels][2 taps x 8 planes] bf16, halves of a row swapped
         # by (co>>3)&1.  stem_steps: w is the stem filter [64][P<=8][7][7]; stem_steps_dgrad: w is the heads filter
@@ -553,6 +571,47 @@ def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
     return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
 
+# Planes per operand of the split-product halo kernels (csrc/conv_halo_x3.hip): 3 = exact three-way bf16 split, six MFMAs per
+# fp32 MFMA-equivalent; 2 = f16 hi / lo split with per-tensor power-of-two scales, THREE MFMAs (r05 default; same fp32-size error,
+# tests/test_x3_parity.py).  The two-plane kernels take each activation operand's largest magnitude from an "absmax slot".
+X3_PLANES = int(os.environ.get("DWC_X3_PLANES", "2"))
+AMAX_SLOTS = 1 << 16
+_AMAX = {}      # device index -> [int64 tensor of AMAX_SLOTS slots, slots handed out so far]
+
+
+def amax_slot(dev):
+    """A fresh (slot address, epoch) pair: slots are handed out round robin, the epoch of a slot grows by one per lap, and a slot is
+    raised by atomic max on (epoch << 32 | magnitude bits) -- so nothing is ever zeroed.  A pair stays valid for AMAX_SLOTS later
+    pairs (hundreds of iterations); a consumer that meets another epoch poisons its result with NaN."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _AMAX.get(key)
+    if pool is None:
+        pool = [torch.zeros(AMAX_SLOTS, dtype=torch.int64, device=dev), 0]
+        _AMAX[key] = pool
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0].data_ptr() + 8 * (i % AMAX_SLOTS), i // AMAX_SLOTS + 1
+
+
+def amax_of(t):
+    """(slot, epoch) holding the largest magnitude of the dense fp32 tensor ``t`` -- the pair a producing op attached to it
+    (``set_amax``) if it still describes it, else one pass of dwc_absmax."""
+    c = getattr(t, "_dwc_amax", None)
+    if c is not None and c[2] == t._version and c[3] == t.data_ptr():
+        return c[0], c[1]
+    if t.dtype != torch.float32 or not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        raise ValueError("amax_of: dense fp32 tensor expected")
+    slot, ep = amax_slot(t.device)
+    _lib.check(_lib.load().dwc_absmax(t.data_ptr(), t.numel(), slot, ep, _stream()), "absmax")
+    set_amax(t, slot, ep)
+    return slot, ep
+
+
+def set_amax(t, slot, ep):
+    t._dwc_amax = (slot, ep, t._version, t.data_ptr())
+    return t
+
+
 def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad, free=False):
     """Whether this fp32 stride-1 'same' convolution (c_in gathered channels -> c_out) runs as split-bf16 products.
     5x5: always when the shape is handled (1.5-1.8x the native kernels).  3x3: Winograd F(2x2) on the fp32 MFMA is about as
@@ -662,12 +721,27 @@ class _Conv2d(torch.autograd.Function):
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        elif use_x3 and X3_PLANES == 2:
+            w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
+            x_amax = amax_of(x)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
+                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1,
+                _p(ks_ws), ks_n, ks_t, st), detail="fwd-h2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=3 * flops),
+                "h2_conv2d_same")
         elif use_x3:
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, _p(ks_ws), ks_n, ks_t, st),
                 detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
+        elif use_x3s2 and X3_PLANES == 2:
+            w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 2)
+            x_amax = amax_of(x)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_ws(
+                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, _p(ks_ws), ks_n, ks_t,
+                st), detail="fwd-h2s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=3 * flops), "h2_conv2d_s2")
         elif use_x3s2:
             # stride-2 4x4 layers, fp32: split products, 2x2 taps per input-pixel parity, space-to-depth in the patch gather
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
@@ -705,6 +779,7 @@ class _Conv2d(torch.autograd.Function):
                 x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
                 st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
         ctx.save_for_backward(x, w, y if act != 0 else None, v_keep if use_wino else None)
+        ctx.x_amax = getattr(x, "_dwc_amax", None)        # (slot, epoch, version, address) if something measured x (two-plane kernels)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
         return y
@@ -772,9 +847,19 @@ class _Conv2d(torch.autograd.Function):
                   and (KH != 3 or X3_WGRAD_HALO3)
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
-                _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
-                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
-                    scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:], exec_flops=6 * flops), "x3_conv2d_wgrad")
+                if X3_PLANES == 2:
+                    if ctx.x_amax is not None and ctx.x_amax[2] == x._version and ctx.x_amax[3] == x.data_ptr():
+                        xa = ctx.x_amax[:2]
+                    else:
+                        xa = amax_of(x)
+                    ga = amax_of(g)
+                    _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_h2_conv2d_wgrad(
+                        x.data_ptr(), xa[0], xa[1], g.data_ptr(), ga[0], ga[1], dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(),
+                        ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-h2" + detail[5:], exec_flops=3 * flops), "h2_conv2d_wgrad")
+                else:
+                    _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv2d_wgrad(
+                        x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(), ws.numel(), st),
+                        scope_name=ctx.bscope, detail="wgrad-x3" + detail[5:], exec_flops=6 * flops), "x3_conv2d_wgrad")
             elif (half and WGRAD_HALO and KH == KW and ((stride == 1 and KH in (3, 5) and 2 * pad == KH - 1)
                                                          or (S2HALO and stride == 2 and KH == 4 and pad == 1))
                   and lib.dwc_bf16_conv2d_wgrad_halo_ws_bytes(B, H, W, Cx, cop, KH)):
@@ -830,16 +915,24 @@ class _Conv2d(torch.autograd.Function):
             x3 = (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, stride, pad, free=True)
             wt = 0 if half or x3 else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
             if x3:
-                # interior = zero-padded convolution of dY with the rotated filter on the split-bf16 kernel; ring direct
-                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
+                # interior = zero-padded convolution of dY with the rotated filter on the split-product kernel; ring direct
+                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner) if X3_PLANES != 2 else None
                 # (one arena: the interior's half sums -- small launches, contraction split -- are dead when the ring strips start)
                 ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1, at_least=nws)
 
                 shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
                 # (two spans: the interior launch carries the layer's flops, the ring strips + fold are time on top of it)
-                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
-                    g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, ws.data_ptr(), ks_n, ks_t,
-                    st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
+                if X3_PLANES == 2:
+                    w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
+                    ga = amax_of(g)
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
+                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0,
+                        ws.data_ptr(), ks_n, ks_t, st), scope_name=ctx.bscope, exec_flops=3 * flops, detail="dgrad-h2" + shape),
+                        "h2_conv2d_same dgrad")
+                else:
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
+                        g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, ws.data_ptr(), ks_n,
+                        ks_t, st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
                 _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
                     g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
@@ -894,10 +987,17 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
                     detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
             else:
-                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
-                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_bwd_data(
-                    g.data_ptr(), w_x3.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope, exec_flops=6 * flops,
-                    detail="dgrad-x3s2" + shape), "x3_conv2d_s2_bwd_data")
+                if X3_PLANES == 2:
+                    w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
+                    ga = amax_of(g)
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_bwd_data(
+                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope,
+                        exec_flops=3 * flops, detail="dgrad-h2s2" + shape), "h2_conv2d_s2_bwd_data")
+                else:
+                    w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner)
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_bwd_data(
+                        g.data_ptr(), w_x3.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope,
+                        exec_flops=6 * flops, detail="dgrad-x3s2" + shape), "x3_conv2d_s2_bwd_data")
                 _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_s2_ring(
                     g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
                     detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")

@@ -405,6 +405,29 @@ int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx
                               void* stream);
 int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
                                 void* stream);
+/* ---- the same layers as TWO-plane f16 split products (r05, "h2"; csrc/conv_halo_x3.hip split2h / h2_scale) -------------------------
+ * s*a = hi + lo 2^-11 with hi = f16(s*a), lo = f16((s*a - hi) 2^11), round to nearest: 22-24 significand bits in two planes, so
+ * a*b needs THREE f16 MFMAs (hi*hi, hi*lo, lo*hi) where the three-plane bf16 split needs six; same fp32-size error
+ * (profiles/r05_split2_lab.txt, tests/test_x3_parity.py).  f16 has five exponent bits: each operand tensor is scaled by a power of
+ * two s (exact) that puts its largest magnitude at 2^13..2^14.  The largest magnitude travels in an "absmax slot": 8 bytes of
+ * caller memory holding (epoch << 32) | bits of max |a|, raised with atomic max by dwc_absmax (or by the kernel that produced the
+ * tensor); slots are zero before their first use and the epochs handed to one slot never decrease, so nothing is ever cleared.
+ * A consumer that finds another epoch in the slot than the one it was told poisons its result with NaN.  Non-finite operands
+ * reach the result as NaN / inf.  Replaces the same reference call sites as the dwc_x3_* entry points beside them. */
+int dwc_absmax(const float* x, size_t n, void* slot, unsigned epoch, void* stream);
+size_t dwc_h2_weight_prepared_elems(int rows, int kdim, int K);      /* 16-bit elements incl. the {s_w, 1/s_w} tail */
+int dwc_h2_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, const void* w_amax,
+                          unsigned w_epoch, void* stream);
+int dwc_h2_conv2d_same_add_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias,
+                              const float* add, float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect,
+                              void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y, int B,
+                        int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H, int W,
+                              int Cin, int Cout, int rows, void* stream);
+int dwc_h2_conv2d_wgrad(const float* x, const void* x_amax, unsigned x_epoch, const float* dy, const void* dy_amax, unsigned dy_epoch,
+                        float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real, int cout_real, void* ws, size_t ws_bytes,
+                        void* stream);
 /* weight gradient of the same layers as split products: dw (fp32, [cout_real][cin_real][K][K]) from the fp32 NHWC tensors x
  * and dy; both operands are split on the fly (x through LDS, dy in registers); pixel ranges go to fp32 slabs in `ws`, summed in
  * a fixed order.  ws_bytes == 0: shape not handled (K in {3,5}, H % 8 == 0, W % 16 == 0, Cin and Cout multiples of 64). */

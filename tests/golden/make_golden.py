@@ -313,6 +313,107 @@ def gen_traj(ref_solver, S, B, steps, lstm_dropout, tag, threads=None):
                            "threads": torch.get_num_threads(), "rows": rows}, f)
 
 
+
+# ----------------------------------------------------------------------------------------
+# full-size single iterations (the shapes tests/test_hip_parity.py::test_full_size_iteration_vs_reference checks)
+# ----------------------------------------------------------------------------------------
+FULL_DIS_GRADS = ("cnns_feat.0.0.conv.weight", "cnns_feat.0.4.conv.weight", "cnns_feat.1.2.conv.weight", "cnns_cls.0.weight")
+FULL_GEN_GRADS = ("enc_content.model.0.conv.weight", "dec.model.0.model.1.model.0.conv.weight", "dec.model.2.conv.weight",
+                  "dec.image_content.conv.weight", "mlp.model.2.fc.weight", "enc_style.model.3.conv.weight",
+                  "enc_txt.lstm.weight_hh_l0", "enc_content.model.3.model.2.model.1.conv.weight")
+FULL_SAMPLE = 8192
+
+
+def sample_idx(n):
+    """The element numbers of a flattened n-element tensor that a full-size fixture keeps (at most FULL_SAMPLE, evenly spread)."""
+    if n <= FULL_SAMPLE:
+        return np.arange(n)
+    return (np.arange(FULL_SAMPLE, dtype=np.int64) * n) // FULL_SAMPLE
+
+
+def grad_record(out, prefix, named):
+    for k, g in named:
+        flat = g.detach().reshape(-1)
+        out["%s/%s/sample" % (prefix, k)] = t2n(flat[torch.from_numpy(sample_idx(flat.numel()))])
+        d = flat.double()
+        out["%s/%s/stats" % (prefix, k)] = np.array([float(d.abs().max()), float(d.sum()), float((d * d).sum())])
+
+
+class DiskOffload:
+    """saved_tensors_hooks that park every large tensor autograd saves for backward in a file (the unmodified reference at batch 64
+    holds ~60 GB of them; this container has 62 GB and no swap).  Values are unchanged: np.save / np.load of the raw fp32."""
+
+    def __init__(self, root, min_bytes=4 << 20):
+        self.root, self.min_bytes, self.n, self.bytes = root, min_bytes, 0, 0
+        os.makedirs(root, exist_ok=True)
+
+    def pack(self, t):
+        if t.device.type != "cpu" or t.numel() * t.element_size() < self.min_bytes or t.dtype not in (torch.float32, torch.int64, torch.bool):
+            return t
+        path = os.path.join(self.root, "t%06d.npy" % self.n)
+        self.n += 1
+        self.bytes += t.numel() * t.element_size()
+        np.save(path, t.detach().contiguous().numpy())
+        return ("disk", path)
+
+    def unpack(self, h):
+        if isinstance(h, tuple) and len(h) == 2 and h[0] == "disk":
+            t = torch.from_numpy(np.load(h[1]))
+            return t
+        return h
+
+
+def gen_full(ref_solver, S, B, offload=False, dis_only=False):
+    """One iteration of the imported reference at the shipped network sizes from the seed-1234 initialisation (which the HIP
+    Solver reproduces bit for bit, tests/test_host_logic.py) on synth.make_batch(B, S, seed=11): the D-step scalars and sampled D
+    gradients (grabbed in front of dis_opt.step), then all 16 scalars and sampled G gradients of the G step."""
+    import shutil
+    cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
+    trainer = build_ref_solver(ref_solver, cfg)
+    batch = synth.make_batch(B, S, seed=11)
+    a = (batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+         batch["label_src"], batch["label_trg"], cfg, 0)
+    out = {"meta": np.frombuffer(json.dumps({"S": S, "B": B, "seed": 1234, "batch_seed": 11, "lstm_dropout": 0.0,
+                                             "torch": torch.__version__, "threads": torch.get_num_threads(),
+                                             "sample": FULL_SAMPLE}).encode(), dtype=np.uint8)}
+    real_dstep, real_gstep = trainer.dis_opt.step, trainer.gen_opt.step
+
+    def dstep(*args, **kw):
+        dp = dict(trainer.dis.named_parameters())
+        grad_record(out, "dgrad", [(k, dp[k].grad) for k in FULL_DIS_GRADS])
+        return real_dstep(*args, **kw)
+
+    def gstep(*args, **kw):
+        gp = dict(trainer.gen.named_parameters())
+        grad_record(out, "ggrad", [(k, gp[k].grad) for k in FULL_GEN_GRADS if gp[k].grad is not None])
+        return real_gstep(*args, **kw)
+    trainer.dis_opt.step, trainer.gen_opt.step = dstep, gstep
+    root = "/tmp/dwc_offload_S%d_B%d" % (S, B)
+    off = DiskOffload(root) if offload else None
+    t0 = time.time()
+    ctx = torch.autograd.graph.saved_tensors_hooks(off.pack, off.unpack) if off else __import__("contextlib").nullcontext()
+    try:
+        with ctx:
+            trainer.dis_update(*a)
+            out["loss_dis"], out["loss_dis_all"] = np.float64(float(trainer.loss_dis)), np.float64(float(trainer.loss_dis_all))
+            print("[full S%d B%d] dis_update %.1fs loss_dis_all %.6f" % (S, B, time.time() - t0, float(trainer.loss_dis_all)), flush=True)
+            if off:
+                shutil.rmtree(root, ignore_errors=True)
+                os.makedirs(root, exist_ok=True)
+            if not dis_only:
+                trainer.gen_update(*a)
+                losses = read_losses(trainer)
+                out["losses_json"] = np.frombuffer(json.dumps(losses).encode(), dtype=np.uint8)
+                print("[full S%d B%d] gen_update %.1fs loss_gen_total %.6f" % (S, B, time.time() - t0, losses["loss_gen_total"]), flush=True)
+    finally:
+        if off:
+            print("[full S%d B%d] offloaded %d tensors, %.1f GB" % (S, B, off.n, off.bytes / 1e9), flush=True)
+            shutil.rmtree(root, ignore_errors=True)
+    path = os.path.join(HERE, "full_s%d_b%d%s.npz" % (S, B, "_dis" if dis_only else ""))
+    np.savez_compressed(path, **out)
+    print(path, "written:", len(out), "arrays")
+
+
 def gen_vgg(ref_solver, ref_nets):
     """compute_vgg_loss of the reference (solver.py:242-247) on a seeded, randomly initialised Vgg16 (the trained
     weights cannot be fetched here): loss, gradient w.r.t. the target image, relu5_3 features of the first image.
@@ -437,3 +538,14 @@ if __name__ == "__main__":
         # the 128x128 / batch-16 reference run again with another CPU thread count: the envelope the 0.15 / 0.06 bounds of
         # tests/test_trajectory.py::test_hip_trajectory_s128_b16_100_steps are derived from
         gen_traj(ref_solver, 128, 16, 100, 0.0, "s128_b16_nolstmdrop_threads3", threads=3)
+    # full-size single iterations (one reference run each; the batch-64 one parks autograd's saved tensors on disk)
+    if "full128b2" in what:
+        gen_full(ref_solver, 128, 2)
+    if "full256b1" in what:
+        gen_full(ref_solver, 256, 1)
+    if "full256b8" in what:
+        gen_full(ref_solver, 256, 8)
+    if "full128b64" in what:
+        gen_full(ref_solver, 128, 64, offload=True)
+    if "full128b128dis" in what:
+        gen_full(ref_solver, 128, 128, offload=True, dis_only=True)
