@@ -63,17 +63,23 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 # several launches of comparable weight (Winograd: transform + product kernels) are labelled as such and never chosen as
 # "the" roofline kernel; small helper launches inside a call (split-K / slab reduces, folds) are part of its span time.
 KIND_KERNEL = {
-    "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
-    "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, ", "bf16x3"),
+    "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
+    "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
     "fwd-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
     "dgrad-heads-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
     "fwd-heads-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     "dgrad-image-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     # (template arguments: ..., PB, S2, KSP -- S2 is the last but one: 1 = stride-2 forward, 2 = its data gradient)
-    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12]>\(", "bf16x3"),
-    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1>\(", "bf16x3"),
+    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 3>\(", "bf16x3"),
+    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1, 3>\(", "bf16x3"),
     "dgrad-s2halo": ("conv_halo16_kernel<2,S2-dgrad>", r"conv_halo16_kernel<2, .*, 2>\(", "bf16"),
-    "wgrad-x3": ("wgrad_x3_kernel<{k}>", r"wgrad_x3_kernel<{k}, ", "bf16x3"),
+    "wgrad-x3": ("wgrad_x3_kernel<{k}>", r"wgrad_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
+    # r05: the same kernels with TWO f16 planes per operand (template argument NPL = 2, the last one): 3 MFMAs per fp32 multiply-add
+    "fwd-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2>\(", "f16x2"),
+    "dgrad-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2>\(", "f16x2"),
+    "fwd-h2s2": ("conv_halo_x3_kernel<2,S2,h2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 2>\(", "f16x2"),
+    "dgrad-h2s2": ("conv_halo_x3_kernel<2,S2-dgrad,h2>", r"conv_halo_x3_kernel<2, .*, 2, 1, 2>\(", "f16x2"),
+    "wgrad-h2": ("wgrad_x3_kernel<{k},h2>", r"wgrad_x3_kernel<{k}, .*, 2>\(", "f16x2"),
     "fwd-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
     "dgrad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
     "fwd-zeropad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
@@ -109,7 +115,7 @@ GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the 
     "dgrad-zeropad": ("conv_gemm_kernel", "gemm_kernel_h"),
     "wgrad": ("conv_wgrad_kernel", "wgrad_kernel_h"), "wgrad-heads": ("conv_wgrad_kernel", "wgrad_kernel_h"),
 }
-PIPE_PEAK = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
+PIPE_PEAK = {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0}
 
 
 def kernel_of_kind(kind_key, precision, split_generic=False):

@@ -126,8 +126,10 @@ def test_h2_wide_dynamic_range_operand():
     assert err <= 2e-6 and err <= 2 * err_32 + 2e-7
 
 
+# (the five shapes of test_x3_parity.py::test_x3_stride2_forward_matches_float64, same data, + two with scaled activations)
 @pytest.mark.parametrize("shape", [(2, 64, 128, 64, 32, "relu", 1.0), (3, 128, 256, 64, 64, "lrelu", 1.0), (1, 16, 64, 32, 32, "none", 1.0),
-                                   (2, 256, 256, 32, 32, "none", 1e-5), (24, 64, 128, 128, 128, "relu", 1.0)],
+                                   (2, 256, 256, 32, 32, "none", 1.0), (24, 64, 128, 128, 128, "relu", 1.0),
+                                   (2, 128, 256, 32, 32, "none", 1e-5), (2, 64, 128, 64, 32, "relu", 3e4)],
                          ids=lambda s: "x".join(str(v) for v in s))
 def test_h2_stride2_forward_matches_float64(shape):
     B, Cin, Cout, H, W, act, sx = shape
