@@ -159,9 +159,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
     constexpr int NTAP = KS * KS;
     constexpr int PAD = (KS - 1) / 2;
-    __shared__ __attribute__((aligned(16))) bf16 smem[PB * NPL * P_PLANE + 3 * W_SLOT];
+    // RAW (the two-plane form): the next slab's fp32 patch travels global -> LDS by DMA (16 bytes per lane, the reflect / zero rule in
+    // the per-lane buffer offset) and is split from there at the slab boundary, instead of waiting in PPASS x 4 registers for a
+    // whole slab.  The registers pay for `big`: every FLUSH slabs the leading-product accumulators are added to fp32 VALU
+    // accumulators (round to nearest) and restart from zero.  The error of a long contraction on the matrix cores is dominated by
+    // the accumulate of each MFMA into an accumulator that has grown large (benchmarks/split2_lab.hip: K = 6400, error / output
+    // scale 8.9e-7 unflushed, 2.0e-7 flushed every 25 steps -- a third of the native fp32 MFMA's).
+    constexpr bool RAW = NPL == 2;
+    static_assert(!RAW || PB == 1, "raw patch staging: the single-buffer form");
+    constexpr int FLUSH = !RAW ? 0 : (NTAP >= 25 ? 1 : (NTAP >= 9 ? 2 : 4));      // slabs between flushes: 16 - 25 k-steps
+    constexpr int RAW_ELEMS = RAW ? PPASS * THREADS * 8 : 0;                      // 16 bytes per thread and pass, in 2-byte elements
+    __shared__ __attribute__((aligned(16))) bf16 smem[PB * NPL * P_PLANE + 3 * W_SLOT + RAW_ELEMS];
     bf16* sP = smem;                                   // [PB buffers][NPL planes][pixel][16]
     bf16* sW = smem + PB * NPL * P_PLANE;              // [3 slots][NPL planes][BN][16]
+    bf16* sR = sW + 3 * W_SLOT;                        // RAW: [pass][thread] f32x4
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -217,7 +228,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     const int nsteps = ncs * NTAP;
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
-    const float* p_src[S2 == 1 ? 1 : PPASS];
+    const float* p_src[(S2 == 1 || RAW) ? 1 : PPASS];
+    unsigned p_off[RAW ? PPASS : 1];                    // RAW: byte offset of the pixel's channel quad in x, 2^31 = "reads as zero"
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (unsigned)min((size_t)0xffffffffu, (size_t)a.B * a.H * a.W * a.Cin * 4), 0x00020000);
     // S2: element offset of the patch pixel's input pixel for parity (0, 0), and what the odd row / column parity adds to it
     // (kept as base + masked delta: indexing a register array by the parity would send it to scratch)
     int p_base[S2 == 1 ? PPASS : 1], p_drow[S2 == 1 ? PPASS : 1], p_dcol[S2 == 1 ? PPASS : 1];
@@ -248,16 +262,34 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
             }
             h = min(max(h, 0), a.H - 1);
             w = min(max(w, 0), a.W - 1);
-            p_src[i] = a.x + ((size_t)(n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4;
+            if constexpr (RAW) p_off[i] = ok ? (unsigned)(((n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4) * 4u : 0x80000000u;
+            else p_src[i] = a.x + ((size_t)(n_img * a.H + h) * a.W + w) * a.Cin + (t & 3) * 4;
         }
         p_dst[i] = py * PITCH + px * CS + (t & 3) * 4;
         p_ok |= ok ? 1u << i : 0u;
         p_in |= pp < PPIX ? 1u << i : 0u;
     }
-    f32x4 pv[PPASS];
+    f32x4 pv[RAW ? 1 : PPASS];
     auto load_patch = [&](int cs_local) {
         const int cs = cs0 + cs_local;
-        if constexpr (S2 == 1) {
+        if constexpr (RAW) {
+            bf16* lr = sR + wave * 512;
+            if constexpr (S2 == 1) {
+                const int par = cs / ncsr, csl = cs - par * ncsr;
+                const int my = -(par >> 1), mx = -(par & 1);
+                const int soff = __builtin_amdgcn_readfirstlane(csl * CS * 4);
+#pragma unroll
+                for (int i = 0; i < PPASS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lr + i * THREADS * 8), 16,
+                                                             (unsigned)(p_base[i] + (p_drow[i] & my) + (p_dcol[i] & mx) + (t & 3) * 4) * 4u, soff, 0, 0);
+            } else {
+                const int soff = __builtin_amdgcn_readfirstlane(cs * CS * 4);
+#pragma unroll
+                for (int i = 0; i < PPASS; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lr + i * THREADS * 8), 16, p_off[i],
+                                                             soff, 0, 0);
+            }
+        } else if constexpr (S2 == 1) {
             const int par = cs / ncsr, csl = cs - par * ncsr;
             const float* base = a.x + csl * CS + (t & 3) * 4;
             const int my = -(par >> 1), mx = -(par & 1);
@@ -273,7 +305,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
         for (int i = 0; i < PPASS; ++i) {
             if (!((p_in >> i) & 1)) continue;                             // slot past the patch
-            const Planes<NPL> q = split_planes<NPL>((p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f}, sx.s);
+            f32x4 v;
+            if constexpr (RAW) v = *reinterpret_cast<const f32x4*>(sR + (i * THREADS + t) * 8);      // (this lane's own DMA: zeros where the rule says so)
+            else v = (p_ok >> i) & 1 ? pv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const Planes<NPL> q = split_planes<NPL>(v, sx.s);
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * P_PLANE + p_dst[i]) = q.p[pl];
         }
@@ -339,10 +374,21 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                 if (SPLIT) lo[SPLIT ? i : 0][SPLIT ? j : 0][r] = 0.f;
             }
 
+    f32x16 big[FLUSH ? TM : 1][FLUSH ? TN : 1];
+    if constexpr (FLUSH != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) big[i][j][r] = 0.f;
+    }
+
     // ---- prologue ----------------------------------------------------------------------------------------------------------
     load_patch(0);
     stage_w(0, 0);
     if (nsteps > 1) stage_w(1, 1);
+    if constexpr (RAW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the patch is read back from LDS
     write_patch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -440,6 +486,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                 pbuf ^= 1;
             } else if (cs < ncs && !(DBG & 16)) {
                 // one patch buffer: every wave is past its last read of the old slab (barrier above) -- convert in place
+                // (RAW: the patch's DMA loads are NTAP steps old, the per-step vmcnt waits above have seen them land)
+                if constexpr (FLUSH != 0) {
+                    if (cs % FLUSH == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int n = 0; n < TN; ++n) {
+                                big[i][n] += acc[i][n];
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+                            }
+                    }
+                }
                 write_patch(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -472,7 +531,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int n = 0; n < TN; ++n) acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0] * LO_W;
+                for (int n = 0; n < TN; ++n) {
+                    acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0] * LO_W;
+                    if constexpr (FLUSH != 0) acc[i][n] += big[i][n];
+                }
         }
         // Both workgroups sit on one XCD: its L2 is the meeting point.  The first arriver's stores are complete (acknowledged by the
         // L2) before it raises the ticket, the second reads the ticket and the half sum past its L1 (sc1) -- no L2 write-back or
@@ -543,6 +605,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         }
       }
     }
+    if constexpr (KSP == 1 && FLUSH != 0) {
+        // (merged before the bias / add vectors are loaded: three accumulator sets and those would not fit the register file)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) acc[i][n] += big[i][n] + lo[i][n] * LO_W;
+    }
     const float slope = dwc_act_slope(a.act);
     f32x4 bv[TN][4];
 #pragma unroll
@@ -578,7 +647,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                     const int col = n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
                     if (col >= a.N) continue;
                     f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                    if (SPLIT && KSP == 1) {
+                    if (SPLIT && KSP == 1 && FLUSH == 0) {
                         const f32x16& c = lo[SPLIT ? i : 0][SPLIT ? n : 0];
                         v += f32x4{c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]} * LO_W;
                     }
@@ -1154,7 +1223,9 @@ template <int NPL>
 static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, const float* add,
                                float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect, void* ws,
                                size_t ws_bytes, unsigned* tickets, void* stream) {
-    if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N || (NPL == 2 && !xs)) return DWC_EINVAL;
+    // (two planes: x is addressed through 31-bit buffer offsets)
+    if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N || (NPL == 2 && (!xs || (size_t)B * H * W * Cin * 4 >= 0x80000000ull)))
+        return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
     a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, K);
@@ -1307,7 +1378,8 @@ int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, 
 template <int NPL>
 static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, float* y, int B, int H,
                          int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
-    if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N || (NPL == 2 && !xs)) return DWC_EINVAL;
+    if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N || (NPL == 2 && (!xs || (size_t)B * H * W * Cin * 4 >= 0x80000000ull)))
+        return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = y;
     a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, 4);
@@ -1331,7 +1403,9 @@ static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, cons
 template <int NPL>
 static int x3_s2_bwd_data_impl(const float* dy, const void* ds, unsigned ds_epoch, const void* w_prepared, float* dx, int B, int H, int W,
                                int Cin, int Cout, int rows, void* stream) {
-    if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin || (NPL == 2 && !ds)) return DWC_EINVAL;
+    if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin ||
+        (NPL == 2 && (!ds || (size_t)B * (H / 2) * (W / 2) * Cout * 4 >= 0x80000000ull)))
+        return DWC_EINVAL;
     X3Args a;
     a.x = dy; a.w = (const bf16*)w_prepared; a.bias = nullptr; a.add = nullptr; a.y = dx;
     a.xs = (const unsigned long long*)ds; a.xs_epoch = ds_epoch; a.w_elems = h2_w_elems(rows, Cout, 4);

@@ -119,7 +119,8 @@ def test_stride2_data_gradient_halo_form(B, ci, co, H, W, prec, monkeypatch):
     try:
         calls = []
         lib = _lib_mod.load()
-        name = "dwc_bf16_conv2d_s2_halo_bwd_data" if prec == "bf16" else "dwc_x3_conv2d_s2_bwd_data"
+        name = "dwc_bf16_conv2d_s2_halo_bwd_data" if prec == "bf16" else (
+            "dwc_h2_conv2d_s2_bwd_data" if ops.X3_PLANES == 2 else "dwc_x3_conv2d_s2_bwd_data")
         real = getattr(lib, name)
         monkeypatch.setattr(lib, name, lambda *a: (calls.append(1), real(*a))[1])
         xd = x.to(DEV).to(ops.act_dtype()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
