@@ -235,3 +235,42 @@ def test_vgg_loss_restatement(golden_dir, tag):
     assert float(loss) == pytest.approx(float(z[tag + "_loss"]), rel=1e-4)
     loss.backward()
     close_scaled(target.grad, T(z[tag + "_dtarget"]), 1e-3, atol=1e-9, msg="d loss / d target")
+
+
+def test_oracle_full_size_iteration_vs_reference(golden_dir):
+    """The oracle at the SHIPPED network sizes (128x128, batch 2) against one iteration of the imported reference recorded by
+    tests/golden/make_golden.py full128b2 (reference solver.py:151-240,317-353): all 16 loss scalars, sampled entries and the sum
+    of squares of representative D and G gradients.  The GPU suite compares the HIP path with the same family of fixtures
+    (tests/test_hip_parity.py::test_full_size_iteration_vs_oracle) instead of running the oracle at batch 64 on the GPU box."""
+    fx = np.load(os.path.join(golden_dir, "full_s128_b2.npz"))
+    cfg = synth.make_config(image_size=128, lstm_dropout=0.0)
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dwc-gan_amd"))
+    from solver import Solver                    # construction only: parameter containers in the reference's init order (CPU)
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        s = Solver(cfg, torch.device("cpu"), None)
+    gen_sd, dis_sd = s.gen.state_dict(), s.dis.state_dict()
+    oracle = orc.OracleSolver(cfg, gen_sd, dis_sd)
+    oracle.copy_nets()
+    batch = synth.make_batch(2, 128, seed=11)
+    oracle.iteration(batch, 0)
+    want = json.loads(bytes(fx["losses_json"]).decode())
+    for k, v in want.items():
+        assert abs(oracle.losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, oracle.losses[k], v)
+
+    def sampled(prefix, grads):
+        names = sorted({k.split("/")[1] for k in fx.files if k.startswith(prefix + "/")})
+        assert names
+        for name in names:
+            flat = grads[name].detach().float().reshape(-1)
+            n = flat.numel()
+            idx = torch.arange(n) if n <= 8192 else (torch.arange(8192, dtype=torch.int64) * n) // 8192
+            ref = T(fx["%s/%s/sample" % (prefix, name)])
+            amax, _, sumsq = (float(v) for v in fx["%s/%s/stats" % (prefix, name)])
+            err = (flat[idx] - ref).abs().max().item()
+            assert err <= 5e-3 * amax + 1e-6, (name, err, amax)
+            assert abs(float(flat.double().pow(2).sum()) - sumsq) <= 2e-2 * sumsq, name
+    sampled("ggrad", oracle.last_gen_grads)

@@ -102,9 +102,9 @@ def _resync_run(S, B, steps, seed=1234, threads=16, precision="fp32", tol=1e-3, 
 
 def test_hip_resync_100_steps_s64_b4():
     """100 optimiser steps at 64x64, batch 4 (BASELINE configs[0] shape): the 16 scalars of a step within 1e-3, checked at
-    steps 0-15, every 4th step after that and step 99 (38 oracle iterations instead of 100: the GPU suite has a wall-clock
-    limit and the CPU oracle is what it spends; r02 measured every one of the 100 steps at <= 9e-7)."""
-    worst, signed = _resync_run(64, 4, 100, check=list(range(16)) + list(range(16, 100, 4)) + [99])
+    steps 0-7, every 8th step after that and step 99 (20 oracle iterations instead of 100: the GPU suite has a wall-clock
+    limit and the CPU oracle is what it spends; r02 measured every one of the 100 steps at <= 9e-7, r04 checked 38)."""
+    worst, signed = _resync_run(64, 4, 100, check=list(range(8)) + list(range(8, 96, 8)) + [99])
     print("worst |rel err| per scalar over 100 steps:", dict(zip(SCALARS, np.round(worst, 7))))
     # a systematic bias would show as a mean signed error comparable to the worst one; report and bound it
     bias = np.abs(signed.mean(axis=0))
