@@ -75,10 +75,10 @@ def main():
             ta = med(lambda: _lib.check(lib.dwc_absmax(x.data_ptr(), x.numel(), xsl, xep, st), "absmax x"))
             _lib.check(lib.dwc_absmax(dy.data_ptr(), dy.numel(), dsl, dep, st), "absmax dy")
             if s == 1:
-                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_same_add_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), None, y.data_ptr(),
+                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_same_add_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), None, y.data_ptr(), None, 0,
                                                                            B, H, H, ci, co, co, k, 1, 1, ksw.data_ptr(), need, kst.data_ptr(), st), "h2"))
             else:
-                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_s2_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), y.data_ptr(), B, H, H, ci,
+                tf2 = med(lambda: _lib.check(lib.dwc_h2_conv2d_s2_ws(x.data_ptr(), xsl, xep, hp.data_ptr(), b.data_ptr(), y.data_ptr(), None, 0, B, H, H, ci,
                                                                      co, co, 1, ksw.data_ptr(), need, kst.data_ptr(), st), "h2s2"))
             tw2 = float("nan")
             if nws:

@@ -103,6 +103,8 @@ struct X3Args {
     const unsigned long long* xs = nullptr;      // NPL == 2: absmax slot of x and the epoch it must carry
     unsigned xs_epoch = 0;
     size_t w_elems = 0;             // NPL == 2: 16-bit elements of the prepared planes; {s_w, 1 / s_w} (fp32) sit behind them
+    unsigned long long* ys = nullptr;            // NPL == 2, optional: absmax slot of y, raised from the store pass (epoch ys_epoch)
+    unsigned ys_epoch = 0;
 };
 
 // WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
@@ -625,6 +627,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
             for (int q4 = 0; q4 < 4; ++q4)
                 bv[n][q4] = *reinterpret_cast<const f32x4*>(a.bias + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, a.N - 4));
     }
+    unsigned y_am = 0;
     auto store = [&](auto general) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -659,12 +662,14 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                         else v[k] = dwc_act_simple(v[k], slope);
                     }
                     if (a.add) v += adv[n][q4];
+                    if constexpr (NPL == 2) y_am = max(max(y_am, max(dwc_abs_bits(v[0]), dwc_abs_bits(v[1]))), max(dwc_abs_bits(v[2]), dwc_abs_bits(v[3])));
                     *reinterpret_cast<f32x4*>(dst + col) = v;
                 }
         }
     };
     if (dwc_act_is_simple(a.act)) store(std::false_type{});
     else store(std::true_type{});
+    if constexpr (NPL == 2) dwc_amax_wave_publish(a.ys, a.ys_epoch, y_am);
 #endif
 }
 
@@ -1222,13 +1227,14 @@ int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS; }
 template <int NPL>
 static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, const float* add,
                                float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect, void* ws,
-                               size_t ws_bytes, unsigned* tickets, void* stream) {
+                               size_t ws_bytes, unsigned* tickets, void* stream, void* ys = nullptr, unsigned ys_epoch = 0) {
     // (two planes: x is addressed through 31-bit buffer offsets)
     if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N || (NPL == 2 && (!xs || (size_t)B * H * W * Cin * 4 >= 0x80000000ull)))
         return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
     a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, K);
+    a.ys = (unsigned long long*)ys; a.ys_epoch = ys_epoch;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     const int blocks = B * a.blocks_per_img;
@@ -1327,10 +1333,10 @@ int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const floa
 /* ---- the same layers as TWO-plane f16 split products (r05; see split2h / h2_scale): x_amax = the absmax slot of x (dwc_absmax or a
  * producing kernel) carrying `x_epoch`, w_prepared = dwc_h2_weight_prepare.  Same tiles, scratch and tickets as the three-plane form. */
 int dwc_h2_conv2d_same_add_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias,
-                              const float* add, float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect,
-                              void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+                              const float* add, float* y, void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows,
+                              int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
     return x3_same_add_ws_impl<2>(x, x_amax, x_epoch, w_prepared, bias, add, y, B, H, W, Cin, N, rows, K, act, reflect, ws, ws_bytes, tickets,
-                                  stream);
+                                  stream, y_amax, y_epoch);
 }
 
 size_t dwc_h2_weight_prepared_elems(int rows, int kdim, int K) { return h2_w_elems(rows, kdim, K) + 8; }
@@ -1377,12 +1383,14 @@ int dwc_x3_conv2d_s2(const float* x, const void* w_prepared, const float* bias, 
 
 template <int NPL>
 static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, float* y, int B, int H,
-                         int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+                         int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream,
+                         void* ys = nullptr, unsigned ys_epoch = 0) {
     if (!x || !w_prepared || !y || !x3_s2_ok(B, H, W, Cin, N) || rows < N || (NPL == 2 && (!xs || (size_t)B * H * W * Cin * 4 >= 0x80000000ull)))
         return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = nullptr; a.y = y;
     a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, 4);
+    a.ys = (unsigned long long*)ys; a.ys_epoch = ys_epoch;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = 1;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = (N + 63) / 64;
@@ -1425,9 +1433,10 @@ int dwc_x3_conv2d_s2_ws(const float* x, const void* w_prepared, const float* bia
     return x3_s2_ws_impl<3>(x, nullptr, 0, w_prepared, bias, y, B, H, W, Cin, N, rows, act, ws, ws_bytes, tickets, stream);
 }
 /* two-plane f16 form (see dwc_h2_conv2d_same_add_ws); w_prepared = dwc_h2_weight_prepare(K = 4) */
-int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y, int B,
-                        int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
-    return x3_s2_ws_impl<2>(x, x_amax, x_epoch, w_prepared, bias, y, B, H, W, Cin, N, rows, act, ws, ws_bytes, tickets, stream);
+int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y,
+                        void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes,
+                        unsigned* tickets, void* stream) {
+    return x3_s2_ws_impl<2>(x, x_amax, x_epoch, w_prepared, bias, y, B, H, W, Cin, N, rows, act, ws, ws_bytes, tickets, stream, y_amax, y_epoch);
 }
 
 /* INTERIOR of the data gradient of the same layers (conv_halo_x3_kernel, S2 == 2): dy:[B,H/2,W/2,Cout] fp32 -> the H x W pixels

@@ -81,6 +81,22 @@ __device__ __forceinline__ unsigned dwc_wave_max_u32(unsigned v) {
     for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off, 64));
     return v;
 }
+// One lane per wave raises the slot, and only if the slot does not hold at least this value already (most waves of a launch find it
+// raised): the atomics of a whole launch on ONE address would otherwise queue up at the L2.  Called by ALL lanes of a wave.
+__device__ __forceinline__ void dwc_amax_wave_publish(unsigned long long* slot, unsigned epoch, unsigned abs_bits) {
+    if (!slot) return;
+    abs_bits = dwc_wave_max_u32(abs_bits);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long v = ((unsigned long long)epoch << 32) | abs_bits;
+        if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) atomicMax(slot, v);
+    }
+}
+template <int V>
+__device__ __forceinline__ unsigned dwc_amax_fold(unsigned am, const float (&o)[V]) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) am = max(am, dwc_abs_bits(o[k]));
+    return am;
+}
 struct H2Scale { float s, inv; };
 __device__ __forceinline__ H2Scale h2_scale(const unsigned long long* slot, unsigned epoch) {
     const unsigned long long v = *slot;

@@ -231,12 +231,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, const T* __restrict__ residual,
-                                                T* __restrict__ y, int HW, int C, int rows_per_chunk, int relu) {
+                                                T* __restrict__ y, int HW, int C, int rows_per_chunk, int relu,
+                                                unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     if (rg >= groups) return;
+    unsigned am = 0;                                       // largest |y| this thread writes (two-plane conv kernels: absmax slot of y)
     const int n = blockIdx.y;
     const size_t s = (size_t)n * C + col * V;
     float mu[V], sc[V], sh[V];
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
             if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
             o[k] = res ? t + res[k] : t;
         }
+        am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows in flight per thread
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
         one(v0, residual ? q0 : nullptr, o0);
         stv(y, i0, o0);
     }
+    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 template <typename T, bool FUSED = false>
@@ -396,12 +400,14 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, T* __restrict__ dx, int HW, int C, int BC,
-                                                    int rows_per_chunk, int relu) {
+                                                    int rows_per_chunk, int relu, unsigned long long* amax = nullptr,
+                                                    unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     if (rg >= groups) return;
+    unsigned am = 0;
     const int n = blockIdx.y;
     const size_t s = (size_t)n * C + col * V;
     const float inv_hw = 1.f / (float)HW;
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
             if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - k1[k] - xh * k2[k]);
         }
+        am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
         ldv(dy, i0, d0);
         one(x0, d0, o0);
         stv(dx, i0, o0);
-    }
+    }    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -521,12 +528,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ inv, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, T* __restrict__ y, int HW, int C, int rows_per_chunk,
-                                                int relu) {
+                                                int relu, unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     if (rg >= groups) return;
+    unsigned am = 0;
     const int n = blockIdx.y;
     const float mu = mean[n], iv = inv[n];
     float sc[V], sh[V];
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
             const float t = (v[k] - mu) * sc[k] + sh[k];
             o[k] = (relu && t < 0.f) ? 0.f : t;          // NaN-preserving
         }
+        am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + groups < r1; r += 2 * groups) {
@@ -561,6 +570,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
         one(v0, o0);
         stv(y, base + (size_t)r * cq, o0);
     }
+    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 // per block: sample sums (sum g, sum g*(x-mu)) with g = dy_eff*gamma, and per-channel
@@ -696,12 +706,14 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
                                                     const float* __restrict__ mean, const float* __restrict__ inv,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ sums, T* __restrict__ dx, int HW, int C,
-                                                    int rows_per_chunk, float eps, int relu) {
+                                                    int rows_per_chunk, float eps, int relu, unsigned long long* amax = nullptr,
+                                                    unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
     if (rg >= groups) return;
+    unsigned am = 0;
     const int n = blockIdx.y;
     const float N = (float)HW * (float)C;
     const float mu = mean[n], iv = inv[n];
@@ -723,6 +735,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
             if (relu) d = (xc * iv * ga[k] + be[k]) > 0.f ? d : 0.f;
             o[k] = (d * ga[k] - mean_g) * iv - xc * k2;
         }
+        am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
@@ -745,7 +758,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
         ldv(dy, i0, d0);
         one(x0, d0, o0);
         stv(dx, i0, o0);
-    }
+    }    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 1 <= C / V <= 256 column groups
@@ -836,7 +849,8 @@ template <typename T, int HW, int THREADS, bool HAS_RES>
 __global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const T* __restrict__ residual,
                                                                T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
-                                                               int C, float eps, int relu, int pairs) {
+                                                               int C, float eps, int relu, int pairs, unsigned long long* amax = nullptr,
+                                                               unsigned amax_ep = 0) {
     constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = THREADS / CQ, NP = HW / ROWS;
     typedef typename Raw4<T>::type Raw;
     __shared__ float sm[(THREADS / 64) * CQ * 2 * V];
@@ -900,6 +914,7 @@ __global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < V; ++k) sc[k] *= rs[k];
     char* yb = reinterpret_cast<char*>(y) + ubase;
+    unsigned am = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         float v[V], q[V], o[V];
@@ -911,10 +926,12 @@ __global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__
             if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
             o[k] = HAS_RES ? t + q[k] : t;
         }
+        am = dwc_amax_fold<V>(am, o);
         Raw out;
         res_pack(o, out);
         *reinterpret_cast<Raw*>(yb + p * pstride + toff) = out;
     }
+    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 template <typename T, int HW, int THREADS>
@@ -922,7 +939,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int C, int relu, int pairs) {
+                                                               int C, int relu, int pairs, unsigned long long* amax = nullptr,
+                                                               unsigned amax_ep = 0) {
     constexpr int V = 4, CQ = Raw4<T>::CQ, ROWS = THREADS / CQ, NP = HW / ROWS;
     typedef typename Raw4<T>::type Raw;
     __shared__ float sm[(THREADS / 64) * CQ * 2 * V];
@@ -976,6 +994,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
     }
     const float inv = 1.f / (float)HW;
     char* ob = reinterpret_cast<char*>(dx) + ubase;
+    unsigned am = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         float xv[V], dv[V], o[V];
@@ -988,10 +1007,12 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
             if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - s[k] * inv - xh * (s[V + k] * inv));
         }
+        am = dwc_amax_fold<V>(am, o);
         Raw out;
         res_pack(o, out);
         *reinterpret_cast<Raw*>(ob + p * pstride + toff) = out;
     }
+    dwc_amax_wave_publish(amax, amax_ep, am);
 }
 
 // plane size when the resident-plane kernels take this shape, else 0
@@ -1014,17 +1035,18 @@ size_t instnorm_ws_bytes(int B, int HW, int C) {
 
 template <typename T>
 int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y, float* mean,
-                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream,
+                     unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (const int rhw = in_resident_hw<T>(HW, C)) {          // small planes: one pass, plane resident in registers
         const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
         const dim3 grid((pairs + 7) / 8 * 16);
-        if (rhw == 1024 && residual) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 512, true>), grid, dim3(512), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
-        else if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
-        else if (residual) hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, true>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
-        else hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs);
+        if (rhw == 1024 && residual) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 512, true>), grid, dim3(512), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
+        else if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
+        else if (residual) hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, true>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
+        else hipLaunchKernelGGL((in_resident_fwd<T, 256, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
@@ -1044,7 +1066,7 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     }
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
-                       ra.rows_per_chunk, relu);
+                       ra.rows_per_chunk, relu, amax, amax_ep);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1052,15 +1074,15 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
 template <typename T>
 int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                     size_t ws_bytes, unsigned* tickets, void* stream) {
+                     size_t ws_bytes, unsigned* tickets, void* stream, unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (const int rhw = in_resident_hw<T>(HW, C)) {
         const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
         const dim3 grid((pairs + 7) / 8 * 16);
-        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 512>), grid, dim3(512), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs);
-        else hipLaunchKernelGGL((in_resident_bwd<T, 256, 256>), grid, dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs);
+        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 512>), grid, dim3(512), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
+        else hipLaunchKernelGGL((in_resident_bwd<T, 256, 256>), grid, dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
     }
@@ -1082,7 +1104,7 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     }
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
-                       B * C, ra.rows_per_chunk, relu);
+                       B * C, ra.rows_per_chunk, relu, amax, amax_ep);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1094,7 +1116,8 @@ size_t layernorm_ws_bytes(int B, int HW, int C) {
 
 template <typename T>
 int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, float* mean, float* inv, int B, int HW,
-                      int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+                      int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream, unsigned long long* amax = nullptr,
+                      unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V) || (size_t)HW * C < 2) return DWC_EINVAL;
     if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1105,7 +1128,8 @@ int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, flo
     hipLaunchKernelGGL(ln_stats_final<T>, dim3((B + 63) / 64), dim3(64), 0, st, x, part, mean, inv, B, HW, C, rs.chunks, eps);
     DWC_LAUNCH_CHECK();
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
-    hipLaunchKernelGGL(ln_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, ra.rows_per_chunk, relu);
+    hipLaunchKernelGGL(ln_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, inv, gamma, beta, y, HW, C, ra.rows_per_chunk, relu,
+                       amax, amax_ep);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1113,7 +1137,7 @@ int layernorm_fwd_t(const T* x, const float* gamma, const float* beta, T* y, flo
 template <typename T>
 int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv, const float* gamma,
                     const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
-                      void* ws, size_t ws_bytes, void* stream) {
+                      void* ws, size_t ws_bytes, void* stream, unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < layernorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1129,7 +1153,7 @@ int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv
     DWC_LAUNCH_CHECK();
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(ln_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, inv, gamma, beta, sums, dx, HW, C,
-                       ra.rows_per_chunk, eps, relu);
+                       ra.rows_per_chunk, eps, relu, amax, amax_ep);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1159,6 +1183,33 @@ int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
                       const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
                       void* ws, size_t ws_bytes, void* stream) {
     return layernorm_bwd_t<float>(dy, x, mean, inv, gamma, beta, dx, dgamma, dbeta, B, HW, C, eps, relu, ws, ws_bytes, stream);
+}
+
+/* The same four with the absmax slot of the tensor they WRITE (y / dx): raised by atomic max on (epoch << 32 | magnitude bits) from
+ * the apply pass, so that a two-plane split-product convolution (dwc_h2_*, include/dwcgan_hip.h) that consumes the tensor needs no
+ * dwc_absmax pass of its own.  out_amax NULL: exactly the plain entry point. */
+int dwc_instnorm_fwd_amax(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          void* out_amax, unsigned out_epoch, void* stream) {
+    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, tickets, stream,
+                                 (unsigned long long*)out_amax, out_epoch);
+}
+int dwc_instnorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+                          size_t ws_bytes, unsigned* tickets, void* out_amax, unsigned out_epoch, void* stream) {
+    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, tickets, stream,
+                                 (unsigned long long*)out_amax, out_epoch);
+}
+int dwc_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
+                           int C, float eps, int relu, void* ws, size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream) {
+    return layernorm_fwd_t<float>(x, gamma, beta, y, mean, inv, B, HW, C, eps, relu, ws, ws_bytes, stream, (unsigned long long*)out_amax,
+                                  out_epoch);
+}
+int dwc_layernorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* inv, const float* gamma,
+                           const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+                           void* ws, size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream) {
+    return layernorm_bwd_t<float>(dy, x, mean, inv, gamma, beta, dx, dgamma, dbeta, B, HW, C, eps, relu, ws, ws_bytes, stream,
+                                  (unsigned long long*)out_amax, out_epoch);
 }
 
 /* bf16 activations (x, residual, y, dy, dx); statistics, gamma/beta and their gradients stay fp32 */

@@ -21,7 +21,8 @@ int grid_for(size_t items, int cap = 4096) {
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy, const T* __restrict__ y,
                                                        T* __restrict__ g, float* __restrict__ part, int rows, int C,
-                                                       int rows_per_chunk, int act) {
+                                                       int rows_per_chunk, int act, unsigned long long* amax = nullptr,
+                                                       unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;                 // 16-byte accesses: 4 fp32 / 8 bf16 per lane
     __shared__ float sm[256 * V];
     const int cq = C / V;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy,
     const int r0 = blockIdx.x * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
     float s[V];
+    unsigned am = 0;                                // largest |g| this thread writes (absmax slot of g, see dwc_amax_wave_publish)
 #pragma unroll
     for (int k = 0; k < V; ++k) s[k] = 0.f;
     auto one = [&](float (&d)[V], const float (&yy)[V]) {
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy,
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) s[k] += d[k];
+        am = dwc_amax_fold<V>(am, d);
     };
     int r = r0 + rg;
     for (; r + groups < r1; r += 2 * groups) {      // two rows in flight per thread
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy,
         one(d0, y0);
         if (g) stv(g, i0, d0);
     }
+    dwc_amax_wave_publish(amax, amax_ep, am);
     if (!part) return;
 #pragma unroll
     for (int k = 0; k < V; ++k) sm[threadIdx.x * V + k] = s[k];
@@ -568,7 +572,8 @@ size_t dwc_act_bwd_bias_ws_bytes(int rows, int C) {
 namespace {
 
 template <typename T>
-int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes, void* stream) {
+int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes, void* stream,
+                   unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     constexpr int V = VecOf<T>::V;
     if (rows <= 0 || C <= 0 || (C % V)) return DWC_EINVAL;
     const int cq = C / V;
@@ -579,7 +584,7 @@ int act_bwd_bias_t(const T* dy, const T* y, T* g, float* db, int rows, int C, in
     int chunks, rpc;
     act_plan(rows, &chunks, &rpc);
     hipLaunchKernelGGL(act_bwd_partial<T>, dim3(chunks, (cq + 255) / 256), dim3(256), 0, st, dy, y, g, db ? (float*)ws : nullptr,
-                       rows, C, rpc, act);
+                       rows, C, rpc, act, g ? amax : nullptr, amax_ep);
     DWC_LAUNCH_CHECK();
     if (db) {
         hipLaunchKernelGGL(colsum_final, dim3((C + 63) / 64), dim3(1024), 0, st, (const float*)ws, db, chunks, C);
@@ -633,6 +638,11 @@ extern "C" {
 int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
                      void* stream) {
     return act_bwd_bias_t<float>(dy, y, g, db, rows, C, act, ws, ws_bytes, stream);
+}
+/* dwc_act_bwd_bias with the absmax slot of g (see dwc_instnorm_fwd_amax) */
+int dwc_act_bwd_bias_amax(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
+                          void* g_amax, unsigned g_epoch, void* stream) {
+    return act_bwd_bias_t<float>(dy, y, g, db, rows, C, act, ws, ws_bytes, stream, (unsigned long long*)g_amax, g_epoch);
 }
 int dwc_bf16_act_bwd_bias(const void* dy, const void* y, void* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
                           void* stream) {

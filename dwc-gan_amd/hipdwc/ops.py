@@ -612,6 +612,23 @@ def set_amax(t, slot, ep):
     return t
 
 
+def out_amax(t):
+    """(slot, epoch) for a kernel that is about to WRITE the fp32 tensor ``t`` and can raise its absmax slot while it does
+    (dwc_*_amax entry points), or (None, 0) when nobody will ask (bf16 tensors, three-plane kernels)."""
+    if X3_PLANES != 2 or t.dtype != torch.float32:
+        return None, 0
+    return amax_slot(t.device)
+
+
+def pass_amax(src, dst):
+    """``dst`` is bounded by ``src`` in magnitude (bilinear up-sampling, average pooling: convex combinations): it inherits src's slot
+    -- an upper bound is all the two-plane kernels need (the scale has 2^27 of headroom)."""
+    c = getattr(src, "_dwc_amax", None)
+    if c is not None and c[2] == src._version and c[3] == src.data_ptr():
+        set_amax(dst, c[0], c[1])
+    return dst
+
+
 def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad, free=False):
     """Whether this fp32 stride-1 'same' convolution (c_in gathered channels -> c_out) runs as split-bf16 products.
     5x5: always when the shape is handled (1.5-1.8x the native kernels).  3x3: Winograd F(2x2) on the fp32 MFMA is about as
@@ -725,10 +742,12 @@ class _Conv2d(torch.autograd.Function):
             w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
             x_amax = amax_of(x)
+            ya, yep = out_amax(y)
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
-                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1,
+                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), None, y.data_ptr(), ya, yep, B, H, W, Cx, cop, cop, KH, act, 1,
                 _p(ks_ws), ks_n, ks_t, st), detail="fwd-h2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=3 * flops),
                 "h2_conv2d_same")
+            set_amax(y, ya, yep)
         elif use_x3:
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
@@ -739,9 +758,11 @@ class _Conv2d(torch.autograd.Function):
             w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 2)
             x_amax = amax_of(x)
+            ya, yep = out_amax(y)
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_ws(
-                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, cop, act, _p(ks_ws), ks_n, ks_t,
-                st), detail="fwd-h2s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=3 * flops), "h2_conv2d_s2")
+                x.data_ptr(), x_amax[0], x_amax[1], w_h2.data_ptr(), _p(bias), y.data_ptr(), ya, yep, B, H, W, Cx, cop, cop, act, _p(ks_ws), ks_n,
+                ks_t, st), detail="fwd-h2s2 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=3 * flops), "h2_conv2d_s2")
+            set_amax(y, ya, yep)
         elif use_x3s2:
             # stride-2 4x4 layers, fp32: split products, 2x2 taps per input-pixel parity, space-to-depth in the patch gather
             w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1, owner)
@@ -809,8 +830,14 @@ class _Conv2d(torch.autograd.Function):
             g_out = empty_cl(B, cop, Ho, Wo, dev, dt) if act != 0 else None
             nws = lib.dwc_act_bwd_bias_ws_bytes(rows, cop)
             ws = workspace(nws, dev)
-            _lib.check(_fn(lib, "act_bwd_bias", x)(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
-                                                   ws.numel(), st), "act_bwd_bias")
+            ga_, gep_ = out_amax(g_out) if g_out is not None else (None, 0)
+            if ga_ is not None:
+                _lib.check(lib.dwc_act_bwd_bias_amax(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
+                                                     ws.numel(), ga_, gep_, st), "act_bwd_bias")
+                set_amax(g_out, ga_, gep_)
+            else:
+                _lib.check(_fn(lib, "act_bwd_bias", x)(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
+                                                       ws.numel(), st), "act_bwd_bias")
             if g_out is not None:
                 g = g_out
             if need_db:
@@ -926,7 +953,7 @@ class _Conv2d(torch.autograd.Function):
                     w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
                     ga = amax_of(g)
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
-                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0,
+                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), None, _p(g_res), dx.data_ptr(), None, 0, B, H, W, cop, Cx, Cx, KH, 0, 0,
                         ws.data_ptr(), ks_n, ks_t, st), scope_name=ctx.bscope, exec_flops=3 * flops, detail="dgrad-h2" + shape),
                         "h2_conv2d_same dgrad")
                 else:
@@ -1607,9 +1634,16 @@ class _InstNorm(torch.autograd.Function):
         mean = torch.empty(B * C, dtype=torch.float32, device=dev)
         rstd = torch.empty(B * C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _norm_tickets(dev),
-                                        _stream()), "instnorm_fwd")
+        ya, yep = out_amax(y)
+        if ya is not None:
+            _lib.check(lib.dwc_instnorm_fwd_amax(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
+                                                 rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(),
+                                                 _norm_tickets(dev), ya, yep, _stream()), "instnorm_fwd")
+            set_amax(y, ya, yep)
+        else:
+            _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(),
+                                                   _norm_tickets(dev), _stream()), "instnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -1628,9 +1662,16 @@ class _InstNorm(torch.autograd.Function):
             dgamma = torch.empty(B * C, dtype=torch.float32, device=dev)
             dbeta = torch.empty(B * C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_instnorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
-                                        dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
-                                        ws.numel(), _norm_tickets(dev), _stream()), "instnorm_bwd")
+        da, dep = out_amax(dx)
+        if da is not None:
+            _lib.check(lib.dwc_instnorm_bwd_amax(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
+                                                 dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
+                                                 ws.numel(), _norm_tickets(dev), da, dep, _stream()), "instnorm_bwd")
+            set_amax(dx, da, dep)
+        else:
+            _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
+                                                   dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
+                                                   ws.numel(), _norm_tickets(dev), _stream()), "instnorm_bwd")
         if ctx.token is not None:                 # the first convolution of the block adds it in its data-gradient epilogue
             ctx.token.g = dy
             return dx, dgamma, dbeta, None, None, None, None
@@ -1656,9 +1697,16 @@ class _LayerNorm(torch.autograd.Function):
         mean = torch.empty(B, dtype=torch.float32, device=dev)
         inv = torch.empty(B, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(_fn(lib, "layernorm_fwd", x)(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                         inv.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
-                   "layernorm_fwd")
+        ya, yep = out_amax(y)
+        if ya is not None:
+            _lib.check(lib.dwc_layernorm_fwd_amax(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), inv.data_ptr(),
+                                                  B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), ya, yep, _stream()),
+                       "layernorm_fwd")
+            set_amax(y, ya, yep)
+        else:
+            _lib.check(_fn(lib, "layernorm_fwd", x)(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                                    inv.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
+                       "layernorm_fwd")
         ctx.save_for_backward(x, mean, inv, g, b)
         ctx.relu, ctx.eps = int(relu), eps
         return y
@@ -1674,9 +1722,16 @@ class _LayerNorm(torch.autograd.Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         ws = workspace(lib.dwc_layernorm_ws_bytes(B, H * W, C), dev)
-        _lib.check(_fn(lib, "layernorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
-                                         b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
-                                         ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), _stream()), "layernorm_bwd")
+        da, dep = out_amax(dx)
+        if da is not None:
+            _lib.check(lib.dwc_layernorm_bwd_amax(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
+                                                  b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
+                                                  ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), da, dep, _stream()), "layernorm_bwd")
+            set_amax(dx, da, dep)
+        else:
+            _lib.check(_fn(lib, "layernorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
+                                                    b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
+                                                    ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), _stream()), "layernorm_bwd")
         return dx, dgamma, dbeta, None, None
 
 
@@ -1701,7 +1756,7 @@ class _Resample(torch.autograd.Function):
         else:
             y = empty_cl(B, C, H // 2, W // 2, x.device, x.dtype)
             _lib.check(_fn(lib, "avgpool2_fwd", x)(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "avgpool2_fwd")
-        return y
+        return pass_amax(x, y)
 
     @staticmethod
     def backward(ctx, dy):

@@ -415,14 +415,32 @@ int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dx
  * A consumer that finds another epoch in the slot than the one it was told poisons its result with NaN.  Non-finite operands
  * reach the result as NaN / inf.  Replaces the same reference call sites as the dwc_x3_* entry points beside them. */
 int dwc_absmax(const float* x, size_t n, void* slot, unsigned epoch, void* stream);
+/* Producers that raise the absmax slot of the tensor they write from their own store pass (no dwc_absmax pass for the consumer):
+ * the fp32 norms' apply kernels (y / dx), the activation backward (g) and the two-plane convolutions themselves (y_amax below).
+ * Arguments before `out_amax` as the plain entry points; out_amax NULL: exactly the plain entry point. */
+int dwc_instnorm_fwd_amax(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          void* out_amax, unsigned out_epoch, void* stream);
+int dwc_instnorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
+                          size_t ws_bytes, unsigned* tickets, void* out_amax, unsigned out_epoch, void* stream);
+int dwc_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
+                           int C, float eps, int relu, void* ws, size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream);
+int dwc_layernorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* inv, const float* gamma,
+                           const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, float eps, int relu,
+                           void* ws, size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream);
+int dwc_act_bwd_bias_amax(const float* dy, const float* y, float* g, float* db, int rows, int C, int act, void* ws, size_t ws_bytes,
+                          void* g_amax, unsigned g_epoch, void* stream);
 size_t dwc_h2_weight_prepared_elems(int rows, int kdim, int K);      /* 16-bit elements incl. the {s_w, 1/s_w} tail */
 int dwc_h2_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int K, int rows, int dgrad, const void* w_amax,
                           unsigned w_epoch, void* stream);
+/* (y_amax: optional absmax slot of y, raised from the store pass with epoch y_epoch -- the next convolution's x_amax; NULL: not wanted) */
 int dwc_h2_conv2d_same_add_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias,
-                              const float* add, float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect,
-                              void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
-int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y, int B,
-                        int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+                              const float* add, float* y, void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows,
+                              int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y,
+                        void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes,
+                        unsigned* tickets, void* stream);
 int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H, int W,
                               int Cin, int Cout, int rows, void* stream);
 int dwc_h2_conv2d_wgrad(const float* x, const void* x_amax, unsigned x_epoch, const float* dy, const void* dy_amax, unsigned dy_epoch,

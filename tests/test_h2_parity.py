@@ -47,7 +47,7 @@ def _conv(xn, wp, bias, add, B, H, W, Cin, N, K, act, reflect, ws=None, tickets=
     slot, ep = amax if amax is not None else _amax(xn)
     _lib.check(lib.dwc_h2_conv2d_same_add_ws(
         xn.data_ptr(), slot, ep, wp.data_ptr(), bias.data_ptr() if bias is not None else None, add.data_ptr() if add is not None else None,
-        y.data_ptr(), B, H, W, Cin, N, N, K, act, reflect, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+        y.data_ptr(), None, 0, B, H, W, Cin, N, N, K, act, reflect, ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
         tickets.data_ptr() if tickets is not None else None, _st()), "h2_conv2d_same_add_ws")
     return y
 
@@ -146,7 +146,7 @@ def test_h2_stride2_forward_matches_float64(shape):
     wp = _prep(wd, Cout, False)
     y = torch.empty(B, H // 2, W // 2, Cout, dtype=torch.float32, device=DEV)
     slot, ep = _amax(xn)
-    _lib.check(lib.dwc_h2_conv2d_s2_ws(xn.data_ptr(), slot, ep, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, Cout, ACT[act],
+    _lib.check(lib.dwc_h2_conv2d_s2_ws(xn.data_ptr(), slot, ep, wp.data_ptr(), bd.data_ptr(), y.data_ptr(), None, 0, B, H, W, Cin, Cout, Cout, ACT[act],
                                        None, 0, None, _st()), "h2_conv2d_s2")
     yn = _native(xd, wd, bd, 2, 1, act)
     torch.cuda.synchronize()
@@ -288,7 +288,7 @@ def test_h2_contraction_split_of_small_launches(shape):
         if stride == 1:
             return _conv(xn, wp, bd, addn, B, H, W, Cin, Cout, K, ACT[act], 1, ws_t, tk, amax)
         y = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.float32, device=DEV)
-        _lib.check(lib.dwc_h2_conv2d_s2_ws(xn.data_ptr(), amax[0], amax[1], wp.data_ptr(), bd.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, Cout,
+        _lib.check(lib.dwc_h2_conv2d_s2_ws(xn.data_ptr(), amax[0], amax[1], wp.data_ptr(), bd.data_ptr(), y.data_ptr(), None, 0, B, H, W, Cin, Cout, Cout,
                                            ACT[act], ws_t.data_ptr() if ws_t is not None else None, ws_t.numel() if ws_t is not None else 0,
                                            tk.data_ptr() if tk is not None else None, _st()), "h2_s2_ws")
         return y
