@@ -607,6 +607,12 @@ def amax_of(t):
     return slot, ep
 
 
+def h2_fits(t):
+    """The two-plane halo kernels address their activation operand through 31-bit byte offsets (bit 31 marks 'reads as zero'):
+    larger tensors (fp32, 3 x 128 images of 128 channels at 128 x 128) stay on the three-plane kernels."""
+    return X3_PLANES == 2 and t.numel() * 4 < (1 << 31)
+
+
 def set_amax(t, slot, ep):
     t._dwc_amax = (slot, ep, t._version, t.data_ptr())
     return t
@@ -738,7 +744,7 @@ class _Conv2d(torch.autograd.Function):
                 x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
                 ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
                 exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
-        elif use_x3 and X3_PLANES == 2:
+        elif use_x3 and h2_fits(x):
             w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
             x_amax = amax_of(x)
@@ -754,7 +760,7 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
                 x.data_ptr(), w_x3.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 1, _p(ks_ws), ks_n, ks_t, st),
                 detail="fwd-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_same")
-        elif use_x3s2 and X3_PLANES == 2:
+        elif use_x3s2 and h2_fits(x):
             w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 2)
             x_amax = amax_of(x)
@@ -943,13 +949,13 @@ class _Conv2d(torch.autograd.Function):
             wt = 0 if half or x3 else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
             if x3:
                 # interior = zero-padded convolution of dY with the rotated filter on the split-product kernel; ring direct
-                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner) if X3_PLANES != 2 else None
+                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner) if not h2_fits(g) else None
                 # (one arena: the interior's half sums -- small launches, contraction split -- are dead when the ring strips start)
                 ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1, at_least=nws)
 
                 shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
                 # (two spans: the interior launch carries the layer's flops, the ring strips + fold are time on top of it)
-                if X3_PLANES == 2:
+                if h2_fits(g):
                     w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
                     ga = amax_of(g)
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
@@ -1014,7 +1020,7 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
                     detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
             else:
-                if X3_PLANES == 2:
+                if h2_fits(g):
                     w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
                     ga = amax_of(g)
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_bwd_data(
