@@ -308,12 +308,17 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         wz = wz.contiguous()
         dg = kind == "h2_dgrad"
         rows, kdim = (cin_pad, cout_pad) if dg else (cout_pad, cin_pad)
-        out = torch.empty(lib.dwc_h2_weight_prepared_elems(rows, kdim, kh), dtype=torch.float16, device=w.device)
+        # (zeros: the last 8 bytes are the filter's absmax slot of the fused refresh, which must start below every epoch)
+        out = torch.zeros(lib.dwc_h2_weight_prepared_elems(rows, kdim, kh), dtype=torch.float16, device=w.device)
         slot, ep = amax_slot(w.device)
         _lib.check(lib.dwc_absmax(wz.data_ptr(), wz.numel(), slot, ep, _stream()), "absmax(weight)")
         _lib.check(lib.dwc_h2_weight_prepare(wz.data_ptr(), out.data_ptr(), cout_pad, cin_pad, kh, rows, int(dg), slot, ep, _stream()),
                    "h2_weight_prepare")
-        ent[key] = (stamp, out, None)
+        recipe = None
+        if co == cout_pad and ci == cin_pad:
+            recipe = _recipe(w, owners, kind=9 if dg else 8, n_items=kh * kh * ((kdim + 15) // 16) * rows * 16, Cout=co, Cin=ci,
+                             KH=kh, KW=kw, rows=rows, kdim=kdim)
+        ent[key] = (stamp, out, recipe)
         return out
     if kind in ("stem_steps", "stem_steps_dgrad"):
         # csrc/conv_narrow_bf16.hip conv_stem_kernel: [25 k-steps][64 channels][2 taps x 8 planes] bf16, halves of a row swapped
@@ -471,6 +476,7 @@ assert _REFRESH_DT.itemsize == 80
 REFRESH_CHUNK = 8192           # DWC_OPT_CHUNK of include/dwcgan_hip.h
 _REFRESH_TABLES = {}           # (src, dst) pointers of a refresh set -> (device descriptor table, chunk maps)
 REFRESH_STATS = {"launches": 0, "layouts": 0}
+_REFRESH_EPOCH = 0
 
 
 def _recipe(w, owners, **fields):
@@ -513,12 +519,15 @@ def refresh_prepared(params):
                 cs.append(s0)
         host = torch.from_numpy(desc.view(np.uint8).reshape(-1)).pin_memory()
         table = (host.to(dev, non_blocking=True), torch.tensor(cd, dtype=torch.int32, device=dev),
-                 torch.tensor(np.array(cs, dtype=np.uint32).view(np.int32), dtype=torch.int32, device=dev), len(cd))
+                 torch.tensor(np.array(cs, dtype=np.uint32).view(np.int32), dtype=torch.int32, device=dev), len(cd),
+                 int(any(int(v[3][2]["kind"]) in (8, 9) for v in todo)))
         if len(_REFRESH_TABLES) > 16:
             _REFRESH_TABLES.clear()
         _REFRESH_TABLES[ident] = table
-    _lib.check(lib.dwc_weight_refresh_multi(table[0].data_ptr(), table[1].data_ptr(), table[2].data_ptr(), table[3], _stream()),
-               "weight_refresh_multi")
+    global _REFRESH_EPOCH
+    _REFRESH_EPOCH += 1          # (epoch of the filters' absmax slots this refresh raises: larger at every call)
+    _lib.check(lib.dwc_weight_refresh_multi(table[0].data_ptr(), table[1].data_ptr(), table[2].data_ptr(), table[3], table[4],
+                                            _REFRESH_EPOCH, _stream()), "weight_refresh_multi")
     for p, ent, key, val, stamp in todo:
         ent[key] = (stamp, val[1], val[2])
     REFRESH_STATS["launches"] += 1

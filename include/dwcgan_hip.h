@@ -318,7 +318,11 @@ int dwc_adv_tail_bwd(const float* src, const float* cls, const float* labels, co
  * the filter with its two spatial axes swapped), X3 = dwc_x3_weight_prepare (work item = one of K*K*ceil(kdim/16)*rows*16
  * source slots), WINO2 = dwc_wino_prepare_filter with tile 2 (work item = one (row, k) pair, sixteen transform-domain values). */
 enum { DWC_REFRESH_FWD_F32 = 0, DWC_REFRESH_DGRAD_F32 = 1, DWC_REFRESH_FWD_BF16 = 2, DWC_REFRESH_DGRAD_BF16 = 3,
-       DWC_REFRESH_X3_FWD = 4, DWC_REFRESH_X3_DGRAD = 5, DWC_REFRESH_WINO2_FWD = 6, DWC_REFRESH_WINO2_DGRAD = 7 };
+       DWC_REFRESH_X3_FWD = 4, DWC_REFRESH_X3_DGRAD = 5, DWC_REFRESH_WINO2_FWD = 6, DWC_REFRESH_WINO2_DGRAD = 7,
+       /* r05: dwc_h2_weight_prepare (two f16 planes, n_items = K*K*ceil(kdim/16)*rows*16 source slots).  The prepared tensor ends
+        * with {s_w, 1 / s_w} (fp32) and the filter's absmax slot (8 bytes, zero when the tensor is created): has_h2 != 0 makes
+        * dwc_weight_refresh_multi raise those slots (epoch `epoch`, larger at every call) in a launch of its own first. */
+       DWC_REFRESH_H2_FWD = 8, DWC_REFRESH_H2_DGRAD = 9 };
 typedef struct {
     const float* src;            /* fp32 OIHW master weight [Cout][Cin][KH][KW] */
     void* dst;                   /* prepared tensor */
@@ -330,7 +334,7 @@ typedef struct {
     int reserved;
 } dwc_refresh_desc;
 int dwc_weight_refresh_multi(const dwc_refresh_desc* descs_dev, const int* chunk_desc_dev, const unsigned* chunk_start_dev,
-                             int n_chunks, void* stream);
+                             int n_chunks, int has_h2, unsigned epoch, void* stream);
 
 /* ---- fp32 convolutions on the bf16 matrix cores by exact three-way operand splits (conv_halo_x3.hip) --------------------
  * An fp32 value is exactly the sum of three bf16 values (truncate / subtract twice); bf16 x bf16 products are exact in the
