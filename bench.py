@@ -179,6 +179,22 @@ def kernel_table(ledger, precision, split_generic=False):
     return out
 
 
+def workload_note(ops, precision):
+    """How the fp32 path computes its inner products (part of config.workload: the record says what was measured)."""
+    if precision != "fp32":
+        return ""
+    six = ("fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 operands, results and accumulation; 6 of the 9 split terms, the "
+           "rest < 2^-23 relative)")
+    if ops.X3 >= 2 and ops.X3_PLANES == 2:
+        return (", stride-1 3x3 / 5x5 and stride-2 4x4 layers (forward, data and weight gradient) as fp32-accurate TWO-plane f16 split "
+                "products on the f16 MFMA (hi + lo 2^-11 per operand, per-tensor power-of-two scales, 3 products per multiply-add, "
+                "matrix-core partial sums flushed to fp32 VALU sums every 16-25 k-steps), the remaining conv / linear products as "
+                "three-plane bf16 split products (6 per multiply-add)")
+    if ops.X3 >= 2:
+        return ", every convolution / linear product as " + six
+    return ", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + ((", 5x5 convs and 3x3 data gradients as " + six) if ops.X3 else "")
+
+
 def run_iteration(trainer, batch, cfg, it):
     a = (batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"], batch["label_src"],
          batch["label_trg"], cfg, it)
@@ -465,6 +481,17 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
             return native
         out["native_mfma"] = native
         out["split_bf16x3"] = split
+        # the same stack in one line each way (fp32 path: its layers run as split products on the 16-bit matrix pipe):
+        #   frac_of_mfma_peak            = matrix work EXECUTED (3 or 6 products per multiply-add) / the pipe's dense peak
+        #   frac_algorithmic_of_pipe     = direct-convolution (useful) flops / the same peak
+        #   algorithmic_vs_fp32_mfma_peak = useful flops / the fp32 MFMA peak the reference's arithmetic would be held to
+        ex_all = total(lambda t: pred(t) and (t.endswith(DOMINANT) or t.endswith(X3)))
+        if native is None:
+            out["pipe_peak"] = MFMA_PEAK_TFLOPS["bf16"]
+            out["frac_of_mfma_peak"] = split["executed_bf16_frac_of_mfma_peak"]
+            out["frac_algorithmic_of_pipe"] = round(tf / MFMA_PEAK_TFLOPS["bf16"], 4)
+            out["algorithmic_vs_fp32_mfma_peak"] = round(tf / MFMA_PEAK_TFLOPS["fp32"], 4)
+            out["products_per_mac"] = round(ex_all["exec_flops"] / max(ex_all["flops"], 1.0), 2)
         return out
 
     ledger = timer.ledger() if timer is not None else {}
@@ -502,8 +529,16 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
     if single:
         r0 = single[0]
         tr, tr_src = kernel_traffic_from_profiles("c4" if config_name == "c5" else config_name, r0["kernel"])
+        # frac = matrix work the kernel EXECUTED / the dense peak of the pipe it occupies (utilisation of that pipe).  On the fp32 path
+        # the kernels are split products: `products_per_mac` MFMAs of the 16-bit pipe per fp32 multiply-add (3: two f16 planes,
+        # r05; 6: three bf16 planes, r02-r04), so the USEFUL fraction of that pipe is `frac_algorithmic_of_pipe` = frac /
+        # products_per_mac, and `algorithmic_vs_fp32_mfma_peak` holds the useful rate against the fp32 MFMA peak (157.3 TF) that
+        # fp32 arithmetic on the native instruction would be bounded by.
         roof = {"bound": "mfma", "kernel": r0["kernel"], "pipe": r0["pipe"], "achieved": r0["executed_tflops"], "peak": r0["peak_tflops"],
                 "unit": "TFLOP/s", "frac": r0["frac"], "algorithmic_tflops": r0["algorithmic_tflops"],
+                "products_per_mac": round(r0["executed_gflop_per_launch"] / max(r0["algorithmic_gflop_per_launch"], 1e-9), 2),
+                "frac_algorithmic_of_pipe": round(r0["algorithmic_tflops"] / r0["peak_tflops"], 4),
+                "algorithmic_vs_fp32_mfma_peak": round(r0["algorithmic_tflops"] / MFMA_PEAK_TFLOPS["fp32"], 4),
                 "traffic": tr, "traffic_source": tr_src, "algorithmic_bytes_per_launch": int(r0["algorithmic_mbytes_per_launch"] * 1e6),
                 "launches_per_step": r0["launches_per_step"], "avg_launch_us": r0["avg_launch_us"], "ms_per_step": r0["ms_per_step"],
                 "share_of_step": round(r0["ms_per_step"] / (elapsed / steps * 1e3), 4),
@@ -532,12 +567,7 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         "vs_baseline": None, "dtype": "bf16" if precision == "bf16" else "f32", "data": "synthetic",
         "config": {"workload": "%s, full iteration (dis_update + gen_update + EMA + LR step), vgg_w=%g%s" % (
                        conf["label"], args.vgg_w,
-                       ((", every convolution / linear product as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 operands, "
-                         "results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)" if ops.X3 >= 2 else
-                         ", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + (
-                             ", 5x5 convs and 3x3 data gradients as fp32-accurate bf16x3 split products on the bf16 MFMA (fp32 "
-                             "operands, results and accumulation; 6 of the 9 split terms, the rest < 2^-23 relative)"
-                             if ops.X3 else ""))) if precision == "fp32" else ""),
+                       workload_note(ops, precision)),
                    "name": config_name, "image_size": image_size, "per_gpu_batch": per_gpu_batch,
                    "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
         # algorithmic (direct-convolution, fp32-equivalent) flops of the launches this step actually made (conv + linear

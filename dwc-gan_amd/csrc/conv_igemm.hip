@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict
 
 extern "C" {
 
-int dwc_version(void) { return 2; }
+int dwc_version(void) { return DWC_ABI_VERSION; }
 
 /* mode >= 0: set the split-product switch of the im2col kernels (bit 0: forward / data-gradient GEMM, bit 1: weight gradient;
  * 0 = native fp32 MFMA everywhere); returns the previous value.  mode < 0: query only. */

@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, 
         for (int k = 0; k < V; ++k) {
             const float xh = (xv[k] - mu[k]) * rs[k];
             float g = dv[k];
-            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            // (the forward's own expression and rounding, (x - mu) * (gamma * rstd) + beta: an element within an ulp of zero must get the
+            // mask its forward output got)
+            if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             s1[k] += g;
             s2[k] += g * xh;
         }
@@ -430,7 +432,9 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
         for (int k = 0; k < V; ++k) {
             const float xh = (xv[k] - mu[k]) * rs[k];
             float g = dv[k];
-            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            // (the forward's own expression and rounding, (x - mu) * (gamma * rstd) + beta: an element within an ulp of zero must get the
+            // mask its forward output got)
+            if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - k1[k] - xh * k2[k]);
         }
         am = dwc_amax_fold<V>(am, o);
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(256) void ln_bwd_partial(const T* __restrict__ dy, 
             const float xc = xv[k] - mu;
             const float xh = xc * iv;
             float d = dv[k];
-            if (relu) d = (xh * ga[k] + be[k]) > 0.f ? d : 0.f;
+            if (relu) d = (xc * (ga[k] * iv) + be[k]) > 0.f ? d : 0.f;      // (the forward's expression and rounding: ln_apply)
             dg[k] += d * xh;
             db[k] += d;
             const float g = d * ga[k];
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
         for (int k = 0; k < V; ++k) {
             const float xc = xv[k] - mu;
             float d = dv[k];
-            if (relu) d = (xc * iv * ga[k] + be[k]) > 0.f ? d : 0.f;
+            if (relu) d = (xc * (ga[k] * iv) + be[k]) > 0.f ? d : 0.f;      // (the forward's expression and rounding: ln_apply)
             o[k] = (d * ga[k] - mean_g) * iv - xc * k2;
         }
         am = dwc_amax_fold<V>(am, o);
@@ -979,7 +983,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
         for (int k = 0; k < V; ++k) {
             const float xh = (xv[k] - mu[k]) * rs[k];
             float g = dv[k];
-            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            // (the forward's own expression and rounding, (x - mu) * (gamma * rstd) + beta: an element within an ulp of zero must get the
+            // mask its forward output got)
+            if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             s[k] += g;
             s[V + k] += g * xh;
         }
@@ -1004,7 +1010,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
         for (int k = 0; k < V; ++k) {
             const float xh = (xv[k] - mu[k]) * rs[k];
             float g = dv[k];
-            if (relu) g = (xh * ga[k] + be[k]) > 0.f ? g : 0.f;
+            // (the forward's own expression and rounding, (x - mu) * (gamma * rstd) + beta: an element within an ulp of zero must get the
+            // mask its forward output got)
+            if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - s[k] * inv - xh * (s[V + k] * inv));
         }
         am = dwc_amax_fold<V>(am, o);

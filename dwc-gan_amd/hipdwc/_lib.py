@@ -187,6 +187,7 @@ SIGNATURES = {
     "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
+ABI_VERSION = 5                # DWC_ABI_VERSION of include/dwcgan_hip.h
 EINVAL = -1
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
            -3: "DWC_ELAUNCH (kernel launch failed)"}
@@ -212,6 +213,10 @@ def load():
         fn = getattr(lib, name)     # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    got = lib.dwc_version()
+    if got != ABI_VERSION:         # (DWC_HIP_LIB may name an older build: same symbols, other argument lists -- undefined behaviour)
+        raise ImportError("%s reports C-ABI version %d, this binding expects %d (include/dwcgan_hip.h DWC_ABI_VERSION): rebuild it with "
+                          "`make -C dwc-gan_amd/csrc`" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -45,6 +45,10 @@ extern "C" {
                               fused into one 4-channel conv (reference networks_v2.py:159-160) */
 #define DWC_ACT_HEADS8 6   /* the same heads on an 8-plane (NHWC8, bf16) image: planes 0..2 tanh, 3 sigmoid, 4..7 zero */
 
+/* Version of this C ABI: bumped with every change of an entry point's signature or of a structure passed through it (r05: 5 --
+ * dwc_weight_refresh_multi gained has_h2 / epoch, the dwc_h2_* / dwc_*_amax entry points).  A binding must refuse a library that
+ * reports another number: symbols alone do not tell a changed argument list (hipdwc/_lib.py does). */
+#define DWC_ABI_VERSION 5
 int dwc_version(void);
 /* The fp32 im2col kernels (dwc_conv2d_fwd / _bwd_data* / _bwd_weight*, ring strips) take their inner products as exact three-way
  * bf16 split products on the bf16 matrix cores by default (r04; fp32 operands, results and accumulation -- see
