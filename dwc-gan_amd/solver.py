@@ -121,7 +121,8 @@ class Solver(nn.Module):
         # backward on a side stream) hold CUs of their own: keep those launches to half of a 256-CU device; larger grids take the
         # per-step kernels (dwc_lstm_seq_* return DWC_EINVAL above the cap)
         # (half of THIS device's CUs, not a constant: on a part with <= 128 CUs or in CPX mode "128" would cap nothing)
-        ops.LSTM_SEQ_MAX_WORKGROUPS = max(1, torch.cuda.get_device_properties(self.device).multi_processor_count // 2)
+        if self.device.type == "cuda":
+            ops.LSTM_SEQ_MAX_WORKGROUPS = max(1, torch.cuda.get_device_properties(self.device).multi_processor_count // 2)
         if os.environ.get("DWC_FORCE_DP") == "1":
             for r in self._reducers.values():
                 r.force = True

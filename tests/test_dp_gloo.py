@@ -123,6 +123,88 @@ def test_data_parallel_world2_gloo():
         assert ok3 and nshard == 2
 
 
+def _solver_worker(rank, world, port, q):
+    """The REAL Solver's data-parallel bookkeeping (enable_data_parallel / _zero_grad / _sync_grads, hipdwc.dp.OverlappedGradReducer)
+    on two gloo ranks.  The networks' kernels need a GPU, so backward is replaced by a synthetic loss that hands every parameter
+    the step would reach a rank-dependent gradient THROUGH autograd (the reducers' post-accumulate hooks fire as in training);
+    everything else -- bucket layout from the real parameter lists, the attention head's skip set at iterations 0 / 1, gradients
+    as bucket views, averaging, grad = None for untouched parameters -- is the product code."""
+    try:
+        import contextlib
+        import io
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from solver import Solver
+        cfg = synth.make_config(image_size=32, tiny=True)
+        torch.manual_seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = Solver(cfg, torch.device("cpu"), None)
+        s.copy_nets()
+        s.enable_data_parallel(bucket_bytes=16 << 10)              # tiny buckets: several per network
+        ok, why = True, []
+
+        def check(cond, msg):
+            nonlocal ok
+            if not cond:
+                ok = False
+                why.append(msg)
+        for which, net in (("dis", s.dis), ("gen", s.gen)):
+            red = s._reducers[which]
+            trainable = [p for p in net.parameters() if p.requires_grad]
+            check(len(red.buckets) >= 3, "%s: expected several buckets" % which)
+            # every trainable parameter sits in exactly one bucket, buckets in REVERSE parameter order
+            flat_order = [p for b in red.buckets for p in b["params"]]
+            check(len(flat_order) == len(trainable) and all(a is b for a, b in zip(flat_order, reversed(trainable))), "%s: layout" % which)
+            # the layout agrees across ranks
+            sizes = torch.tensor([b["flat"].numel() for b in red.buckets], dtype=torch.int64)
+            both = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(both, sizes)
+            check(all(torch.equal(both[0], t) for t in both), "%s: bucket sizes differ across ranks" % which)
+        att = {id(p) for p in s.gen.dec.image_attention.parameters()}
+        check(len(att) > 0, "attention head has parameters")
+        for it in (0, 1):
+            s.use_attention = it == 0                               # what update_attention_status leaves after iterations 0 / 1
+            for which, net in (("dis", s.dis), ("gen", s.gen)):
+                red = s._reducers[which]
+                s._zero_grad(which)
+                named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+                reached = [(i, p) for i, (n, p) in enumerate(named) if not (which == "gen" and it == 1 and id(p) in att)]
+                loss = sum((p * float((rank + 1) * (1 + 0.001 * i))).sum() for i, p in reached)
+                loss.backward()
+                early = red.launched_early
+                s._sync_grads(which)
+                check(early >= 1, "%s it%d: no bucket was reduced from inside backward" % (which, it))
+                for i, (n, p) in enumerate(named):
+                    if which == "gen" and it == 1 and id(p) in att:
+                        check(p.grad is None, "%s it%d: %s must have grad None (Adam skips it)" % (which, it, n))
+                        continue
+                    want = 1.5 * (1 + 0.001 * i)                    # mean over the two ranks of (rank + 1) * c_i
+                    check(p.grad is not None and torch.allclose(p.grad, torch.full_like(p.grad, want), rtol=1e-6, atol=0), "%s it%d: %s" % (which, it, n))
+                    bk = red.buckets[red.where[id(p)]]
+                    j = [k for k, q_ in enumerate(bk["params"]) if q_ is p][0]
+                    check(p.grad.data_ptr() == bk["views"][j].data_ptr(), "%s it%d: %s is not its bucket's view" % (which, it, n))
+        q.put((rank, ok, "; ".join(why[:5])))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, False, repr(e) + traceback.format_exc()[-600:]))
+
+
+def test_solver_data_parallel_bookkeeping_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_solver_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, why in sorted(results):
+        assert ok, (rank, why)
+
+
 def test_shard_batch_rejects_ragged():
     b = synth.make_batch(3, 8)
     with pytest.raises(ValueError):
