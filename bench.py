@@ -60,7 +60,7 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 
 # Launch kind (ops.KernelTimer.ledger: first word of the span detail) -> the kernel the C-ABI call runs, as
 # (label, regex matching its rocprofv3 kernel-stats "Name", matrix pipe).  `{k}` = filter size.  Kinds whose call makes
-# several launches of comparable weight (Winograd: transform + product kernels) are labelled as such and never chosen as
+# several launches of comparable weight (ring strips + fold) are labelled as such and never chosen as
 # "the" roofline kernel; small helper launches inside a call (split-K / slab reduces, folds) are part of its span time.
 KIND_KERNEL = {
     "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
@@ -92,21 +92,15 @@ KIND_KERNEL = {
     "dgrad-image-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
     "wgrad-stem": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
     "wgrad-heads-small": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
-    "fwd-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
-    "dgrad-wino2": ("wino_input_kernel + wino_fused_kernel (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel", "fp32"),
-    "wgrad-wino2": ("wino_dy_kernel + conv_wgrad_kernel + wino_wgrad_reduce_kernel (multi-launch call)", r"wino_dy_kernel|wino_wgrad_reduce_kernel|conv_wgrad_kernel<", "fp32"),
     "dgrad-ring": ("conv_gemm_strips_kernel + fold_ring_kernel (multi-launch call)", r"(conv_)?gemm_strips_kernel|fold_ring_kernel", None),
 }
-# the fp32 im2col / Winograd kernels with split-product inner products (ops._timed appends -g3 to the kind)
+# the fp32 im2col kernels with split-product inner products (ops._timed appends -g3 to the kind)
 for _k, _lab, _rx in (("fwd", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("dgrad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
                       ("dgrad-image", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("fwd-heads", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
                       ("dgrad-heads", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("), ("fwd-zeropad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
                       ("dgrad-zeropad", "conv_gemm_kernel<X3>", r"conv_gemm_kernel<.*true>\("),
                       ("wgrad", "conv_wgrad_kernel<X3>", r"conv_wgrad_kernel<.*true>\("), ("wgrad-heads", "conv_wgrad_kernel<X3>", r"conv_wgrad_kernel<.*true>\("),
-                      ("fwd-wino2", "wino_input_kernel + wino_fused_kernel<X3> (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel"),
-                      ("dgrad-wino2", "wino_input_kernel + wino_fused_kernel<X3> (multi-launch call)", r"wino_(input|fused|output)_kernel|conv_gemm_batched_kernel"),
-                      ("wgrad-wino2", "wino_dy_kernel + conv_wgrad_kernel<X3> + wino_wgrad_reduce_kernel (multi-launch call)",
-                       r"wino_dy_kernel|wino_wgrad_reduce_kernel|conv_wgrad_kernel<.*true>\(")):
+                      ):
     KIND_KERNEL[_k + "-g3"] = (_lab, _rx, "bf16x3")
 GENERIC_KERNEL = {   # kinds on the generic im2col kernels: name depends on the activation precision
     "fwd": ("conv_gemm_kernel", "gemm_kernel_h"), "dgrad": ("conv_gemm_kernel", "gemm_kernel_h"),
@@ -192,7 +186,7 @@ def workload_note(ops, precision):
                 "three-plane bf16 split products (6 per multiply-add)")
     if ops.X3 >= 2:
         return ", every convolution / linear product as " + six
-    return ", 3x3 convs as Winograd tile %d" % ops.WINOGRAD_TILE + ((", 5x5 convs and 3x3 data gradients as " + six) if ops.X3 else "")
+    return ", 5x5 convs and 3x3 data gradients as " + six if ops.X3 else ""
 
 
 def run_iteration(trainer, batch, cfg, it):
@@ -510,11 +504,9 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         executed = dom["exec_flops"] / (dom["ms"] * 1e-3) / 1e12
         traffic, traffic_source = traffic_from_profiles("c4" if config_name == "c5" else config_name, DOMINANT)
-        # achieved: ALGORITHMIC flops (the direct convolution's) over the spans' time.  On the fp32 path the
-        # 3x3 layers run as Winograd F(2x2,3x3) and issue 2.25x fewer multiply-adds than that, so `executed` (what the
-        # matrix cores actually did, transforms' time included in the spans) is the figure to hold against the MFMA roof.
-        roof_family = {"bound": "mfma", "kernel": DOMINANT + " family (every forward / data-gradient conv call on the native pipe; "
-                                                             "Winograd calls credited with direct-convolution flops in `achieved`)",
+        # achieved: ALGORITHMIC flops (the direct convolution's) over the spans' time; `executed` = what the matrix
+        # cores actually did in them (split-product launches: 3 or 6 products per multiply-add).
+        roof_family = {"bound": "mfma", "kernel": DOMINANT + " family (every forward / data-gradient conv call on the im2col kernels)",
                        "achieved": round(achieved, 2), "peak": peak,
                        "unit": "TFLOP/s", "frac": round(executed / peak, 4), "algorithmic_frac": round(achieved / peak, 4),
                        "executed": round(executed, 2), "executed_frac": round(executed / peak, 4),
@@ -522,7 +514,7 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
                        "launches_per_step": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                        "algorithmic_gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3)}
     # THE roofline record: the single kernel with the largest share of the instrumented step (multi-launch calls such as the
-    # Winograd chain are not "a kernel" and are skipped here; they stay visible in `kernels`).  `achieved` = flops the
+    # ring strips + fold are not "a kernel" and are skipped here; they stay visible in `kernels`).  `achieved` = flops the
     # matrix cores EXECUTED in that kernel / its span time; `peak` = the dense peak of the pipe it runs on; the
     # direct-convolution (fp32-equivalent) rate sits under `algorithmic_tflops`.
     single = [r for r in table if r["pipe"] and "multi-launch" not in r["kernel"] and r["executed_gflop_per_launch"] > 0]
@@ -572,7 +564,7 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
                    "global_batch": per_gpu_batch * world, "parallelism": "dp%d" % world},
         # algorithmic (direct-convolution, fp32-equivalent) flops of the launches this step actually made (conv + linear
         # kernels; the text encoder's library GEMMs, < 0.01 %, are not counted) over the step time.  NOT a fraction of any one
-        # roof on the fp32 path (Winograd launches issue 2.25x fewer multiply-adds, split-product launches run on the bf16
+        # roof on the fp32 path (split-product launches run on the 16-bit
         # pipe): the per-pipe fractions are `roofline`, `roofline_split_bf16x3` and `decode_conv_stack`.
         "whole_step_tflops": round(step_tflops, 2),
         "algorithmic_gflop_per_image_executed": round(step_flops / per_gpu_batch / 1e9, 2),
@@ -629,10 +621,7 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=None, help="development knob; overrides the config's per-GPU batch")
     ap.add_argument("--x3", type=int, default=None, choices=(0, 1, 2),
                     help="fp32 path: 0 = native fp32 MFMA kernels only; 1 (default) = 5x5 layers as fp32-accurate bf16x3 split "
-                         "products on the bf16 MFMA; 2 = 3x3 layers too (instead of Winograd)")
-    ap.add_argument("--winograd", type=int, default=None, choices=(0, 2, 4),
-                    help="development knob: Winograd output tile of the fp32 3x3 convolutions (default 2 = F(2x2,3x3); 4 = "
-                         "F(4x4,3x3), faster but ~10x the rounding error, see hipdwc/ops.py; 0 = direct)")
+                         "products on the bf16 MFMA; 2 = 3x3 layers too")
     ap.add_argument("--vgg-w", type=float, default=0.0,
                     help="development knob: perceptual-loss weight (the reference's shipped default is 0.1) with a RANDOMLY "
                          "initialised VGG16 (the trained weights cannot be fetched here); the contract workload is 0")
@@ -650,8 +639,6 @@ def main():
     import torch
     from hipdwc import ops, synth
 
-    if args.winograd is not None:
-        ops.WINOGRAD_TILE = args.winograd
     if args.x3 is not None:
         ops.X3 = args.x3
     rank = int(os.environ.get("RANK", 0))

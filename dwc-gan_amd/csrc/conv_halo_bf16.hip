@@ -38,7 +38,6 @@ struct HaloArgs {
     bf16* y;             // [B][H][W][N]
     int B, H, W, Cin, logCin, N, K, Kp, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
-    int stagger = 0;     // two-workgroups-per-CU forms: 10 ns ticks the SECOND workgroup of a CU sleeps before its first tile (0: off)
 };
 
 // bf16 + bf16 as torch adds them: both to fp32, one rounding of the sum
@@ -693,8 +692,6 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
         // results): 5x5 256->128 B=384 1950 -> 1698 us (52.8 -> 60.7 % of 2.5 PF), B=128 688 -> 603; 5x5 64->128 (data
         // gradient) 758 -> 689; 3x3 256->256 B=384 401 -> 387, B=128 139 -> 138; 5x5 128->64: 3 % slower (stays 8-wave).
         const bool duo = h16 >= 2 && (long)nblk * (Cout / 64) >= 512;
-        static const int stagger = getenv("DWC_HALO_STAGGER") ? atoi(getenv("DWC_HALO_STAGGER")) : 0;    // development: 10 ns ticks
-        a.stagger = duo ? stagger : 0;
         if (K == 3) {
             if (Cout > 128 && duo && Cout % 128 == 0) HALO16_LAUNCH(3, 128, 2, 2, 1);
             else if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);

@@ -96,7 +96,6 @@ struct X3Args {
     float* y;            // [B][H][W][N] fp32
     int B, H, W, Cin, N, rows, act, reflect;
     int blocks_x, blocks_per_img, tiles_n;
-    int stagger = 0;     // two-workgroups-per-CU form: 10 ns ticks the CU's second workgroup sleeps before its first tile (dwc_duo_stagger)
     float* part = nullptr;          // KSP == 2: [tiles][256 pixels x 64 channels] fp32, the first arriver's half sum
     unsigned* tickets = nullptr;    // KSP == 2: [tiles], zero between launches (caller-owned, self-resetting)
     int split_from = 0;             // KSP == 2: tiles [0, split_from) run whole (one workgroup), [split_from, tiles) as two halves
@@ -180,7 +179,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
-    if constexpr (PB == 1) dwc_duo_stagger(a.stagger, 512);
     H2Scale sx = {1.f, 1.f}, sw = {1.f, 1.f};
     if constexpr (NPL == 2) {
         sx = h2_scale(a.xs, a.xs_epoch);
@@ -1085,12 +1083,9 @@ __global__ void x3_wgrad_reduce_kernel(const float* __restrict__ slab, float* __
     dw[((size_t)co * cin_real + ci) * KHW + tap] = s;
 }
 
-// 64: one 8-wave workgroup per CU (default); 32 (DWC_X3_WDUO=1): two 4-wave workgroups per CU -- no gain for this kernel
-// (-3..+1 %: it is bound by the dY fragments it reads straight from L2 / HBM, not by lock-step), kept as a variant
-static int x3_wgrad_ciw() {
-    static const int duo = getenv("DWC_X3_WDUO") ? atoi(getenv("DWC_X3_WDUO")) : 0;
-    return duo ? 32 : 64;
-}
+// 64 channels of x per workgroup: one 8-wave workgroup per CU.  (The kernel's CIW = 32 form -- two 4-wave workgroups per CU -- was
+// measured in r02-r04 at -3..+6 % by batch and is no longer instantiated.)
+static int x3_wgrad_ciw() { return 64; }
 
 // (K == 4 is the stride-2 form: H, W are the dimensions of x, the dY grid is H/2 x W/2 and is cut into 4x16-pixel units)
 int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
@@ -1138,16 +1133,14 @@ constexpr int X3_KSPLIT_TILES = 256, X3_KSPLIT_TICKETS = 512;
 constexpr size_t X3_KSPLIT_TILE_BYTES = 256 * 64 * sizeof(float);
 // Number of tiles that run whole (a multiple of 8; the remaining tiles - split_from <= 256 are split), or -1: the launch is not
 // split.  512 = the workgroups resident at once (two per CU): a last round of at most 256 tiles is the one worth halving.
-// DWC_X3_KSPLIT: 0 off, 1 (default) launches of <= 256 tiles only, 2 also the tail of larger launches (measured: no gain -- 3x3
-// 256->256 at batch 48, 768 tiles: 330.6 against 323.8 us; workgroups are dispatched as slots free up, there is no "last round").
+// DWC_X3_KSPLIT=0 switches the split off.  (Splitting only the tail of larger launches -- 768 tiles on 512 slots -- was measured in
+// r04: no gain, 330.6 against 323.8 us; workgroups are dispatched as slots free up, there is no "last round".  The kernel still
+// understands split_from > 0, the launcher no longer asks for it.)
 long x3_ksplit_from(long tiles, int slabs) {
     static const int on = getenv("DWC_X3_KSPLIT") ? atoi(getenv("DWC_X3_KSPLIT")) : 1;
     if (!on || slabs < 8 || (slabs & 1) || (tiles & 7)) return -1;                              // (tiles % 8: pairs share an XCD)
     // (launches of up to 512 tiles split whole were measured too: no gain at 5x5 batch 16, worse at 3x3 batch 32 and stride 2)
-    if (tiles <= X3_KSPLIT_TILES) return 0;
-    const long tail = tiles % 512;
-    if (tail == 0 || tail > X3_KSPLIT_TILES || on < 2) return -1;
-    return tiles - tail;
+    return tiles <= X3_KSPLIT_TILES ? 0 : -1;
 }
 bool x3_ksplit_on(long tiles, int slabs) { return x3_ksplit_from(tiles, slabs) >= 0; }
 size_t x3_ksplit_bytes(long tiles, int slabs) {
@@ -1238,87 +1231,24 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.rows = rows; a.act = act; a.reflect = reflect;
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     const int blocks = B * a.blocks_per_img;
-    // channel tile: measured MFMA utilisation of a full round of workgroups by tile width (256: 65 %, 128: 52 %, 64: 43 %)
-    // times the fill of the last round of 256 CUs; e.g. 192 blocks x 256 channels: one 256-wide workgroup on 192 CUs (0.49)
-    // beats 384 128-wide ones in two rounds (0.39)
-    int bn = 64;
-    static const int force = getenv("DWC_X3_BN") ? atoi(getenv("DWC_X3_BN")) : 0;
-    {
-        double best = 0.0;
-        const int widths[3] = {256, 128, 64};
-        const double eff[3] = {0.65, 0.52, 0.43};
-        for (int i = 0; i < 3; ++i) {
-            const int w = widths[i];
-            // 256-wide tiles (4x2 accumulators per wave) have no registers for the separate correction accumulators: 1.6e-6
-            // against 6.4e-7 of the output scale on the 3x3 layers, for +1.2 % on the c1 step -- opt-in only (DWC_X3_WIDE=1)
-            static const int wide = getenv("DWC_X3_WIDE") ? atoi(getenv("DWC_X3_WIDE")) : 0;
-            if (w == 256 && (K == 5 || !wide)) continue;   // (5x5: the patch twice + three 256-row weight slots exceed the LDS)
-            if (w > 64 && w / 2 >= N) continue;        // more than half of the tile would be padding
-            const long wgs = (long)blocks * ((N + w - 1) / w);
-            const double score = eff[i] * (double)wgs / (double)((wgs + 255) / 256 * 256);
-            if (score > best) best = score, bn = w;
-        }
-    }
-    if (force) {
-        if (force != 64 && force != 128 && force != 256) return DWC_EINVAL;      // DWC_X3_BN: only the tile widths that exist
-        if (force == 256 && K == 5) return DWC_EINVAL;
-        bn = force;
-    }
-    // Default: two 4-wave workgroups of 256 pixels x 64 channels per CU (single patch buffer, <= 64 KB of LDS each).  Two
-    // independent workgroups drift out of phase, so one's MFMAs run beside the other's fragment reads, staging and barriers;
-    // measured against the best one-workgroup-per-CU tile: 5x5 128->64 +27 %, 5x5 256->128 +5 %, 3x3 256->256 at B=48 +16 %,
-    // small launches (<= 256 workgroups) equal.  DWC_X3_DUO=0: the 8-wave tiles below.
-    static const int duo = getenv("DWC_X3_DUO") ? atoi(getenv("DWC_X3_DUO")) : 1;
-    static const int stagger = getenv("DWC_X3_STAGGER") ? atoi(getenv("DWC_X3_STAGGER")) : 0;     // development: 10 ns ticks
-    if (NPL == 2 || (duo && !force)) {
-        a.tiles_n = (N + 63) / 64;
-        a.stagger = (long)blocks * a.tiles_n > 512 ? stagger : 0;      // (a launch of one round gains nothing from an offset)
-        // r04: launches that would leave half of the 512 two-per-CU slots empty (3x3 256->256 at batch 16: 256 workgroups, one per
-        // CU, nothing to overlap with) run 32-channel tiles instead: twice the workgroups, two per CU again
-        static const int bn32 = getenv("DWC_X3_BN32") ? atoi(getenv("DWC_X3_BN32")) : 0;      // (lab: B=16 121.6 -> 117.0 us; no gain visible in the step: opt-in)
-        if constexpr (NPL == 3) {
-            if (bn32 && K == 3 && (long)blocks * a.tiles_n <= 256 && N % 32 == 0) {
-                a.tiles_n = N / 32;
-                x3_launch<3, 32, 4, 1, 2, 1, 0, 1>(a, dim3(blocks * a.tiles_n), (hipStream_t)stream);
-                DWC_LAUNCH_CHECK();
-                return DWC_OK;
-            }
-        }
-        const dim3 g2(blocks * a.tiles_n);
-        const size_t need = dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, K, 1);
-        if (need && ws && tickets && ws_bytes >= need) {
-            a.part = (float*)ws;
-            a.tickets = tickets;
-            a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
-            const dim3 g4(2 * g2.x - a.split_from);
-            if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
-            else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
-        } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
-        else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
-    if constexpr (NPL == 3) {
-    a.tiles_n = (N + bn - 1) / bn;
-    const dim3 grid(blocks * a.tiles_n);
-    hipStream_t st = (hipStream_t)stream;
-    if (K == 3) {
-        if (bn == 256) x3_launch<3, 256, 2, 4, 4, 2>(a, grid, st);
-        else if (bn == 128) x3_launch<3, 128, 4, 2, 2, 2>(a, grid, st);
-        else x3_launch<3, 64, 8, 1, 1, 2>(a, grid, st);
-    } else {
-#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only by `make ABLATIONS=1`, never in the shipped .so
-        static const int dbg = getenv("DWC_X3_DBG") ? atoi(getenv("DWC_X3_DBG")) : 0;
-        if (bn == 128 && dbg == 1) x3_launch<5, 128, 4, 2, 2, 2, 1>(a, grid, st);
-        else if (bn == 128 && dbg == 2) x3_launch<5, 128, 4, 2, 2, 2, 2>(a, grid, st);
-        else if (bn == 128 && dbg == 30) x3_launch<5, 128, 4, 2, 2, 2, 30>(a, grid, st);
-        else
-#endif
-        if (bn == 128) x3_launch<5, 128, 4, 2, 2, 2>(a, grid, st);
-        else x3_launch<5, 64, 8, 1, 1, 2>(a, grid, st);
-    }
+    // Two 4-wave workgroups of 256 pixels x 64 channels per CU (single patch buffer, <= 67 KB of LDS each).  Two independent
+    // workgroups drift out of phase, so one's MFMAs run beside the other's fragment reads, staging and barriers; measured in r02-r04
+    // against one 8-wave workgroup per CU with 64- / 128- / 256-channel tiles: 5x5 128->64 +27 %, 5x5 256->128 +5 %, 3x3 256->256 at
+    // B=48 +16 %, small launches equal -- the 8-wave tiles, the 32-channel tile for small launches and the phase offset between the
+    // two workgroups (no effect at any offset) are no longer instantiated (r05; numbers in DESIGN.md sections 3.9 / 9).
+    a.tiles_n = (N + 63) / 64;
+    const dim3 g2(blocks * a.tiles_n);
+    const size_t need = dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, K, 1);
+    if (need && ws && tickets && ws_bytes >= need) {
+        a.part = (float*)ws;
+        a.tickets = tickets;
+        a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
+        const dim3 g4(2 * g2.x - a.split_from);
+        if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
+        else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
+    } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
+    else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
-    }
     return DWC_OK;
 }
 
@@ -1496,18 +1426,8 @@ static int x3_wgrad_impl(const float* x, const void* xs, unsigned xs_epoch, cons
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(a.roles * splits);
     if (K == 4) {
-        if (ciw != 64) return DWC_EINVAL;      // (DWC_X3_WDUO has no stride-2 instantiation)
         if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<4, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((wgrad_x3_kernel<4, 64, 64, 2, NPL>), grid, dim3(512), 0, st, a);
-    } else if (ciw == 32) {
-        if constexpr (NPL == 3) {
-            if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 32>), grid, dim3(256), 0, st, a);
-            else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 32>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 32>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((wgrad_x3_kernel<5, 64, 32>), grid, dim3(256), 0, st, a);
-        } else {
-            return DWC_EINVAL;
-        }
     } else if (K == 3 && bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<3, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);
     else if (K == 3) hipLaunchKernelGGL((wgrad_x3_kernel<3, 64, 64, 2, NPL>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_x3_kernel<5, 128, 64, 2, NPL>), grid, dim3(512), 0, st, a);

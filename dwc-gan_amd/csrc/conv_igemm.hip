@@ -393,146 +393,6 @@ __global__ __launch_bounds__(256) void conv_gemm_strips_kernel(StripSet ss) {
                                            blockIdx.y * ss.part_stride, false, s.oph, s.opw, blockIdx.x, s.tiles);
 }
 
-// gridDim.z independent products of one geometry: source, weights and destination advance by a fixed stride per
-// class (the 16 transform-domain products of a Winograd convolution).
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
-__global__ __launch_bounds__(256) void conv_gemm_batched_kernel(Gather g, const float* __restrict__ wmat, size_t w_class_stride,
-                                                                size_t src_class_stride, Scatter o, size_t dst_class_stride,
-                                                                int tiles_n, int nk) {
-    DWC_PROBE();
-    const int cls = blockIdx.z;
-    g.src = (const float*)g.src + (size_t)cls * src_class_stride;
-    o.dst = (float*)o.dst + (size_t)cls * dst_class_stride;
-    conv_gemm_body<BM, BN, WM, WN, TM, TN, X3>(g, wmat + (size_t)cls * w_class_stride, o, nullptr, DWC_ACT_NONE, tiles_n, 0, nk, 0, false,
-                                               0, 0, blockIdx.x, gridDim.x);
-}
-
-// ------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions (the ResBlocks: 44 % of the GEMM time): 2.25x fewer
-// multiply-adds.  y = A^T [ (G g G^T) (.) (B^T d B) ] A per 4x4 input tile / 2x2 output tile, summed over channels, i.e.
-// 16 products M_e[tile][co] = V_e[tile][ci] . U_e[ci][co] on the GEMM body above, between an input transform (which
-// applies the reflect or zero boundary rule while gathering) and an output transform (+bias, +activation).
-//   V, M: [16][T][C] with T = B*(H/2)*(W/2) tiles, channels contiguous (what the GEMM stages as K / writes as N)
-//   U: [16][N][K] (K contiguous), from wino_filter_kernel
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
-                                                          int for_dgrad) {
-    // forward: row = co, k = ci, filter g = W[co][ci]; data gradient: row = ci, k = co, g = W[co][ci] rotated by 180 degrees
-    const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * K) return;
-    const int k = idx % K, row = idx / K;
-    const int co = for_dgrad ? k : row, ci = for_dgrad ? row : k;
-    const float* gp = w + ((size_t)co * Cin + ci) * 9;
-    float g[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = for_dgrad ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
-    float t[4][3];                                     // G g
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        t[0][b] = g[0][b];
-        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-        t[3][b] = g[2][b];
-    }
-    const size_t plane = (size_t)rows * K;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {                      // (G g) G^T
-        U[(size_t)(a * 4 + 0) * plane + idx] = t[a][0];
-        U[(size_t)(a * 4 + 1) * plane + idx] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-        U[(size_t)(a * 4 + 2) * plane + idx] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-        U[(size_t)(a * 4 + 3) * plane + idx] = t[a][2];
-    }
-}
-
-// one thread per (tile, 4 channels): V = B^T d B of the 4x4 patch at rows 2*ty-1.., cols 2*tx-1..
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
-                                                         int cq, int reflect, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % cq;
-    size_t tl = idx / cq;
-    const int TW = W >> 1, TH = H >> 1;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const f32x4* xs = reinterpret_cast<const f32x4*>(x) + (size_t)n * H * W * cq + c;
-    f32x4 d[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        int h = 2 * ty - 1 + a;
-        const bool hin = h >= 0 && h < H;
-        h = reflect ? reflect_idx(h, H) : min(max(h, 0), H - 1);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            int w = 2 * tx - 1 + b;
-            const bool in = hin && w >= 0 && w < W;
-            w = reflect ? reflect_idx(w, W) : min(max(w, 0), W - 1);
-            const f32x4 v = xs[((size_t)h * W + w) * cq];
-            d[a][b] = (reflect || in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    f32x4 t[4][4];                                     // B^T d
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        t[0][b] = d[0][b] - d[2][b];
-        t[1][b] = d[1][b] + d[2][b];
-        t[2][b] = d[2][b] - d[1][b];
-        t[3][b] = d[1][b] - d[3][b];
-    }
-    const size_t plane4 = total;                       // f32x4 elements per transform plane: T * cq
-    f32x4* out = reinterpret_cast<f32x4*>(V) + idx;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {                      // (B^T d) B
-        out[(size_t)(a * 4 + 0) * plane4] = t[a][0] - t[a][2];
-        out[(size_t)(a * 4 + 1) * plane4] = t[a][1] + t[a][2];
-        out[(size_t)(a * 4 + 2) * plane4] = t[a][2] - t[a][1];
-        out[(size_t)(a * 4 + 3) * plane4] = t[a][1] - t[a][3];
-    }
-}
-
-// one thread per (tile, 4 channels): Y = A^T M A (+bias, +activation) -> the tile's 2x2 output pixels
-__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
-                                                          float* __restrict__ y, int B, int H, int W, int cq, int act, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % cq;
-    size_t tl = idx / cq;
-    const int TW = W >> 1, TH = H >> 1;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const f32x4* in = reinterpret_cast<const f32x4*>(Mt) + idx;
-    f32x4 m[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) m[a][b] = in[(size_t)(a * 4 + b) * total];
-    f32x4 t[2][4];                                     // A^T m
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        t[0][b] = m[0][b] + m[1][b] + m[2][b];
-        t[1][b] = m[1][b] - m[2][b] - m[3][b];
-    }
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias) bv = reinterpret_cast<const f32x4*>(bias)[c];
-    f32x4* ys = reinterpret_cast<f32x4*>(y) + (size_t)n * H * W * cq + c;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        f32x4 o0 = t[a][0] + t[a][1] + t[a][2] + bv;
-        f32x4 o1 = t[a][1] - t[a][2] - t[a][3] + bv;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o0[k] = dwc_act_apply(o0[k], act, c * 4 + k);
-            o1[k] = dwc_act_apply(o1[k], act, c * 4 + k);
-        }
-        ys[((size_t)(2 * ty + a) * W + 2 * tx) * cq] = o0;
-        ys[((size_t)(2 * ty + a) * W + 2 * tx + 1) * cq] = o1;
-    }
-}
-
 // dst[i] = act(sum_s part[s][i] + bias[i % N]), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dst,
                                                             const float* __restrict__ bias, size_t total4, size_t stride4, int splits,
@@ -955,232 +815,6 @@ int launch_gemm(const Gather& g, const float* w, size_t w_class_stride, int clas
 
 }  // namespace
 
-// F(2x2,3x3) with the output transform FUSED into the GEMM: a workgroup owns BM tiles x BN output channels and walks all
-// 16 transform-domain products for them as ONE flattened K loop of 16 * Cin/32 slabs (no per-product prologue/epilogue,
-// no transform-domain output tensor in HBM).  At the end of product e = (xi, nu) its accumulator M_e is folded into the
-// four output pixels of the tile, Y[a][b] += A^T[a][xi] * A^T[b][nu] * M_e (coefficients 0, +-1), and cleared; the
-// epilogue adds the bias, applies the activation and scatters the 2x2 pixels.
-//   V:[16][T][Cin] (wino_input_kernel), U:[16][N][Cin], y:[B][H][W][N]
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool X3 = false>
-__global__ __launch_bounds__(256) void wino_fused_kernel(const float* __restrict__ V, const float* __restrict__ U,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int T, int Cin,
-                                                         int N, int H, int W, int act, int tiles_n) {
-    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
-    DWC_PROBE();
-    constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-    constexpr int A_TILE = BM * BK, B_TILE = BN * BK;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (A_TILE + B_TILE)];
-    float* sA = smem;
-    float* sB = smem + 2 * A_TILE;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if (nb >= 16) {
-            const int q = nb >> 3, r = nb & 7, x = bid & 7, yy = bid >> 3;
-            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + yy;
-        }
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int arow = t >> 3;
-    const int acol = (((t & 7) ^ ((arow >> 1) & 7))) * 4;
-    const float* a_ptr[A_PASSES];
-    const float* b_ptr[B_PASSES];
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) a_ptr[i] = V + (size_t)min(m0 + arow + 32 * i, T - 1) * Cin + acol;
-#pragma unroll
-    for (int p = 0; p < B_PASSES; ++p) b_ptr[p] = U + (size_t)min(n0 + arow + 32 * p, N - 1) * Cin + acol;
-    const int nk = Cin / BK;                                  // slabs per product (Cin is a power of two >= 32)
-    const int total = 16 * nk;
-    const size_t v_class = (size_t)T * Cin, u_class = (size_t)N * Cin;
-    auto stage_slab = [&](int s, int buf) {                  // s = e * nk + kt
-        const int e = s / nk, kt = s - e * nk;
-        const size_t ao = (size_t)e * v_class + kt * BK, bo = (size_t)e * u_class + kt * BK;
-        float* la = sA + buf * A_TILE + wave * (8 * BK);
-        float* lb = sB + buf * B_TILE + wave * (8 * BK);
-#pragma unroll
-        for (int i = 0; i < A_PASSES; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr[i] + ao),
-                                             (__attribute__((address_space(3))) void*)(la + i * 32 * BK), 16, 0, 0);
-#pragma unroll
-        for (int p = 0; p < B_PASSES; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[p] + bo),
-                                             (__attribute__((address_space(3))) void*)(lb + p * 32 * BK), 16, 0, 0);
-    };
-    f32x16 acc[TM][TN], Y[4][TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[i][j][r] = 0.f;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) Y[o][i][j][r] = 0.f;
-            }
-    const int fsw = (l31 >> 1) & 7;
-    int frag_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) frag_off[q] = ((2 * q + hi) ^ fsw) * 4;
-    const int a_row = (wm * TM * 32 + l31) * BK;
-    const int b_row = (wn * TN * 32 + l31) * BK;
-    f32x4 fa[2][TM], fb[2][TN];
-    auto load_frags = [&](int set, int buf, int q) {
-        const float* a = sA + buf * A_TILE + a_row + frag_off[q];
-        const float* b = sB + buf * B_TILE + b_row + frag_off[q];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(a + i * 32 * BK);
-#pragma unroll
-        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const f32x4*>(b + n * 32 * BK);
-    };
-    auto mfma_group = [&](int set) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][j], fb[set][n][j], acc[i][n], 0, 0, 0);
-    };
-    // X3 (r04): the 16 transform-domain products as exact bf16 split products (conv_gemm_body explains): Winograd's 2.25x fewer
-    // multiply-adds AND the bf16 matrix cores -- 6 / 2.25 bf16 MFMA-equivalents per multiply-add of the direct convolution.
-    f32x16 lo[X3 ? TM : 1][X3 ? TN : 1];
-    int xoff[2][2];
-    gx3_bf16x8 pa[3][TM], pb[3][TN];
-    if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lo[i][j][r] = 0.f;
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) xoff[ss][q] = ((4 * ss + 2 * hi + q) ^ fsw) * 4;
-    }
-    auto frags_x3 = [&](int buf_, int ss) {
-        const float* a = sA + buf_ * A_TILE + a_row;
-        const float* b = sB + buf_ * B_TILE + b_row;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-            gx3_split8(*reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][0]),
-                       *reinterpret_cast<const f32x4*>(a + i * 32 * BK + xoff[ss][1]), pa[0][i], pa[1][i], pa[2][i]);
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-            gx3_split8(*reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][0]),
-                       *reinterpret_cast<const f32x4*>(b + n * 32 * BK + xoff[ss][1]), pb[0][n], pb[1][n], pb[2][n]);
-    };
-    auto mfma_x3 = [&]() {
-        constexpr int TA[6] = {0, 1, 0, 2, 1, 0}, TB[6] = {0, 0, 1, 0, 1, 2};
-#pragma unroll
-        for (int term = 0; term < 6; ++term)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    if (term == 0) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], acc[i][n], 0, 0, 0);
-                    else lo[X3 ? i : 0][X3 ? n : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[TA[term]][i], pb[TB[term]][n], lo[X3 ? i : 0][X3 ? n : 0], 0, 0, 0);
-                }
-    };
-    stage_slab(0, 0);
-    lds_dma_barrier();
-    int buf = 0, kt = 0, e = 0;
-    if constexpr (!X3) load_frags(0, 0, 0);
-    for (int s = 0; s < total; ++s) {
-        const bool more = s + 1 < total;
-        if (more) stage_slab(s + 1, buf ^ 1);
-        if constexpr (X3) {
-            frags_x3(buf, 0);
-            mfma_x3();
-            frags_x3(buf, 1);
-            lds_dma_barrier();
-            mfma_x3();
-        } else {
-            load_frags(1, buf, 1);
-            mfma_group(0);
-            load_frags(0, buf, 2);
-            mfma_group(1);
-            load_frags(1, buf, 3);
-            mfma_group(0);
-            lds_dma_barrier();
-            if (more) load_frags(0, buf ^ 1, 0);
-            mfma_group(1);
-        }
-        buf ^= 1;
-        if (++kt == nk) {                                    // product e = (xi, nu) complete: fold into the 2x2 outputs
-            kt = 0;
-            const int xi = e >> 2, nu = e & 3;
-            // A^T = [[1,1,1,0],[0,1,-1,-1]]
-            const float ca0 = xi < 3 ? 1.f : 0.f, ca1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
-            const float cb0 = nu < 3 ? 1.f : 0.f, cb1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
-            const float c00 = ca0 * cb0, c01 = ca0 * cb1, c10 = ca1 * cb0, c11 = ca1 * cb1;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int n = 0; n < TN; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float m = acc[i][n][r];
-                        if constexpr (X3) {
-                            m += lo[X3 ? i : 0][X3 ? n : 0][r];
-                            lo[X3 ? i : 0][X3 ? n : 0][r] = 0.f;
-                        }
-                        Y[0][i][n][r] += c00 * m;
-                        Y[1][i][n][r] += c01 * m;
-                        Y[2][i][n][r] += c10 * m;
-                        Y[3][i][n][r] += c11 * m;
-                        acc[i][n][r] = 0.f;
-                    }
-            ++e;
-        }
-    }
-    const int TW = W >> 1, TH = H >> 1;
-    const float slope = dwc_act_slope(act);
-    float bcol[TN];                                       // bias of this lane's columns: one batch of loads (see conv_gemm_body)
-#pragma unroll
-    for (int n = 0; n < TN; ++n) bcol[n] = 0.f;
-    if (bias) {
-#pragma unroll
-        for (int n = 0; n < TN; ++n) bcol[n] = bias[min(n0 + (wn * TN + n) * 32 + l31, N - 1)];
-    }
-    auto store = [&](auto general) {
-        auto fin = [&](float v, int col) {
-            if constexpr (decltype(general)::value) return dwc_act_apply(v, act, col);
-            else return dwc_act_simple(v, slope);
-        };
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int m = m0 + row;
-                if (m >= T) continue;
-                const int tx = m % TW;
-                const int ty = (m / TW) % TH;
-                const int nimg = m / (TW * TH);
-                float* base = y + (((size_t)nimg * H + 2 * ty) * W + 2 * tx) * N;
-#pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    const int col = n0 + (wn * TN + n) * 32 + l31;
-                    if (col >= N) continue;
-                    const float bv = bcol[n];
-                    base[col] = fin(Y[0][i][n][r] + bv, col);
-                    base[(size_t)N + col] = fin(Y[1][i][n][r] + bv, col);
-                    base[(size_t)W * N + col] = fin(Y[2][i][n][r] + bv, col);
-                    base[(size_t)(W + 1) * N + col] = fin(Y[3][i][n][r] + bv, col);
-                }
-            }
-        }
-    };
-    if (dwc_act_is_simple(act)) store(std::false_type{});
-    else store(std::true_type{});
-}
-
 extern "C" {
 
 int dwc_version(void) { return DWC_ABI_VERSION; }
@@ -1234,471 +868,6 @@ int dwc_conv2d_fwd(const float* x, const float* w_hwio, const float* bias, float
     FwdGeom f;
     if (!fwd_geom(x, y, B, H, W, Cin, Cout, KH, KW, stride, pad, &f)) return DWC_EINVAL;
     return launch_gemm(f.g, w_hwio, 0, 1, f.o, bias, act, f.dst_elems, ws, ws_bytes, (hipStream_t)stream);
-}
-
-// Z = A dY A^T: the 2x2 output-gradient tile lifted to the 4x4 transform domain.  One thread per (tile, 4 channels).
-__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Z, int B, int H, int W, int cq,
-                                                      size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % cq;
-    size_t tl = idx / cq;
-    const int TW = W >> 1, TH = H >> 1;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const f32x4* ds = reinterpret_cast<const f32x4*>(dy) + (size_t)n * H * W * cq + c;
-    f32x4 d[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) d[a][b] = ds[((size_t)(2 * ty + a) * W + 2 * tx + b) * cq];
-    f32x4 t[4][2];                                     // A d,  A = [[1,0],[1,1],[1,-1],[0,-1]]
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        t[0][b] = d[0][b];
-        t[1][b] = d[0][b] + d[1][b];
-        t[2][b] = d[0][b] - d[1][b];
-        t[3][b] = -d[1][b];
-    }
-    f32x4* out = reinterpret_cast<f32x4*>(Z) + idx;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {                      // (A d) A^T
-        out[(size_t)(a * 4 + 0) * total] = t[a][0];
-        out[(size_t)(a * 4 + 1) * total] = t[a][0] + t[a][1];
-        out[(size_t)(a * 4 + 2) * total] = t[a][0] - t[a][1];
-        out[(size_t)(a * 4 + 3) * total] = -t[a][1];
-    }
-}
-
-// slab[(class*splits + s)][ci][co] summed over s (fixed order) = dU_class[ci][co];  dg = G^T dU G -> dw[co][ci][3][3].
-// 256 threads = 64 consecutive (ci,co) pairs x 4 class groups: each thread sums the split slabs of 4 of the 16 classes
-// (coalesced 256-byte rows), the 16 sums of a pair meet in LDS, one thread per pair applies the inverse filter transform.
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits,
-                                                                int Cin, int Cout, int cin_real, int cout_real) {
-    __shared__ float us[16][65];
-    const size_t plane = (size_t)Cin * Cout;
-    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const size_t idx = (size_t)blockIdx.x * 64 + lane;
-    if (idx < plane) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = cg + 4 * k;
-            float s = 0.f;
-            for (int z = 0; z < splits; ++z) s += slab[((size_t)e * splits + z) * plane + idx];
-            us[e][lane] = s;
-        }
-    }
-    __syncthreads();
-    if (cg != 0 || idx >= plane) return;
-    const int co = idx % Cout, ci = idx / Cout;
-    if (co >= cout_real || ci >= cin_real) return;
-    float u[4][4];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) u[e >> 2][e & 3] = us[e][lane];
-    float t[3][4];                                     // G^T u,  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-        t[1][b] = 0.5f * (u[1][b] - u[2][b]);
-        t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
-    }
-    float* o = dw + ((size_t)co * cin_real + ci) * 9;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {                      // (G^T u) G
-        o[a * 3 + 0] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
-        o[a * 3 + 1] = 0.5f * (t[a][1] - t[a][2]);
-        o[a * 3 + 2] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Winograd F(4x4, 3x3): 6x6 input tiles -> 4x4 outputs, 36 transform-domain products, 4x fewer multiply-adds than the
-// direct product (F(2x2,3x3): 2.25x) and a 2.25x instead of 4x data expansion.  Interpolation points 0, +-1, +-2, inf
-// (Lavin & Gray); the transforms now carry factors up to 8 and 1/24, which costs about one decimal digit: measured
-// max error 2e-5 of the output maximum on 256-channel sums against 2e-6 for F(2x2,3x3) and 3e-7 for the direct product.
-// One thread per (tile, channel): a 6x6 patch of scalars fits the register file, a patch of float4 does not.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&t)[6]) {      // t = B^T d
-    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
-    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
-    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
-__device__ __forceinline__ void w4_at(const float (&m)[6], float (&t)[4]) {      // t = A^T m
-    t[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-    t[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
-    t[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
-    t[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
-}
-__device__ __forceinline__ void w4_a(const float (&d)[4], float (&z)[6]) {       // z = A d
-    z[0] = d[0];
-    z[1] = d[0] + d[1] + d[2] + d[3];
-    z[2] = d[0] - d[1] + d[2] - d[3];
-    z[3] = d[0] + 2.f * d[1] + 4.f * d[2] + 8.f * d[3];
-    z[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
-    z[5] = d[3];
-}
-__device__ __forceinline__ void w4_g(const float (&g)[3], float (&r)[6]) {       // r = G g
-    r[0] = 0.25f * g[0];
-    r[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
-    r[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
-    r[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
-    r[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
-    r[5] = g[2];
-}
-__device__ __forceinline__ void w4_gt(const float (&u)[6], float (&r)[3]) {      // r = G^T u
-    r[0] = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
-    r[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
-    r[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
-}
-
-__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin,
-                                                           int for_dgrad) {
-    const int rows = for_dgrad ? Cin : Cout, K = for_dgrad ? Cout : Cin;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * K) return;
-    const int k = idx % K, row = idx / K;
-    const int co = for_dgrad ? k : row, ci = for_dgrad ? row : k;
-    const float* gp = w + ((size_t)co * Cin + ci) * 9;
-    float t[6][3];                                     // G g  (columns of g)
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        float col[3], r[6];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) col[a] = for_dgrad ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
-        w4_g(col, r);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) t[a][b] = r[a];
-    }
-    const size_t plane = (size_t)rows * K;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {                      // (G g) G^T
-        float r[6];
-        w4_g(t[a], r);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * plane + idx] = r[b];
-    }
-}
-
-__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
-                                                          int C, int reflect, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % C;
-    size_t tl = idx / C;
-    const int TW = W >> 2, TH = H >> 2;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const float* xs = x + (size_t)n * H * W * C + c;
-    float t[6][6];                                     // B^T d, built one input column at a time
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        int w = 4 * tx - 1 + b;
-        const bool win = w >= 0 && w < W;
-        w = reflect ? reflect_idx(w, W) : min(max(w, 0), W - 1);
-        float col[6], r[6];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            int h = 4 * ty - 1 + a;
-            const bool in = win && h >= 0 && h < H;
-            h = reflect ? reflect_idx(h, H) : min(max(h, 0), H - 1);
-            const float v = xs[((size_t)h * W + w) * C];
-            col[a] = (reflect || in) ? v : 0.f;
-        }
-        w4_bt(col, r);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) t[a][b] = r[a];
-    }
-    float* out = V + idx;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {                      // (B^T d) B
-        float r[6];
-        w4_bt(t[a], r);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) out[(size_t)(a * 6 + b) * total] = r[b];
-    }
-}
-
-__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
-                                                           float* __restrict__ y, int B, int H, int W, int C, int act, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % C;
-    size_t tl = idx / C;
-    const int TW = W >> 2, TH = H >> 2;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const float* in = Mt + idx;
-    float t[4][6];                                     // A^T m, one column of m at a time
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float col[6], r[4];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) col[a] = in[(size_t)(a * 6 + b) * total];
-        w4_at(col, r);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) t[a][b] = r[a];
-    }
-    const float bv = bias ? bias[c] : 0.f;
-    float* ys = y + (size_t)n * H * W * C + c;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        float r[4];
-        w4_at(t[a], r);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) ys[((size_t)(4 * ty + a) * W + 4 * tx + b) * C] = dwc_act_apply(r[b] + bv, act, c);
-    }
-}
-
-__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, float* __restrict__ Z, int B, int H, int W, int C,
-                                                       size_t total) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int c = idx % C;
-    size_t tl = idx / C;
-    const int TW = W >> 2, TH = H >> 2;
-    const int tx = tl % TW;
-    const int ty = (tl / TW) % TH;
-    const int n = tl / ((size_t)TW * TH);
-    const float* ds = dy + (size_t)n * H * W * C + c;
-    float t[6][4];                                     // A d, one column at a time
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        float col[4], r[6];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) col[a] = ds[((size_t)(4 * ty + a) * W + 4 * tx + b) * C];
-        w4_a(col, r);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) t[a][b] = r[a];
-    }
-    float* out = Z + idx;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {                      // (A d) A^T
-        float r[6];
-        w4_a(t[a], r);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) out[(size_t)(a * 6 + b) * total] = r[b];
-    }
-}
-
-__global__ void wino4_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int Cin, int Cout,
-                                          int cin_real, int cout_real) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t plane = (size_t)Cin * Cout;
-    if (idx >= plane) return;
-    const int co = idx % Cout, ci = idx / Cout;
-    if (co >= cout_real || ci >= cin_real) return;
-    float t[3][6];                                     // G^T u, one column of u at a time
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float col[6], r[3];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            float s = 0.f;
-            for (int z = 0; z < splits; ++z) s += slab[((size_t)(a * 6 + b) * splits + z) * plane + idx];
-            col[a] = s;
-        }
-        w4_gt(col, r);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) t[a][b] = r[a];
-    }
-    float* o = dw + ((size_t)co * cin_real + ci) * 9;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {                      // (G^T u) G
-        float r[3];
-        w4_gt(t[a], r);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) o[a * 3 + b] = r[b];
-    }
-}
-
-// ---- Winograd entry points: tile = 2 -> F(2x2,3x3) (16 products), tile = 4 -> F(4x4,3x3) (36 products) ---------------
-static bool wino_ok(int B, int H, int W, int Cin, int Cout, int tile) {
-    return (tile == 2 || tile == 4) && B > 0 && H >= tile && W >= tile && !(H % tile) && !(W % tile) && H >= 2 && W >= 2 &&
-           dwc_ilog2_exact(Cin) >= 5 && Cout >= 32 && !(Cout & 3);
-}
-static inline int wino_classes(int tile) { return (tile + 2) * (tile + 2); }
-
-size_t dwc_wino_filter_elems(int Cout, int Cin, int tile) { return (size_t)wino_classes(tile) * Cout * Cin; }
-
-int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, int tile, void* stream) {
-    if (Cout <= 0 || Cin <= 0 || (tile != 2 && tile != 4)) return DWC_EINVAL;
-    const size_t total = (size_t)Cout * Cin;
-    if (tile == 2)
-        hipLaunchKernelGGL(wino_filter_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin,
-                           for_dgrad);
-    else
-        hipLaunchKernelGGL(wino4_filter_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw, U, Cout, Cin,
-                           for_dgrad);
-    DWC_LAUNCH_CHECK();
-    return DWC_OK;
-}
-
-size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile) {
-    if (!wino_ok(B, H, W, Cin, Cout, tile)) return 0;
-    const size_t T = (size_t)B * (H / tile) * (W / tile);
-    return wino_classes(tile) * T * ((size_t)Cin + Cout) * sizeof(float);
-}
-
-// y = act(conv3x3(pad1(x)) + bias), stride 1; pad rule reflect (reflect != 0) or zero.  U from dwc_wino_prepare_filter
-// (for the data gradient: prepared with for_dgrad = 1, x := dY, Cin := channels of dY, Cout := channels of dx, zero rule).
-int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, int act,
-                    int reflect, int tile, float* v_keep, void* ws, size_t ws_bytes, void* stream) {
-    if (!wino_ok(B, H, W, Cin, Cout, tile)) return DWC_EINVAL;
-    if (!ws || ws_bytes < dwc_conv2d_wino_ws_bytes(B, H, W, Cin, Cout, tile)) return DWC_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const int T = B * (H / tile) * (W / tile), NC = wino_classes(tile);
-    // v_keep: caller-owned [classes][T][Cin] buffer that receives the transformed input (kept for the weight gradient)
-    float* V = v_keep ? v_keep : (float*)ws;
-    float* Mt = (float*)ws + (size_t)NC * T * Cin;
-    if (tile == 2) {
-        const size_t tin = (size_t)T * (Cin / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, reflect, tin);
-    } else {
-        const size_t tin = (size_t)T * Cin;
-        hipLaunchKernelGGL(wino4_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin, reflect, tin);
-    }
-    DWC_LAUNCH_CHECK();
-    static const bool unfused = getenv("DWC_WINO_UNFUSED") != nullptr;      // development knob: separate GEMM + output transform
-    // Fused GEMM + output transform (one workgroup walks all 16 products of its 64 tiles x 64 channels): 14 % faster than the
-    // separate kernels when it yields at least two workgroups per CU; with fewer (batch 16: one per CU) the 16x smaller grid
-    // loses to the separate launches.
-    const long fused_wgs = (long)((T + 63) / 64) * ((Cout + 63) / 64);
-    if (tile == 2 && !unfused && fused_wgs >= 2 * NUM_CU) {
-        const int tn = (Cout + 63) / 64;
-        if (gemm_x3_on(Cin))
-            hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1, true>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T,
-                               Cin, Cout, H, W, act, tn);
-        else
-            hipLaunchKernelGGL((wino_fused_kernel<64, 64, 2, 2, 1, 1>), dim3(((T + 63) / 64) * tn), dim3(256), 0, st, V, U, bias, y, T, Cin,
-                               Cout, H, W, act, tn);
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
-    // the products [T x Cin] . [Cin x Cout] as 1x1 "convolutions" over T one-pixel images, one class each
-    Gather g;
-    g.tap_t = 0;
-    g.src = V; g.SH = 1; g.SW = 1; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = 1; g.OW = 1; g.logOW = 0; g.logOHW = 0; g.KH = 1; g.KW = 1; g.kw_magic = 65536;
-    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = g.off_w = 0; g.reflect = 1; g.M = T; g.K = Cin;
-    Scatter o;
-    o.dst = Mt; o.N = Cout; o.OHf = 1; o.OWf = 1; o.os = 1;
-    const Plan p = plan_gemm(T, Cout, Cin, NC);
-    const int nk = (Cin + BK - 1) / BK;
-    const size_t ws_w = (size_t)Cout * Cin, ws_s = (size_t)T * Cin, ws_d = (size_t)T * Cout;
-#define WINO_LAUNCH(BM, BN, WM, WN, TM, TN, X3)                                                                                   \
-    hipLaunchKernelGGL((conv_gemm_batched_kernel<BM, BN, WM, WN, TM, TN, X3>),                                                    \
-                       dim3(((T + BM - 1) / BM) * ((Cout + BN - 1) / BN), 1, NC), dim3(256), 0, st, g, U, ws_w, ws_s, o, ws_d,    \
-                       (Cout + BN - 1) / BN, nk)
-    if (gemm_x3_on(Cin)) {
-        if (p.bm == 128 && p.bn >= 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1, true);
-        else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1, true);
-        else WINO_LAUNCH(128, 32, 4, 1, 1, 1, true);
-    } else if (p.bm == 128 && p.bn == 128) WINO_LAUNCH(128, 128, 2, 2, 2, 2, false);
-    else if (p.bm == 128 && p.bn == 64) WINO_LAUNCH(128, 64, 2, 2, 2, 1, false);
-    else if (p.bm == 64 && p.bn == 64) WINO_LAUNCH(64, 64, 2, 2, 1, 1, false);
-    else WINO_LAUNCH(128, 32, 4, 1, 1, 1, false);
-#undef WINO_LAUNCH
-    DWC_LAUNCH_CHECK();
-    if (tile == 2) {
-        const size_t tout = (size_t)T * (Cout / 4);
-        hipLaunchKernelGGL(wino_output_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, Mt, bias, y, B, H, W, Cout / 4, act, tout);
-    } else {
-        const size_t tout = (size_t)T * Cout;
-        hipLaunchKernelGGL(wino4_output_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, Mt, bias, y, B, H, W, Cout, act, tout);
-    }
-    DWC_LAUNCH_CHECK();
-    return DWC_OK;
-}
-
-static void wino_wgrad_sizes(int B, int H, int W, int Cin, int Cout, int tile, size_t* v, size_t* z, size_t* slabs, int* splits,
-                             int* chunk) {
-    const size_t T = (size_t)B * (H / tile) * (W / tile);
-    const int NC = wino_classes(tile);
-    *v = NC * T * Cin;
-    *z = NC * T * Cout;
-    wgrad_plan((int)T, Cin, Cout, splits, chunk, NC);
-    *slabs = (size_t)NC * *splits * Cin * Cout;
-}
-
-size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile) {
-    if (!wino_ok(B, H, W, Cin, Cout, tile)) return 0;
-    size_t v, z, sl;
-    int splits, chunk;
-    wino_wgrad_sizes(B, H, W, Cin, Cout, tile, &v, &z, &sl, &splits, &chunk);
-    return (v + z + sl) * sizeof(float);
-}
-
-// dw (OIHW, [cout_real][cin_real][3][3]) of a reflect-padded stride-1 3x3 convolution from x:[B,H,W,Cin], dy:[B,H,W,Cout]:
-// dU_e = V_e^T Z_e over the tiles (one product per class on the weight-gradient GEMM), then dg = G^T dU G.
-int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw_oihw, int B, int H, int W, int Cin,
-                               int Cout, int cin_real, int cout_real, int tile, void* ws, size_t ws_bytes, void* stream) {
-    if (!wino_ok(B, H, W, Cin, Cout, tile) || cin_real > Cin || cout_real > Cout) return DWC_EINVAL;
-    size_t nv, nz, nsl;
-    int splits, chunk;
-    wino_wgrad_sizes(B, H, W, Cin, Cout, tile, &nv, &nz, &nsl, &splits, &chunk);
-    if (!ws || ws_bytes < (nv + nz + nsl) * sizeof(float)) return DWC_EWORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    const int T = B * (H / tile) * (W / tile), NC = wino_classes(tile);
-    float* V = (float*)ws;
-    float* Z = V + nv;
-    float* slab = Z + nz;
-    if (v_saved) {                 // the forward kept B^T x B (dwc_conv2d_wino's v_keep): no second transform
-        V = const_cast<float*>(v_saved);
-    } else {
-        if (!x) return DWC_EINVAL;
-        if (tile == 2) {
-            const size_t tin = (size_t)T * (Cin / 4);
-            hipLaunchKernelGGL(wino_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin / 4, 1, tin);
-        } else {
-            const size_t tin = (size_t)T * Cin;
-            hipLaunchKernelGGL(wino4_input_kernel, dim3((tin + 255) / 256), dim3(256), 0, st, x, V, B, H, W, Cin, 1, tin);
-        }
-        DWC_LAUNCH_CHECK();
-    }
-    if (tile == 2) {
-        const size_t tout = (size_t)T * (Cout / 4);
-        hipLaunchKernelGGL(wino_dy_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, dy, Z, B, H, W, Cout / 4, tout);
-    } else {
-        const size_t tout = (size_t)T * Cout;
-        hipLaunchKernelGGL(wino4_dy_kernel, dim3((tout + 255) / 256), dim3(256), 0, st, dy, Z, B, H, W, Cout, tout);
-    }
-    DWC_LAUNCH_CHECK();
-    Gather g;
-    g.tap_t = 0;
-    g.src = V; g.SH = 1; g.SW = 1; g.SC = Cin; g.logSC = dwc_ilog2_exact(Cin);
-    g.OH = 1; g.OW = 1; g.logOW = 0; g.logOHW = 0; g.KH = 1; g.KW = 1; g.kw_magic = 65536;
-    g.mul_h = g.mul_w = 1; g.kstep = 1; g.off_h = g.off_w = 0; g.reflect = 1; g.M = T; g.K = Cin;
-    const int tk = (Cin + 127) / 128;
-    const size_t sv = (size_t)T * Cin, sz = (size_t)T * Cout;
-    if (Cout > 64 && wgrad_x3_on()) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2, true>), dim3(tk, (Cout + 127) / 128, NC * splits), dim3(256), 0, st, g, Z,
-                           Cout, slab, chunk, splits, sv, sz);
-    } else if (Cout > 64) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<128, 2, 2, 2, 2>), dim3(tk, (Cout + 127) / 128, NC * splits), dim3(256), 0, st, g, Z,
-                           Cout, slab, chunk, splits, sv, sz);
-    } else if (wgrad_x3_on()) {
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1, true>), dim3(tk, 1, NC * splits), dim3(256), 0, st, g, Z, Cout, slab, chunk,
-                           splits, sv, sz);
-    } else {
-        hipLaunchKernelGGL((conv_wgrad_kernel<64, 2, 2, 2, 1>), dim3(tk, 1, NC * splits), dim3(256), 0, st, g, Z, Cout, slab, chunk,
-                           splits, sv, sz);
-    }
-    DWC_LAUNCH_CHECK();
-    const size_t plane = (size_t)Cin * Cout;
-    if (tile == 2)
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((plane + 63) / 64), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
-                           cin_real, cout_real);
-    else
-        hipLaunchKernelGGL(wino4_wgrad_reduce_kernel, dim3((plane + 255) / 256), dim3(256), 0, st, slab, dw_oihw, splits, Cin, Cout,
-                           cin_real, cout_real);
-    DWC_LAUNCH_CHECK();
-    return DWC_OK;
 }
 
 // Zero-padded convolutions (the frozen VGG16 of the perceptual loss, reference networks.py:639-688: nn.Conv2d(padding=1)):

@@ -179,19 +179,3 @@ __device__ __forceinline__ float dwc_act_grad(float y, int act, int ch) {
     }
 }
 
-// Two independent workgroups share a CU so that one's matrix work runs under the other's prologue / store burst -- but the two
-// first-round workgroups of a CU start together, and so do their successors (a slot is refilled when its workgroup ends): they
-// reach every phase TOGETHER.  dwc_duo_stagger() delays the workgroup with the odd thread-group slot of its CU once, in the first
-// round only (blockIdx < the resident capacity); every later workgroup inherits the offset from the slot it takes over.
-__device__ __forceinline__ void dwc_duo_stagger(int ticks, int first_round) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (ticks > 0 && (int)blockIdx.x < first_round) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if ((hwid >> 16) & 1) {                               // TG_ID bit 0: the CU's second resident workgroup
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)ticks) __builtin_amdgcn_s_sleep(64);
-        }
-    }
-#endif
-}

@@ -4,11 +4,11 @@
 //
 // The conv kernels do not read the OIHW master weights: they stream prepared copies -- [N][Kp] im2col rows (fp32 or bf16,
 // forward / data-gradient / transposed-filter data-gradient, four parity classes for stride 2), three-way bf16 split planes
-// (conv_halo_x3.hip) and Winograd F(2x2,3x3) transform-domain banks.  Rounds 1-2 rebuilt each of them lazily with its own
+// (conv_halo_x3.hip), two-plane f16 split planes with their scales (r05).  Rounds 1-2 rebuilt each of them lazily with its own
 // launch the first time a layer ran after the step: ~137 launches per iteration (weight_prepare_dgrad 66, _fwd 35,
 // x3_weight_prepare 20, wino_filter 16).  Here a device descriptor table lists every (master weight, prepared tensor, layout)
 // pair; workgroup b rebuilds DWC_OPT_CHUNK work items of descriptor chunk_desc[b] from chunk_start[b].  The element formulas
-// are those of weight_prepare_*_kernel (conv_igemm.hip, conv_bf16.hip), x3_weight_prepare_kernel and wino_filter_kernel --
+// are those of weight_prepare_*_kernel (conv_igemm.hip, conv_bf16.hip), x3_weight_prepare_kernel / h2_weight_prepare_kernel --
 // tests/test_hip_parity.py::test_weight_refresh_multi_matches_single_layout_kernels holds the two bit for bit.
 #include "dwc_common.h"
 
@@ -140,38 +140,6 @@ __global__ __launch_bounds__(256) void weight_refresh_multi_kernel(const dwc_ref
                 o[base] = (unsigned short)(hb >> 16);
                 o[base + (size_t)rows * CS] = (unsigned short)(mb >> 16);
                 o[base + 2 * (size_t)rows * CS] = (unsigned short)(__float_as_uint(r2) >> 16);
-                break;
-            }
-            case DWC_REFRESH_WINO2_FWD:
-            case DWC_REFRESH_WINO2_DGRAD: {
-                // conv_igemm.hip wino_filter_kernel: U[16][rows][K] = G g G^T (forward: g = W[co][ci]; data gradient: rotated, transposed)
-                const bool dg = d.kind == DWC_REFRESH_WINO2_DGRAD;
-                const int rows = dg ? d.Cin : d.Cout, K = dg ? d.Cout : d.Cin;
-                const int k = idx % K, row = idx / K;
-                const int co = dg ? k : row, ci = dg ? row : k;
-                const float* gp = d.src + ((size_t)co * d.Cin + ci) * 9;
-                float g[3][3];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) g[a][b] = dg ? gp[(2 - a) * 3 + (2 - b)] : gp[a * 3 + b];
-                float t[4][3];
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    t[0][b] = g[0][b];
-                    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-                    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-                    t[3][b] = g[2][b];
-                }
-                float* U = reinterpret_cast<float*>(d.dst);
-                const size_t plane = (size_t)rows * K;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    U[(size_t)(a * 4 + 0) * plane + idx] = t[a][0];
-                    U[(size_t)(a * 4 + 1) * plane + idx] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-                    U[(size_t)(a * 4 + 2) * plane + idx] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-                    U[(size_t)(a * 4 + 3) * plane + idx] = t[a][2];
-                }
                 break;
             }
             default: break;

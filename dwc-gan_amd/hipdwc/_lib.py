@@ -38,12 +38,6 @@ SIGNATURES = {
     "dwc_conv2d_bwd_data_same_ws_bytes": (c_sz, [c_int] * 8),
     "dwc_conv2d_bwd_data_same": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_bwd_data_ring": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
-    "dwc_wino_filter_elems": (c_sz, [c_int] * 3),
-    "dwc_wino_prepare_filter": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
-    "dwc_conv2d_wino_ws_bytes": (c_sz, [c_int] * 6),
-    "dwc_conv2d_wino": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_fp, c_sz, c_fp]),
-    "dwc_conv2d_wino_bwd_weight_ws_bytes": (c_sz, [c_int] * 6),
-    "dwc_conv2d_wino_bwd_weight": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_bwd_data_image_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_conv2d_bwd_data_image": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 7 + [c_fp, c_sz, c_fp]),
     "dwc_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),

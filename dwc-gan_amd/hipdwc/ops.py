@@ -161,10 +161,9 @@ class scope:
         SCOPE = self.prev
 
 
-# launch kinds of the fp32 im2col / Winograd kernels whose inner products run as split products when dwc_x3_gemm_mode says so (r04)
-_G3_GEMM = {"fwd", "dgrad", "dgrad-image", "fwd-heads", "dgrad-heads", "fwd-zeropad", "dgrad-zeropad", "fwd-wino2", "dgrad-wino2",
-            "fwd-wino4", "dgrad-wino4", "fwd-zeropad-wino2", "dgrad-zeropad-wino2", "fwd-zeropad-wino4", "dgrad-zeropad-wino4"}
-_G3_WGRAD = {"wgrad", "wgrad-heads", "wgrad-wino2", "wgrad-wino4"}
+# launch kinds of the fp32 im2col kernels whose inner products run as split products when dwc_x3_gemm_mode says so (r04)
+_G3_GEMM = {"fwd", "dgrad", "dgrad-image", "fwd-heads", "dgrad-heads", "fwd-zeropad", "dgrad-zeropad"}
+_G3_WGRAD = {"wgrad", "wgrad-heads"}
 
 
 def _timed(tag, flops, fn, scope_name=None, detail="", exec_flops=None):
@@ -263,21 +262,6 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
     if ent.get(key, (None, None))[0] == stamp:
         return ent[key][1]
     lib = _lib.load()
-    if kind in ("wino_fwd", "wino_dgrad"):
-        # transform-domain filter bank [classes][N][K] (dwc_wino_prepare_filter); `stride` carries the Winograd output tile
-        co, ci, kh, kw = w.shape
-        wz = w.detach()
-        if co != cout_pad or ci != cin_pad:
-            wz = torch.zeros((cout_pad, cin_pad, 3, 3), dtype=torch.float32, device=w.device)
-            wz[:co, :ci] = w.detach()
-        out = torch.empty(lib.dwc_wino_filter_elems(cout_pad, cin_pad, stride), dtype=torch.float32, device=w.device)
-        _lib.check(lib.dwc_wino_prepare_filter(wz.contiguous().data_ptr(), out.data_ptr(), cout_pad, cin_pad,
-                                               int(kind == "wino_dgrad"), stride, _stream()), "wino_prepare_filter")
-        recipe = None
-        if stride == 2 and co == cout_pad and ci == cin_pad:          # (F(2x2,3x3) only; `stride` carries the Winograd tile)
-            recipe = _recipe(w, owners, kind=7 if kind == "wino_dgrad" else 6, n_items=cout_pad * cin_pad, Cout=co, Cin=ci, KH=3, KW=3)
-        ent[key] = (stamp, out, recipe)
-        return out
     if kind in ("x3_fwd", "x3_dgrad"):
         # three bf16 planes per (tap, 16-channel slab) [tap][slab][plane][row][16] (dwc_x3_weight_prepare); rows = cout_pad
         # forward / cin_pad for the data gradient, the contraction runs over the other (zero-padded) channel count
@@ -538,20 +522,12 @@ def refresh_prepared(params):
 # --------------------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------------------
-# Winograd output tile of the stride-1 3x3 convolutions: 2 -> F(2x2,3x3) (the default), 4 -> F(4x4,3x3) where the image
-# size allows it (else F(2x2,3x3)), 0 -> direct products.  F(2x2,3x3) does 2.25x fewer multiply-adds than the direct
-# product at a max error of ~2e-6 of the output maximum (direct: ~3e-7) and keeps every parity check of the test-suite,
-# the "loss within 1e-3 of the reference after the first optimiser step" one included.  F(4x4,3x3) does 4x fewer
-# (+7.5 % images/s) at ~2e-5: single-op and single-iteration parity still hold, but the first Adam steps are sign descent,
-# so ten times the gradient error flips ten times as many near-zero gradient signs and the step-1 loss lands 1.8e-3 from
-# the reference's.  Opt in with DWC_WINOGRAD=4 (or ops.WINOGRAD_TILE = 4) where that is acceptable.
-WINOGRAD_TILE = int(os.environ.get("DWC_WINOGRAD", "2"))
 # bf16 path: halo-tiled kernel for the stride-1 "same" 3x3 / 5x5 layers (0: im2col GEMM everywhere; development knob)
 # fp32 stride-1 "same" 5x5 (and with DWC_X3=2 also 3x3) convolutions as exact three-way bf16 splits on the bf16 MFMA
 # (csrc/conv_halo_x3.hip): 0 = native fp32 MFMA kernels only
-# (r04: 2 is the default -- every stride-1 3x3 / 5x5 layer as split products, forward, data gradient and weight gradient; same-box
-# A/B on c1, interleaved: 256.7 / 252.2 images/s against 249.4 / 247.2 with Winograd (1) for the taped 3x3 forwards and their
-# weight gradients.  Winograd F(2x2,3x3) / F(4x4,3x3) stay available behind DWC_X3=1 (+ DWC_WINOGRAD).)
+# (r04: every stride-1 3x3 / 5x5 layer as split products, forward, data gradient and weight gradient.  The Winograd F(2x2,3x3) /
+# F(4x4,3x3) family of rounds 1-4 -- fp32 MFMA, 2.25x / 4x fewer multiply-adds, 3 - 30x the rounding error -- lost every A/B
+# against the split products from r04 on and was removed in r05; DWC_X3=1 keeps the 3x3 layers on the im2col kernels.)
 X3 = int(os.environ.get("DWC_X3", "2"))
 HALO = int(os.environ.get("DWC_BF16_HALO", "1"))
 WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
@@ -565,19 +541,6 @@ S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forward
 S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
 X3_WGRAD_HALO3 = int(os.environ.get("DWC_X3_WGRAD_HALO3", "1"))   # 0: 3x3 weight gradients on the im2col kernel (split-product inner product)
 S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
-
-
-_WINO_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}      # multiply-adds issued / multiply-adds of the direct product
-
-
-def _wino_ok(H, W, KH, KW, stride, pad, c_gather, c_out):
-    """Output tile (4, 2) if this stride-1 3x3 pad-1 convolution runs as Winograd (dwc_conv2d_wino), else 0."""
-    if not (WINOGRAD_TILE and KH == 3 and KW == 3 and stride == 1 and pad == 1 and H >= 4 and W >= 4 and c_gather >= 64
-            and (c_gather & (c_gather - 1)) == 0 and c_out >= 64):
-        return 0
-    if WINOGRAD_TILE >= 4 and H % 4 == 0 and W % 4 == 0:
-        return 4
-    return 2 if H % 2 == 0 and W % 2 == 0 else 0
 
 
 # Planes per operand of the split-product halo kernels (csrc/conv_halo_x3.hip): 3 = exact three-way bf16 split, six MFMAs per
@@ -646,9 +609,8 @@ def pass_amax(src, dst):
 
 def _x3_use(lib, B, H, W, c_in, c_out, KH, KW, stride, pad, free=False):
     """Whether this fp32 stride-1 'same' convolution (c_in gathered channels -> c_out) runs as split-bf16 products.
-    5x5: always when the shape is handled (1.5-1.8x the native kernels).  3x3: Winograd F(2x2) on the fp32 MFMA is about as
-    fast, and its forward hands the transformed input to the weight gradient -- so only where nothing is lost (``free``: a
-    data gradient, or a forward whose weights need no gradient; 5-20 % faster there), or everywhere when forced (DWC_X3=2)."""
+    5x5: always when the shape is handled.  3x3: with DWC_X3=1 only where ``free`` (a data gradient, or a forward whose weights need
+    no gradient), everywhere with the default DWC_X3=2."""
     if not X3 or stride != 1 or KH != KW or 2 * pad != KH - 1 or c_in % 16 or c_out % 16:
         return False
     if KH == 3 and X3 < 2 and not free:
@@ -715,25 +677,19 @@ class _Conv2d(torch.autograd.Function):
         cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
         Wo = (W + 2 * pad - KW) // stride + 1
-        # (inside torch.no_grad() needs_input_grad still reports the parameters' requires_grad.  Measured on c1, same box: treating
-        # those forwards -- 48 3x3 layers per step -- as gradient-free and sending them to the split-product kernel costs 4 ms per
-        # step (206 vs 218 images/s), and so does merely dropping their v_keep buffer so that V lands in the shared scratch arena
-        # (207 vs 220): both decisions therefore follow needs_input_grad alone.)
-        # r04: the split-product 3x3 forward is now ahead of Winograd at every batch (B=16: 121 vs 135 us, B=48: 265 vs 312), so
-        # the forwards made under torch.no_grad() -- the caller tells, grad mode is always off in here -- take it; forwards on
-        # the tape keep Winograd, whose transformed input the weight gradient reuses.
+        # (inside torch.no_grad() needs_input_grad still reports the parameters' requires_grad: the caller tells, grad mode is always
+        # off in here)
         w_grad = ctx.needs_input_grad[1] and not nograd
         use_x3 = (not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad, free=not w_grad)
         # (>= 160 workgroups of 256 output pixels x 64 channels: below that the launch leaves most CUs idle -- B=16 32x32 256->256 ran
         # 200 us on 64 workgroups against 118 us on the native kernel)
         use_x3s2 = bool((not half) and X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1 and cop % 64 == 0
                         and B * (H // 32) * (W // 32) * (cop // 64) >= 160 and lib.dwc_x3_conv2d_s2_ok(B, H, W, Cx, cop))
-        use_wino = 0 if half or use_x3 else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)
         use_stem = bool(half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
                         and lib.dwc_bf16_conv2d_stem_ok(B, H, W, H, W, KH, act))
         use_stem_x3 = bool((not half) and X3 and NARROW_X3 and Cx == 4 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
                            and lib.dwc_x3_conv2d_stem_ok(B, H, W, H, W, KH, act))
-        w_hwio = None if use_wino or use_x3 or use_x3s2 or use_stem or use_stem_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
+        w_hwio = None if use_x3 or use_x3s2 or use_stem or use_stem_x3 else _prepped(w, "fwd", cop, Cx, stride, owner, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
@@ -741,19 +697,7 @@ class _Conv2d(torch.autograd.Function):
         y = empty_cl(B, cop, Ho, Wo, x.device, x.dtype)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
         st = _stream()
-        v_keep = None
-        if use_wino:
-            wt = use_wino
-            U = _prepped(w, "wino_fwd", cop, Cx, wt, owner)
-            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop, wt), x.device)
-            # the transformed input is what the weight gradient contracts with: keep it instead of transforming x again
-            v_keep = torch.empty((wt + 2) ** 2 * B * (H // wt) * (W // wt) * Cx, dtype=torch.float32,
-                                 device=x.device) if w_grad else None
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
-                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 1, wt, _p(v_keep), ws.data_ptr(),
-                ws.numel(), st), detail="fwd-wino%d B%d %dx%d %d>%d k%d s%d" % (wt, B, H, W, Cx, cop, KH, stride),
-                exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
-        elif use_x3 and h2_fits(x):
+        if use_x3 and h2_fits(x):
             w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1, owner)
             ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
             x_amax = amax_of(x)
@@ -814,7 +758,7 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_fwd", x)(
                 x.data_ptr(), w_hwio.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, KW, stride, pad, act, wsp, nws,
                 st), detail="fwd B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)), "conv2d_fwd")
-        ctx.save_for_backward(x, w, y if act != 0 else None, v_keep if use_wino else None)
+        ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.x_amax = getattr(x, "_dwc_amax", None)        # (slot, epoch, version, address) if something measured x (two-plane kernels)
         ctx.geom = (B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, b is not None)
         ctx.bscope = ("bwd:" + SCOPE) if SCOPE else ""
@@ -823,7 +767,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
-        x, w, y, v_keep = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         B, H, W, Cx, cop, KH, KW, stride, pad, act, Cin, Cout, has_b = ctx.geom
         owner = ctx.owner
         dt = x.dtype
@@ -871,14 +815,7 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=dev)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             detail = "wgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-            wt = 0 if half or v_keep is None else _wino_ok(H, W, KH, KW, stride, pad, Cx, cop)   # v_keep: the forward ran Winograd
-            if wt:
-                ws = workspace(lib.dwc_conv2d_wino_bwd_weight_ws_bytes(B, H, W, Cx, cop, wt), dev)
-                _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_conv2d_wino_bwd_weight(
-                    x.data_ptr(), _p(v_keep), g.data_ptr(), dw.data_ptr(), B, H, W, Cx, cop, Cin, Cout, wt, ws.data_ptr(),
-                    ws.numel(), st), scope_name=ctx.bscope, detail="wgrad-wino%d" % wt + detail[5:],
-                    exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino_bwd_weight")
-            elif half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3 and Cout == 64:
+            if half and NARROW and STEM and Cx == 8 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3 and Cout == 64:
                 # 7x7 stem on an NHWC8 image: 4 taps x 8 planes per MFMA row tile (csrc/conv_narrow_bf16.hip)
                 ws = workspace(lib.dwc_bf16_conv7_smallk_wgrad_ws_bytes(B, H, W, 0), dev)
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
@@ -955,7 +892,6 @@ class _Conv2d(torch.autograd.Function):
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = _fn(lib, "conv2d_bwd_data_same_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, pad)
             x3 = (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, stride, pad, free=True)
-            wt = 0 if half or x3 else _wino_ok(H, W, KH, KW, stride, pad, cop, Cx)
             if x3:
                 # interior = zero-padded convolution of dY with the rotated filter on the split-product kernel; ring direct
                 w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner) if not h2_fits(g) else None
@@ -979,19 +915,6 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
-            elif wt:
-                # interior = zero-padded 3x3 convolution of dY with the rotated filter: Winograd; the ring stays direct
-                U = _prepped(w, "wino_dgrad", cop, Cx, wt, owner)
-                nwino = lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt)
-                ws = workspace(nwino + nws, dev)
-
-                shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
-                    g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, wt, None, ws.data_ptr(), nwino, st),
-                    scope_name=ctx.bscope, exec_flops=flops * _WINO_RATIO[wt], detail="dgrad-wino%d" % wt + shape), "conv2d_wino dgrad")
-                _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad,
-                    ws.data_ptr() + nwino, nws, st), scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
             elif half and HALO and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):
                 # interior on the halo-tiled kernel (zero rule, dgrad weights), the ring stays on the strip GEMMs
                 ws = workspace(nws, dev)
@@ -1240,22 +1163,32 @@ class _Conv2dZeroPad(torch.autograd.Function):
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
         cop = _padc(Cout, x.dtype)
-        wt = 0 if half else _wino_ok(H, W, KH, KW, 1, pad, Cx, cop)
+        # fp32: the split-product halo kernel with the zero rule where the shape allows (r05; rounds 1-4 ran Winograd F(2x2,3x3) here)
+        sp = bool((not half) and _x3_use(lib, B, H, W, Cx, cop, KH, KW, 1, pad, free=True))
         halo = bool(half and HALO and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, Cx, cop, KH))
-        w_prep = None if wt else _prepped(w, "fwd", cop, Cx, 1, None, half)
+        w_prep = None if sp else _prepped(w, "fwd", cop, Cx, 1, None, half)
         bias = None
         if b is not None:
             bias = b.detach() if cop == Cout else torch.nn.functional.pad(b.detach(), (0, cop - Cout))
         y = empty_cl(B, cop, H, W, x.device, x.dtype)
         st = _stream()
         flops = 2.0 * B * H * W * Cout * Cin * KH * KW
-        if wt:
-            U = _prepped(w, "wino_fwd", cop, Cx, wt)
-            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, Cx, cop, wt), x.device)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
-                x.data_ptr(), U.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, act, 0, wt, None, ws.data_ptr(), ws.numel(),
-                st), detail="fwd-zeropad-wino%d B%d %dx%d %d>%d k%d" % (wt, B, H, W, Cx, cop, KH),
-                exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        if sp and h2_fits(x):
+            w_h2 = _prepped(w, "h2_fwd", cop, Cx, 1)
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
+            xa = amax_of(x)
+            ya, yep = out_amax(y)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
+                x.data_ptr(), xa[0], xa[1], w_h2.data_ptr(), _p(bias), None, y.data_ptr(), ya, yep, B, H, W, Cx, cop, cop, KH, act, 0,
+                _p(ks_ws), ks_n, ks_t, st), detail="fwd-h2 B%d %dx%d %d>%d k%d zeropad" % (B, H, W, Cx, cop, KH), exec_flops=3 * flops),
+                "h2_conv2d_same zeropad")
+            set_amax(y, ya, yep)
+        elif sp:
+            w_x3 = _prepped(w, "x3_fwd", cop, Cx, 1)
+            ks_ws, ks_n, ks_t = _x3_ksplit(lib, x.device, B, H, W, Cx, cop, KH, 1)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
+                x.data_ptr(), w_x3.data_ptr(), _p(bias), None, y.data_ptr(), B, H, W, Cx, cop, cop, KH, act, 0, _p(ks_ws), ks_n, ks_t, st),
+                detail="fwd-x3 B%d %dx%d %d>%d k%d zeropad" % (B, H, W, Cx, cop, KH), exec_flops=6 * flops), "x3_conv2d_same zeropad")
         elif halo:               # bf16: the halo-tiled kernel with the zero rule
             _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo(
                 x.data_ptr(), w_prep.data_ptr(), _p(bias), y.data_ptr(), B, H, W, Cx, cop, KH, act, 0, st),
@@ -1288,14 +1221,21 @@ class _Conv2dZeroPad(torch.autograd.Function):
                                                     ws.numel(), st), "act_bwd_bias")
         dx = empty_cl(B, Cx, H, W, dev, dy.dtype)
         flops = 2.0 * rows * Cout * Cin * KH * KW
-        wt = 0 if half else _wino_ok(H, W, KH, KW, 1, pad, cop, Cx)
-        if wt:                                                # the adjoint of zero padding is a crop: no ring at all
-            U = _prepped(w, "wino_dgrad", cop, Cx, wt)
-            ws = workspace(lib.dwc_conv2d_wino_ws_bytes(B, H, W, cop, Cx, wt), dev)
-            _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_conv2d_wino(
-                g.data_ptr(), U.data_ptr(), None, dx.data_ptr(), B, H, W, cop, Cx, 0, 0, wt, None, ws.data_ptr(), ws.numel(), st),
-                detail="dgrad-zeropad-wino%d B%d %dx%d %d>%d k%d" % (wt, B, H, W, Cx, cop, KH),
-                exec_flops=flops * _WINO_RATIO[wt]), "conv2d_wino")
+        if (not half) and _x3_use(lib, B, H, W, cop, Cx, KH, KW, 1, pad, free=True):
+            # the adjoint of zero padding is a crop: the zero-rule convolution of dY with the rotated filter, no ring at all
+            ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1)
+            if h2_fits(g):
+                w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1)
+                ga = amax_of(g)
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
+                    g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), None, None, dx.data_ptr(), None, 0, B, H, W, cop, Cx, Cx, KH, 0, 0, _p(ws),
+                    ks_n, ks_t, st), detail="dgrad-h2 B%d %dx%d %d>%d k%d zeropad" % (B, H, W, Cx, cop, KH), exec_flops=3 * flops),
+                    "h2_conv2d_same zeropad dgrad")
+            else:
+                w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1)
+                _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
+                    g.data_ptr(), w_x3.data_ptr(), None, None, dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, _p(ws), ks_n, ks_t, st),
+                    detail="dgrad-x3 B%d %dx%d %d>%d k%d zeropad" % (B, H, W, Cx, cop, KH), exec_flops=6 * flops), "x3_conv2d_same zeropad dgrad")
             return dx, None, None, None, None
         w_dg = _prepped(w, "dgrad", cop, Cx, 1, None, half)
         if half and HALO and KH == KW and 2 * pad == KH - 1 and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):

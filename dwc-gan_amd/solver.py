@@ -79,16 +79,8 @@ class Solver(nn.Module):
         # set_n_critic / resume / init_network) -- never wrong, only one wasted taped encode.
         self.n_critic = 1
         self._tape_content = True
-        # The text encoder (embedding, two bi-LSTM layers of ~40 sequential steps, heads) is latency-bound and keeps < 80 of the
-        # 256 CUs busy: DWC_TXT_STREAM=1 runs it on a side stream beside the convolution work that does not depend on it
-        # (enc_content in the D step, the detached x_fake2 decode in the G step; autograd replays its backward on the same
-        # stream).  Random draws are made at CALL time, so their order is unchanged and results are identical.  Measured r04 on
-        # one MI355X: c1 245.4 vs 249.3 images/s, c2 1336.6 vs 1325.6 (on / off) -- nothing beyond run-to-run spread: the
-        # persistent LSTM workgroups want 84 KB of LDS each and wait for the convolution workgroups (2 x 77 KB per CU) to retire
-        # before they become resident, so the two streams mostly take turns.  Off by default.
-        self._txt_stream = None
-        self._txt_async = os.environ.get("DWC_TXT_STREAM", "0") == "1"
-
+        # (r04 measured the text encoder on a side stream beside the convolution work that does not depend on it: nothing beyond
+        # run-to-run spread -- its persistent LSTM workgroups want 84 KB of LDS and wait for convolution workgroups to retire; removed)
         adam = dict(lr=configs["lr"], betas=(configs["beta1"], configs["beta2"]), weight_decay=configs["weight_decay"])
         # torch.optim.Adam subclasses (same param_groups / state_dict / scheduler interface) whose step()
         # is one multi-tensor HIP launch per network
@@ -206,23 +198,8 @@ class Solver(nn.Module):
         return torch.where(keep, z_src, z_trg)
 
     def _encode_txt_side(self, style, txt, lens):
-        """gen.encode_txt on the side stream (see __init__).  Returns (result, join): call ``join()`` on the consuming stream
-        before the result is read.  Falls back to a plain call on CPU tensors / when switched off."""
-        if not (self._txt_async and style.is_cuda):
-            return self.gen.encode_txt(style, txt, lens), (lambda: None)
-        if self._txt_stream is None:
-            self._txt_stream = torch.cuda.Stream(device=style.device)
-        main, side = torch.cuda.current_stream(), self._txt_stream
-        side.wait_stream(main)                               # style (and everything before it) was produced on the main stream
-        with torch.cuda.stream(side):
-            out = self.gen.encode_txt(style, txt, lens)
-        style.record_stream(side)
-        for t in (flat_heads(out[0]), flat_heads(out[1])):
-            t.record_stream(main)
-
-        def join():
-            torch.cuda.current_stream().wait_stream(side)
-        return out, join
+        """gen.encode_txt; returns (result, join) -- ``join()`` is a no-op kept for the call sites' shape."""
+        return self.gen.encode_txt(style, txt, lens), (lambda: None)
 
     def _decode(self, content, style, x_real4):
         """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out."""

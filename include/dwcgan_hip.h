@@ -106,31 +106,10 @@ size_t dwc_conv2d_bwd_data_same_ws_bytes(int B, int H, int W, int Cin, int Cout,
 int dwc_conv2d_bwd_data_same(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
                              int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                              void* ws, size_t ws_bytes, void* stream);
-/* Only the ring part of dwc_conv2d_bwd_data_same: dx already holds the interior (dwc_conv2d_wino with the zero rule). */
+/* Only the ring part of dwc_conv2d_bwd_data_same: dx already holds the interior (dwc_x3_ / dwc_h2_conv2d_same_add_ws with the zero rule). */
 int dwc_conv2d_bwd_data_ring(const float* dy, const float* w_dgrad, const float* w_dgrad_t, float* dx,
                              int B, int H, int W, int Cin, int Cout, int KH, int KW, int pad,
                              void* ws, size_t ws_bytes, void* stream);
-/* Winograd for stride-1 3x3 convolutions with pad 1 (the ResBlock convolutions, reference networks.py:514-515).
- * tile = 2: F(2x2,3x3), 16 transform-domain products, 2.25x fewer multiply-adds than the direct product;
- * tile = 4: F(4x4,3x3), 36 products, 4x fewer (about one decimal digit less accurate).  H, W multiples of tile.
- * U:[classes][N][K] from dwc_wino_prepare_filter (for_dgrad = 0: N = Cout, K = Cin; for_dgrad = 1: the 180-degree rotated,
- * transposed filter, N = Cin, K = Cout).  dwc_conv2d_wino computes y = act(conv3x3(pad1(x)) + bias) with the reflect rule
- * (reflect != 0) or the zero rule; the data gradient's interior is the same call on dY with the for_dgrad filter and the
- * zero rule.  Cin a power of two >= 32; Cout % 4 == 0.  Scratch: the two transform-domain tensors,
- * classes * B*H*W/tile^2 * (Cin + Cout) floats.
- * v_keep (may be NULL): caller-owned [classes][B*H*W/tile^2][Cin] buffer that receives the transformed input instead of
- * the scratch, so that dwc_conv2d_wino_bwd_weight can reuse it (v_saved) instead of transforming x again. */
-size_t dwc_wino_filter_elems(int Cout, int Cin, int tile);
-int dwc_wino_prepare_filter(const float* w_oihw, float* U, int Cout, int Cin, int for_dgrad, int tile, void* stream);
-size_t dwc_conv2d_wino_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile);
-int dwc_conv2d_wino(const float* x, const float* U, const float* bias, float* y, int B, int H, int W, int Cin, int Cout,
-                    int act, int reflect, int tile, float* v_keep, void* ws, size_t ws_bytes, void* stream);
-/* Weight gradient of the same convolutions in the transform domain: dU_e = V_e^T Z_e over the tiles (V = B^T x B with the
- * reflect rule, Z = A dY A^T), then dg = G^T dU G, written in OIHW [cout_real][cin_real][3][3]. */
-size_t dwc_conv2d_wino_bwd_weight_ws_bytes(int B, int H, int W, int Cin, int Cout, int tile);
-int dwc_conv2d_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw_oihw,
-                               int B, int H, int W, int Cin, int Cout, int cin_real, int cout_real, int tile,
-                               void* ws, size_t ws_bytes, void* stream);
 /* Data gradient w.r.t. an NHWC4 IMAGE dx:[B,H,W,4] of a stride-1 "same" convolution (2*pad == K-1; the 7x7 stems,
  * reference networks.py:432, networks_v2.py:106, reached when generated images are re-encoded, solver.py:176-180).
  * 8 adjacent pixels x 4 channels are produced as 32 GEMM columns.  w_wide: dwc_weight_prepare_fwd layout of the bank
@@ -320,9 +299,9 @@ int dwc_adv_tail_bwd(const float* src, const float* cls, const float* labels, co
  * the single-layout entry points: FWD / DGRAD = dwc_weight_prepare_fwd / _dgrad (fp32) and dwc_bf16_weight_prepare_fwd /
  * _dgrad (work item = output element; n_items = rows * Kp, x 4 parity classes for the stride-2 data gradient; transpose_hw:
  * the filter with its two spatial axes swapped), X3 = dwc_x3_weight_prepare (work item = one of K*K*ceil(kdim/16)*rows*16
- * source slots), WINO2 = dwc_wino_prepare_filter with tile 2 (work item = one (row, k) pair, sixteen transform-domain values). */
+ * source slots).  (Kinds 6 / 7 were the Winograd F(2x2,3x3) banks of rounds 1-4; the family was removed in r05.) */
 enum { DWC_REFRESH_FWD_F32 = 0, DWC_REFRESH_DGRAD_F32 = 1, DWC_REFRESH_FWD_BF16 = 2, DWC_REFRESH_DGRAD_BF16 = 3,
-       DWC_REFRESH_X3_FWD = 4, DWC_REFRESH_X3_DGRAD = 5, DWC_REFRESH_WINO2_FWD = 6, DWC_REFRESH_WINO2_DGRAD = 7,
+       DWC_REFRESH_X3_FWD = 4, DWC_REFRESH_X3_DGRAD = 5,
        /* r05: dwc_h2_weight_prepare (two f16 planes, n_items = K*K*ceil(kdim/16)*rows*16 source slots).  The prepared tensor ends
         * with {s_w, 1 / s_w} (fp32) and the filter's absmax slot (8 bytes, zero when the tensor is created): has_h2 != 0 makes
         * dwc_weight_refresh_multi raise those slots (epoch `epoch`, larger at every call) in a launch of its own first. */

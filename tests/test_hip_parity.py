@@ -45,8 +45,8 @@ CONV_SHAPES = [
     (3, 4, 32, 16, 5, 1, 2, "lrelu"),       # same, 5x5 / 32 gathered channels
     (2, 64, 128, 32, 4, 2, 1, "relu"),      # downsample
     (2, 128, 256, 64, 4, 2, 1, "lrelu"),    # downsample, several blocks per image (split-product forward, stride-2 form)
-    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv (Winograd F(2x2,3x3) forward and data-gradient interior)
-    (3, 64, 128, 12, 3, 1, 1, "relu"),      # Winograd, rectangular channel counts, non power-of-two size
+    (2, 256, 256, 16, 3, 1, 1, "none"),     # ResBlock conv (below the halo kernel's 16x16 block: im2col kernels + ring strips)
+    (3, 64, 128, 12, 3, 1, 1, "relu"),      # rectangular channel counts, non power-of-two size
     (2, 64, 64, 10, 3, 1, 1, "none"),       # size not a multiple of 4: F(2x2,3x3)
     (1, 256, 128, 16, 5, 1, 2, "none"),     # upsample-block conv
     (2, 128, 64, 24, 5, 1, 2, "none"),      # BN=64 path, non power-of-two spatial size
@@ -59,19 +59,6 @@ CONV_SHAPES = [
     (2, 8, 16, 12, 3, 1, 1, "sigmoid"),     # small channel counts (tiny config)
     (1, 16, 32, 6, 4, 2, 1, "tanh"),
 ]
-
-
-@pytest.fixture(params=[2, 4], ids=["wino2", "wino4"])
-def winograd_tile(request, monkeypatch):
-    monkeypatch.setattr(ops, "X3", 1)              # (r04: split products are the default for the 3x3 layers; Winograd is opt-in)
-    monkeypatch.setattr(ops, "WINOGRAD_TILE", request.param)
-    return request.param
-
-
-@pytest.mark.parametrize("shape", [s for s in CONV_SHAPES if s[4] == 3 and s[1] >= 64], ids=lambda s: "x".join(str(v) for v in s))
-def test_conv3x3_winograd_tiles(shape, winograd_tile):
-    """The stride-1 3x3 layers under both Winograd tiles (F(2x2,3x3) default, F(4x4,3x3) opt-in), same tolerances."""
-    test_conv_forward_backward(shape)
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
@@ -194,7 +181,7 @@ def test_alternative_paths_agree(prec, switch):
         ops.set_precision("fp32")
 
 
-# (Cin, Cout, H, k, stride, pad): generic GEMM (stride 2), Winograd forward, split-product 5x5; bf16: halo 3x3, generic
+# (Cin, Cout, H, k, stride, pad): generic GEMM (stride 2), split-product 3x3 and 5x5; bf16: halo 3x3, generic
 NONFINITE_SHAPES = [(64, 64, 16, 4, 2, 1), (256, 256, 16, 3, 1, 1), (128, 64, 16, 5, 1, 2)]
 
 
@@ -1031,12 +1018,12 @@ def test_weight_refresh_multi_matches_single_layout_kernels():
     """after an optimiser step every prepared weight layout is rebuilt by ONE dwc_weight_refresh_multi
     launch.  Its output must equal, bit for bit, what the single-layout entry points build from the same weights: fp32 and
     bf16 im2col rows (forward, data gradient, transposed-filter data gradient, the four stride-2 parity classes), the
-    three-plane bf16 splits, the two-plane f16 splits with their scales (r05) and the Winograd F(2x2,3x3) banks."""
+    three-plane bf16 splits and the two-plane f16 splits with their scales (r05)."""
     g = torch.Generator().manual_seed(9)
     cases = [  # (Cout, Cin, k, [(kind, cout_pad, cin_pad, stride, half)])
         (128, 64, 4, [("fwd", 128, 64, 2, False), ("dgrad", 128, 64, 2, False), ("fwd", 128, 64, 2, True), ("dgrad", 128, 64, 2, True)]),
         (256, 256, 3, [("fwd", 256, 256, 1, True), ("dgrad", 256, 256, 1, True), ("dgrad_t", 256, 256, 1, True), ("dgrad", 256, 256, 1, False),
-                       ("dgrad_t", 256, 256, 1, False), ("wino_fwd", 256, 256, 2, False), ("wino_dgrad", 256, 256, 2, False),
+                       ("dgrad_t", 256, 256, 1, False),
                        ("x3_fwd", 256, 256, 1, False), ("x3_dgrad", 256, 256, 1, False), ("h2_fwd", 256, 256, 1, False),
                        ("h2_dgrad", 256, 256, 1, False)]),
         (128, 256, 5, [("x3_fwd", 128, 256, 1, False), ("x3_dgrad", 128, 256, 1, False), ("fwd", 128, 256, 1, True), ("dgrad_t", 128, 256, 1, True),

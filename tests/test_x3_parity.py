@@ -224,22 +224,19 @@ def test_x3_split_is_exact():
 GEMM_SHAPES = [(6, 256, 512, 16, 16, 4, 2, 1, "lrelu"),     # discriminator tail: too small for the halo form, split-K
                (3, 4, 64, 32, 32, 7, 1, 3, "relu"),          # 7x7 stem on an NHWC4 image (K = 196, image data gradient)
                (4, 128, 128, 8, 8, 3, 1, 1, "none"),         # 3x3 below the halo kernel's 16x16 block (ring strips in the data gradient)
-               (5, 256, 256, 1, 1, 1, 1, 0, "relu"),         # nn.Linear as a 1x1 convolution
-               (3, 256, 256, 16, 16, 3, 1, 1, "relu")]       # Winograd F(2x2,3x3) with split-product transform-domain products
+               (5, 256, 256, 1, 1, 1, 1, 0, "relu")]         # nn.Linear as a 1x1 convolution
 
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
 def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
-    """r04: the im2col kernels (conv_gemm_body / conv_wgrad_kernel / the Winograd product kernels of csrc/conv_igemm.hip) take
+    """r04: the im2col kernels (conv_gemm_body / conv_wgrad_kernel of csrc/conv_igemm.hip) take
     their inner products as split products too (dwc_x3_gemm_mode, default 3).  Forward, data gradient and weight gradient through
     ops.conv2d against the float64 convolution, with the native fp32 MFMA result (mode 0) of the SAME kernels and the fp32 CPU
     convolution as yardsticks: error <= 5e-6 of the output scale and <= 2x the larger yardstick error (+2e-7)."""
     B, Cin, Cout, H, W, K, stride, pad, act = shape
-    wino = shape == GEMM_SHAPES[-1]
-    monkeypatch.setattr(ops, "X3", 0)                  # keep the layer on the im2col / Winograd kernels
+    monkeypatch.setattr(ops, "X3", 0)                  # keep the layer on the im2col kernels
     monkeypatch.setattr(ops, "X3_S2", 0)
     monkeypatch.setattr(ops, "S2DGRAD", 0)
-    monkeypatch.setattr(ops, "WINOGRAD_TILE", 2 if wino else 0)
     g = torch.Generator().manual_seed(B + Cin + Cout + K)
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, K, K, generator=g) * (1.0 / (Cin * K * K) ** 0.5)
@@ -277,7 +274,7 @@ def test_x3_im2col_gemm_and_wgrad_match_float64(shape, monkeypatch):
         scale = r.abs().max().item()
         e, en, e32 = ((t - r).abs().max().item() / scale for t in (a, n_, c32))
         print("%s %s: split %.2e native %.2e cpu-fp32 %.2e" % ("x".join(str(v) for v in shape), name, e, en, e32))
-        assert e <= (1e-5 if wino else 5e-6) and e <= 2 * max(en, e32) + 2e-7, (name, e, en, e32)
+        assert e <= 5e-6 and e <= 2 * max(en, e32) + 2e-7, (name, e, en, e32)
 
 
 @pytest.mark.parametrize("shape", [(16, 256, 256, 32, 32, 3, 1, "relu", True), (4, 128, 256, 32, 32, 3, 1, "none", False),
