@@ -520,7 +520,8 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
     single = [r for r in table if r["pipe"] and "multi-launch" not in r["kernel"] and r["executed_gflop_per_launch"] > 0]
     if single:
         r0 = single[0]
-        tr, tr_src = kernel_traffic_from_profiles("c4" if config_name == "c5" else config_name, r0["kernel"])
+        # (profiles/*pmc_hbm_traffic*.json keys a kernel by name<first template argument>: "conv_halo_x3_kernel<3>")
+        tr, tr_src = kernel_traffic_from_profiles("c4" if config_name == "c5" else config_name, r0["kernel"].replace(",h2>", ">"))
         # frac = matrix work the kernel EXECUTED / the dense peak of the pipe it occupies (utilisation of that pipe).  On the fp32 path
         # the kernels are split products: `products_per_mac` MFMAs of the 16-bit pipe per fp32 multiply-add (3: two f16 planes,
         # r05; 6: three bf16 planes, r02-r04), so the USEFUL fraction of that pipe is `frac_algorithmic_of_pipe` = frac /

@@ -10,7 +10,8 @@ the launches, algorithmic and executed flops, problem shapes of ONE training ite
     kernel, csv_names, pipe, launches_per_iter (rocprof), avg_us (rocprof), ms_per_iter (rocprof),
     algorithmic_gflop_per_launch, executed_gflop_per_launch, algorithmic_mbytes_per_launch (input + output + weights once),
     executed_tflops = executed flops per iteration / rocprof time per iteration, peak_tflops (dense peak of the pipe the kernel
-    runs on: fp32 MFMA 157.3, bf16 MFMA 2500; "bf16x3" = fp32 layers as six bf16 products per multiply-add, same bf16 peak),
+    runs on: fp32 MFMA 157.3, bf16 MFMA 2500; "bf16x3" = fp32 layers as six bf16 products per multiply-add, "f16x2" = as three f16
+    products per multiply-add (r05), same 2500 peak),
     frac = executed_tflops / peak_tflops, algorithmic_tflops (direct-convolution fp32-equivalent rate)
 
 Kernels the ledger does not know (norms, pointwise, reduces, stock torch) are listed with their rocprof time and
@@ -84,6 +85,9 @@ def main():
             "executed_tflops": None if ex_tf is None else round(ex_tf, 2),
             "algorithmic_tflops": None if ms_iter <= 0 else round(al_fl / (ms_iter * 1e-3) / 1e12, 2),
             "frac": None if (ex_tf is None or not peak) else round(ex_tf / peak, 4),
+            # executed / algorithmic multiply-adds (split products: 3 = two f16 planes, 6 = three bf16 planes) and the USEFUL fraction
+            "products_per_mac": None if al_fl <= 0 else round(ex_fl / al_fl, 2),
+            "frac_algorithmic_of_pipe": None if (ms_iter <= 0 or not peak) else round(al_fl / (ms_iter * 1e-3) / 1e12 / peak, 4),
             "span_avg_us_hip_events": k["avg_launch_us"]})
     rest = {}
     for r in rows_csv:
@@ -105,7 +109,7 @@ def main():
     table.sort(key=lambda r: -r["ms_per_iter"])
     res = {"config": led["config"], "precision": led["precision"], "per_gpu_batch": led["per_gpu_batch"], "image_size": led["image_size"],
            "commit": commit, "iterations_profiled": iters, "kernel_ms_per_iter": round(total_ns / 1e6 / iters, 3),
-           "peaks_tflops": {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0},
+           "peaks_tflops": {"fp32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0},
            "source": {"kernel_stats": stats_csv.split("/")[-1], "ledger": ledger_json.split("/")[-1]}, "kernels": table}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
