@@ -166,6 +166,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // accumulators (round to nearest) and restart from zero.  The error of a long contraction on the matrix cores is dominated by
     // the accumulate of each MFMA into an accumulator that has grown large (benchmarks/split2_lab.hip: K = 6400, error / output
     // scale 8.9e-7 unflushed, 2.0e-7 flushed every 25 steps -- a third of the native fp32 MFMA's).
+    // (Ablation of this form, profiles/r05_h2_ablation.txt, 3x3 256->256 at B=48: the conversion at the slab boundary accounts for 54
+    // of 219 us.  Spreading it over the taps of the previous slab into a SECOND pair of plane buffers -- 79.5 KB of LDS, no extra
+    // barrier -- was built and measured SLOWER: 3x3 170 -> 189 us, stride 2 177 -> 201 us, c1 332 -> 319 images/s: the work moves
+    // into the taps, where it delays this wave's MFMAs, while at the boundary the CU's OTHER workgroup covers it.  Not kept.)
     constexpr bool RAW = NPL == 2;
     static_assert(!RAW || PB == 1, "raw patch staging: the single-buffer form");
     constexpr int FLUSH = !RAW ? 0 : (NTAP >= 25 ? 1 : (NTAP >= 9 ? 2 : 4));      // slabs between flushes: 16 - 25 k-steps
@@ -1246,7 +1250,32 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
         const dim3 g4(2 * g2.x - a.split_from);
         if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
         else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
-    } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
+    }
+#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only with -DDWC_DEV_ABLATIONS, never in the shipped .so
+    // (benchmarks/h2_ablation_bench.py; DWC_X3_DBG: 1 no MFMA, 2 no fragment reads, 4 no weight staging, 8 no barrier, 16 no patch
+    // refresh / flush, other: empty skeleton -- profiles/r05_h2_ablation.txt)
+    else if (NPL == 2 && getenv("DWC_X3_DBG") && atoi(getenv("DWC_X3_DBG"))) {
+        const int dbg = atoi(getenv("DWC_X3_DBG"));
+        if constexpr (NPL == 2) {
+            if (K == 3) {
+                if (dbg == 1) x3_launch<3, 64, 4, 1, 2, 2, 1, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 2) x3_launch<3, 64, 4, 1, 2, 2, 2, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 4) x3_launch<3, 64, 4, 1, 2, 2, 4, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 8) x3_launch<3, 64, 4, 1, 2, 2, 8, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 16) x3_launch<3, 64, 4, 1, 2, 2, 16, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else x3_launch<3, 64, 4, 1, 2, 2, 31, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+            } else {
+                if (dbg == 1) x3_launch<5, 64, 4, 1, 2, 2, 1, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 2) x3_launch<5, 64, 4, 1, 2, 2, 2, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 4) x3_launch<5, 64, 4, 1, 2, 2, 4, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 8) x3_launch<5, 64, 4, 1, 2, 2, 8, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 16) x3_launch<5, 64, 4, 1, 2, 2, 16, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else x3_launch<5, 64, 4, 1, 2, 2, 31, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+            }
+        }
+    }
+#endif
+    else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
     else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
