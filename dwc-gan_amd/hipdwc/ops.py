@@ -565,12 +565,28 @@ def amax_slot(dev):
     return pool[0].data_ptr() + 8 * (i % AMAX_SLOTS), i // AMAX_SLOTS + 1
 
 
+def amax_live(t, c=False):
+    """The (slot, epoch) pair attached to ``t`` (or the record ``c`` taken from it earlier) if it still describes it: same version
+    counter and address, and the slot has not come up for re-use -- a pair is trusted for AMAX_SLOTS - 4096 later pairs only (a
+    long-lived tensor, e.g. a fixed input batch, is measured again instead of meeting a slot that a later lap of the pool has
+    raised to another epoch)."""
+    if c is False:
+        c = getattr(t, "_dwc_amax", None)
+    if c is None or c[2] != t._version or c[3] != t.data_ptr():
+        return None
+    pool = _AMAX.get(t.device.index if t.device.index is not None else torch.cuda.current_device())
+    if pool is None:
+        return None
+    index = (c[1] - 1) * AMAX_SLOTS + (c[0] - pool[0].data_ptr()) // 8
+    return (c[0], c[1]) if 0 <= pool[1] - index < AMAX_SLOTS - 4096 else None
+
+
 def amax_of(t):
     """(slot, epoch) holding the largest magnitude of the dense fp32 tensor ``t`` -- the pair a producing op attached to it
     (``set_amax``) if it still describes it, else one pass of dwc_absmax."""
-    c = getattr(t, "_dwc_amax", None)
-    if c is not None and c[2] == t._version and c[3] == t.data_ptr():
-        return c[0], c[1]
+    c = amax_live(t)
+    if c is not None:
+        return c
     if t.dtype != torch.float32 or not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError("amax_of: dense fp32 tensor expected")
     slot, ep = amax_slot(t.device)
@@ -601,8 +617,8 @@ def out_amax(t):
 def pass_amax(src, dst):
     """``dst`` is bounded by ``src`` in magnitude (bilinear up-sampling, average pooling: convex combinations): it inherits src's slot
     -- an upper bound is all the two-plane kernels need (the scale has 2^27 of headroom)."""
-    c = getattr(src, "_dwc_amax", None)
-    if c is not None and c[2] == src._version and c[3] == src.data_ptr():
+    c = amax_live(src)
+    if c is not None:
         set_amax(dst, c[0], c[1])
     return dst
 
@@ -827,10 +843,7 @@ class _Conv2d(torch.autograd.Function):
                   and lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH)):
                 ws = workspace(lib.dwc_x3_conv2d_wgrad_ws_bytes(B, H, W, Cx, cop, KH), dev)
                 if X3_PLANES == 2:
-                    if ctx.x_amax is not None and ctx.x_amax[2] == x._version and ctx.x_amax[3] == x.data_ptr():
-                        xa = ctx.x_amax[:2]
-                    else:
-                        xa = amax_of(x)
+                    xa = amax_live(x, ctx.x_amax) or amax_of(x)          # the forward's measurement if it still stands
                     ga = amax_of(g)
                     _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_h2_conv2d_wgrad(
                         x.data_ptr(), xa[0], xa[1], g.data_ptr(), ga[0], ga[1], dw.data_ptr(), B, H, W, Cx, cop, KH, Cin, Cout, ws.data_ptr(),
