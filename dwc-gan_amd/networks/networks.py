@@ -75,45 +75,75 @@ class _PlainInstanceNorm(nn.InstanceNorm2d):
 # basic blocks
 # --------------------------------------------------------------------------------------
 class Conv2dBlock(nn.Module):
-    """pad -> conv -> norm -> activation (reference networks.py:524-585) as at most two fused passes."""
+    """pad -> conv -> norm -> activation (reference networks.py:524-585) as at most two fused passes.
+
+    What the shipped configurations use -- reflect padding, norm in {none, in, ln, adain}, activation in {relu, lrelu, tanh, sigmoid,
+    none} -- is all HIP: the padding rule inside the convolution's gather, bias / activation in its epilogue, ReLU and the residual
+    add in the norm's apply pass.  The rest of the reference's signature is reachable too (r05), through stock PyTorch-ROCm DEVICE
+    ops around the HIP convolution: ``pad_type`` zero / replicate (``F.pad``, then the convolution without padding), ``norm='bn'``
+    (``nn.BatchNorm2d``), ``activation`` prelu / selu (``nn.PReLU`` / ``F.selu``), and any norm followed by an activation other than
+    ReLU (the norm unfused, then the activation).  ``norm='sn'`` (the reference's SpectralNorm wrapper) is not built."""
 
     def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, norm="none", activation="relu",
                  pad_type="zero"):
         super().__init__()
         if pad_type not in ("reflect", "replicate", "zero"):
             raise AssertionError("Unsupported padding type: {}".format(pad_type))
-        if pad_type != "reflect" and padding > 0:
-            raise NotImplementedError("the HIP conv kernels implement reflect padding (the only mode the shipped "
-                                      "configs use); got pad_type=%r" % pad_type)
-        if activation not in _CONV_ACTS:
-            raise NotImplementedError("activation %r is not on the HIP path" % activation)
+        if activation not in _CONV_ACTS and activation not in ("prelu", "selu"):
+            raise AssertionError("Unsupported activation: {}".format(activation))
         self.use_bias = True
         self.stride, self.padding = stride, padding
+        self.pad_type = pad_type
         self.norm_kind, self.act_kind = norm, activation
-        # norm is created before the conv, as in the reference: LayerNorm draws its gamma then
+        # norm (then activation) is created before the conv, as in the reference: LayerNorm draws its gamma then
         if norm == "in":
             self.norm = _PlainInstanceNorm(output_dim)
         elif norm == "ln":
             self.norm = LayerNorm(output_dim)
         elif norm == "adain":
             self.norm = AdaptiveInstanceNorm2d(output_dim)
+        elif norm == "bn":
+            self.norm = nn.BatchNorm2d(output_dim)
         elif norm == "none":
             self.norm = None
+        elif norm == "sn":
+            raise NotImplementedError("norm='sn' (the reference's SpectralNorm wrapper, networks.py:755-800) is not built: no shipped "
+                                      "configuration uses it")
         else:
-            raise NotImplementedError("normalization %r is not on the HIP path" % norm)
-        if self.norm is not None and activation not in ("relu", "none"):
-            raise NotImplementedError("norm followed by %r is not fused" % activation)
+            raise AssertionError("Unsupported normalization: {}".format(norm))
+        if activation == "prelu":
+            self.activation = nn.PReLU()
         self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, stride, bias=self.use_bias)  # parameter container
+
+    def _torch_act(self, y):
+        if self.act_kind == "prelu":
+            return self.activation(y)
+        if self.act_kind == "selu":
+            return torch.nn.functional.selu(y)
+        return {"lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.1), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[self.act_kind](y)
 
     def forward(self, x, residual=None, conv_token=None, res_token=None):
         """``conv_token`` / ``res_token`` (hipdwc.ops.ResGradToken, both optional): this block's convolution opens / this block's
         norm closes a residual block whose identity-branch gradient is added in the convolution's data-gradient epilogue."""
         if x.shape[1] < 4:
             x = ops.pack_image(x)
+        pad = self.padding
+        if self.pad_type != "reflect" and pad > 0:        # zero / replicate: a device pad in front of the unpadded HIP convolution
+            x = torch.nn.functional.pad(x, (pad,) * 4, mode="constant" if self.pad_type == "zero" else "replicate")
+            pad = 0
+        fused_act = self.act_kind in _CONV_ACTS
         if self.norm is None:
-            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, self.act_kind, token=conv_token)
+            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, pad, self.act_kind if fused_act else "none", token=conv_token)
+            if not fused_act:
+                y = self._torch_act(y)
             return y if residual is None else y + residual
-        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, self.padding, "none",
+        if self.norm_kind == "bn" or self.act_kind not in ("relu", "none"):
+            # off the shipped configurations: the norm on its own (HIP for in / ln / adain, torch for bn), then the activation
+            y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, pad, "none", token=conv_token)
+            y = self.norm(y) if self.norm_kind in ("bn", "ln") else self.norm(y, relu=False)
+            y = torch.relu(y) if self.act_kind == "relu" else (y if self.act_kind == "none" else self._torch_act(y))
+            return y if residual is None else y + residual
+        y = ops.conv2d(x, self.conv.weight, self.conv.bias, self.stride, pad, "none",
                        bias_grad=self.norm_kind == "ln", token=conv_token)   # IN / AdaIN subtract the per-(n,c) mean: d/d bias == 0
         relu = self.act_kind == "relu"
         if self.norm_kind == "ln":

@@ -358,29 +358,30 @@ class Solver(nn.Module):
         self.gen_opt.step()
         self._gen_steps += 1
 
-    # ---- visualisation path (reference solver.py:249-289), batched instead of per image ---------
+    # ---- visualisation path (reference solver.py:249-289) ----------------------------------------
     @torch.no_grad()
     def sample(self, x_real, txt_src2trg, txt_lens):
+        """The reference walks the images one by one.  Here the convolutional work is batched -- ONE encode of all images and ONE
+        decode of the 3 x B (reconstruction, text target, sampled style) codes; every op on that path is per sample (IN / AdaIN per
+        (n, c), LayerNorm per n), so the results are the per-image ones.  What stays per image: the text encoder (its ``view``
+        interleaves the samples of a batch, reference networks_v2.py:249 -- the reference calls it with batch 1 here) and the
+        style draws (one ``dist_sampling_split`` per image, in the reference's order, so a seeded run consumes the same stream)."""
         self.eval()
-        outs = {"rec": [], "trg": [], "sam": [], "att": []}
-        for i in range(x_real.size(0)):
-            x4 = ops.pack_image(x_real[i:i + 1])
-            content, style_real, _ = self.gen.encode(x4)
-            style_real = flat_heads(style_real)
-            style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg[i:i + 1], txt_lens[i:i + 1])
-            style_txt = flat_heads(style_txt)
-            sign = lambda s: torch.where(s.view(1, self.num_cls, self.c_dim).mean(2) < 0, -1.0, 1.0)
-            mus_real, mus_txt = sign(style_real), sign(style_txt)
-            z = dist_sampling_split(mus_txt, self.c_dim, self.stddev, self.device)
-            z = self.style_replace(mus_real, mus_txt, style_real, z)
-            h_trg = self.gen.decode_nhwc4(content, style_txt)
-            outs["rec"].append(self._decode(content, style_real, x4)[:, :3].float())
-            outs["trg"].append((ops.attention_blend(h_trg, x4) if self.use_attention else h_trg)[:, :3].float())
-            outs["sam"].append(self._decode(content, z, x4)[:, :3].float())
-            outs["att"].append(h_trg[:, 3:4].float().expand(-1, 3, -1, -1))
-        res = [x_real, torch.cat(outs["rec"]), torch.cat(outs["trg"]), torch.cat(outs["sam"])]
+        B = x_real.size(0)
+        x4 = ops.pack_image(x_real)
+        content, style_real, _ = self.gen.encode(x4)
+        style_real = flat_heads(style_real)
+        style_txt = torch.cat([flat_heads(self.gen.encode_txt(style_real[i:i + 1], txt_src2trg[i:i + 1], txt_lens[i:i + 1])[0])
+                               for i in range(B)])
+        sign = lambda s: torch.where(s.view(-1, self.num_cls, self.c_dim).mean(2) < 0, -1.0, 1.0)
+        mus_real, mus_txt = sign(style_real), sign(style_txt)
+        z = torch.cat([dist_sampling_split(mus_txt[i:i + 1], self.c_dim, self.stddev, self.device) for i in range(B)])
+        z = self.style_replace(mus_real, mus_txt, style_real, z)
+        heads = self.gen.decode_nhwc4(torch.cat([content] * 3), torch.cat([style_real, style_txt, z]))
+        out = ops.attention_blend(heads, torch.cat([x4] * 3)) if self.use_attention else heads
+        res = [x_real, out[:B, :3].float(), out[B:2 * B, :3].float(), out[2 * B:, :3].float()]
         if self.use_attention:
-            res.append((torch.cat(outs["att"]) - 0.5) / 0.5)
+            res.append((heads[B:2 * B, 3:4].float().expand(-1, 3, -1, -1) - 0.5) / 0.5)
         self.train()
         return res
 

@@ -414,6 +414,55 @@ def gen_full(ref_solver, S, B, offload=False, dis_only=False):
     print(path, "written:", len(out), "arrays")
 
 
+
+# ----------------------------------------------------------------------------------------
+# Conv2dBlock beyond the shipped configurations (reference networks.py:524-585: pad_type zero / replicate, norm bn, activation prelu / selu)
+# ----------------------------------------------------------------------------------------
+REACH_CASES = [  # (name, B, Cin, Cout, H, k, s, p, norm, act, pad_type)
+    ("zero3_bn_prelu", 3, 8, 16, 10, 3, 1, 1, "bn", "prelu", "zero"),
+    ("rep5_none_selu", 2, 8, 8, 12, 5, 1, 2, "none", "selu", "replicate"),
+    ("zero4s2_in_lrelu", 2, 8, 16, 12, 4, 2, 1, "in", "lrelu", "zero"),
+    ("rep3_ln_prelu", 2, 16, 8, 8, 3, 1, 1, "ln", "prelu", "replicate"),
+    ("zero3_none_relu", 2, 8, 8, 9, 3, 1, 1, "none", "relu", "zero"),
+]
+
+
+def gen_reach(ref_nets):
+    g = torch.Generator().manual_seed(31)
+    rnd = lambda *shape: torch.randn(*shape, generator=g)
+    out = {}
+    for (name, B, ci, co, H, k, s, p, norm, act, pad) in REACH_CASES:
+        blk = ref_nets.Conv2dBlock(ci, co, k, s, p, norm=norm, activation=act, pad_type=pad)
+        with torch.no_grad():
+            blk.conv.weight.copy_(rnd(co, ci, k, k) * 0.2)
+            blk.conv.bias.copy_(rnd(co) * 0.1)
+            if norm == "ln":
+                blk.norm.gamma.copy_(torch.rand(co, generator=g))
+                blk.norm.beta.copy_(rnd(co) * 0.1)
+            if norm == "bn":
+                blk.norm.weight.copy_(torch.rand(co, generator=g) + 0.5)
+                blk.norm.bias.copy_(rnd(co) * 0.1)
+            if act == "prelu":
+                blk.activation.weight.fill_(0.3)
+        x = rnd(B, ci, H, H).requires_grad_(True)
+        y = blk(x)                                  # training mode: batch statistics, running statistics updated once
+        gy = rnd(*y.shape)
+        (y * gy).sum().backward()
+        rec = {"x": x, "w": blk.conv.weight, "b": blk.conv.bias, "y": y, "gy": gy, "dx": x.grad, "dw": blk.conv.weight.grad,
+               "db": blk.conv.bias.grad}
+        if norm == "ln":
+            rec.update({"gamma": blk.norm.gamma, "beta": blk.norm.beta, "dgamma": blk.norm.gamma.grad, "dbeta": blk.norm.beta.grad})
+        if norm == "bn":
+            rec.update({"bn_w": blk.norm.weight, "bn_b": blk.norm.bias, "dbn_w": blk.norm.weight.grad, "dbn_b": blk.norm.bias.grad,
+                        "running_mean": blk.norm.running_mean, "running_var": blk.norm.running_var})
+        if act == "prelu":
+            rec.update({"dprelu": blk.activation.weight.grad})
+        for kk, v in rec.items():
+            out["%s/%s" % (name, kk)] = t2n(v)
+    np.savez_compressed(os.path.join(HERE, "conv_reach.npz"), **out)
+    print("conv_reach.npz:", len(out), "arrays")
+
+
 def gen_vgg(ref_solver, ref_nets):
     """compute_vgg_loss of the reference (solver.py:242-247) on a seeded, randomly initialised Vgg16 (the trained
     weights cannot be fetched here): loss, gradient w.r.t. the target image, relu5_3 features of the first image.
@@ -519,6 +568,8 @@ if __name__ == "__main__":
         gen_tiny(ref_solver)
     if "init" in what:
         gen_init_checksums(ref_solver)
+    if "reach" in what:
+        gen_reach(ref_nets)
     if "vgg" in what:
         gen_vgg(ref_solver, ref_nets)
     if "sample" in what:

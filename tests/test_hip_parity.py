@@ -653,6 +653,57 @@ def test_golden_conv_blocks(golden_dir):
             close(blk.norm.bias.grad, gg("dab"), rel=3e-4, msg=name + " dab")
 
 
+REACH_CASES = [  # (name, B, Cin, Cout, H, k, s, p, norm, act, pad_type) -- tests/golden/make_golden.py REACH_CASES
+    ("zero3_bn_prelu", 3, 8, 16, 10, 3, 1, 1, "bn", "prelu", "zero"),
+    ("rep5_none_selu", 2, 8, 8, 12, 5, 1, 2, "none", "selu", "replicate"),
+    ("zero4s2_in_lrelu", 2, 8, 16, 12, 4, 2, 1, "in", "lrelu", "zero"),
+    ("rep3_ln_prelu", 2, 16, 8, 8, 3, 1, 1, "ln", "prelu", "replicate"),
+    ("zero3_none_relu", 2, 8, 8, 9, 3, 1, 1, "none", "relu", "zero"),
+]
+
+
+@pytest.mark.parametrize("case", REACH_CASES, ids=lambda c: c[0])
+def test_conv_block_beyond_shipped_configs_vs_reference(golden_dir, case):
+    """The part of the reference's Conv2dBlock signature no shipped configuration uses (networks.py:530-567): zero / replicate
+    padding, BatchNorm, PReLU / SELU and a norm followed by a non-ReLU activation -- reachable since r05 through device torch ops
+    around the HIP convolution.  Forward, dx, dw, db and the norm / activation parameters' gradients against vectors recorded
+    from the imported reference (tests/golden/make_golden.py reach), BatchNorm's running statistics included."""
+    import networks.networks as nets
+    gold = np.load(os.path.join(golden_dir, "conv_reach.npz"))
+    name, B, ci, co, H, k, s_, p, norm, act, pad = case
+    gg = lambda key: T(gold["%s/%s" % (name, key)])
+    blk = nets.Conv2dBlock(ci, co, k, s_, p, norm=norm, activation=act, pad_type=pad).to(DEV)
+    with torch.no_grad():
+        blk.conv.weight.copy_(gg("w"))
+        blk.conv.bias.copy_(gg("b"))
+        if norm == "ln":
+            blk.norm.gamma.copy_(gg("gamma"))
+            blk.norm.beta.copy_(gg("beta"))
+        if norm == "bn":
+            blk.norm.weight.copy_(gg("bn_w"))
+            blk.norm.bias.copy_(gg("bn_b"))
+        if act == "prelu":
+            blk.activation.weight.fill_(0.3)
+    x = dev(gg("x"), True)
+    y = blk(x)
+    close(y, gg("y"), rel=5e-5, atol=2e-6, msg=name + " y")
+    (y * gg("gy").to(DEV)).sum().backward()
+    close(x.grad, gg("dx"), rel=3e-4, atol=2e-6, msg=name + " dx")
+    close(blk.conv.weight.grad, gg("dw"), rel=3e-4, atol=2e-6, msg=name + " dw")
+    if norm == "none":
+        close(blk.conv.bias.grad, gg("db"), rel=3e-4, atol=2e-6, msg=name + " db")
+    if norm == "ln":
+        close(blk.norm.gamma.grad, gg("dgamma"), rel=3e-4, msg=name + " dgamma")
+        close(blk.norm.beta.grad, gg("dbeta"), rel=3e-4, msg=name + " dbeta")
+    if norm == "bn":
+        close(blk.norm.weight.grad, gg("dbn_w"), rel=3e-4, msg=name + " dbn_w")
+        close(blk.norm.bias.grad, gg("dbn_b"), rel=3e-4, msg=name + " dbn_b")
+        close(blk.norm.running_mean, gg("running_mean"), rel=1e-5, msg=name + " running_mean")
+        close(blk.norm.running_var, gg("running_var"), rel=1e-5, msg=name + " running_var")
+    if act == "prelu":
+        close(blk.activation.weight.grad, gg("dprelu"), rel=3e-4, msg=name + " dprelu")
+
+
 # ----------------------------------------------------------------------------------------
 # whole modules / solver on the tiny config, against the reference's recorded run
 # ----------------------------------------------------------------------------------------
