@@ -80,7 +80,7 @@ class Conv2dBlock(nn.Module):
     What the shipped configurations use -- reflect padding, norm in {none, in, ln, adain}, activation in {relu, lrelu, tanh, sigmoid,
     none} -- is all HIP: the padding rule inside the convolution's gather, bias / activation in its epilogue, ReLU and the residual
     add in the norm's apply pass.  The rest of the reference's signature is reachable too (r05), through stock PyTorch-ROCm DEVICE
-    ops around the HIP convolution: ``pad_type`` zero / replicate (``F.pad``, then the convolution without padding), ``norm='bn'``
+    ops around the HIP convolution: ``pad_type`` zero / replicate at stride 1 (``F.pad``, then the convolution without padding), ``norm='bn'``
     (``nn.BatchNorm2d``), ``activation`` prelu / selu (``nn.PReLU`` / ``F.selu``), and any norm followed by an activation other than
     ReLU (the norm unfused, then the activation).  ``norm='sn'`` (the reference's SpectralNorm wrapper) is not built."""
 
@@ -89,6 +89,9 @@ class Conv2dBlock(nn.Module):
         super().__init__()
         if pad_type not in ("reflect", "replicate", "zero"):
             raise AssertionError("Unsupported padding type: {}".format(pad_type))
+        if pad_type != "reflect" and padding > 0 and stride != 1:
+            raise NotImplementedError("pad_type=%r with stride %d: the strided data gradient of the HIP kernels is built for the reflect rule "
+                                      "(4x4, stride 2, pad 1); zero / replicate padding is reachable at stride 1" % (pad_type, stride))
         if activation not in _CONV_ACTS and activation not in ("prelu", "selu"):
             raise AssertionError("Unsupported activation: {}".format(activation))
         self.use_bias = True

@@ -656,7 +656,7 @@ def test_golden_conv_blocks(golden_dir):
 REACH_CASES = [  # (name, B, Cin, Cout, H, k, s, p, norm, act, pad_type) -- tests/golden/make_golden.py REACH_CASES
     ("zero3_bn_prelu", 3, 8, 16, 10, 3, 1, 1, "bn", "prelu", "zero"),
     ("rep5_none_selu", 2, 8, 8, 12, 5, 1, 2, "none", "selu", "replicate"),
-    ("zero4s2_in_lrelu", 2, 8, 16, 12, 4, 2, 1, "in", "lrelu", "zero"),
+    ("zero3_in_lrelu", 2, 8, 16, 12, 3, 1, 1, "in", "lrelu", "zero"),
     ("rep3_ln_prelu", 2, 16, 8, 8, 3, 1, 1, "ln", "prelu", "replicate"),
     ("zero3_none_relu", 2, 8, 8, 9, 3, 1, 1, "none", "relu", "zero"),
 ]
