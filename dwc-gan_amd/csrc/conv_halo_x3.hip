@@ -679,7 +679,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     };
     if (dwc_act_is_simple(a.act)) store(std::false_type{});
     else store(std::true_type{});
-    if constexpr (NPL == 2) dwc_amax_wave_publish(a.ys, a.ys_epoch, y_am);
+    if constexpr (NPL == 2) {
+        __shared__ unsigned s_am[NW];
+        dwc_amax_block_publish(a.ys, a.ys_epoch, y_am, s_am);      // (a.ys is uniform over the launch; a split tile's first arriver has left)
+    }
 #endif
 }
 

@@ -17,6 +17,8 @@
 
 #include <atomic>
 
+#include <type_traits>
+
 #include "dwc_common.h"
 
 namespace {
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
             if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
             o[k] = res ? t + res[k] : t;
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows in flight per thread
@@ -288,7 +290,10 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
         one(v0, residual ? q0 : nullptr, o0);
         stv(y, i0, o0);
     }
-    dwc_amax_wave_publish(amax, amax_ep, am);
+    if constexpr (std::is_same<T, float>::value) {      // (every thread of the block gets here: C is a power of two, groups * cq == 256)
+        __shared__ unsigned s_am[4];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 template <typename T, bool FUSED = false>
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
             if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - k1[k] - xh * k2[k]);
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
@@ -460,7 +465,10 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
         ldv(dy, i0, d0);
         one(x0, d0, o0);
         stv(dx, i0, o0);
-    }    dwc_amax_wave_publish(amax, amax_ep, am);
+    }    if constexpr (std::is_same<T, float>::value) {      // (every thread of the block gets here: C is a power of two, groups * cq == 256)
+        __shared__ unsigned s_am[4];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -555,7 +563,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
             const float t = (v[k] - mu) * sc[k] + sh[k];
             o[k] = (relu && t < 0.f) ? 0.f : t;          // NaN-preserving
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + groups < r1; r += 2 * groups) {
@@ -574,7 +582,10 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
         one(v0, o0);
         stv(y, base + (size_t)r * cq, o0);
     }
-    dwc_amax_wave_publish(amax, amax_ep, am);
+    if constexpr (std::is_same<T, float>::value) {      // (every thread of the block gets here: C is a power of two, groups * cq == 256)
+        __shared__ unsigned s_am[4];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 // per block: sample sums (sum g, sum g*(x-mu)) with g = dy_eff*gamma, and per-channel
@@ -739,7 +750,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
             if (relu) d = (xc * (ga[k] * iv) + be[k]) > 0.f ? d : 0.f;      // (the forward's expression and rounding: ln_apply)
             o[k] = (d * ga[k] - mean_g) * iv - xc * k2;
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
     };
     int r = r0 + rg;
     for (; r + 3 * groups < r1; r += 4 * groups) {        // four rows of x and dy in flight per thread
@@ -762,7 +773,10 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
         ldv(dy, i0, d0);
         one(x0, d0, o0);
         stv(dx, i0, o0);
-    }    dwc_amax_wave_publish(amax, amax_ep, am);
+    }    if constexpr (std::is_same<T, float>::value) {      // (every thread of the block gets here: C is a power of two, groups * cq == 256)
+        __shared__ unsigned s_am[4];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 bool norm_shape_ok(int B, int HW, int C, int V) {      // C a power of two with 1 <= C / V <= 256 column groups
@@ -930,12 +944,15 @@ __global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__
             if (relu) t = t < 0.f ? 0.f : t;              // NaN-preserving
             o[k] = HAS_RES ? t + q[k] : t;
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
         Raw out;
         res_pack(o, out);
         *reinterpret_cast<Raw*>(yb + p * pstride + toff) = out;
     }
-    dwc_amax_wave_publish(amax, amax_ep, am);
+    if constexpr (std::is_same<T, float>::value) {
+        __shared__ unsigned s_am[THREADS / 64];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 template <typename T, int HW, int THREADS>
@@ -1015,12 +1032,15 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_b
             if (relu) g = ((xv[k] - mu[k]) * (ga[k] * rs[k]) + be[k]) > 0.f ? g : 0.f;
             o[k] = ga[k] * rs[k] * (g - s[k] * inv - xh * (s[V + k] * inv));
         }
-        am = dwc_amax_fold<V>(am, o);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, o);
         Raw out;
         res_pack(o, out);
         *reinterpret_cast<Raw*>(ob + p * pstride + toff) = out;
     }
-    dwc_amax_wave_publish(amax, amax_ep, am);
+    if constexpr (std::is_same<T, float>::value) {
+        __shared__ unsigned s_am[THREADS / 64];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
 }
 
 // plane size when the resident-plane kernels take this shape, else 0

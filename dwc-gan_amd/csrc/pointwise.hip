@@ -6,6 +6,8 @@
 //   * mean |a-b|                                (reference solver.py:113-114)
 //   * Adam (+coupled L2) and the EMA lerp       (reference solver.py:62-68, utils.py:52-54)
 // All use 16-byte accesses with the channel axis on the lanes and grid-stride loops.
+#include <type_traits>
+
 #include "dwc_common.h"
 
 namespace {
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy,
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) s[k] += d[k];
-        am = dwc_amax_fold<V>(am, d);
+        if constexpr (std::is_same<T, float>::value) am = dwc_amax_fold<V>(am, d);
     };
     int r = r0 + rg;
     for (; r + groups < r1; r += 2 * groups) {      // two rows in flight per thread
@@ -69,7 +71,10 @@ __global__ __launch_bounds__(256) void act_bwd_partial(const T* __restrict__ dy,
         one(d0, y0);
         if (g) stv(g, i0, d0);
     }
-    dwc_amax_wave_publish(amax, amax_ep, am);
+    if constexpr (std::is_same<T, float>::value) {
+        __shared__ unsigned s_am[4];
+        dwc_amax_block_publish(amax, amax_ep, am, s_am);
+    }
     if (!part) return;
 #pragma unroll
     for (int k = 0; k < V; ++k) sm[threadIdx.x * V + k] = s[k];
