@@ -30,7 +30,8 @@ __device__ __forceinline__ void split3(float v, __bf16& p0, __bf16& p1, __bf16& 
     p2 = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(r2) >> 16));
 }
 
-// mode 0: x3, 1: h2 (two accumulators), 2: fp32 MFMA, 3: h2 without scales (plain f16 range), 4 / 5 / 6: h2 whose MFMA accumulators
+// mode 0: x3, 1: h2 (two accumulators), 2: fp32 MFMA, 3: h2 without scales (plain f16 range), 7 / 8: unscaled lo + one accumulator,
+// 4 / 5 / 6: h2 whose MFMA accumulators
 // are flushed into fp32 VALU accumulators (round to nearest) every 4 / 9 / 25 k-steps
 __global__ void lab_kernel(const float* A, const float* B, float* C, int K, int mode, float sa, float sb) {
     const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
@@ -57,6 +58,32 @@ __global__ void lab_kernel(const float* A, const float* B, float* C, int K, int 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
         }
         for (int r = 0; r < 16; ++r) acc[r] += lo[r];
+    } else if (mode >= 7) {
+        // UNSCALED lo plane (lo = f16(s a - hi): full precision down to 2^-16 of the tensor's largest magnitude instead of 2^-27) -- all
+        // three products carry the same weight and go into ONE MFMA accumulator, flushed every F k-steps
+        const int F = mode == 7 ? 9 : 25;
+        f32x16 big;
+        for (int r = 0; r < 16; ++r) big[r] = 0.f;
+        int cnt = 0;
+        for (int k = 0; k < K; k += 16) {
+            f16x8 a[2], b[2];
+            for (int e = 0; e < 8; ++e) {
+                const float va = A[l31 * K + k + 8 * hi + e] * sa, vb = B[l31 * K + k + 8 * hi + e] * sb;
+                a[0][e] = (_Float16)va;
+                a[1][e] = (_Float16)(va - (float)a[0][e]);
+                b[0][e] = (_Float16)vb;
+                b[1][e] = (_Float16)(vb - (float)b[0][e]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], acc, 0, 0, 0);
+            if (++cnt == F) {
+                cnt = 0;
+                for (int r = 0; r < 16; ++r) big[r] += acc[r], acc[r] = 0.f;
+            }
+        }
+        const float inv = 1.f / (sa * sb);
+        for (int r = 0; r < 16; ++r) acc[r] = (big[r] + acc[r]) * inv;
     } else if (mode >= 4) {
         const int F = mode == 4 ? 4 : (mode == 5 ? 9 : 25);
         f32x16 big;
@@ -176,8 +203,8 @@ int main() {
             hipMemcpy(dB, B.data(), 32 * K * 4, hipMemcpyHostToDevice);
             const float sa = pow2_scale(A), sb = pow2_scale(B);
             printf("%-52s K=%5d scale %.3e sa 2^%d sb 2^%d | fp32-fma-cpu %.2e", dist_names[d], K, scale, (int)std::log2(sa), (int)std::log2(sb), cpu_max / scale);
-            const char* mn[] = {"x3", "h2", "mfma32", "h2-unscaled", "h2-flush4", "h2-flush9", "h2-flush25"};
-            for (int mode = 0; mode < 7; ++mode) {
+            const char* mn[] = {"x3", "h2", "mfma32", "h2-unscaled", "h2-flush4", "h2-flush9", "h2-flush25", "h2u1acc-flush9", "h2u1acc-flush25"};
+            for (int mode = 0; mode < 9; ++mode) {
                 const int m = mode == 3 ? 1 : mode;
                 hipLaunchKernelGGL(lab_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC, K, m, mode == 3 ? 1.f : sa, mode == 3 ? 1.f : sb);
                 hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);

@@ -51,35 +51,37 @@ __device__ __forceinline__ void split3(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2)
 }
 
 // ---- two-plane f16 split ("h2", r05) ------------------------------------------------------------------------------------------
-// s*a = hi + lo * 2^-11 with hi = f16(s*a) and lo = f16((s*a - hi) * 2^11), both ROUNDED TO NEAREST (v_cvt_pk_f16_f32): hi holds 11
-// significand bits, the residual (exact in fp32) is at most half an ulp of hi and lo holds 11 of its bits -- |s*a - hi - lo 2^-11| <=
-// 2^-24 |s*a|, the size of an fp32 rounding.  a*b = [hi*hi + 2^-11 (hi*lo + lo*hi)] / (sa sb) up to lo*lo <= 2^-24 |ab|: THREE f16
-// MFMAs per fp32 MFMA-equivalent instead of the six of the three-plane bf16 split (f16 products are 22 bits: exact in the fp32
-// accumulator).  f16 has 5 exponent bits, so every operand TENSOR is brought to a working range by a power of two s (exact): its
-// largest magnitude lands in [2^13, 2^14), values down to 2^-27 of it keep all bits, smaller ones lose them gradually (f16
-// subnormals, which the MFMA honours: benchmarks/split2_lab.hip) with an absolute error of 2^-49 of the largest magnitude.
+// s*a = hi + lo with hi = f16(s*a) and lo = f16(s*a - hi), both ROUNDED TO NEAREST: hi holds 11 significand bits, the residual (exact
+// in fp32) is at most half an ulp of hi and lo holds 11 of its bits -- |s*a - hi - lo| <= 2^-24 |s*a|, the size of an fp32 rounding.
+// a*b = [hi*hi + hi*lo + lo*hi] / (sa sb) up to lo*lo <= 2^-24 |ab|: THREE f16 MFMAs per fp32 MFMA-equivalent instead of the six of
+// the three-plane bf16 split (f16 products are 22 bits: exact in the fp32 accumulator).  f16 has 5 exponent bits, so every operand
+// TENSOR is brought to a working range by a power of two s (exact): its largest magnitude lands in [2^13, 2^14); values down to
+// 2^-16 of it keep all 22-24 bits (their residual is a normal f16), smaller ones lose bits gradually (f16 subnormals, which the
+// MFMA honours: benchmarks/split2_lab.hip) with an absolute error of at most 2^-38 of the tensor's largest magnitude -- invisible at
+// the output scale.  (r05 first carried lo as (s*a - hi) * 2^11: full precision down to 2^-27 of the largest magnitude, but then the
+// corrections weigh 2^-11 and need an accumulator set of their own.  With lo unscaled all three products have the same weight and
+// share ONE matrix-core accumulator, which is flushed into fp32 vector accumulators every 16-25 k-steps anyway; the 64 registers
+// pay for a second fragment set.  Lab, K = 6400: 2.6e-7 of the output scale against 2.0e-7 -- the native fp32 MFMA: 3.1e-6.)
 // The largest magnitude comes from a caller-owned 64-bit slot: (epoch << 32) | bits of max |a|, raised by atomic max from the
 // kernel that produced the tensor or from dwc_absmax; a slot whose epoch is not the one the caller names poisons the result
 // with NaN (a stale or never-written slot must not pass for a small tensor).  Non-finite input: the slot reads inf / NaN, s = 1,
 // and the NaN of inf - inf in the lo plane reaches every output the value touches.
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// fp32 x4 and the tensor's scale s -> two planes of 4 f16: hi = f16(s v), lo = f16((s v - hi) 2^11).  Five vector instructions per
-// pair of elements: two packed multiplies (s v and s 2^11 v), one packed conversion, and the lo plane straight from
-// v_fma_mixlo/hi_f16 -- fma(hi read as f16, -2^11, s 2^11 v), exact in fp32, rounded once to f16 and written to its half of the
-// packed register (bit-identical to converting hi back, subtracting, scaling and converting: seven instructions, which is what the
-// compiler emits for the C form; checked on 2^20 values incl. +-0, inf, NaN).  The weight-gradient kernel is bound by exactly this
-// arithmetic (5-7 vector instructions per MFMA before).
+// fp32 x4 and the tensor's scale s -> two planes of 4 f16: hi = f16(s v), lo = f16(s v - hi).  Four vector instructions per pair of
+// elements: one packed multiply, one packed conversion, and the lo plane straight from v_fma_mixlo/hi_f16 -- fma(hi read as f16,
+// -1, s v), exact in fp32, rounded once to f16 and written to its half of the packed register (the C form -- convert hi back,
+// subtract, convert -- compiles to six; the fused form was checked bit-identical on 2^20 values incl. +-0, inf, NaN).  The
+// weight-gradient kernel is bound by exactly this arithmetic.
 __device__ __forceinline__ void split2h(f32x4 v, float s, u32x2& p0, u32x2& p1) {
-    const float s2k = s * 2048.f, m2k = -2048.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const f32x2 x = {v[2 * k], v[2 * k + 1]};
-        const f32x2 t = x * s, u = x * s2k;
+        const f32x2 t = x * s;
         const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(t, f16x2));
         unsigned l;
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(m2k), "v"(u[0]));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "s"(m2k), "v"(u[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(t[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(t[1]));
         p0[k] = h;
         p1[k] = l;
     }
@@ -162,7 +164,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // the same eight 16-byte bank slots (every fragment read 2-way conflicted); with the half-slot offset all 16 differ.
     constexpr int PITCH = PW * CS + 8;
     constexpr int P_PLANE = PW * PITCH;                // elements per plane of a patch buffer
-    static_assert(NPL == 3 || (NPL == 2 && TM * TN <= 4), "two planes: separate correction accumulators only");
     constexpr int W_CHUNKS = NPL * BN * 2;             // 16-byte chunks of one tap's weight slab (NPL planes x BN rows x 32 B)
     constexpr int W_INSTR = (W_CHUNKS + THREADS - 1) / THREADS;    // LDS-DMA instructions per thread and tap
     constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // six; merged once in the epilogue.  (The 4x2-tile instantiation has no registers for a second set and adds all six in
     // place: measured error 2.7e-6 of the output scale on 6400-term sums against 6e-7 split -- both inside the 2e-5 fp32
     // tolerance of the parity suite, only the split form is used by default.)
-    constexpr bool SPLIT = TM * TN <= 4;
+    constexpr bool SPLIT = NPL == 3 && TM * TN <= 4;      // (two planes: the three products have one weight and share the accumulator)
     f32x16 acc[TM][TN], lo[SPLIT ? TM : 1][SPLIT ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // the last third of the MFMAs runs while they arrive; the patch conversion (VALU + ds_write) is placed between MFMA groups
     // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
     // eight waves of the one resident workgroup reach every phase together.)
-    constexpr bool PIPE = PB == 2 && TM * TN <= 2;
+    constexpr bool PIPE = (PB == 2 && TM * TN <= 2) || (NPL == 2 && TM * TN <= 4);
     bf16x8 fa[PIPE ? 2 : 1][NPL][TM], fb[PIPE ? 2 : 1][NPL][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     typedef std::integral_constant<int, NPL == 3 ? 2 : 1> I2;
     typedef std::integral_constant<int, NPL == 3 ? 4 : 2> I4;
     typedef std::integral_constant<int, NPL == 3 ? 6 : 3> I6;
-    constexpr float LO_W = NPL == 2 ? 1.f / 2048.f : 1.f;                // weight of the correction accumulator
+    constexpr float LO_W = 1.f;
 
     int pbuf = 0, tap = 0, cs = 0, slot = 0;
     auto step = [&](auto curc, auto nxtc, int s) {
@@ -539,12 +540,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     if constexpr (KSP == 2) {
         // (whole tiles of a mixed launch skip the exchange; the correction accumulators are merged here either way)
         __shared__ unsigned s_role;
-        if (SPLIT) {
+        if constexpr (SPLIT || FLUSH != 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int n = 0; n < TN; ++n) {
-                    acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0] * LO_W;
+                    if constexpr (SPLIT) acc[i][n] += lo[SPLIT ? i : 0][SPLIT ? n : 0] * LO_W;
                     if constexpr (FLUSH != 0) acc[i][n] += big[i][n];
                 }
         }
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int n = 0; n < TN; ++n) acc[i][n] += big[i][n] + lo[i][n] * LO_W;
+            for (int n = 0; n < TN; ++n) acc[i][n] += big[i][n];
     }
     const float slope = dwc_act_slope(a.act);
     f32x4 bv[TN][4];
@@ -749,7 +750,7 @@ __global__ void h2_weight_prepare_kernel(const float* __restrict__ w, unsigned s
     }
     v *= sw.s;
     const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+    const _Float16 l = (_Float16)(v - (float)h);
     const size_t base = ((size_t)(tap * ncs + cs) * 2 * rows + row) * CS + (j ^ (((row >> 3) & 1) << 3));
     out[base] = __builtin_bit_cast(unsigned short, h);
     out[base + (size_t)rows * CS] = __builtin_bit_cast(unsigned short, l);
@@ -977,11 +978,14 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
         return __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
-    f32x16 acc[KS], lo[KS];
+    f32x16 acc[KS], lo[NPL == 3 ? KS : 1];
 #pragma unroll
     for (int j = 0; j < KS; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f, lo[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            acc[j][r] = 0.f;
+            if (NPL == 3) lo[NPL == 3 ? j : 0][r] = 0.f;
+        }
 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, AHEAD - 1> S1;
@@ -1031,9 +1035,9 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
                         lo[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], lo[kh], 0, 0, 0);
                         acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kh], 0, 0, 0);
                     } else {
+                        acc[kh] = x3_mfma<2>(fa[1], fb[0], acc[kh]);      // (one weight, one accumulator: see split2h)
+                        acc[kh] = x3_mfma<2>(fa[0], fb[1], acc[kh]);
                         acc[kh] = x3_mfma<2>(fa[0], fb[0], acc[kh]);
-                        lo[kh] = x3_mfma<2>(fa[1], fb[0], lo[kh]);
-                        lo[kh] = x3_mfma<2>(fa[0], fb[1], lo[kh]);
                     }
                 }
             }
@@ -1064,7 +1068,7 @@ __global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgra
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int k = tap * a.Cin + cs * CIW + ci_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if constexpr (NPL == 2) out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = (acc[kh][r] + lo[kh][r] * (1.f / 2048.f)) * sx.inv * sdy.inv;
+            if constexpr (NPL == 2) out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[kh][r] * sx.inv * sdy.inv;
             else out[(size_t)k * a.N + tn * BN + co_tile * 32 + l31] = acc[kh][r] + lo[kh][r];
         }
     }

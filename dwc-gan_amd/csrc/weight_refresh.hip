@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void weight_refresh_multi_kernel(const dwc_ref
                 size_t base;
                 const float v = split_layout_elem(d, idx, d.kind == DWC_REFRESH_H2_DGRAD, 2, &base) * sw.s;
                 const _Float16 h = (_Float16)v;
-                const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+                const _Float16 l = (_Float16)(v - (float)h);
                 h2_planes[base] = __builtin_bit_cast(unsigned short, h);
                 h2_planes[base + (size_t)d.rows * 16] = __builtin_bit_cast(unsigned short, l);
                 break;

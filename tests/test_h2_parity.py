@@ -1,6 +1,6 @@
 """fp32 convolutions on the f16 matrix cores through TWO-plane operand splits (csrc/conv_halo_x3.hip, NPL == 2; r05).
 
-s*a = hi + lo 2^-11 (hi = f16(s*a), lo = f16((s*a - hi) 2^11), round to nearest; s a per-tensor power of two from the tensor's
+s*a = hi + lo (hi = f16(s*a), lo = f16(s*a - hi), round to nearest; s a per-tensor power of two from the tensor's
 absmax slot), three MFMAs per fp32 MFMA-equivalent instead of the six of the three-plane bf16 split (tests/test_x3_parity.py).  The
 claim under test is the same: this is an fp32 computation.  Gates are those of test_x3_parity.py -- error <= 5e-6 of the output
 scale and <= 2x the larger of the native-fp32-MFMA / fp32-CPU errors (+2e-7) against float64 -- on the same shapes, PLUS operands
@@ -108,8 +108,8 @@ def test_h2_forward_matches_float64(shape):
 
 
 def test_h2_wide_dynamic_range_operand():
-    """A lognormal operand (sigma 4: magnitudes over ~2^40).  Values below 2^-27 of the tensor's largest magnitude lose bits (f16
-    subnormals) -- by at most 2^-49 of that largest magnitude each: invisible at the output scale."""
+    """A lognormal operand (sigma 4: magnitudes over ~2^40).  Values below 2^-16 of the tensor's largest magnitude lose bits (f16
+    subnormals) -- by at most 2^-38 of that largest magnitude each: invisible at the output scale."""
     B, Cin, Cout, H, W, K = 2, 128, 128, 32, 32, 3
     g = torch.Generator().manual_seed(77)
     x = torch.exp(4.0 * torch.randn(B, Cin, H, W, generator=g)) * torch.sign(torch.randn(B, Cin, H, W, generator=g))
@@ -208,9 +208,9 @@ def test_h2_weight_gradient_matches_float64(shape):
 
 
 def test_h2_planes_reconstruct_the_weight():
-    """(hi + lo 2^-11) / s_w of the prepared planes against the fp32 weight, over ten decades of magnitude inside one tensor: to
-    2^-22.9 relative for every element down to 2^-27 of the tensor's largest magnitude (the split keeps 22-24 significand bits),
-    and to 2^-48 of that largest magnitude below (f16 subnormals)."""
+    """(hi + lo) / s_w of the prepared planes against the fp32 weight, over ten decades of magnitude inside one tensor: to 2^-21.9
+    relative for every element down to 2^-16 of the tensor's largest magnitude (the split keeps 22-24 significand bits while the
+    residual is a normal f16), and to 2^-37.9 of that largest magnitude below (f16 subnormals)."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(5)
     w = torch.randn(32, 16, 3, 3, generator=g) * torch.logspace(-6, 1, 32).view(32, 1, 1, 1)
@@ -226,12 +226,12 @@ def test_h2_planes_reconstruct_the_weight():
     swap = ((torch.arange(32) >> 3) & 1).bool()
     pl[:, :, :, swap] = pl[:, :, :, swap].flip(4)
     pl = pl.reshape(9, 1, 2, 32, 16)
-    total = (pl[:, 0, 0] + pl[:, 0, 1] / 2048.0) * inv
+    total = (pl[:, 0, 0] + pl[:, 0, 1]) * inv
     want = w.permute(2, 3, 0, 1).reshape(9, 32, 16).double()
     err = (total - want).abs()
-    lim = torch.maximum(want.abs() * 2.0 ** -22.9, torch.full_like(want, wmax * 2.0 ** -48))
+    lim = torch.maximum(want.abs() * 2.0 ** -21.9, torch.full_like(want, wmax * 2.0 ** -37.9))
     assert (err <= lim).all(), float((err / lim).max())
-    assert (want.abs() < wmax * 2.0 ** -27).any() and (want.abs() > wmax * 2.0 ** -3).any()      # both regimes are exercised
+    assert (want.abs() < wmax * 2.0 ** -16).any() and (want.abs() > wmax * 2.0 ** -3).any()      # both regimes are exercised
 
 
 def test_h2_stale_slot_poisons_and_nonfinite_propagates():
