@@ -838,12 +838,27 @@ __device__ __forceinline__ void res_reduce(float (&v)[NV], float* sm) {
         for (int k = 0; k < NV; ++k) sm[(wave * CQ + cq) * NV + k] = v[k];
     }
     __syncthreads();
+    if constexpr ((THREADS / 64) * NV > 32) {
+        // Many partials (the backward's 8 sums of 8+ waves): every thread summing all of them keeps waves x NV LDS loads in flight
+        // beside the resident plane -- 14-16 spilled registers in in_resident_bwd.  One thread per column sums (same order), the
+        // totals are read back after one more barrier.
+        if (threadIdx.x < CQ * NV) {
+            float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        float t = 0.f;
+            for (int w = 0; w < THREADS / 64; ++w) t += sm[w * CQ * NV + threadIdx.x];
+            sm[threadIdx.x] = t;                           // (slot (wave 0, column) is read by this thread only)
+        }
+        __syncthreads();
 #pragma unroll
-        for (int w = 0; w < THREADS / 64; ++w) t += sm[(w * CQ + cq) * NV + k];
-        v[k] = t;
+        for (int k = 0; k < NV; ++k) v[k] = sm[cq * NV + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) t += sm[(w * CQ + cq) * NV + k];
+            v[k] = t;
+        }
     }
 }
 
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(THREADS) void in_resident_fwd(const T* __restrict__
 }
 
 template <typename T, int HW, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? 4 : 1) void in_resident_bwd(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(THREADS, THREADS >= 512 ? 4 : 1) void in_resident_bwd(const T* __restrict__ dy, const T* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -1109,7 +1124,12 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     if (const int rhw = in_resident_hw<T>(HW, C)) {
         const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
         const dim3 grid((pairs + 7) / 8 * 16);
-        if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 512>), grid, dim3(512), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
+        // (r05, per-kernel time inside the bench step: bf16 127.5 us with 512 threads and 14-16 spilled registers, 115.8 with the
+        // two-stage reduction alone, 98.2 with 1024 threads -- 8 pieces per thread and tensor, no spills; fp32 31.2 -> 25.4 with the
+        // reduction alone, 26.1 with 1024 threads)
+        constexpr bool wide = sizeof(T) == 2;
+        if (rhw == 1024 && wide) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 1024>), grid, dim3(1024), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
+        else if (rhw == 1024) hipLaunchKernelGGL((in_resident_bwd<T, 1024, 512>), grid, dim3(512), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
         else hipLaunchKernelGGL((in_resident_bwd<T, 256, 256>), grid, dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, C, relu, pairs, amax, amax_ep);
         DWC_LAUNCH_CHECK();
         return DWC_OK;
