@@ -137,90 +137,120 @@ __device__ __forceinline__ void up_taps(int o, int n_in, int& i0, int& i1, float
     l0 = 1.f - l1;
 }
 
-// One thread = one INPUT pixel x V channels: it reads the 3x3 neighbourhood (neighbours come from L1/L2: every input byte
-// leaves HBM once) and writes the 2x2 output quad, all 16-byte accesses; grid (W*cq / 256, H, B) -- no per-element divisions.
+// One thread = one INPUT pixel column x V channels over UP_ROWS input rows (grid (W*cq / 256, ceil(H / UP_ROWS), B)): per input row it
+// reads the pixel and its two horizontal neighbours (the neighbours are the next waves' own pixels: L1), forms the two horizontal
+// blends, and writes the 2x2 output quad from the blends of rows i-1, i, i+1 kept in registers -- 3 loads per 4 stores, all 16-byte
+// accesses, no per-element divisions.  (r05: the one-row form read the whole 3x3 neighbourhood per thread, 9 loads per 4 stores:
+// bf16 128x32x32x256 205.7 us = 1.6 TB/s of algorithmic bytes, fp32 16x... 44.5 us.)
 // Output row 2i reads rows (i-1: 0.25, i: 0.75), row 2i+1 reads (i: 0.75, i+1: 0.25); at the borders the missing neighbour is
 // the pixel itself (torch clamps the source coordinate), which the clamped index reproduces exactly.
+constexpr int UP_ROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int cq) {
     constexpr int V = VecOf<T>::V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= W * cq) return;
     const int ix = idx / cq, c = idx - ix * cq;
-    const int iy = blockIdx.y;
+    const int iy0 = blockIdx.y * UP_ROWS;
     const size_t n = blockIdx.z;
-    const int ym = max(iy - 1, 0), yp = min(iy + 1, H - 1), xm = max(ix - 1, 0), xp = min(ix + 1, W - 1);
+    const int xm = max(ix - 1, 0), xp = min(ix + 1, W - 1);
     const size_t b = n * H * W;
-    float p[3][3][V];
-    const int ys[3] = {ym, iy, yp}, xs[3] = {xm, ix, xp};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) ldv(x, (b + (size_t)ys[a] * W + xs[q]) * cq + c, p[a][q]);
-    // horizontal pass: h[a][0] = 0.25*left + 0.75*mid, h[a][1] = 0.75*mid + 0.25*right
-    float h[3][2][V];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
+    // horizontal blends of input row r: h[0] = 0.25*left + 0.75*mid, h[1] = 0.75*mid + 0.25*right
+    auto blend = [&](int r, float (&h)[2][V]) {
+        float l[V], m[V], q[V];
+        const size_t rb = (b + (size_t)r * W) * cq + c;
+        ldv(x, rb + (size_t)xm * cq, l);
+        ldv(x, rb + (size_t)ix * cq, m);
+        ldv(x, rb + (size_t)xp * cq, q);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            h[a][0][k] = 0.75f * p[a][1][k] + 0.25f * p[a][0][k];
-            h[a][1][k] = 0.75f * p[a][1][k] + 0.25f * p[a][2][k];
+            h[0][k] = 0.75f * m[k] + 0.25f * l[k];
+            h[1][k] = 0.75f * m[k] + 0.25f * q[k];
         }
-    const size_t ob = (n * (2 * H) + 2 * iy) * (size_t)(2 * W) + 2 * ix;
+    };
+    float hm[2][V], hc[2][V], hp[2][V];
+    blend(max(iy0 - 1, 0), hm);
+    blend(iy0, hc);
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        float o0[V], o1[V];
+    for (int r = 0; r < UP_ROWS; ++r) {
+        const int iy = iy0 + r;
+        if (iy >= H) break;
+        blend(min(iy + 1, H - 1), hp);
+        const size_t ob = (n * (2 * H) + 2 * iy) * (size_t)(2 * W) + 2 * ix;
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            o0[k] = 0.75f * h[1][d][k] + 0.25f * h[0][d][k];      // output row 2*iy
-            o1[k] = 0.75f * h[1][d][k] + 0.25f * h[2][d][k];      // output row 2*iy + 1
+        for (int d = 0; d < 2; ++d) {
+            float o0[V], o1[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                o0[k] = 0.75f * hc[d][k] + 0.25f * hm[d][k];      // output row 2*iy
+                o1[k] = 0.75f * hc[d][k] + 0.25f * hp[d][k];      // output row 2*iy + 1
+            }
+            stv(y, (ob + d) * cq + c, o0);
+            stv(y, (ob + (size_t)(2 * W) + d) * cq + c, o1);
         }
-        stv(y, (ob + d) * cq + c, o0);
-        stv(y, (ob + (size_t)(2 * W) + d) * cq + c, o1);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int k = 0; k < V; ++k) hm[d][k] = hc[d][k], hc[d][k] = hp[d][k];
     }
 }
 
 // adjoint, gather form: input pixel i collects from output rows 2i-1 (0.25), 2i, 2i+1 (0.75 each), 2i+2 (0.25); rows outside the
-// image do not exist and the clamped border taps fold onto rows 0 / 2H-1 (weight 1 there instead of 0.75).  4x4 gather.
+// image do not exist and the clamped border taps fold onto rows 0 / 2H-1 (weight 1 there instead of 0.75).  Same walk as the
+// forward: the horizontal gathers (4 loads) of output rows 2i+1 and 2i+2 are new per input row, those of 2i-1 and 2i are the
+// previous row's -- 8 loads per store instead of 16.
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int cq) {
     constexpr int V = VecOf<T>::V;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= W * cq) return;
     const int ix = idx / cq, c = idx - ix * cq;
-    const int iy = blockIdx.y;
+    const int iy0 = blockIdx.y * UP_ROWS;
     const size_t n = blockIdx.z;
-    float wy[4], wx[4];
-    wy[0] = iy > 0 ? 0.25f : 0.f;
-    wy[1] = iy > 0 ? 0.75f : 1.f;
-    wy[2] = iy < H - 1 ? 0.75f : 1.f;
-    wy[3] = iy < H - 1 ? 0.25f : 0.f;
+    float wx[4];
     wx[0] = ix > 0 ? 0.25f : 0.f;
     wx[1] = ix > 0 ? 0.75f : 1.f;
     wx[2] = ix < W - 1 ? 0.75f : 1.f;
     wx[3] = ix < W - 1 ? 0.25f : 0.f;
+    int ox[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ox[q] = min(max(2 * ix - 1 + q, 0), 2 * W - 1);
     const size_t base = n * (size_t)(2 * H) * (2 * W);
-    float s[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) s[k] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int oy = min(max(2 * iy - 1 + a, 0), 2 * H - 1);      // clamped rows carry weight 0
-        float row[V];
+    auto gather = [&](int oy, float (&row)[V]) {                     // clamped rows carry weight 0
+        const size_t rb = (base + (size_t)min(max(oy, 0), 2 * H - 1) * (2 * W)) * cq + c;
 #pragma unroll
         for (int k = 0; k < V; ++k) row[k] = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ox = min(max(2 * ix - 1 + q, 0), 2 * W - 1);
             float v[V];
-            ldv(dy, (base + (size_t)oy * (2 * W) + ox) * cq + c, v);
+            ldv(dy, rb + (size_t)ox[q] * cq, v);
 #pragma unroll
             for (int k = 0; k < V; ++k) row[k] += wx[q] * v[k];
         }
+    };
+    float ha[V], hb[V], hc[V], hd[V];
+    gather(2 * iy0 - 1, ha);
+    gather(2 * iy0, hb);
 #pragma unroll
-        for (int k = 0; k < V; ++k) s[k] += wy[a] * row[k];
+    for (int r = 0; r < UP_ROWS; ++r) {
+        const int iy = iy0 + r;
+        if (iy >= H) break;
+        gather(2 * iy + 1, hc);
+        gather(2 * iy + 2, hd);
+        const float wy0 = iy > 0 ? 0.25f : 0.f, wy1 = iy > 0 ? 0.75f : 1.f, wy2 = iy < H - 1 ? 0.75f : 1.f, wy3 = iy < H - 1 ? 0.25f : 0.f;
+        float s[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            s[k] = 0.f;
+            s[k] += wy0 * ha[k];
+            s[k] += wy1 * hb[k];
+            s[k] += wy2 * hc[k];
+            s[k] += wy3 * hd[k];
+        }
+        stv(dx, ((n * H + iy) * (size_t)W + ix) * cq + c, s);
+#pragma unroll
+        for (int k = 0; k < V; ++k) ha[k] = hc[k], hb[k] = hd[k];
     }
-    stv(dx, ((n * H + iy) * (size_t)W + ix) * cq + c, s);
 }
 
 template <typename T>
@@ -602,7 +632,7 @@ template <typename T>
 int upsample2x_fwd_t(const T* x, T* y, int B, int H, int W, int C, void* stream) {
     constexpr int V = VecOf<T>::V;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % V) || H > 65535 || B > 65535) return DWC_EINVAL;
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3((W * (C / V) + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<T>, dim3((W * (C / V) + 255) / 256, (H + UP_ROWS - 1) / UP_ROWS, B), dim3(256), 0, (hipStream_t)stream, x, y, H, W,
                        C / V);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
@@ -612,7 +642,7 @@ template <typename T>
 int upsample2x_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, void* stream) {
     constexpr int V = VecOf<T>::V;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % V) || H > 65535 || B > 65535) return DWC_EINVAL;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((W * (C / V) + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W,
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<T>, dim3((W * (C / V) + 255) / 256, (H + UP_ROWS - 1) / UP_ROWS, B), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W,
                        C / V);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
