@@ -1,5 +1,6 @@
 """Timing-only ablations of the two-plane halo kernel (WRONG results; library built with -DDWC_DEV_ABLATIONS, loaded through
 DWC_HIP_LIB): DWC_X3_DBG = 1 no MFMA, 2 no fragment reads, 4 no weight staging, 8 no barrier, 16 no patch refresh / flush,
+32 no conversion at the slab boundary, 64 no flush, 128 no patch DMA, 3 = 1 + 2,
 31 = empty skeleton.  usage: DWC_HIP_LIB=.../libdwcgan_hip_abl.so DWC_X3_DBG=<n> python benchmarks/h2_ablation_bench.py"""
 import os
 import sys
@@ -10,16 +11,20 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from hipdwc import _lib, ops  # noqa: E402
 
 
+REPS = 8
+
+
 def med(fn, n=15, skip=3):
     ts = []
     for it in range(n):
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(REPS):                    # back-to-back launches: the event pair's own ~10 us are shared
+            fn()
         e.record()
         torch.cuda.synchronize()
         if it >= skip:
-            ts.append(a.elapsed_time(e) * 1e3)
+            ts.append(a.elapsed_time(e) * 1e3 / REPS)
     ts.sort()
     return ts[len(ts) // 2]
 

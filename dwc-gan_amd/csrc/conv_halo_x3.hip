@@ -183,10 +183,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     static_assert(!RAW || PB == 1, "raw patch staging: the single-buffer form");
     constexpr int FLUSH = !RAW ? 0 : (NTAP >= 25 ? 1 : (NTAP >= 9 ? 2 : 4));      // slabs between flushes: 16 - 25 k-steps
     constexpr int RAW_ELEMS = RAW ? PPASS * THREADS * 8 : 0;                      // 16 bytes per thread and pass, in 2-byte elements
-    __shared__ __attribute__((aligned(16))) bf16 smem[PB * NPL * P_PLANE + 3 * W_SLOT + RAW_ELEMS];
+    // PIPE (the two-plane form): two fragment sets, see the main loop
+    constexpr bool PIPE = NPL == 2 && PB == 1 && TM * TN <= 4;
+    constexpr int NRING = 3, AHEAD = NRING - 1;        // weight ring: filled two taps ahead
+    __shared__ __attribute__((aligned(16))) bf16 smem[PB * NPL * P_PLANE + NRING * W_SLOT + RAW_ELEMS];
     bf16* sP = smem;                                   // [PB buffers][NPL planes][pixel][16]
-    bf16* sW = smem + PB * NPL * P_PLANE;              // [3 slots][NPL planes][BN][16]
-    bf16* sR = sW + 3 * W_SLOT;                        // RAW: [pass][thread] f32x4
+    bf16* sW = smem + PB * NPL * P_PLANE;              // [NRING slots][NPL planes][BN][16]
+    bf16* sR = sW + NRING * W_SLOT;                    // RAW: [pass][thread] f32x4
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     const int ncsr = a.Cin / CS;                                        // 16-channel slabs of the input tensor
     const int ncs_all = S2 == 1 ? 4 * ncsr : ncsr;                      // slabs of the contraction: x 4 input-pixel parities
     const int ncs = halved ? ncs_all >> 1 : ncs_all, cs0 = khalf * ncs; // slabs this workgroup walks: cs0 .. cs0 + ncs - 1
-    const int nsteps = ncs * NTAP;
+    const int nsteps = (DBG & 512) ? 0 : ncs * NTAP;      // (DBG: development ablations, DWC_DEV_ABLATIONS builds only)
 
     // ---- patch gather map: thread = (patch pixel t>>2 [+128 per pass], channel quad t&3) -----------------------------------
     const float* p_src[(S2 == 1 || RAW) ? 1 : PPASS];
@@ -407,13 +410,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     __syncthreads();
 
     // ---- main loop: one step = one filter tap of one 16-channel slab, one barrier per step -----------------------------------
-    // Software pipeline (PIPE, the 1x2 tile shape; 2x2 with split accumulators and 4x2 have no registers for a second fragment
-    // set -- 115+ spills): the
-    // barrier sits after two thirds of a step's MFMAs, right behind it the NEXT step's 3*(TM+TN) fragments are requested, and
-    // the last third of the MFMAs runs while they arrive; the patch conversion (VALU + ds_write) is placed between MFMA groups
-    // as well.  (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all -- the
-    // eight waves of the one resident workgroup reach every phase together.)
-    constexpr bool PIPE = (PB == 2 && TM * TN <= 2) || (NPL == 2 && TM * TN <= 4);
+    // (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all; r05 ablation of the
+    // two-plane form, profiles/r05_h2_ablation.txt: still close to additive -- 5x5 256->128 at B=16: 273 us = ~131 us of loop without
+    // MFMAs + 129 us of MFMAs at the nominal clock + ~13 us of launch, prologue and stores.)
+    // PIPE: the barrier sits after two thirds of a step's MFMAs, right behind it the NEXT step's fragments are requested into the
+    // second fragment set, and the last third of the MFMAs runs while they arrive (-3..8 % per kernel against reading them at the
+    // top of their own step).  Requesting them a whole step early instead -- at the top of step s for step s + 1, or behind its
+    // first MFMA group, with a four-slot ring filled three taps ahead so that the weights are in LDS one barrier earlier -- was built
+    // and measured 3-6 % SLOWER per kernel (r05, ratios against the three-plane kernel of the same run: 1.59/1.62/1.52 against
+    // 1.63/1.72/1.57); the four-slot ring alone made no difference (same box: 182/275/279 against 181/276/280 us).  Not kept.
     bf16x8 fa[PIPE ? 2 : 1][NPL][TM], fb[PIPE ? 2 : 1][NPL][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 
     int pbuf = 0, tap = 0, cs = 0, slot = 0;
     auto step = [&](auto curc, auto nxtc, int s) {
-        const bool fetch = tap == 0 && cs + 1 < ncs && !(DBG & 16);       // next slab's patch: registers now, LDS at tap 3
+        const bool fetch = tap == 0 && cs + 1 < ncs && !(DBG & 16) && !(DBG & 128);      // next slab's patch: registers now, LDS at tap 3
         if (fetch) load_patch(cs + 1);
         if constexpr (!PIPE) read_frags(curc, tap, pbuf, slot);
         mfma_terms(curc, I0{}, I2{});
@@ -477,13 +482,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
         // this step's weight slab is issued, so that wait only sees loads that are at least a step old)
         // (waves w and w+4 share a SIMD: they convert one tap apart, so one of them is always free to feed the matrix pipe)
         if (PB == 2 && tap == 3 + (wave >> 2) && cs + 1 < ncs && !(DBG & 16)) write_patch(pbuf ^ 1);
-        // two taps ahead, into the slot every wave left before the previous barrier
-        if (s + 2 < nsteps && !(DBG & 4)) stage_w(s + 2, slot >= 1 ? slot - 1 : 2);
+        // AHEAD taps ahead, into the slot every wave left before the previous barrier
+        if (s + AHEAD < nsteps && !(DBG & 4)) stage_w(s + AHEAD, slot >= 1 ? slot - 1 : NRING - 1);
         mfma_terms(curc, I2{}, I4{});
         if constexpr (!PIPE) mfma_terms(curc, I4{}, I6{});
-        // the next step's weights (issued one step ago) must have landed; what this step issued (its weight slab and, at tap 0,
-        // the PPASS register loads of the next patch) may stay in flight
-        if (s + 2 < nsteps) {
+        // the weights of step s + AHEAD - 1 (issued one step ago) must have landed; what this step issued (its weight slab and, at
+        // tap 0, the PPASS loads of the next patch) may stay in flight
+        if (s + AHEAD < nsteps) {
             if (fetch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR + PPASS) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_INSTR) : "memory");
         } else {
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
             } else if (cs < ncs && !(DBG & 16)) {
                 // one patch buffer: every wave is past its last read of the old slab (barrier above) -- convert in place
                 // (RAW: the patch's DMA loads are NTAP steps old, the per-step vmcnt waits above have seen them land)
-                if constexpr (FLUSH != 0) {
+                if constexpr (FLUSH != 0 && !(DBG & 64)) {
                     if (cs % FLUSH == 0) {
 #pragma unroll
                         for (int i = 0; i < TM; ++i)
@@ -512,12 +517,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                             }
                     }
                 }
-                write_patch(0);
+                if (!(DBG & 32)) write_patch(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == NRING - 1 ? 0 : slot + 1;
         if constexpr (PIPE) {
             if (s + 1 < nsteps) read_frags(nxtc, tap, pbuf, slot);
             mfma_terms(curc, I4{}, I6{});
@@ -674,7 +679,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                     }
                     if (a.add) v += adv[n][q4];
                     if constexpr (NPL == 2) y_am = max(max(y_am, max(dwc_abs_bits(v[0]), dwc_abs_bits(v[1]))), max(dwc_abs_bits(v[2]), dwc_abs_bits(v[3])));
-                    *reinterpret_cast<f32x4*>(dst + col) = v;
+                    if (!(DBG & 256)) *reinterpret_cast<f32x4*>(dst + col) = v;
+                    else asm volatile("" ::"v"(v));
                 }
         }
     };
@@ -1268,7 +1274,8 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
     }
 #ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only with -DDWC_DEV_ABLATIONS, never in the shipped .so
     // (benchmarks/h2_ablation_bench.py; DWC_X3_DBG: 1 no MFMA, 2 no fragment reads, 4 no weight staging, 8 no barrier, 16 no patch
-    // refresh / flush, other: empty skeleton -- profiles/r05_h2_ablation.txt)
+    // refresh / flush, 32 no conversion at the slab boundary, 64 no flush, 128 no patch DMA, 256 no epilogue stores, 512 no main loop, sums of those, other: empty skeleton --
+    // profiles/r05_h2_ablation.txt)
     else if (NPL == 2 && getenv("DWC_X3_DBG") && atoi(getenv("DWC_X3_DBG"))) {
         const int dbg = atoi(getenv("DWC_X3_DBG"));
         if constexpr (NPL == 2) {
@@ -1278,6 +1285,14 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
                 else if (dbg == 4) x3_launch<3, 64, 4, 1, 2, 2, 4, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else if (dbg == 8) x3_launch<3, 64, 4, 1, 2, 2, 8, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else if (dbg == 16) x3_launch<3, 64, 4, 1, 2, 2, 16, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 32) x3_launch<3, 64, 4, 1, 2, 2, 32, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 64) x3_launch<3, 64, 4, 1, 2, 2, 64, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 128) x3_launch<3, 64, 4, 1, 2, 2, 128, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 3) x3_launch<3, 64, 4, 1, 2, 2, 3, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 287) x3_launch<3, 64, 4, 1, 2, 2, 287, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 543) x3_launch<3, 64, 4, 1, 2, 2, 543, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 799) x3_launch<3, 64, 4, 1, 2, 2, 799, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 256) x3_launch<3, 64, 4, 1, 2, 2, 256, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else x3_launch<3, 64, 4, 1, 2, 2, 31, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
             } else {
                 if (dbg == 1) x3_launch<5, 64, 4, 1, 2, 2, 1, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
@@ -1285,6 +1300,14 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
                 else if (dbg == 4) x3_launch<5, 64, 4, 1, 2, 2, 4, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else if (dbg == 8) x3_launch<5, 64, 4, 1, 2, 2, 8, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else if (dbg == 16) x3_launch<5, 64, 4, 1, 2, 2, 16, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 32) x3_launch<5, 64, 4, 1, 2, 2, 32, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 64) x3_launch<5, 64, 4, 1, 2, 2, 64, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 128) x3_launch<5, 64, 4, 1, 2, 2, 128, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 3) x3_launch<5, 64, 4, 1, 2, 2, 3, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 287) x3_launch<5, 64, 4, 1, 2, 2, 287, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 543) x3_launch<5, 64, 4, 1, 2, 2, 543, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 799) x3_launch<5, 64, 4, 1, 2, 2, 799, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
+                else if (dbg == 256) x3_launch<5, 64, 4, 1, 2, 2, 256, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
                 else x3_launch<5, 64, 4, 1, 2, 2, 31, 1, 0, 1, 2>(a, g2, (hipStream_t)stream);
             }
         }
