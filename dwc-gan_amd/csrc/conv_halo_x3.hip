@@ -815,7 +815,8 @@ struct X3WgradArgs {
 // CIW = 64: 8 waves, one workgroup per CU.  CIW = 32: 4 waves, <= 74 KB of LDS, TWO independent workgroups per CU (see
 // conv_halo_x3_kernel: they drift out of phase and overlap each other's MFMA and load phases).
 template <int KS, int BN, int CIW = 64, int AHEAD = 2, int NPL = 3>
-__global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? 1 : 2) void wgrad_x3_kernel(X3WgradArgs a) {
+// (two planes, K = 3 / 4: two 8-wave workgroups per CU -- four waves per SIMD, at most 128 registers -- see x3_wgrad_plan)
+__global__ __launch_bounds__(CIW == 64 ? 512 : 256, CIW == 64 ? (NPL == 2 && KS != 5 ? 4 : 1) : 2) void wgrad_x3_kernel(X3WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert((BN == 128 || BN == 64) && (CIW == 64 || CIW == 32), "tile shape");
     constexpr int HALVES = BN == 128 ? 1 : 2;
@@ -1123,11 +1124,14 @@ int x3_wgrad_bn(int B, int H, int W, int Cin, int Cout, int K) {
     return (Cout >= 64 && !(Cout % 64)) ? 64 : 0;
 }
 
-void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int* splits, int* ups) {
+void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int npl, int* splits, int* ups) {
     const int ciw = x3_wgrad_ciw();
     const int roles = (Cin / ciw) * (Cout / bn) * K;
     const int units = K == 4 ? B * (H / 8) * (W / 32) : B * (H / 8) * (W / 16);
-    const int cus = ciw == 64 ? 256 : 512;              // resident workgroups (LDS): whole rounds, see wgrad_halo_plan
+    // resident workgroups: whole rounds, see wgrad_halo_plan.  The two-plane kernels of K = 3 and K = 4 need 106-124 registers and
+    // exactly half of the LDS (81,920 bytes): two workgroups per CU (r05, wgrad + reduce planned for 256 / 512 slots: 3x3 256->256
+    // B=48 250 -> 223 us, 4x4 stride 2 200 -> 186 and 184 -> 179 us, B=16 unchanged; K = 5 holds 96 KB and stays at one per CU).
+    const int cus = (npl == 2 && K != 5) ? 512 : 256;
     const int smax = units / 4 > 0 ? units / 4 : 1;
     int s = 1;
     double best = 0.0;
@@ -1457,8 +1461,12 @@ int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_
 size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {
     const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
     if (!bn) return 0;
-    int splits, ups;
-    x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    int splits = 0;
+    for (int npl = 2; npl <= 3; ++npl) {      // (one scratch size for both forms: the larger of the two plans)
+        int s, ups;
+        x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, npl, &s, &ups);
+        splits = s > splits ? s : splits;
+    }
     return (size_t)splits * (bn == 128 ? 1 : 2) * K * K * Cin * Cout * sizeof(float);
 }
 
@@ -1474,7 +1482,7 @@ static int x3_wgrad_impl(const float* x, const void* xs, unsigned xs_epoch, cons
     const int bn = x3_wgrad_bn(B, H, W, Cin, Cout, K);
     if (!x || !dy || !dw_oihw || !bn || cin_real > Cin || cout_real > Cout || (NPL == 2 && (!xs || !dys))) return DWC_EINVAL;
     int splits, ups;
-    x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, &splits, &ups);
+    x3_wgrad_plan(B, H, W, Cin, Cout, K, bn, NPL, &splits, &ups);
     const int halves = bn == 128 ? 1 : 2;
     if (!ws || ws_bytes < (size_t)splits * halves * K * K * Cin * Cout * sizeof(float)) return DWC_EWORKSPACE;
     X3WgradArgs a;
