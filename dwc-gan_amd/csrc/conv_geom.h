@@ -159,7 +159,9 @@ Plan plan_gemm(int M, int N, int K, int classes, int bk = 32) {
     }
     // split-K: too few output tiles to fill the chip but a long contraction
     const long blocks = (long)((M + best.bm - 1) / best.bm) * ((N + best.bn - 1) / best.bn) * classes;
-    if (blocks < NUM_CU / 2 && nk >= 8) {
+    // (r05: the threshold was NUM_CU / 2 -- 128 tiles of a 4096-deep contraction ran 128 slabs each, one barrier per slab: c1's
+    // discriminator tail launches 32.9 -> 28.5 us with up to 2 * NUM_CU tiles split, +28 reduce launches; net -0.2 ms per step)
+    if (blocks < 2 * NUM_CU && nk >= 8) {
         int s = (int)((2 * NUM_CU + blocks - 1) / blocks);
         if (s > nk / 4) s = nk / 4;
         if (s > 32) s = 32;
