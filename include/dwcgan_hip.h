@@ -393,9 +393,10 @@ int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx
 int dwc_conv2d_bwd_data_s2_ring(const float* dy, const float* w_dgrad, float* dxp, float* dx, int B, int H, int W, int Cin, int Cout,
                                 void* stream);
 /* ---- the same layers as TWO-plane f16 split products (r05, "h2"; csrc/conv_halo_x3.hip split2h / h2_scale) -------------------------
- * s*a = hi + lo 2^-11 with hi = f16(s*a), lo = f16((s*a - hi) 2^11), round to nearest: 22-24 significand bits in two planes, so
- * a*b needs THREE f16 MFMAs (hi*hi, hi*lo, lo*hi) where the three-plane bf16 split needs six; same fp32-size error
- * (profiles/r05_split2_lab.txt, tests/test_x3_parity.py).  f16 has five exponent bits: each operand tensor is scaled by a power of
+ * s*a = hi + lo with hi = f16(s*a), lo = f16(s*a - hi), round to nearest: at least 23 significand bits in two planes, so
+ * a*b needs THREE f16 MFMAs (hi*hi, hi*lo, lo*hi: one fp32 accumulator, flushed into fp32 vector sums every 16-25 k-steps) where the
+ * three-plane bf16 split needs six; error against float64 2-5e-7 of the output scale, below the three-plane kernels' and the native
+ * fp32 MFMA path's (profiles/r05_split2_lab.txt, profiles/r05_h2_parity_errors.txt, tests/test_h2_parity.py).  f16 has five exponent bits: each operand tensor is scaled by a power of
  * two s (exact) that puts its largest magnitude at 2^13..2^14.  The largest magnitude travels in an "absmax slot": 8 bytes of
  * caller memory holding (epoch << 32) | bits of max |a|, raised with atomic max by dwc_absmax (or by the kernel that produced the
  * tensor); slots are zero before their first use and the epochs handed to one slot never decrease, so nothing is ever cleared.
