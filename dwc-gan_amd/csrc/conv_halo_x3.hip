@@ -149,7 +149,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
     // SIMD with up to 512 registers -- 4x2 tiles, a second fragment set, all latency hiding inside the wave's own instruction
-    // stream -- compile from the same source and were measured 15-25 % SLOWER.)
+    // stream -- compile from the same source and were measured 15-25 % SLOWER.  r05, two-plane form: 8 waves of 2x1 tiles, ~101 registers,
+    // TWO such workgroups per CU = 4 waves per SIMD, no second fragment set: 3-7 % slower than the 4-wave 2x2 tile -- 188 / 285 / 285
+    // against 182 / 267 / 268 us, profiles/r05_h2_ablation.txt -- the smaller tile reads 6 fragments per 6 MFMAs instead of 8 per 12.)
     constexpr int NW = WM * WN, THREADS = 64 * NW;
     constexpr int PPT = THREADS / 4;                   // patch pixels per gather pass (4 threads x 4 channels per pixel)
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
