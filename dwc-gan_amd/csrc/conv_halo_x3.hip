@@ -108,6 +108,7 @@ struct X3Args {
     int blocks_x, blocks_per_img, tiles_n;
     float* part = nullptr;          // KSP == 2: [tiles][256 pixels x 64 channels] fp32, the first arriver's half sum
     unsigned* tickets = nullptr;    // KSP == 2: [tiles], zero between launches (caller-owned, self-resetting)
+    unsigned* status = nullptr;     // KSP == 2: sticky word, bit 0 set when a tile's hand-off expired or crossed XCDs (the tile is NaN)
     int split_from = 0;             // KSP == 2: tiles [0, split_from) run whole (one workgroup), [split_from, tiles) as two halves
     const unsigned long long* xs = nullptr;      // NPL == 2: absmax slot of x and the epoch it must carry
     unsigned xs_epoch = 0;
@@ -603,6 +604,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                 __builtin_amdgcn_s_sleep(1);
             }
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (sticky: the caller polls it -- hipdwc.ops.ksplit_status_poll -- raises and re-zeroes the ticket row, which a late first
+            // arriver of this tile may still dirty)
+            if (!ok && a.status) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ok = ok;
         }
         __syncthreads();
@@ -1242,7 +1246,7 @@ size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K,
     const long tiles = (long)B * (H / TB) * (W / TB) * ((N + 63) / 64);
     return x3_ksplit_bytes(tiles, Cin / CS);
 }
-int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS; }
+int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS + 1; }      // (+ the sticky status word behind the tickets)
 
 /* dwc_x3_conv2d_same_add with the scratch of the contraction split: ws / tickets may be NULL (or ws_bytes too small), the launch
  * then runs unsplit.  Results do not depend on which form ran beyond fp32 summation order (two half sums instead of one). */
@@ -1273,6 +1277,7 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
     if (need && ws && tickets && ws_bytes >= need) {
         a.part = (float*)ws;
         a.tickets = tickets;
+        a.status = tickets + X3_KSPLIT_TICKETS;
         a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
         const dim3 g4(2 * g2.x - a.split_from);
         if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
@@ -1401,6 +1406,7 @@ static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, cons
     if (need && ws && tickets && ws_bytes >= need) {
         a.part = (float*)ws;
         a.tickets = tickets;
+        a.status = tickets + X3_KSPLIT_TICKETS;
         const int tiles = B * a.blocks_per_img * a.tiles_n;
         a.split_from = (int)x3_ksplit_from(tiles, 4 * (Cin / CS));
         x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 1, 2, NPL>(a, dim3(2 * tiles - a.split_from), (hipStream_t)stream);

@@ -673,6 +673,36 @@ def _x3_ksplit(lib, dev, B, H, W, Cx, cop, K, stride, at_least=0):
     return workspace(n, dev), n, row.data_ptr()
 
 
+_KSPLIT_POLL = {}            # (device index, stream) -> [pinned host copy of the row's status word, event of the last copy or None]
+
+
+def ksplit_status_poll(wait=False):
+    """Check the sticky status word behind every contraction-split ticket row (dwc_x3_conv2d_ksplit_ticket_words) without stalling
+    the stream, the way lstm_status_poll does: each call looks at the copy the PREVIOUS call started (if it has landed, or ``wait``)
+    and starts a new one.  Set status = a tile's two halves missed each other (a ticket left dirty by an aborted launch) or ran on
+    different XCDs; the kernel wrote NaN into that tile.  Raises, after re-zeroing the ticket row so that later launches do not keep
+    timing out on it.  Solver calls this once per step."""
+    for key, row in list(_X3_TICKETS.items()):
+        ent = _KSPLIT_POLL.get(key)
+        if ent is None:
+            ent = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+            _KSPLIT_POLL[key] = ent
+        if ent[1] is not None and (wait or ent[1].query()):
+            if wait:
+                ent[1].synchronize()
+            ent[1] = None
+            if int(ent[0][0]) != 0:
+                row.zero_()
+                ent[0].zero_()
+                raise _lib.HipKernelError(
+                    "contraction split of a split-product convolution: the two halves of a tile did not meet (status %d); the tile was "
+                    "overwritten with NaN and the ticket row has been re-zeroed.  DWC_X3_KSPLIT=0 runs these launches unsplit." % 1)
+        if ent[1] is None and key[1] == _stream():          # (a row is polled from the stream its launches run on)
+            ent[0].copy_(row[-1:], non_blocking=True)
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
+
+
 class _Conv2d(torch.autograd.Function):
     """act(conv(reflect_pad(x)) + b).  Output has Cout rounded up to a multiple of 4 (fp32) / 8 (bf16); its dtype is x's.
     ``owner``: the parameter(s) ``w`` is derived from when ``w`` is a fresh tensor on every call (prepared-weight cache)."""

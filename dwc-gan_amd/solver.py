@@ -222,6 +222,7 @@ class Solver(nn.Module):
         self._zero_grad("dis")
         x4 = ops.pack_image(x_real)
         ops.lstm_status_poll(x4.device)     # persistent text-encoder kernels: raise if a hand-off of an earlier step timed out
+        ops.ksplit_status_poll()            # contraction-split convolutions: the same for their tile hand-offs
         B = x4.shape[0]
         with torch.no_grad():
             style_real, _ = self.gen.enc_style(x4)              # draw: mapping dropout (same order as gen.encode)

@@ -367,7 +367,10 @@ int dwc_reflect_pad_adjoint_band(const float* dxp, float* dx, int B, int H, int 
  * its own (a + b = b + a: no dependence on arrival order) and applies bias / activation / add.  dwc_x3_conv2d_ksplit_ws_bytes:
  * bytes of `ws` wanted for a shape (stride 1: K in {3,5}; stride 2: the 4x4 layers, K ignored; 0 = the launch is not split);
  * `tickets`: dwc_x3_conv2d_ksplit_ticket_words() 32-bit words owned by the caller PER STREAM, zero before the first call and
- * left at zero by every call.  ws / tickets NULL or ws_bytes too small: the plain launch.  DWC_X3_KSPLIT=0 disables the split. */
+ * left at zero by every call.  The LAST word is a sticky status: bit 0 is set when a tile's hand-off expired (a ticket left dirty by
+ * an aborted launch) or its two halves ran on different XCDs -- that tile's result is NaN; the caller should then stop, or zero
+ * the whole row before the next call.  ws / tickets NULL or ws_bytes too small: the plain launch.  DWC_X3_KSPLIT=0 disables the
+ * split. */
 size_t dwc_x3_conv2d_ksplit_ws_bytes(int B, int H, int W, int Cin, int N, int K, int stride);
 int dwc_x3_conv2d_ksplit_ticket_words(void);
 int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,

@@ -346,3 +346,41 @@ def test_h2_cached_slot_is_not_trusted_past_a_lap_of_the_pool():
     y = _conv(x, _prep(w, 64, False), None, None, 1, 16, 16, 64, 64, 3, 0, 1, amax=a1)
     torch.cuda.synchronize()
     assert torch.isfinite(y).all()
+
+
+def test_contraction_split_dirty_ticket_is_reported_and_healed():
+    """a ticket left dirty by an aborted launch makes both halves of its tile wait for a partner that never publishes.
+    The wait is bounded and the tile is overwritten with NaN; the sticky status word behind the ticket row must be set, so that
+    ops.ksplit_status_poll raises (instead of a run that silently turns NaN) and re-zeroes the row: the next launch is clean."""
+    lib = _lib.load()
+    B, H, W, Cin, N, K = 16, 32, 32, 128, 128, 3                       # 128 tiles: split whole
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    w = (torch.randn(N, Cin, K, K, generator=g) * 0.03).to(DEV)
+    wp = _prep(w, N, False)
+    need = lib.dwc_x3_conv2d_ksplit_ws_bytes(B, H, W, Cin, N, K, 1)
+    assert need > 0
+    ws, n, row_ptr = ops._x3_ksplit(lib, torch.device(DEV), B, H, W, Cin, N, K, 1)
+    row = ops._X3_TICKETS[(0, _st())]
+    assert row.numel() == lib.dwc_x3_conv2d_ksplit_ticket_words() and int(row[-1]) == 0
+    ops.ksplit_status_poll(wait=True)                                  # drain a poll an earlier test may have started
+    xa = _amax(x)
+
+    def run():
+        y = torch.empty(B, H, W, N, device=DEV)
+        _lib.check(lib.dwc_h2_conv2d_same_add_ws(x.data_ptr(), xa[0], xa[1], wp.data_ptr(), None, None, y.data_ptr(), None, 0, B, H, W, Cin, N, N,
+                                                 K, 0, 1, ws.data_ptr(), n, row_ptr, _st()), "h2_conv2d_same_add_ws")
+        torch.cuda.synchronize()
+        return y
+
+    clean = run()
+    assert torch.isfinite(clean).all() and int(row[-1]) == 0
+    row[5] = 2                                                         # what a late first arriver of an aborted launch leaves behind
+    bad = run()
+    assert torch.isnan(bad).any() and int(row[-1]) == 1
+    ops.ksplit_status_poll()                                           # starts the copy of the status word ...
+    with pytest.raises(_lib.HipKernelError):
+        ops.ksplit_status_poll(wait=True)                              # ... and finds it set
+    assert int(row.abs().sum()) == 0
+    again = run()
+    assert torch.equal(again, clean)
