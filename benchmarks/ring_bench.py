@@ -1,6 +1,5 @@
 """Border-ring step of the "same" data gradients (strip GEMMs + fold) through the C ABI, per layer shape and batch, both precisions.
-The row-tile height of the strips is read once per process (DWC_STRIP_BM=64|128, default: by tile count): run once per value.
-usage: [DWC_STRIP_BM=64] python benchmarks/ring_bench.py"""
+usage: python benchmarks/ring_bench.py"""
 import os
 import sys
 
@@ -31,7 +30,6 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
-    print("DWC_STRIP_BM =", os.environ.get("DWC_STRIP_BM", "auto"))
     for half, batches in ((False, (16, 48)), (True, (128, 384))):
         dt = torch.bfloat16 if half else torch.float32
         pre = "bf16_" if half else ""

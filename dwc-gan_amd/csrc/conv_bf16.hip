@@ -872,15 +872,9 @@ Plan plan_gemm_h(int M, int N, int K, int classes) {
     const int nk = (K + BK - 1) / BK;
     Plan best = {128, 32, 1, nk};
     float best_cost = 3.0e38f;
-    static const char* force = getenv("DWC_BF16_TILE");      // development knob: pin a tile, e.g. 128x128
     for (const Cand& c : all) {
         const bool ok = N <= 32 ? c.bn == 32 : (N <= 64 ? c.bn == 64 : (c.bn != 32 && (c.bn <= 128 || N > 128)));
         if (!ok) continue;
-        if (force) {
-            char tag[16];
-            snprintf(tag, sizeof tag, "%dx%d", c.bm, c.bn);
-            if (strcmp(tag, force) != 0 && !(N <= 64)) continue;
-        }
         const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
         const long n = (blocks + NUM_CU - 1) / NUM_CU;
         const long full = n / c.resident, rem = n % c.resident;
@@ -925,10 +919,8 @@ int launch_gemm_h(const Gather& g, const bf16* w, size_t w_class_stride, int cla
         }
     }
     const bool f32out = p.splits > 1;
-    static const bool stages3 = getenv("DWC_BF16_STAGES3") != nullptr;      // development knob: 3-slab ring for the 128x128 tile too
     if (p.bm == 256 && p.bn == 256) launch_variant_h<256, 256, 2, 4, 4, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 256 && p.bn == 128) launch_variant_h<256, 128, 4, 2, 2, 2, 3>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
-    else if (p.bm == 128 && p.bn == 128 && stages3) launch_variant_h<128, 128, 2, 2, 2, 2, 3>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 128 && p.bn == 128) launch_variant_h<128, 128, 2, 2, 2, 2>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 128 && p.bn == 64) launch_variant_h<128, 64, 2, 2, 2, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);
     else if (p.bm == 64 && p.bn == 64) launch_variant_h<64, 64, 2, 2, 1, 1>(g, w, w_class_stride, classes, o, bias, act, p, part_stride, f32out, st);

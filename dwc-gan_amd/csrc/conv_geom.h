@@ -135,17 +135,8 @@ Plan plan_gemm(int M, int N, int K, int classes, int bk = 32) {
         if (N <= 64) return c.bn == 64;
         return c.bn != 32;
     };
-    // development knob: DWC_GEMM_TILE=128x128|128x64|64x64 pins the tile where it is valid for this N
-    const char* force = getenv("DWC_GEMM_TILE");
-    const Cand* pinned = nullptr;
-    if (force)
-        for (const Cand& c : all) {
-            char tag[16];
-            snprintf(tag, sizeof tag, "%dx%d", c.bm, c.bn);
-            if (valid(c) && strcmp(tag, force) == 0) pinned = &c;
-        }
     for (const Cand& c : all) {
-        if (!valid(c) || (pinned && pinned != &c)) continue;
+        if (!valid(c)) continue;
         const long blocks = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * classes;
         const long n = (blocks + NUM_CU - 1) / NUM_CU;
         const long full = n / c.resident, rem = n % c.resident;
@@ -452,11 +443,9 @@ inline bool s2_ring_geom(const void* dy, const void* w_dgrad, void* dxp, size_t 
 // Row-tile height of the ring-strip launches (64-column tiles either way).  bf16: 128 rows per workgroup -- two 32x32 accumulators
 // per wave sharing every weight fragment -- once the strips hold enough rows to fill the chip with tiles of that size (measured,
 // benchmarks/ring_bench.py: -10..15 % at batch 128, equal at 384), 64 below that.  fp32 (split products): always 64 -- the
-// 128-row form has to halve its accumulator tile per MFMA group and lost 10..30 % at every batch.  DWC_STRIP_BM=64|128 pins it.
+// 128-row form has to halve its accumulator tile per MFMA group and lost 10..30 % at every batch.
 // `rows` = GEMM rows of the longest strip, `strips` x `tiles_n` x `parts` workgroups per row tile.
 inline int strip_bm(long rows, int tiles_n, int strips, int parts, bool half) {
-    static const int force = getenv("DWC_STRIP_BM") ? atoi(getenv("DWC_STRIP_BM")) : 0;
-    if (force == 64 || force == 128) return force;
     if (!half) return 64;
     return ((rows + 127) / 128) * tiles_n * strips * parts >= 2 * NUM_CU ? 128 : 64;
 }

@@ -48,266 +48,8 @@ __device__ __forceinline__ bf16x8 halo_add8(bf16x8 a, bf16x8 b) {
     return r;
 }
 
-// WM x WN waves (8), each TM x TN 32x32 accumulators: block = 256 pixels x BN channels
-// PB: patch buffers (2: the next channel slab's patch is staged during the taps of the current one; 1: it is staged at the slab
-// boundary, one exposed load per K*K taps -- the 5x5 patch does not fit twice beside the weight slabs)
-// DBG (development, timing only -- results are wrong when set): 1 no MFMA, 2 no fragment reads in the loop, 4 no weight staging
-// in the loop, 8 no vmcnt wait, 16 no barrier
-// 8 waves: one workgroup per CU.  4 waves (PB == 1, <= 80 KB of LDS): TWO independent workgroups per CU -- they drift out of
-// phase, so one's MFMAs run beside the other's fragment reads, staging and barriers, which the lock-stepped waves of a single
-// workgroup never do (conv_halo_x3.hip measured +5..27 % from exactly this).
-template <int KS, int BN, int WM, int WN, int TM, int TN, int PB, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_kernel(HaloArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NW = WM * WN, THREADS = 64 * NW, RP = 8 * NW;      // rows (pixels / channels) staged per pass
-    static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN && BN % RP == 0, "tile shape");
-    constexpr int PW = TB + KS - 1;                    // patch edge
-    constexpr int PPIX = PW * PW;                      // patch pixels
-    constexpr int PPASS = (PPIX + RP - 1) / RP;        // staging passes of RP pixels (one wave instruction = 8 pixels)
-    constexpr int P_TILE = PPASS * RP * BK;            // elements per patch buffer
-    constexpr int W_TILE = BN * BK;
-    constexpr int W_PASSES = BN / RP;
-    constexpr int LDC = BN + 8;
-    constexpr int OPER = PB * P_TILE + 2 * W_TILE;
-    constexpr int SMEM = OPER > 256 * LDC ? OPER : 256 * LDC;
-    __shared__ __attribute__((aligned(16))) bf16 smem[SMEM];
-    bf16* sP = smem;
-    bf16* sW = smem + PB * P_TILE;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if (nb >= 16) {     // XCD-aware remap (neighbouring blocks share halo pixels and the weight slabs in one L2)
-            const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
-            bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-        }
-    }
-    const int tile_n = bid % a.tiles_n, blk = bid / a.tiles_n;
-    const int n_img = blk / a.blocks_per_img, bi = blk - n_img * a.blocks_per_img;
-    const int by = bi / a.blocks_x, bx = bi - by * a.blocks_x;
-    const int y0 = by * TB, x0 = bx * TB, n0 = tile_n * BN;
-    constexpr int PAD = (KS - 1) / 2;
-
-    const unsigned x_bytes = (unsigned)a.B * a.H * a.W * a.Cin * 2u;
-    const unsigned w_bytes = (unsigned)a.N * a.Kp * 2u;
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;
-
-    // ---- staging maps ------------------------------------------------------------------------------------------------
-    // patch: thread = (patch pixel prow [+64 per pass], physical chunk t&7); logical chunk = slot ^ ((pp>>1)&7)
-    const int prow = t >> 3;
-    unsigned p_off[PPASS];
-#pragma unroll
-    for (int i = 0; i < PPASS; ++i) {
-        const int pp = prow + RP * i;
-        const int py = pp / PW, px = pp - py * PW;
-        int h = y0 - PAD + py, w = x0 - PAD + px;
-        bool ok = pp < PPIX;
-        if (a.reflect) {
-            h = reflect_idx(h, a.H);
-            w = reflect_idx(w, a.W);
-        } else {
-            ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-        }
-        h = min(max(h, 0), a.H - 1);
-        w = min(max(w, 0), a.W - 1);
-        // chunk swizzle by the patch COLUMN: a ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
-        // (MI355X_MICROARCH.md), i.e. 8 pixels of one patch row and 8 of the next; keyed on the linear pixel index the second
-        // row's key is rotated by PW/2 and every fragment read of the patch was 2-way bank conflicted
-        const int lc = (t & 7) ^ ((px >> 1) & 7);
-        const unsigned off = ((unsigned)(((n_img * a.H + h) * a.W + w) << a.logCin) + (unsigned)(lc * 8)) * 2u;
-        p_off[i] = ok ? off : OOB;
-    }
-    // weights: thread = (row wrow [+64 per pass], chunk); row = output channel
-    unsigned w_off[W_PASSES];
-#pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) {
-        const int row = prow + RP * p;
-        const int lc = (t & 7) ^ ((row >> 1) & 7);
-        w_off[p] = ((unsigned)min(n0 + row, a.N - 1) * a.Kp + lc * 8) * 2u;
-    }
-    const int ncs = a.Cin >> 6;                       // 64-channel slabs
-    constexpr int NTAP = KS * KS;
-    const int nsteps = ncs * NTAP;
-
-    auto stage_patch = [&](int cs, int buf, int first, int last) {
-        bf16* lp = sP + buf * P_TILE + wave * (8 * BK);
-        const int soff = cs * (BK * 2);
-#pragma unroll
-        for (int i = 0; i < PPASS; ++i) {
-            if (i < first || i >= last) continue;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * RP * BK), 16, p_off[i],
-                                                     soff, 0, 0);
-        }
-    };
-    auto stage_w = [&](int step, int buf) {           // step = cs * NTAP + tap
-        const int cs = step / NTAP, tap = step - cs * NTAP;
-        bf16* lw = sW + buf * W_TILE + wave * (8 * BK);
-        const int soff = __builtin_amdgcn_readfirstlane((tap * a.Cin + cs * BK) * 2);
-#pragma unroll
-        for (int p = 0; p < W_PASSES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lw + p * RP * BK), 16, w_off[p],
-                                                     soff, 0, 0);
-    };
-
-    // ---- fragment addressing -----------------------------------------------------------------------------------------
-    // A tile i of this wave: block pixels pb = (wm*TM + i)*32 + l31 -> (py, px) = (pb>>4, pb&15); under tap (kh,kw) the
-    // patch pixel is pp = (py+kh)*PW + px+kw; chunk 2q+hi of that pixel sits at slot (2q+hi) ^ ((pp>>1)&7)
-    int pp0[TM], px0l[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int pb = (wm * TM + i) * 32 + l31;
-        pp0[i] = (pb >> 4) * PW + (pb & 15);
-        px0l[i] = pb & 15;
-    }
-    const int b_row = (wn * TN * 32 + l31) * BK;
-    const int fsw_b = (l31 >> 1) & 7;
-    int frag_b[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) frag_b[q] = ((2 * q + hi) ^ fsw_b) * 8;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    bf16x8 fa[2][TM], fb[2][TN];
-    int a_base[TM], a_sw[TM];                         // element offset of the tap's patch pixel row, its swizzle
-    auto set_tap = [&](int tap) {
-        const int kh = tap / KS, kw = tap - kh * KS;
-        const int d = kh * PW + kw;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int pp = pp0[i] + d;
-            a_base[i] = pp * BK;
-            a_sw[i] = ((px0l[i] + kw) >> 1) & 7;
-        }
-    };
-    auto load_frags = [&](int set, int pbuf, int wbuf, int q) {
-        if ((DBG & 2) && set >= 0 && q != 0) return;
-        const bf16* p = sP + pbuf * P_TILE;
-        const bf16* w = sW + wbuf * W_TILE + b_row + frag_b[q];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(p + a_base[i] + (((2 * q + hi) ^ a_sw[i]) << 3));
-#pragma unroll
-        for (int n = 0; n < TN; ++n) fb[set][n] = *reinterpret_cast<const bf16x8*>(w + n * 32 * BK);
-    };
-    auto mfma_group = [&](int set) {
-        if (DBG & 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[set][i]));
-#pragma unroll
-            for (int n = 0; n < TN; ++n) asm volatile("" ::"v"(fb[set][n]));
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][n], fa[set][i], acc[i][n], 0, 0, 0);
-    };
-
-    // ---- main loop: one barrier per (tap, channel slab) step; the next step's weight slab and, spread over the taps of a
-    // channel slab, the next slab's patch are in flight meanwhile ------------------------------------------------------
-    stage_patch(0, 0, 0, PPASS);
-    stage_w(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int pbuf = 0, wbuf = 0, tap = 0, cs = 0;
-    set_tap(0);
-    load_frags(0, 0, 0, 0);
-    constexpr int PPT = (PPASS + NTAP - 2) / (NTAP - 1);          // patch passes issued per step (all but the last tap)
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more && !(DBG & 4)) stage_w(s + 1, wbuf ^ 1);
-        if (PB == 2 && cs + 1 < ncs && tap < NTAP - 1) stage_patch(cs + 1, pbuf ^ 1, tap * PPT, min(PPASS, (tap + 1) * PPT));
-        load_frags(1, pbuf, wbuf, 1);
-        mfma_group(0);
-        load_frags(0, pbuf, wbuf, 2);
-        mfma_group(1);
-        load_frags(1, pbuf, wbuf, 3);
-        mfma_group(0);
-        if (!(DBG & 8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(DBG & 16)) __syncthreads();
-        if (more) {
-            if (++tap == NTAP) {
-                tap = 0;
-                ++cs;
-                if (PB == 2) {
-                    pbuf ^= 1;
-                } else {                      // every wave is past its last read of the patch (barrier above): restage in place
-                    stage_patch(cs, 0, 0, PPASS);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                }
-            }
-            set_tap(tap);
-            load_frags(0, pbuf, wbuf ^ 1, 0);
-        }
-        mfma_group(1);
-        wbuf ^= 1;
-    }
-
-    // ---- epilogue: bias + activation, pack to bf16, stage through LDS, 16-byte row chunks ---------------------------------
-    __syncthreads();
-    bf16* sC = smem;
-    const float slope = dwc_act_slope(a.act);
-    f32x4 bvec[TN][4];                                  // bias vectors of this lane's columns: one batch of loads (see conv_halo16_bf16.inc)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-            bvec[n][q4] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + min(n0 + (wn * TN + n) * 32 + 8 * q4 + 4 * hi, a.N - 4))
-                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-    auto to_lds = [&](auto general) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 32 + l31;
-#pragma unroll
-            for (int n = 0; n < TN; ++n)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int cl = (wn * TN + n) * 32 + 8 * q4 + 4 * hi;
-                    const int col = n0 + cl;
-                    f32x4 v = {acc[i][n][4 * q4], acc[i][n][4 * q4 + 1], acc[i][n][4 * q4 + 2], acc[i][n][4 * q4 + 3]};
-                    if (col < a.N) {
-                        v += bvec[n][q4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if constexpr (decltype(general)::value) v[k] = dwc_act_apply(v[k], a.act, col + k);
-                            else v[k] = dwc_act_simple(v[k], slope);
-                        }
-                    }
-                    *reinterpret_cast<bf16x4*>(sC + row * LDC + cl) = pack4h(v[0], v[1], v[2], v[3]);
-                }
-        }
-    };
-    if (dwc_act_is_simple(a.act)) to_lds(std::false_type{});
-    else to_lds(std::true_type{});
-    __syncthreads();
-    constexpr int CPR = BN / 8;
-    for (int idx = t; idx < 256 * CPR; idx += THREADS) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const int col = n0 + ch * 8;
-        if (col >= a.N) continue;
-        const int yy = y0 + (row >> 4), xx = x0 + (row & 15);
-        const size_t off = ((size_t)(n_img * a.H + yy) * a.W + xx) * a.N + col;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(sC + row * LDC + ch * 8);
-        if (a.add) v = halo_add8(v, *reinterpret_cast<const bf16x8*>(a.add + off));
-        *reinterpret_cast<bf16x8*>(a.y + off) = v;
-    }
-#endif
-}
-
+// (The compiler-scheduled 32x32x16 kernel of round 2, conv_halo_kernel, and its knobs DWC_HALO16 / DWC_HALO_DUO / DWC_HALO_BN128 were
+// removed in round 5: the hand-scheduled kernels below replaced it in round 3 -- measurements in DESIGN.md 3.8 / 3.8b.)
 #include "conv_halo16_bf16.inc"
 
 // ------------------------------------------------------------------------------------------
@@ -331,7 +73,7 @@ struct WgradHaloArgs {
     int n_tiles, tap_groups;
 };
 
-// PROBE (benchmarks/halo_lab.hip only): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
+// PROBE (the round-3 laboratory benchmarks/halo_lab.hip, removed in round 5, instantiated it): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
 // DBG (timing only, results wrong; lab and -DDWC_DEV_ABLATIONS builds): 1 no MFMA, 2 no fragment reads, 4 no staging in the
 // loop, 8 no wait + barrier per unit.
 template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 0>
@@ -482,7 +224,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
             }
             const unsigned pbase = lds0 + (unsigned)(buf * P_TILE) * 2u, dbase = lds0 + (unsigned)(2 * P_TILE + buf * D_TILE) * 2u;
             // Fragment reads run PF patch rows ahead of the MFMAs that use them (register rings).
-            constexpr int PF = PFT < 0 ? 1 : PFT;     // PFT: benchmarks/halo_lab.hip compares depths
+            constexpr int PF = PFT < 0 ? 1 : PFT;     // PFT: the round-3 laboratory compared depths
             constexpr int FA = PF + 1, FB = TH + PF;     // ring sizes: x rows r..r+PF, dY rows r-TH+1..r+PF
             bf16x4 fa[FA][TW][2], fb[FB][2];
             auto row_reads = [](int r) { return r < PH ? 2 * TW + (r < UH ? 2 : 0) : 0; };     // ds_read instructions of row r
@@ -645,97 +387,29 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
     a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
     hipStream_t st = (hipStream_t)stream;
     const int nblk = B * a.blocks_per_img;
-#define HALO_LAUNCH(KS, BN, WM, WN, TM, TN)                                                                             \
-    do {                                                                                                                  \
-        a.tiles_n = (Cout + BN - 1) / BN;                                                                                 \
-        hipLaunchKernelGGL((conv_halo_kernel<KS, BN, WM, WN, TM, TN, (KS == 3 ? 2 : 1)>), dim3(nblk * a.tiles_n), dim3(512), 0, st, \
-                           a);                                                                                            \
-    } while (0)
-#ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only by `make ABLATIONS=1`, never in the shipped .so
-    static const int dbg = getenv("DWC_HALO_DBG") ? atoi(getenv("DWC_HALO_DBG")) : 0;
-    if (dbg && K == 3 && Cout > 128) {
-        a.tiles_n = (Cout + 255) / 256;
-#define HALO_DBG(D)                                                                                                         \
-    case D:                                                                                                                  \
-        hipLaunchKernelGGL((conv_halo_kernel<3, 256, 2, 4, 4, 2, 2, D>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);        \
-        break;
-        switch (dbg) {
-            HALO_DBG(1) HALO_DBG(2) HALO_DBG(3) HALO_DBG(4) HALO_DBG(8) HALO_DBG(16) HALO_DBG(24) HALO_DBG(28) HALO_DBG(31)
-            default: return DWC_EINVAL;
-        }
-#undef HALO_DBG
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
-#endif
-    static const int bn128 = getenv("DWC_HALO_BN128") ? atoi(getenv("DWC_HALO_BN128")) : 0;   // development: 1 -> PB 1, 2 -> PB 2
-    if (K == 3 && Cout > 128 && bn128) {
-        a.tiles_n = (Cout + 127) / 128;
-        if (bn128 == 1)
-            hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
-        else
-            hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 2, 2, 2, 2>), dim3(nblk * a.tiles_n), dim3(512), 0, st, a);
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
-    // Default: the hand-scheduled 16x16x32 kernels (conv_halo16_bf16.inc).  DWC_HALO16=0: the compiler-scheduled 32x32x16 kernels
-    // below; DWC_HALO16=1: the 8-wave tiles only (no two-workgroups-per-CU forms).
-    static const int h16 = getenv("DWC_HALO16") ? atoi(getenv("DWC_HALO16")) : 2;
-    if (h16) {
+    // the hand-scheduled 16x16x32 kernels (conv_halo16_bf16.inc)
 #define HALO16_LAUNCH(KS, BN, WM, WN, PB)                                                                                  \
     do {                                                                                                                  \
         a.tiles_n = (Cout + BN - 1) / BN;                                                                                 \
         hipLaunchKernelGGL((conv_halo16_kernel<KS, BN, WM, WN, PB>), dim3(nblk * a.tiles_n), dim3(64 * WM * WN), 0, st, a, nullptr); \
     } while (0)
-        // Two 4-wave workgroups per CU (256 pixels x 128 / x 64 channels, single patch buffer, <= 80 KB of LDS) where a full round
-        // of them exists.  r03, same operands, 8-wave tile -> two workgroups per CU (benchmarks/halo_lab.hip, bit-identical
-        // results): 5x5 256->128 B=384 1950 -> 1698 us (52.8 -> 60.7 % of 2.5 PF), B=128 688 -> 603; 5x5 64->128 (data
-        // gradient) 758 -> 689; 3x3 256->256 B=384 401 -> 387, B=128 139 -> 138; 5x5 128->64: 3 % slower (stays 8-wave).
-        const bool duo = h16 >= 2 && (long)nblk * (Cout / 64) >= 512;
-        if (K == 3) {
-            if (Cout > 128 && duo && Cout % 128 == 0) HALO16_LAUNCH(3, 128, 2, 2, 1);
-            else if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);
-            else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
-            else HALO16_LAUNCH(3, 64, 4, 2, 2);
-        } else {
-            if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
-            else if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
-            else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
-            else HALO16_LAUNCH(5, 64, 4, 2, 1);
-        }
-#undef HALO16_LAUNCH
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
-    // DWC_HALO_DUO=1: two 4-wave workgroups per CU (256 pixels x 128 channels for the 3x3, x 64 for the 5x5: <= 80 KB of LDS).
-    // Unlike the split-product kernels (conv_halo_x3.hip: +5..27 %) the plain bf16 kernels gain nothing from it (-7..+4 %):
-    // they are bound by LDS fragment reads and L2->LDS ingest, which a second workgroup shares, not by lock-step -- off.
-    static const int duo = getenv("DWC_HALO_DUO") ? atoi(getenv("DWC_HALO_DUO")) : 0;
-    if (duo) {
-        if (K == 3) {
-            a.tiles_n = (Cout + 127) / 128;
-            if (Cout > 64) hipLaunchKernelGGL((conv_halo_kernel<3, 128, 4, 1, 2, 4, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
-            else {
-                a.tiles_n = (Cout + 63) / 64;
-                hipLaunchKernelGGL((conv_halo_kernel<3, 64, 4, 1, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
-            }
-        } else {
-            a.tiles_n = (Cout + 63) / 64;
-            hipLaunchKernelGGL((conv_halo_kernel<5, 64, 4, 1, 2, 2, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a);
-        }
-        DWC_LAUNCH_CHECK();
-        return DWC_OK;
-    }
+    // Two 4-wave workgroups per CU (256 pixels x 128 / x 64 channels, single patch buffer, <= 80 KB of LDS) where a full round
+    // of them exists.  r03, same operands, 8-wave tile -> two workgroups per CU (bit-identical results): 5x5 256->128 B=384
+    // 1950 -> 1698 us (52.8 -> 60.7 % of 2.5 PF), B=128 688 -> 603; 5x5 64->128 (data gradient) 758 -> 689; 3x3 256->256 B=384
+    // 401 -> 387, B=128 139 -> 138; 5x5 128->64: 3 % slower (stays 8-wave).
+    const bool duo = (long)nblk * (Cout / 64) >= 512;
     if (K == 3) {
-        if (Cout > 128) HALO_LAUNCH(3, 256, 2, 4, 4, 2);
-        else if (Cout > 64) HALO_LAUNCH(3, 128, 4, 2, 2, 2);
-        else HALO_LAUNCH(3, 64, 4, 2, 2, 1);
+        if (Cout > 128 && duo && Cout % 128 == 0) HALO16_LAUNCH(3, 128, 2, 2, 1);
+        else if (Cout > 128) HALO16_LAUNCH(3, 256, 2, 4, 2);
+        else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
+        else HALO16_LAUNCH(3, 64, 4, 2, 2);
     } else {
-        if (Cout > 128) HALO_LAUNCH(5, 256, 2, 4, 4, 2);
-        else if (Cout > 64) HALO_LAUNCH(5, 128, 4, 2, 2, 2);
-        else HALO_LAUNCH(5, 64, 4, 2, 2, 1);
+        if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
+        else if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
+        else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
+        else HALO16_LAUNCH(5, 64, 4, 2, 1);
     }
-#undef HALO_LAUNCH
+#undef HALO16_LAUNCH
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

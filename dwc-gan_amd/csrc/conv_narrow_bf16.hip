@@ -625,11 +625,8 @@ int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias3
     a.x = (const bf16*)x; a.w = (const bf16*)w_frag; a.bias = bias32; a.y = (bf16*)y;
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg;
     a.off_h = off_h; a.off_w = off_w; a.act = act; a.reflect = reflect;
-    static const int rows16 = getenv("DWC_NARROW_ROWS16") ? atoi(getenv("DWC_NARROW_ROWS16")) : 0;
-    const int nb_rows = rows16 ? 16 : 8;
-    a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + nb_rows - 1) / nb_rows;
-    if (rows16) hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 16>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + 7) / 8;      // (8-row blocks; 16-row blocks measured equal, not instantiated)
+    hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
