@@ -596,6 +596,10 @@ if __name__ == "__main__":
         gen_full(ref_solver, 256, 1)
     if "full256b8" in what:
         gen_full(ref_solver, 256, 8)
+    if "full256b2" in what:     # (+ full64b4: the shapes tests/test_bf16_parity.py::test_bf16_full_size_iteration_vs_reference runs)
+        gen_full(ref_solver, 256, 2)
+    if "full64b4" in what:
+        gen_full(ref_solver, 64, 4)
     if "full128b64" in what:
         gen_full(ref_solver, 128, 64, offload=True)
     if "full128b128dis" in what:

@@ -12,8 +12,10 @@ max|ref| like the fp32 tests:
   * fp32 weight / bias gradients behind an activation: 1e-2
   * a whole training iteration: losses within 3e-2 relative of the fp32 oracle's (stated per test).
 """
+import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -305,16 +307,37 @@ def test_bf16_tiny_iterations_vs_fp32_oracle():
 
 
 @pytest.mark.parametrize("S,B", [(64, 4), (128, 2), (256, 2)])
-def test_bf16_full_size_iteration_vs_fp32_oracle(S, B):
-    """The shipped configuration at full width on the bf16 path, one iteration against the fp32 oracle: the two headline
-    losses within 2e-2 relative, every other scalar within 3e-2 of max(1, |value|).  (256, 2): the 256x256 architecture of
-    BASELINE configs[4] (64x64 content code, 8x8 / 4x4 discriminator heads) under bf16."""
+def test_bf16_full_size_iteration_vs_fp32_oracle(S, B, golden_dir):
+    """The shipped configuration at full width on the bf16 path, one iteration against the fp32 run of the IMPORTED REFERENCE from
+    the same seeded initialisation, batch and random stream (tests/golden/full_s{S}_b{B}.npz, tests/golden/make_golden.py full64b4 /
+    full128b2 / full256b2; rounds 2-4 ran the fp32 CPU oracle here, 20-66 s of the GPU suite per case -- the test keeps its name
+    and ids): the two headline losses within 2e-2 relative, every other scalar within 3e-2 of max(1, |value|).  (256, 2): the
+    256x256 architecture of BASELINE configs[4] (64x64 content code, 8x8 / 4x4 discriminator heads) under bf16."""
+    from solver import Solver
+    fx = np.load(os.path.join(golden_dir, "full_s%d_b%d.npz" % (S, B)))
+    want = json.loads(bytes(fx["losses_json"]).decode())
     cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
-    h, o, _ = _run_iteration(cfg, B, S, 4321)
-    for k in ("loss_dis_all", "loss_gen_total"):
-        assert abs(h[0][k] - o[0][k]) <= 2e-2 * abs(o[0][k]), (k, h[0][k], o[0][k])
-    for k in LOSS_KEYS:
-        assert abs(h[0][k] - o[0][k]) <= 3e-2 * max(1.0, abs(o[0][k])), (k, h[0][k], o[0][k])
+    host.set_noise(host.HostNoise())
+    try:
+        torch.manual_seed(1234)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        s.copy_nets()
+        batch = synth.make_batch(B, S, seed=11)
+        db = {k: v.to(DEV) for k, v in batch.items()}
+        a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
+        s.dis_update(*a)
+        got_dis = float(s.loss_dis_all)
+        assert abs(got_dis - float(fx["loss_dis_all"])) <= 2e-2 * abs(float(fx["loss_dis_all"])), (got_dis, float(fx["loss_dis_all"]))
+        s.gen_update(*a)
+        torch.cuda.synchronize()
+        got = {k: float(torch.as_tensor(getattr(s, k)).detach()) for k in want}
+        assert abs(got["loss_gen_total"] - want["loss_gen_total"]) <= 2e-2 * abs(want["loss_gen_total"]), (got["loss_gen_total"], want["loss_gen_total"])
+        for k in want:
+            assert abs(got[k] - want[k]) <= 3e-2 * max(1.0, abs(want[k])), (k, got[k], want[k])
+        for p in s.gen.parameters():
+            assert p.grad is None or torch.isfinite(p.grad).all()
+    finally:
+        host.set_noise(host.DeviceNoise())
 
 
 def test_bf16_iteration_with_vgg_loss_vs_fp32_oracle(tmp_path):

@@ -237,13 +237,14 @@ def test_vgg_loss_restatement(golden_dir, tag):
     close_scaled(target.grad, T(z[tag + "_dtarget"]), 1e-3, atol=1e-9, msg="d loss / d target")
 
 
-def test_oracle_full_size_iteration_vs_reference(golden_dir):
-    """The oracle at the SHIPPED network sizes (128x128, batch 2) against one iteration of the imported reference recorded by
-    tests/golden/make_golden.py full128b2 (reference solver.py:151-240,317-353): all 16 loss scalars, sampled entries and the sum
+@pytest.mark.parametrize("S,B", [(128, 2), (64, 4)])
+def test_oracle_full_size_iteration_vs_reference(S, B, golden_dir):
+    """The oracle at the SHIPPED network sizes (128x128, batch 2; 64x64, batch 4) against one iteration of the imported reference recorded by
+    tests/golden/make_golden.py full128b2 / full64b4 (reference solver.py:151-240,317-353): all 16 loss scalars, sampled entries and the sum
     of squares of representative D and G gradients.  The GPU suite compares the HIP path with the same family of fixtures
     (tests/test_hip_parity.py::test_full_size_iteration_vs_oracle) instead of running the oracle at batch 64 on the GPU box."""
-    fx = np.load(os.path.join(golden_dir, "full_s128_b2.npz"))
-    cfg = synth.make_config(image_size=128, lstm_dropout=0.0)
+    fx = np.load(os.path.join(golden_dir, "full_s%d_b%d.npz" % (S, B)))
+    cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
     import contextlib
     import io
     import sys
@@ -255,7 +256,7 @@ def test_oracle_full_size_iteration_vs_reference(golden_dir):
     gen_sd, dis_sd = s.gen.state_dict(), s.dis.state_dict()
     oracle = orc.OracleSolver(cfg, gen_sd, dis_sd)
     oracle.copy_nets()
-    batch = synth.make_batch(2, 128, seed=11)
+    batch = synth.make_batch(B, S, seed=11)
     oracle.iteration(batch, 0)
     want = json.loads(bytes(fx["losses_json"]).decode())
     for k, v in want.items():
