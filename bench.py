@@ -92,6 +92,8 @@ KIND_KERNEL = {
     "dgrad-image-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
     "wgrad-stem": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
     "wgrad-heads-small": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
+    "wgrad-stem-x3": ("smallk_wgrad_x3_kernel", r"smallk_wgrad_x3_kernel", "bf16x3"),
+    "wgrad-heads-small-x3": ("smallk_wgrad_x3_kernel", r"smallk_wgrad_x3_kernel", "bf16x3"),
     "dgrad-ring": ("conv_gemm_strips_kernel + fold_ring_kernel (multi-launch call)", r"(conv_)?gemm_strips_kernel|fold_ring_kernel", None),
 }
 # the fp32 im2col kernels with split-product inner products (ops._timed appends -g3 to the kind)

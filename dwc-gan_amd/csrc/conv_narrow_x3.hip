@@ -31,6 +31,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NX_GROUPS = 4, NX_CH = 64;
+constexpr int SMALLK_X3_SLOTS = 256;      // workgroups of smallk_wgrad_x3_kernel resident at once (61 KB of LDS, see its registers)
 
 // fp32 x4 -> three planes of 4 bf16 (packed two per dword), exact: v = p0 + p1 + p2 (see conv_halo_x3.hip)
 __device__ __forceinline__ void nx_split3(f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
@@ -429,6 +430,225 @@ bool narrow_x3_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int K
            (size_t)B * IH * IW * NX_CH * 4 < 0x7fffffffull;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Weight gradients of both 7x7 shapes in fp32 (r05; the fp32 twin of smallk_wgrad_kernel, conv_narrow_bf16.hip -- until then these
+// ran on conv_wgrad_kernel<X3> at 0.14 of the peak, 1.05 ms of a c1 step): a correlation between a 4-plane fp32 image A and a
+// 64-channel fp32 tensor Bt over the pixels q of a grid, for the 49 offsets:
+//     C[tap][plane][c] = sum_q A[q + tap + offA][plane] * Bt[q + offB][c]
+//   stems:  A = x image (reflect rule, offA = -3), Bt = dY, grid = H x W               -> dW[c][plane][kh][kw] = C
+//   heads:  A = gradient image g (zero rule, offA = -6), Bt = x (reflect, offB = -3), grid = (H+6) x (W+6) padded positions
+//           -> dW[plane][c][6-kh][6-kw] = C
+// as exact split products (three bf16 planes per operand, six of the nine cross products, leading product and corrections in
+// separate accumulators -- conv_halo_x3.hip).  An MFMA row tile is ONE filter row: 8 horizontally adjacent taps (the 8th a dummy) x
+// 4 planes = the 32 contiguous bf16 of 8 patch pixels in a pixel-major plane image, fetched with the transposing LDS read at a
+// per-lane pixel offset; the 7 filter rows go to waves 0..6 (all 8 waves stage).  Contraction over 8x16-pixel units: the fp32 A
+// patch (14 x 24 pixels) and Bt block (128 pixels x 64 channels) of the NEXT unit are loaded into registers during the MFMAs of the
+// current one, split and written to the single LDS buffer between two barriers.  fp32 slabs per pixel split, summed in a fixed
+// order by smallk_x3_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+struct SmallWgradX3Args {
+    const float* a4;     // [B][AH][AW][4]
+    const float* b64;    // [B][BH][BW][64]
+    float* slab;         // [splits][7*32][64]
+    int B, AH, AW, BH, BW, GH, GW, offA, offB, reflA, reflB;
+    int units_x, units_per_img, total_units, units_per_split;
+};
+
+__global__ __launch_bounds__(512) void smallk_wgrad_x3_kernel(SmallWgradX3Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PCA = 24, PRA = 14;                   // A patch: (8+6) rows x (16+7 -> 24) pixels
+    constexpr int A_PL = 512 * 4, B_PL = 128 * 64;      // elements of one plane: A [pixel slot][4 planes], Bt [pixel][64 channels]
+    __shared__ __attribute__((aligned(16))) bf16 smem[3 * (A_PL + B_PL)];
+    bf16* sA = smem;                                    // [plane of the split][pixel][4]
+    bf16* sB = smem + 3 * A_PL;                         // [plane of the split][pixel][64], 16-byte chunks swizzled by (pixel >> 1) & 1
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int split = blockIdx.x;
+    const int u0 = split * a.units_per_split, u1 = min(a.total_units, u0 + a.units_per_split);
+
+    // ---- staging: fp32 global -> registers (next unit, during the MFMAs) -> three bf16 planes in LDS -------------------------
+    f32x4 ra, rb[4];
+    auto load_unit = [&](int u) {
+        const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
+        const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
+        const int gy0 = uy * 8, gx0 = ux * 16;
+        {   // A patch: thread t = patch pixel t
+            const int pr = t / PCA, pc = t - pr * PCA;
+            int h = gy0 + pr + a.offA, w = gx0 + pc + a.offA;
+            bool ok = t < PRA * PCA;
+            if (a.reflA) {
+                h = reflect_idx(h, a.AH);
+                w = reflect_idx(w, a.AW);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.AH && (unsigned)w < (unsigned)a.AW;
+            }
+            h = min(max(h, 0), a.AH - 1);
+            w = min(max(w, 0), a.AW - 1);
+            ra = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) ra = *reinterpret_cast<const f32x4*>(a.a4 + ((size_t)(n * a.AH + h) * a.AW + w) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // Bt block: quad id -> (pixel m, channels 4q..4q+3); pixels outside the grid contribute zeros
+            const int id = t + 512 * i;
+            const int m = id >> 4, q = id & 15;
+            const int gy = gy0 + (m >> 4), gx = gx0 + (m & 15);
+            int h = gy + a.offB, w = gx + a.offB;
+            bool ok = gy < a.GH && gx < a.GW;
+            if (a.reflB) {
+                h = reflect_idx(h, a.BH);
+                w = reflect_idx(w, a.BW);
+            } else {
+                ok = ok && (unsigned)h < (unsigned)a.BH && (unsigned)w < (unsigned)a.BW;
+            }
+            h = min(max(h, 0), a.BH - 1);
+            w = min(max(w, 0), a.BW - 1);
+            rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) rb[i] = *reinterpret_cast<const f32x4*>(a.b64 + ((size_t)(n * a.BH + h) * a.BW + w) * 64 + q * 4);
+        }
+    };
+    auto write_unit = [&]() {
+        {
+            u32x2 p0, p1, p2;
+            nx_split3(ra, p0, p1, p2);
+            *reinterpret_cast<u32x2*>(sA + 0 * A_PL + t * 4) = p0;
+            *reinterpret_cast<u32x2*>(sA + 1 * A_PL + t * 4) = p1;
+            *reinterpret_cast<u32x2*>(sA + 2 * A_PL + t * 4) = p2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = t + 512 * i;
+            const int m = id >> 4, q = id & 15;
+            const int el = m * 64 + (((q >> 1) ^ (4 * ((m >> 1) & 1))) << 3) + (q & 1) * 4;
+            u32x2 p0, p1, p2;
+            nx_split3(rb[i], p0, p1, p2);
+            *reinterpret_cast<u32x2*>(sB + 0 * B_PL + el) = p0;
+            *reinterpret_cast<u32x2*>(sB + 1 * B_PL + el) = p1;
+            *reinterpret_cast<u32x2*>(sB + 2 * B_PL + el) = p2;
+        }
+    };
+
+    // ---- fragments: transposing reads (ds_read_b64_tr_b16), lane 4q+p of a 16-lane group addresses pixel q, elements 4p..4p+3 ------
+    const int kh = wave;                                // waves 0..6: filter row kh; wave 7 only stages
+    f32x16 acc[2], lo[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f, lo[c][r] = 0.f;
+    const int li = lane & 15, gam = (lane >> 4) & 1, hi = lane >> 5;
+    const int tq = li >> 2, tp = li & 3;
+    const int pxl = 8 * hi + tq;
+    // A: row (kw, plane) = kw*4 + plane IS the element offset from the row's first pixel (taps are consecutive pixels, planes
+    // consecutive elements): this lane addresses pixel + (4*gam + tp), all four planes
+    const int row_el = 16 * gam + 4 * tp;
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    auto tr = [](const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p); };
+    auto step = [&](int ks) {
+        bf16x8 fa[3], fb[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const bf16* pa = sA + pl * A_PL + ((ks + kh) * PCA + pxl) * 4 + row_el;
+            fa[pl] = __builtin_shufflevector(tr(pa), tr(pa + 4 * 4), 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int col = ct * 32 + 16 * gam + 4 * tp;
+                const int m0 = ks * 16 + pxl, m1 = m0 + 4;
+                const bf16* b0 = sB + pl * B_PL + m0 * 64 + (((col >> 3) ^ (4 * ((m0 >> 1) & 1))) << 3) + (col & 7);
+                const bf16* b1 = sB + pl * B_PL + m1 * 64 + (((col >> 3) ^ (4 * ((m1 >> 1) & 1))) << 3) + (col & 7);
+                fb[ct][pl] = __builtin_shufflevector(tr(b0), tr(b1), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ct][0], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ct][1], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][2], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ct][0], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][1], lo[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][0], acc[ct], 0, 0, 0);
+        }
+    };
+
+    if (u0 < u1) {
+        load_unit(u0);
+        write_unit();
+        __syncthreads();
+        for (int u = u0; u < u1; ++u) {
+            const bool next = u + 1 < u1;
+            if (next) load_unit(u + 1);                  // in flight during the MFMAs of this unit
+            if (kh < 7) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) step(ks);
+            }
+            __syncthreads();                             // every wave has read the unit
+            if (next) {
+                write_unit();
+                __syncthreads();
+            }
+        }
+    }
+    // slab[split][kh*32 + row][c]: D[row][c], lane = column c, registers = rows
+    if (kh < 7) {
+        const int l31 = lane & 31;
+        float* out = a.slab + (size_t)split * (7 * 32 * 64);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                out[(size_t)(kh * 32 + row) * 64 + c * 32 + l31] = acc[c][r] + lo[c][r];
+            }
+    }
+#endif
+}
+
+// sum the slabs in a fixed order; (kh, row) -> column kw = row >> 2 (column 7 is the dummy), plane row & 3;
+// dst index = c * sc + plane * sp + kh' * 7 + kw' with (kh', kw') flipped for the heads  (smallk_reduce_kernel of conv_narrow_bf16.hip)
+__global__ __launch_bounds__(256) void smallk_x3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int splits, int planes,
+                                                               int sc, int sp, int flip) {
+    constexpr int N = 7 * 32 * 64;
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    const int per = (splits + 7) / 8;
+    const int z0 = g * per, z1 = min(splits, z0 + per);
+    float s = 0.f;
+    if (idx < N) {
+        const float* p = slab + idx;
+        int z = z0;
+        for (; z + 8 <= z1; z += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(z + u) * N];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < z1; ++z) s += p[(size_t)z * N];
+    }
+    part[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= N) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s += part[q][e];
+    const int c = idx & 63, k = idx >> 6;
+    const int kh = k >> 5, row = k & 31;
+    const int kw = row >> 2, pl = row & 3;
+    if (kw >= 7 || pl >= planes) return;
+    const int khd = flip ? 6 - kh : kh, kwd = flip ? 6 - kw : kw;
+    dw[(size_t)c * sc + (size_t)pl * sp + khd * 7 + kwd] = s;
+}
+
+void smallk_x3_plan(int B, int GH, int GW, int* splits, int* ups, int* units_x, int* upi) {
+    *units_x = (GW + 15) / 16;
+    *upi = ((GH + 7) / 8) * *units_x;
+    const int units = B * *upi;
+    int s = SMALLK_X3_SLOTS;
+    if (s > units / 4) s = units / 4 > 0 ? units / 4 : 1;
+    *ups = (units + s - 1) / s;
+    *splits = (units + *ups - 1) / *ups;
+}
+
 }  // namespace
 
 extern "C" {
@@ -501,6 +721,39 @@ int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bi
 int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, float* y, int B, int IH, int IW, int OH, int OW, int K,
                        int off, int act, int reflect, void* stream) {
     return dwc_x3_conv2d_stem_crop(x, w_steps, bias, y, nullptr, 0, B, IH, IW, OH, OW, K, off, act, reflect, stream);
+}
+
+size_t dwc_x3_conv7_smallk_wgrad_ws_bytes(int B, int H, int W, int heads) {
+    int splits, ups, ux, upi;
+    smallk_x3_plan(B, heads ? H + 6 : H, heads ? W + 6 : W, &splits, &ups, &ux, &upi);
+    return (size_t)splits * 7 * 32 * 64 * sizeof(float);
+}
+
+/* Weight gradient of the two 7x7 layer shapes between an NHWC4 fp32 image (img4: [B][H][W][4]) and a 64-channel fp32 tensor
+ * (t64: [B][H][W][64]), pad 3, reflect padding in the forward, as exact split products (smallk_wgrad_x3_kernel):
+ *   heads == 0 (stems, 4 -> 64): img4 = the input image x, t64 = dY;                            dw: [64][planes][7][7] fp32
+ *   heads != 0 (image heads, 64 -> 4): img4 = dY (pre-activation gradient), t64 = the input x;   dw: [planes][64][7][7] fp32
+ * `planes` <= 4 real planes are written.  Scratch: dwc_x3_conv7_smallk_wgrad_ws_bytes.  Replaces the same reference call sites
+ * (networks_v2.py:106,159-160, networks.py:432 through autograd) as dwc_bf16_conv7_smallk_wgrad. */
+int dwc_x3_conv7_smallk_wgrad(const float* img4, const float* t64, float* dw, int B, int H, int W, int planes, int heads, void* ws,
+                              size_t ws_bytes, void* stream) {
+    if (!img4 || !t64 || !dw || B <= 0 || H < 7 || W < 7 || planes < 1 || planes > 4) return DWC_EINVAL;
+    SmallWgradX3Args a;
+    int splits;
+    a.GH = heads ? H + 6 : H; a.GW = heads ? W + 6 : W;
+    smallk_x3_plan(B, a.GH, a.GW, &splits, &a.units_per_split, &a.units_x, &a.units_per_img);
+    if (!ws || ws_bytes < (size_t)splits * 7 * 32 * 64 * sizeof(float)) return DWC_EWORKSPACE;
+    a.a4 = img4; a.b64 = t64; a.slab = (float*)ws;
+    a.B = B; a.AH = H; a.AW = W; a.BH = H; a.BW = W;
+    a.offA = heads ? -6 : -3; a.offB = heads ? -3 : 0; a.reflA = heads ? 0 : 1; a.reflB = heads ? 1 : 0;
+    a.total_units = B * a.units_per_img;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(smallk_wgrad_x3_kernel, dim3(splits), dim3(512), 0, st, a);
+    DWC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(smallk_x3_reduce_kernel, dim3((7 * 32 * 64 + 31) / 32), dim3(256), 0, st, (const float*)ws, dw, splits, planes,
+                       heads ? 49 : planes * 49, heads ? 64 * 49 : 49, heads ? 1 : 0);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
 }
 
 }  // extern "C"

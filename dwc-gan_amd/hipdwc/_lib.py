@@ -152,6 +152,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_wgrad_halo": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv7_smallk_wgrad_ws_bytes": (c_sz, [c_int] * 4),
     "dwc_bf16_conv7_smallk_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp, c_sz, c_fp]),
+    "dwc_x3_conv7_smallk_wgrad_ws_bytes": (c_sz, [c_int] * 4),
+    "dwc_x3_conv7_smallk_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 5 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_stem_ok": (c_int, [c_int] * 7),
     "dwc_bf16_conv2d_stem": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
     "dwc_bf16_conv2d_stem_crop": (c_int, [c_fp] * 5 + [c_int] * 10 + [c_fp]),
@@ -181,7 +183,7 @@ SIGNATURES = {
     "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
-ABI_VERSION = 5                # DWC_ABI_VERSION of include/dwcgan_hip.h
+ABI_VERSION = 6                # DWC_ABI_VERSION of include/dwcgan_hip.h
 EINVAL = -1
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
            -3: "DWC_ELAUNCH (kernel launch failed)"}

@@ -534,6 +534,7 @@ WGRAD_HALO = int(os.environ.get("DWC_BF16_WGRAD_HALO", "1"))
 STEM = int(os.environ.get("DWC_BF16_STEM", "1"))
 NARROW = int(os.environ.get("DWC_BF16_NARROW", "1"))      # 64 -> 8-plane 7x7 convolutions on csrc/conv_narrow_bf16.hip
 NARROW_X3 = int(os.environ.get("DWC_X3_NARROW", "1"))     # fp32: 64 -> 4-plane 7x7 convolutions on csrc/conv_narrow_x3.hip (split products)
+SMALLK_X3 = int(os.environ.get("DWC_X3_SMALLK", "1"))     # fp32 7x7 weight gradients on smallk_wgrad_x3_kernel (0: the im2col weight gradient)
 LSTM_SEQ = int(os.environ.get("DWC_LSTM_SEQ", "1"))       # text-encoder LSTM forward: all time steps in one persistent launch
 DGRAD_FOLD = int(os.environ.get("DWC_DGRAD_FOLD", "1"))   # data gradients through a reflect pad: interior straight into dx + band fold
 X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 forwards as split products (csrc/conv_halo_x3.hip, S2)
@@ -867,6 +868,14 @@ class _Conv2d(torch.autograd.Function):
                 _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
                     x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st),
                     scope_name=ctx.bscope, detail="wgrad-stem" + detail[5:]), "conv7_smallk_wgrad")
+            elif ((not half) and X3 and SMALLK_X3 and Cx == 4 and cop == 64 and stride == 1 and KH == 7 and KW == 7 and pad == 3
+                  and Cout == 64):
+                # fp32 7x7 stem on an NHWC4 image: one filter row (8 taps x 4 planes) per MFMA row tile, split products
+                # (csrc/conv_narrow_x3.hip smallk_wgrad_x3_kernel)
+                ws = workspace(lib.dwc_x3_conv7_smallk_wgrad_ws_bytes(B, H, W, 0), dev)
+                _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv7_smallk_wgrad(
+                    x.data_ptr(), g.data_ptr(), dw.data_ptr(), B, H, W, Cin, 0, ws.data_ptr(), ws.numel(), st),
+                    scope_name=ctx.bscope, detail="wgrad-stem-x3" + detail[5:], exec_flops=6 * flops), "x3_conv7_smallk_wgrad")
             elif ((not half) and (_x3_use(lib, B, H, W, Cx, cop, KH, KW, stride, pad)
                                   or (X3 and X3_S2 and stride == 2 and KH == 4 and KW == 4 and pad == 1))
                   and (KH != 3 or X3_WGRAD_HALO3)
@@ -1167,6 +1176,13 @@ class _HeadsConvWide(torch.autograd.Function):
             _lib.check(_timed("conv_wgrad_kernel+reduce", flops, lambda: lib.dwc_bf16_conv7_smallk_wgrad(
                 g.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, P, 1, ws.data_ptr(), ws.numel(), st), scope_name=ctx.bscope,
                 detail="wgrad-heads-small B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH)), "conv7_smallk_wgrad")
+        elif ctx.needs_input_grad[1] and (not half) and X3 and SMALLK_X3 and P == 4 and C == 64 and KH == 7 and KW == 7:
+            # fp32 image heads: the same kernel with the roles swapped (A = the gradient image, Bt = x on the padded grid)
+            dw = torch.empty((P, C, KH, KW), dtype=torch.float32, device=dev)
+            ws = workspace(lib.dwc_x3_conv7_smallk_wgrad_ws_bytes(B, H, W, 1), dev)
+            _lib.check(_timed("wgrad_x3_kernel+reduce", flops, lambda: lib.dwc_x3_conv7_smallk_wgrad(
+                g.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, P, 1, ws.data_ptr(), ws.numel(), st), scope_name=ctx.bscope,
+                detail="wgrad-heads-small-x3 B%d %dx%d %d>%d k%d" % (B, H, W, C, P, KH), exec_flops=6 * flops), "x3_conv7_smallk_wgrad")
         elif ctx.needs_input_grad[1]:        # weight gradient of the wide filter bank, folded back onto the real taps
             dwide = torch.empty((32, C, KH, KW + px - 1), dtype=torch.float32, device=dev)
             nws = _fn(lib, "conv2d_bwd_weight_ex_ws_bytes", x)(B, H, W, C, 32, KH, KW + px - 1, 1, px, pad, pad)

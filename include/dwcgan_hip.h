@@ -48,7 +48,7 @@ extern "C" {
 /* Version of this C ABI: bumped with every change of an entry point's signature or of a structure passed through it (r05: 5 --
  * dwc_weight_refresh_multi gained has_h2 / epoch, the dwc_h2_* / dwc_*_amax entry points).  A binding must refuse a library that
  * reports another number: symbols alone do not tell a changed argument list (hipdwc/_lib.py does). */
-#define DWC_ABI_VERSION 5
+#define DWC_ABI_VERSION 6
 int dwc_version(void);
 /* The fp32 im2col kernels (dwc_conv2d_fwd / _bwd_data* / _bwd_weight*, ring strips) take their inner products as exact three-way
  * bf16 split products on the bf16 matrix cores by default (r04; fp32 operands, results and accumulation -- see
@@ -361,6 +361,14 @@ int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, f
 int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bias, float* y, float* inner, int crop, int B, int IH, int IW,
                             int OH, int OW, int K, int off, int act, int reflect, void* stream);
 int dwc_reflect_pad_adjoint_band(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream);
+/* r05: weight gradient of the two 7x7 layer shapes in fp32 as exact split products -- the fp32 twin of dwc_bf16_conv7_smallk_wgrad
+ * (reference networks_v2.py:106,159-160, networks.py:432 through autograd): between an NHWC4 fp32 image img4:[B][H][W][4] and a
+ * 64-channel fp32 tensor t64:[B][H][W][64], pad 3, reflect padding in the forward.  heads == 0 (stems, 4 -> 64): img4 = x, t64 = dY,
+ * dw:[64][planes][7][7]; heads != 0 (image heads, 64 -> 4): img4 = dY (pre-activation gradient), t64 = x, dw:[planes][64][7][7].
+ * planes <= 4 real planes are written.  Scratch: dwc_x3_conv7_smallk_wgrad_ws_bytes. */
+size_t dwc_x3_conv7_smallk_wgrad_ws_bytes(int B, int H, int W, int heads);
+int dwc_x3_conv7_smallk_wgrad(const float* img4, const float* t64, float* dw, int B, int H, int W, int planes, int heads, void* ws,
+                              size_t ws_bytes, void* stream);
 /* Small launches (r04): when a shape yields at most 256 tiles of 256 pixels x 64 channels (3x3 256->256 on 32x32 at batch 16) the
  * two-workgroups-per-CU kernel would run one workgroup per CU; the _ws forms cut such launches along the CONTRACTION instead --
  * two workgroups per tile, each half of the channel slabs; the first to finish leaves its half sum in `ws`, the second adds it to

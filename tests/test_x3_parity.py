@@ -341,3 +341,44 @@ def test_x3_contraction_split_of_small_launches(shape):
         assert torch.equal(again, first), "run %d differs" % it
     torch.cuda.synchronize()
     assert int(tickets.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("heads", [0, 1])
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (1, 21, 24), (3, 16, 40), (2, 9, 7)])
+def test_x3_smallk_weight_gradient_matches_float64(B, H, W, heads):
+    """r05: the 7x7 weight gradients of the stems (4-plane image -> 64 channels) and of the image heads (64 channels -> 4 planes) on
+    smallk_wgrad_x3_kernel (csrc/conv_narrow_x3.hip) through the C ABI, against the float64 gradient of the reflect-padded
+    convolution: error <= 5e-6 of the gradient's scale and <= 2x the fp32 CPU gradient's (+2e-7).  Sizes that are not multiples of the
+    8x16-pixel unit included; plane 3 of the image is the attention plane for the heads and zero padding for the stems."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 * B + H + W + heads)
+    planes = 4 if heads else 3
+    img = torch.randn(B, planes, H, W, generator=g)
+    t64 = torch.randn(B, 64, H, W, generator=g)
+
+    def cpu(dtype):
+        if heads:      # y = conv(pad(x64), w[4,64,7,7]); dY = img
+            w = torch.zeros(planes, 64, 7, 7, dtype=dtype, requires_grad=True)
+            y = F.conv2d(F.pad(t64.to(dtype), (3,) * 4, mode="reflect"), w)
+            (y * img.to(dtype)).sum().backward()
+        else:          # y = conv(pad(img), w[64,3,7,7]); dY = t64
+            w = torch.zeros(64, planes, 7, 7, dtype=dtype, requires_grad=True)
+            y = F.conv2d(F.pad(img.to(dtype), (3,) * 4, mode="reflect"), w)
+            (y * t64.to(dtype)).sum().backward()
+        return w.grad.double()
+
+    ref, ref32 = cpu(torch.float64), cpu(torch.float32)
+    img4 = torch.zeros(B, H, W, 4)
+    img4[..., :planes] = img.permute(0, 2, 3, 1)
+    img4 = img4.to(DEV).contiguous()
+    t = t64.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.full(tuple(ref.shape), float("nan"), dtype=torch.float32, device=DEV)
+    ws = torch.empty(lib.dwc_x3_conv7_smallk_wgrad_ws_bytes(B, H, W, heads), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.dwc_x3_conv7_smallk_wgrad(img4.data_ptr(), t.data_ptr(), dw.data_ptr(), B, H, W, planes, heads, ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream), "x3_conv7_smallk_wgrad")
+    torch.cuda.synchronize()
+    got = dw.double().cpu()
+    scale = ref.abs().max().item()
+    e, e32 = (got - ref).abs().max().item() / scale, (ref32 - ref).abs().max().item() / scale
+    print("smallk x3 heads=%d B%d %dx%d: split %.2e cpu-fp32 %.2e" % (heads, B, H, W, e, e32))
+    assert e <= 5e-6 and e <= 2 * e32 + 2e-7, (e, e32)
