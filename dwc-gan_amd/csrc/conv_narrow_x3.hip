@@ -544,29 +544,32 @@ __global__ __launch_bounds__(512) void smallk_wgrad_x3_kernel(SmallWgradX3Args a
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) bf16x4* lds4;
     auto tr = [](const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)p); };
-    auto step = [&](int ks) {
-        bf16x8 fa[3], fb[2][3];
+    // fragments of k-step ks into set `st` (two sets: the reads of step ks + 1 are issued in front of the MFMAs of step ks)
+    bf16x8 fa[2][3], fb[2][2][3];
+    auto fetch = [&](int st, int ks) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             const bf16* pa = sA + pl * A_PL + ((ks + kh) * PCA + pxl) * 4 + row_el;
-            fa[pl] = __builtin_shufflevector(tr(pa), tr(pa + 4 * 4), 0, 1, 2, 3, 4, 5, 6, 7);
+            fa[st][pl] = __builtin_shufflevector(tr(pa), tr(pa + 4 * 4), 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int col = ct * 32 + 16 * gam + 4 * tp;
                 const int m0 = ks * 16 + pxl, m1 = m0 + 4;
                 const bf16* b0 = sB + pl * B_PL + m0 * 64 + (((col >> 3) ^ (4 * ((m0 >> 1) & 1))) << 3) + (col & 7);
                 const bf16* b1 = sB + pl * B_PL + m1 * 64 + (((col >> 3) ^ (4 * ((m1 >> 1) & 1))) << 3) + (col & 7);
-                fb[ct][pl] = __builtin_shufflevector(tr(b0), tr(b1), 0, 1, 2, 3, 4, 5, 6, 7);
+                fb[st][ct][pl] = __builtin_shufflevector(tr(b0), tr(b1), 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
+    };
+    auto compute = [&](int st) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[ct][0], lo[ct], 0, 0, 0);
-            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ct][1], lo[ct], 0, 0, 0);
-            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][2], lo[ct], 0, 0, 0);
-            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[ct][0], lo[ct], 0, 0, 0);
-            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][1], lo[ct], 0, 0, 0);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[ct][0], acc[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][2], fb[st][ct][0], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][1], fb[st][ct][1], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][0], fb[st][ct][2], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][1], fb[st][ct][0], lo[ct], 0, 0, 0);
+            lo[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][0], fb[st][ct][1], lo[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st][0], fb[st][ct][0], acc[ct], 0, 0, 0);
         }
     };
 
@@ -578,8 +581,12 @@ __global__ __launch_bounds__(512) void smallk_wgrad_x3_kernel(SmallWgradX3Args a
             const bool next = u + 1 < u1;
             if (next) load_unit(u + 1);                  // in flight during the MFMAs of this unit
             if (kh < 7) {
+                fetch(0, 0);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) step(ks);
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks + 1 < 8) fetch((ks + 1) & 1, ks + 1);
+                    compute(ks & 1);
+                }
             }
             __syncthreads();                             // every wave has read the unit
             if (next) {
