@@ -79,68 +79,20 @@ __device__ __forceinline__ void colsum_groups(float (&a)[V], float (&b)[V], floa
     }
 }
 
-// Last-arriver finalisation (r03): the workgroups of a statistics pass publish their partials with write-through (agent-scope)
-// stores, drain them, and take a ticket per sample; the workgroup that draws the last ticket of a sample reads every partial of
-// that sample back (agent-scope loads: another XCD's L2 may hold none of them) and does what the *_final kernel did -- one launch
-// less per norm pass (a c1 step has 92 of them at ~7 us each).  Nobody waits for anybody, so there is nothing to hang; the
-// summation order is the fixed chunk order, independent of which workgroup arrives last.  Tickets reset themselves.
-// The tickets are CALLER-OWNED device words (>= B of them, zero before first use; one row per stream that may run norm launches
-// concurrently): the library keeps no mutable state of its own, on any device.  Ordering: the ticket increment is an
-// agent-scope ACQ_REL read-modify-write behind the workgroup barrier that follows every wave's drained write-through stores
-// (release side), and every thread of the last-arriving workgroup passes an agent-scope acquire fence before it reads the
-// other workgroups' partials back (acquire side).
-typedef __attribute__((address_space(1))) unsigned norm_gu32;
-constexpr int NORM_TICKET_MAX_B = 64;     // above this batch the per-workgroup publish + ticket costs more than the *_final launch it saves
-
-__device__ __forceinline__ void norm_publish(float* p, float v) {
-    __hip_atomic_store((norm_gu32*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float norm_read(const float* p) {
-    return __uint_as_float(__hip_atomic_load((norm_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-// a += sum_k p[k*C], b += sum_k p[plane + k*C] in chunk order, eight loads of each plane in flight at a time
-__device__ __forceinline__ void norm_sum_partials(const float* p, size_t plane, int C, int chunks, float& a, float& b) {
-    int k = 0;
-    for (; k + 8 <= chunks; k += 8) {
-        float va[8], vb[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            va[u] = norm_read(p + (size_t)(k + u) * C);
-            vb[u] = norm_read(p + plane + (size_t)(k + u) * C);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a += va[u], b += vb[u];
-    }
-    for (; k < chunks; ++k) {
-        a += norm_read(p + (size_t)k * C);
-        b += norm_read(p + plane + (size_t)k * C);
-    }
-}
-
-// true in every thread of the workgroup that arrived last at `ticket` (of `expected` workgroups); call after the partial stores
-__device__ __forceinline__ bool norm_last_arriver(unsigned* ticket, unsigned expected) {
-    __shared__ unsigned s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's published partials have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add((norm_gu32*)ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev + 1 == expected;
-        if (s_last) __hip_atomic_store((norm_gu32*)ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-reset for the next launch
-    }
-    __syncthreads();
-    if (s_last != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // before any thread reads the others' partials
-    return s_last != 0;
-}
+// (Rounds 3-4 finalised the statistics inside the partial launch at small batches -- write-through partials, a ticket per sample, the
+// last-arriving workgroup of a sample summing them -- to save the *_final launch.  r05 measured what that costs at batch 16 on the
+// planes the resident kernels do not take: 2 048 agent-scope acquire/release tickets per launch, in_stats_partial 71.9 us fused
+// against 13.0 + 5.2 us as two launches once the final kernel is parallel over the chunks (in_stats_final_wide), in_bwd_partial 89.0
+// against 21.4 + 4.8.  The mechanism was removed; the `tickets` argument of the entry points is accepted and ignored.)
+constexpr int NORM_TICKET_WORDS = 64;     // dwc_instnorm_ticket_words(): what rounds 3-4 asked callers to keep per stream
 
 // ---------------------------------------------------------------------------------------
 // instance norm
 // ---------------------------------------------------------------------------------------
 // partial[(n*chunks+chunk)*C + c] = sum (x-pivot), second plane = sum (x-pivot)^2
-template <typename T, bool FUSED = false>
+template <typename T>
 __global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
-                                                        int rows_per_chunk, size_t plane, float* __restrict__ mean = nullptr,
-                                                        float* __restrict__ rstd = nullptr, float eps = 0.f,
-                                                        unsigned* __restrict__ tickets = nullptr) {
+                                                        int rows_per_chunk, size_t plane) {
     constexpr int V = VecOf<T>::V;
     __shared__ float sm[2 * 256 * V];
     const int cq = C / V;
@@ -184,49 +136,74 @@ __global__ __launch_bounds__(256) void in_stats_partial(const T* __restrict__ x,
     colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
         const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
-        if constexpr (FUSED) {
-#pragma unroll
-            for (int k = 0; k < V; ++k) {
-                norm_publish(part + o + k, s1[k]);
-                norm_publish(part + plane + o + k, s2[k]);
-            }
-        } else {
-            stf<V>(part, o, s1);
-            stf<V>(part + plane, o, s2);
-        }
-    }
-    if constexpr (FUSED) {
-        if (!norm_last_arriver(tickets + n, gridDim.x)) return;
-        // what in_stats_final does, for the C channels of sample n
-        const int chunks = gridDim.x;
-        const float inv = 1.f / (float)HW;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float a = 0.f, b = 0.f;
-            norm_sum_partials(part + (size_t)n * chunks * C + c, plane, C, chunks, a, b);
-            const float d = a * inv;
-            const float var = fmaxf(b * inv - d * d, 0.f);
-            mean[(size_t)n * C + c] = (float)xs[c] + d;
-            rstd[(size_t)n * C + c] = 1.f / sqrtf(var + eps);
-        }
+        stf<V>(part, o, s1);
+        stf<V>(part + plane, o, s2);
     }
 }
 
-template <typename T>
-__global__ void in_stats_final(const T* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
-                               float* __restrict__ rstd, int B, int HW, int C, int chunks, size_t plane, float eps) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * C) return;
-    const int n = idx / C, c = idx - n * C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-        s1 += part[(size_t)(n * chunks + k) * C + c];
-        s2 += part[plane + (size_t)(n * chunks + k) * C + c];
+// Sum of the per-chunk partials of one (sample, channel): 64 channels x 4 chunk lanes per workgroup, chunk lane q takes chunks q, q + 4, ...
+// with eight loads per plane in flight, the four lane sums are added in lane order (fixed order: bitwise reproducible).  r05: the
+// one-thread-per-channel loops of in_stats_final / in_bwd_final took 17-33 us at batch 16 (64-128 chunks, one dependent load after
+// the other), and the fused finalisation in the last-arriving workgroup of a sample 20-60 us more than that (2 048 agent-scope
+// acquire/release tickets per launch): in_stats_partial 71.9 us fused against 12.6 + 33.1 unfused at 16 x 128 x 128 x 64.
+__device__ __forceinline__ void norm_chunk_lanes(const float* __restrict__ p, size_t plane, int C, int chunks, int q, float& a, float& b) {
+    int k = q;
+    for (; k + 28 < chunks; k += 32) {
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            va[u] = p[(size_t)(k + 4 * u) * C];
+            vb[u] = p[plane + (size_t)(k + 4 * u) * C];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += va[u], b += vb[u];
     }
+    for (; k < chunks; k += 4) {
+        a += p[(size_t)k * C];
+        b += p[plane + (size_t)k * C];
+    }
+}
+
+// grid (ceil(C / 64), B), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void in_stats_final_wide(const T* __restrict__ x, const float* __restrict__ part, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int HW, int C, int chunks, size_t plane, float eps) {
+    __shared__ float sm[2][4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C) norm_chunk_lanes(part + (size_t)n * chunks * C + c, plane, C, chunks, q, a, b);
+    sm[0][q][cl] = a;
+    sm[1][q][cl] = b;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+    const float s1 = ((sm[0][0][cl] + sm[0][1][cl]) + sm[0][2][cl]) + sm[0][3][cl];
+    const float s2 = ((sm[1][0][cl] + sm[1][1][cl]) + sm[1][2][cl]) + sm[1][3][cl];
     const float inv = 1.f / (float)HW;
     const float d = s1 * inv;
     const float var = fmaxf(s2 * inv - d * d, 0.f);
-    mean[idx] = (float)x[(size_t)n * HW * C + c] + d;
-    rstd[idx] = 1.f / sqrtf(var + eps);
+    mean[(size_t)n * C + c] = (float)x[(size_t)n * HW * C + c] + d;
+    rstd[(size_t)n * C + c] = 1.f / sqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void in_bwd_final_wide(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int BC, int C, int chunks, size_t plane) {
+    __shared__ float sm[2][4][64];
+    const int n = blockIdx.y, cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C) norm_chunk_lanes(part + (size_t)n * chunks * C + c, plane, C, chunks, q, a, b);
+    sm[0][q][cl] = a;
+    sm[1][q][cl] = b;
+    __syncthreads();
+    if (q != 0 || c >= C) return;
+    const float s1 = ((sm[0][0][cl] + sm[0][1][cl]) + sm[0][2][cl]) + sm[0][3][cl];
+    const float s2 = ((sm[1][0][cl] + sm[1][1][cl]) + sm[1][2][cl]) + sm[1][3][cl];
+    const size_t idx = (size_t)n * C + c;
+    sums[idx] = s1;
+    sums[BC + idx] = s2;
+    if (dgamma) dgamma[idx] = s2;
+    if (dbeta) dbeta[idx] = s1;
 }
 
 template <typename T>
@@ -296,14 +273,12 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
     }
 }
 
-template <typename T, bool FUSED = false>
+template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       float* __restrict__ part, int HW, int C, int rows_per_chunk, size_t plane,
-                                                      int relu, float* __restrict__ sums = nullptr, float* __restrict__ dgamma = nullptr,
-                                                      float* __restrict__ dbeta = nullptr, int BC = 0,
-                                                      unsigned* __restrict__ tickets = nullptr) {
+                                                      int relu) {
     constexpr int V = VecOf<T>::V;
     __shared__ float sm[2 * 256 * V];
     const int cq = C / V;
@@ -358,48 +333,9 @@ __global__ __launch_bounds__(256) void in_bwd_partial(const T* __restrict__ dy, 
     colsum_groups<V>(s1, s2, sm, groups, cq, col, rg);
     if (rg == 0) {
         const size_t o = ((size_t)(n * gridDim.x + chunk) * C) + col * V;
-        if constexpr (FUSED) {
-#pragma unroll
-            for (int k = 0; k < V; ++k) {
-                norm_publish(part + o + k, s1[k]);
-                norm_publish(part + plane + o + k, s2[k]);
-            }
-        } else {
-            stf<V>(part, o, s1);
-            stf<V>(part + plane, o, s2);
-        }
+        stf<V>(part, o, s1);
+        stf<V>(part + plane, o, s2);
     }
-    if constexpr (FUSED) {
-        if (!norm_last_arriver(tickets + n, gridDim.x)) return;
-        // what in_bwd_final does, for the C channels of sample n
-        const int chunks = gridDim.x;
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float a = 0.f, b = 0.f;
-            norm_sum_partials(part + (size_t)n * chunks * C + c, plane, C, chunks, a, b);
-            const size_t idx = (size_t)n * C + c;
-            sums[idx] = a;
-            sums[BC + idx] = b;
-            if (dgamma) dgamma[idx] = b;
-            if (dbeta) dbeta[idx] = a;
-        }
-    }
-}
-
-// sums[0..BC) = sum dy_eff, sums[BC..2BC) = sum dy_eff*xhat; also dgamma/dbeta when requested
-__global__ void in_bwd_final(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ dgamma,
-                             float* __restrict__ dbeta, int BC, int C, int chunks, size_t plane) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= BC) return;
-    const int n = idx / C, c = idx - n * C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-        s1 += part[(size_t)(n * chunks + k) * C + c];
-        s2 += part[plane + (size_t)(n * chunks + k) * C + c];
-    }
-    sums[idx] = s1;
-    sums[BC + idx] = s2;
-    if (dgamma) dgamma[idx] = s2;
-    if (dbeta) dbeta[idx] = s1;
 }
 
 template <typename T>
@@ -1069,7 +1005,6 @@ int in_resident_hw(int HW, int C) {
 // The caller's ticket row for one statistics launch, or null when the batch is too large for the fused finalisation to pay
 // (measured r03: worth it at small batches -- c1, B = 16..48: 0.80 -> 0.71 ms and 0.86 -> 0.79 ms of statistics kernels per step plus
 // 92 launch boundaries; at B >= 128 the per-workgroup publish + ticket costs more than the *_final launch it saves).
-inline unsigned* norm_tickets(unsigned* tickets, int B) { return (tickets && B <= NORM_TICKET_MAX_B) ? tickets : nullptr; }
 
 size_t instnorm_ws_bytes(int B, int HW, int C) {
     const RowSplit rs = plan_rows(B, HW);
@@ -1099,17 +1034,10 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
     const RowSplit rs = plan_rows(B, HW);
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
-    if (unsigned* tk = norm_tickets(tickets, B)) {            // statistics + finalisation in one launch (last-arriver workgroup per sample)
-        hipLaunchKernelGGL((in_stats_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane,
-                           mean, rstd, eps, tk);
-        DWC_LAUNCH_CHECK();
-    } else {
-        hipLaunchKernelGGL(in_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
-        DWC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(in_stats_final<T>, dim3((B * C + 255) / 256), dim3(256), 0, st, x, part, mean, rstd, B, HW, C, rs.chunks,
-                           plane, eps);
-        DWC_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(in_stats_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, x, part, HW, C, rs.rows_per_chunk, plane);
+    DWC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(in_stats_final_wide<T>, dim3((C + 63) / 64, B), dim3(256), 0, st, x, part, mean, rstd, HW, C, rs.chunks, plane, eps);
+    DWC_LAUNCH_CHECK();
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, x, mean, rstd, gamma, beta, residual, y, HW, C,
                        ra.rows_per_chunk, relu, amax, amax_ep);
@@ -1141,18 +1069,11 @@ int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd
     const size_t plane = (size_t)B * rs.chunks * C;
     float* part = (float*)ws;
     float* sums = part + 2 * plane;
-    if (unsigned* tk = norm_tickets(tickets, B)) {
-        hipLaunchKernelGGL((in_bwd_partial<T, true>), dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
-                           rs.rows_per_chunk, plane, relu, sums, dgamma, dbeta, B * C, tk);
-        DWC_LAUNCH_CHECK();
-    } else {
-        hipLaunchKernelGGL(in_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
-                           rs.rows_per_chunk, plane, relu);
-        DWC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(in_bwd_final, dim3((B * C + 255) / 256), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks,
-                           plane);
-        DWC_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(in_bwd_partial<T>, dim3(rs.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, part, HW, C,
+                       rs.rows_per_chunk, plane, relu);
+    DWC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(in_bwd_final_wide, dim3((C + 63) / 64, B), dim3(256), 0, st, part, sums, dgamma, dbeta, B * C, C, rs.chunks, plane);
+    DWC_LAUNCH_CHECK();
     const RowSplit ra = plan_apply(B, HW, C, VecOf<T>::V);
     hipLaunchKernelGGL(in_bwd_apply<T>, dim3(ra.chunks, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, beta, sums, dx, HW, C,
                        B * C, ra.rows_per_chunk, relu, amax, amax_ep);
@@ -1214,7 +1135,7 @@ int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv
 extern "C" {
 
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C) { return instnorm_ws_bytes(B, HW, C); }
-size_t dwc_instnorm_ticket_words(void) { return NORM_TICKET_MAX_B; }
+size_t dwc_instnorm_ticket_words(void) { return NORM_TICKET_WORDS; }
 size_t dwc_layernorm_ws_bytes(int B, int HW, int C) { return layernorm_ws_bytes(B, HW, C); }
 
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,

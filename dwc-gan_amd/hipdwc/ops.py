@@ -1614,21 +1614,9 @@ def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh, owners=None):
 # --------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------
-NORM_FUSED_FINAL = int(os.environ.get("DWC_NORM_FUSED_FINAL", "1"))   # 0: statistics always finalised by the separate *_final launches
-_NORM_TICKETS = {}           # (device index, stream) -> persistent zero-initialised ticket row (self-resetting, caller-owned)
-
-
 def _norm_tickets(device):
-    """Ticket row of the instance-norm statistics launches for the CURRENT stream of `device` (dwc_instnorm_*: launches on one
-    stream are ordered and share a row, concurrent streams get a row each), or None when the fused finalisation is off."""
-    if not NORM_FUSED_FINAL:
-        return None
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
-    row = _NORM_TICKETS.get(key)
-    if row is None:
-        row = torch.zeros(int(_lib.load().dwc_instnorm_ticket_words()), dtype=torch.int32, device=device)
-        _NORM_TICKETS[key] = row
-    return row.data_ptr()
+    """The `tickets` argument of dwc_instnorm_*: unused since r05 (the statistics are finalised by their own launch), always NULL."""
+    return None
 
 
 class _InstNorm(torch.autograd.Function):

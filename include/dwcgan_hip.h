@@ -148,11 +148,9 @@ int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int r
  *      networks.py:706-719 AdaptiveInstanceNorm2d; residual add networks.py:518-522) --------- */
 /* y = relu?( (x-mean[n,c])*rstd[n,c]*gamma[n,c] + beta[n,c] ) + residual?
  * gamma/beta: [B*C] or NULL (plain IN).  mean/rstd [B*C] are outputs kept for the backward.
- * tickets: NULL, or a CALLER-OWNED row of dwc_instnorm_ticket_words() device words that are zero before first use and belong
- * to this stream (launches on one stream may share a row; concurrent streams need a row each).  With a row and a small batch
- * the statistics launch finalises itself (the last-arriving workgroup of a sample sums the partials; tickets return to zero
- * when the launch completes) and the separate finalise launch is skipped; results are identical either way (fixed summation
- * order).  The library keeps no mutable state of its own.  If a launch is aborted, re-zero the row. */
+ * tickets: accepted and IGNORED since r05 (pass NULL).  Rounds 3-4 finalised the statistics inside the partial launch through a
+ * caller-owned ticket row of dwc_instnorm_ticket_words() words; measured at batch 16 that cost 3-5x what a parallel finalise launch
+ * costs (csrc/norm.hip), so the statistics are always finalised by their own small launch now.  The library keeps no mutable state. */
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C);
 size_t dwc_instnorm_ticket_words(void);
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,

@@ -404,14 +404,15 @@ def test_lstm_persistent_launch_refuses_grids_that_cannot_be_resident(monkeypatc
     close(a, b.cpu(), rel=1e-5)
 
 
-def test_instance_norm_last_arriver_two_streams_stress(monkeypatch):
-    """The statistics launches finalise themselves through caller-owned ticket rows (one per stream, acquire/release ordering,
-    no library-global state).  Two streams run norm forward + backward launches of different shapes
-    concurrently, 200 rounds: every result must equal, BIT FOR BIT (fixed summation order, whoever arrives last), what the same
-    launches give when run alone on one stream, agree with the separate *_final launches to rounding (the two finalisers sum
-    the partials in a different association), and every ticket row must be back at zero."""
+def test_instance_norm_last_arriver_two_streams_stress():
+    """Two streams run norm forward + backward launches of different shapes concurrently, 200 rounds: every result must equal, BIT FOR
+    BIT, what the same launches give when run alone on one stream (per-stream scratch, fixed summation order, no library-global
+    state).  (Rounds 3-4 finalised the statistics in the last-arriving workgroup of a sample through caller-owned
+    ticket rows, which is what the test's name refers to; r05 removed that mechanism -- csrc/norm.hip -- and the test keeps guarding the
+    concurrency of what replaced it: partial + parallel finalise launches, and the resident-plane kernels.)  Shapes on both kinds of
+    kernels: 32x32 / 16x16 planes are resident, 8x8 and 64x64 go through the multi-pass kernels."""
     d = torch.device(DEV)
-    shapes = [(16, 256, 32), (48, 64, 16), (5, 128, 8), (32, 256, 32)]
+    shapes = [(16, 256, 32), (48, 64, 16), (5, 128, 8), (8, 128, 64)]
     g = torch.Generator().manual_seed(5)
     data = []
     for (B, C, H) in shapes:
@@ -427,15 +428,8 @@ def test_instance_norm_last_arriver_two_streams_stress(monkeypatch):
         (y * gy).sum().backward()
         return [y.detach(), xr.grad, gr.grad, br.grad]
 
-    monkeypatch.setattr(ops, "NORM_FUSED_FINAL", 0)
-    unfused = [run(*t) for t in data]
+    want = [run(*t) for t in data]                              # alone on the default stream
     torch.cuda.synchronize()
-    monkeypatch.setattr(ops, "NORM_FUSED_FINAL", 1)
-    want = [run(*t) for t in data]                              # fused, alone on the default stream
-    torch.cuda.synchronize()
-    for res, ref in zip(want, unfused):
-        for a, b, name in zip(res, ref, ("y", "dx", "dgamma", "dbeta")):
-            close(a, b, rel=2e-6, msg="fused vs separate finalise: " + name)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     got = {}
     for rnd in range(200):
@@ -444,9 +438,6 @@ def test_instance_norm_last_arriver_two_streams_stress(monkeypatch):
                 k = (rnd + 2 * si) % len(data)
                 got[(si, k)] = run(*data[k])
     torch.cuda.synchronize()
-    assert len(ops._NORM_TICKETS) >= 2                       # a row per stream
-    for row in ops._NORM_TICKETS.values():
-        assert int(row.abs().sum().item()) == 0              # self-reset
     for (si, k), res in got.items():
         for a, b, name in zip(res, want[k], ("y", "dx", "dgamma", "dbeta")):
             assert torch.equal(a, b), (si, k, name, (a - b).abs().max().item())
