@@ -460,7 +460,18 @@ __global__ void ln_stats_final(const T* __restrict__ x, const float* __restrict_
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= B) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < chunks; ++k) {
+    int k = 0;
+    for (; k + 8 <= chunks; k += 8) {                      // (eight pairs in flight, summed in chunk order)
+        float va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            va[u] = part[(size_t)(n * chunks + k + u) * 2];
+            vb[u] = part[(size_t)(n * chunks + k + u) * 2 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s1 += va[u], s2 += vb[u];
+    }
+    for (; k < chunks; ++k) {
         s1 += part[(size_t)(n * chunks + k) * 2];
         s2 += part[(size_t)(n * chunks + k) * 2 + 1];
     }
@@ -633,11 +644,25 @@ __global__ __launch_bounds__(1024) void ln_bwd_final(const float* __restrict__ p
     }
     const int c = ((int)blockIdx.x - B) * 64 + cl;
     float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int k = g; k < B * chunks; k += 16) {
+    if (c < C) {
+        // (r05: eight loads per sum in flight -- the plain loop was 126 dependent loads at batch 48, 35-47 us per launch)
+        const int total = B * chunks;
+        int k = g;
+        for (; k + 7 * 16 < total; k += 8 * 16) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = part_c[(size_t)(k + 16 * u) * 2 * C + c];
+                vb[u] = part_c[(size_t)(k + 16 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += va[u], b += vb[u];
+        }
+        for (; k < total; k += 16) {
             a += part_c[(size_t)k * 2 * C + c];
             b += part_c[(size_t)k * 2 * C + C + c];
         }
+    }
     sm[0][g][cl] = a;
     sm[1][g][cl] = b;
     __syncthreads();
