@@ -272,6 +272,8 @@ struct StemX3Args {
     // lies inside CH x CW goes straight to `inner` ([B][CH][CW][64]), only the border ring to y; a band fold follows
     int crop, CH, CW;
     float* inner;
+    unsigned long long* ys = nullptr;      // optional absmax slot of y (two-plane consumers, dwc_common.h), raised from the store pass
+    unsigned ys_epoch = 0;
 };
 
 __global__ __launch_bounds__(512, 1) void conv_stem_x3_kernel(StemX3Args a) {
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(512, 1) void conv_stem_x3_kernel(StemX3Args a) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    unsigned y_am = 0;                                  // largest |y| this thread stores
     // ---- the filter, once -------------------------------------------------------------------------------------------------
     {
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w), 0, 3 * W_PLANE * 2u, 0x00020000);
@@ -395,10 +398,13 @@ __global__ __launch_bounds__(512, 1) void conv_stem_x3_kernel(StemX3Args a) {
                     v += bvs[c][q4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = dwc_act_simple(v[k], slope);
+                    y_am = max(max(y_am, max(dwc_abs_bits(v[0]), dwc_abs_bits(v[1]))), max(dwc_abs_bits(v[2]), dwc_abs_bits(v[3])));
                     *reinterpret_cast<f32x4*>(d + c * 32 + 8 * q4 + 4 * hi) = v;
                 }
         }
     }
+    __shared__ unsigned s_am[8];
+    dwc_amax_block_publish(a.ys, a.ys_epoch, y_am, s_am);      // (a.ys is uniform over the launch)
 #endif
 }
 
@@ -728,6 +734,22 @@ int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bi
 int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, float* y, int B, int IH, int IW, int OH, int OW, int K,
                        int off, int act, int reflect, void* stream) {
     return dwc_x3_conv2d_stem_crop(x, w_steps, bias, y, nullptr, 0, B, IH, IW, OH, OW, K, off, act, reflect, stream);
+}
+
+/* dwc_x3_conv2d_stem raising the absmax slot of y from its store pass (see dwc_instnorm_fwd_amax; y_amax NULL: the plain call) */
+int dwc_x3_conv2d_stem_amax(const float* x, const void* w_steps, const float* bias, float* y, void* y_amax, unsigned y_epoch, int B, int IH,
+                            int IW, int OH, int OW, int K, int off, int act, int reflect, void* stream) {
+    if (!x || !w_steps || !y || !stem_x3_ok(B, IH, IW, OH, OW, K, act)) return DWC_EINVAL;
+    StemX3Args a;
+    a.x = x; a.w = (const bf16*)w_steps; a.bias = bias; a.y = y;
+    a.crop = 0; a.CH = OH; a.CW = OW; a.inner = nullptr;
+    a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OW = OW; a.off = off; a.act = act; a.reflect = reflect;
+    a.ys = (unsigned long long*)y_amax; a.ys_epoch = y_epoch;
+    a.blocks_x = (OW + 15) / 16; a.blocks_y = (OH + 15) / 16; a.nblocks = a.blocks_x * a.blocks_y * B;
+    const int grid = a.nblocks < 256 ? a.nblocks : 256;
+    hipLaunchKernelGGL(conv_stem_x3_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, a);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
 }
 
 size_t dwc_x3_conv7_smallk_wgrad_ws_bytes(int B, int H, int W, int heads) {

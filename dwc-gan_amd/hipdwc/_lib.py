@@ -121,6 +121,7 @@ SIGNATURES = {
     "dwc_x3_conv2d_stem_weight_elems": (c_sz, []),
     "dwc_x3_conv2d_stem": (c_int, [c_fp] * 4 + [c_int] * 9 + [c_fp]),
     "dwc_x3_conv2d_stem_crop": (c_int, [c_fp] * 5 + [c_int] * 10 + [c_fp]),
+    "dwc_x3_conv2d_stem_amax": (c_int, [c_fp] * 5 + [c_u] + [c_int] * 9 + [c_fp]),
     "dwc_reflect_pad_adjoint_band": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_fp]),
     "dwc_x3_conv2d_ksplit_ws_bytes": (c_sz, [c_int] * 7),
     "dwc_x3_conv2d_ksplit_ticket_words": (c_int, []),
@@ -183,7 +184,7 @@ SIGNATURES = {
     "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
-ABI_VERSION = 6                # DWC_ABI_VERSION of include/dwcgan_hip.h
+ABI_VERSION = 7                # DWC_ABI_VERSION of include/dwcgan_hip.h
 EINVAL = -1
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
            -3: "DWC_ELAUNCH (kernel launch failed)"}

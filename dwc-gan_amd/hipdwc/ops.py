@@ -779,9 +779,12 @@ class _Conv2d(torch.autograd.Function):
         elif use_stem_x3:
             # fp32 7x7 stem on an NHWC4 image as split products: filter planes resident in LDS, persistent workgroups (csrc/conv_narrow_x3.hip)
             w_st = _prepped(w, "stem_steps_x3", cop, Cx, 1, owner)
-            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_stem(
-                x.data_ptr(), w_st.data_ptr(), _p(bias), y.data_ptr(), B, H, W, H, W, KH, -pad, act, 1, st),
+            ya, yep = out_amax(y)                     # (the stride-2 layer behind the stem is a two-plane kernel: it wants y's absmax)
+            _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_stem_amax(
+                x.data_ptr(), w_st.data_ptr(), _p(bias), y.data_ptr(), ya, yep, B, H, W, H, W, KH, -pad, act, 1, st),
                 detail="fwd-stem-x3 B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride), exec_flops=6 * flops), "x3_conv2d_stem")
+            if ya is not None:
+                set_amax(y, ya, yep)
         elif use_stem:
             # 7x7 stem on an NHWC8 image: filter resident in LDS, persistent workgroups (csrc/conv_narrow_bf16.hip)
             w_st = _prepped(w, "stem_steps", cop, Cx, 1, owner, True)

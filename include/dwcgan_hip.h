@@ -48,7 +48,7 @@ extern "C" {
 /* Version of this C ABI: bumped with every change of an entry point's signature or of a structure passed through it (r05: 5 --
  * dwc_weight_refresh_multi gained has_h2 / epoch, the dwc_h2_* / dwc_*_amax entry points).  A binding must refuse a library that
  * reports another number: symbols alone do not tell a changed argument list (hipdwc/_lib.py does). */
-#define DWC_ABI_VERSION 6
+#define DWC_ABI_VERSION 7
 int dwc_version(void);
 /* The fp32 im2col kernels (dwc_conv2d_fwd / _bwd_data* / _bwd_weight*, ring strips) take their inner products as exact three-way
  * bf16 split products on the bf16 matrix cores by default (r04; fp32 operands, results and accumulation -- see
@@ -358,6 +358,9 @@ int dwc_x3_conv2d_stem(const float* x, const void* w_steps, const float* bias, f
                        int off, int act, int reflect, void* stream);
 int dwc_x3_conv2d_stem_crop(const float* x, const void* w_steps, const float* bias, float* y, float* inner, int crop, int B, int IH, int IW,
                             int OH, int OW, int K, int off, int act, int reflect, void* stream);
+/* dwc_x3_conv2d_stem raising the absmax slot of y from its store pass (r05; see dwc_instnorm_fwd_amax; y_amax NULL: the plain call) */
+int dwc_x3_conv2d_stem_amax(const float* x, const void* w_steps, const float* bias, float* y, void* y_amax, unsigned y_epoch, int B, int IH,
+                            int IW, int OH, int OW, int K, int off, int act, int reflect, void* stream);
 int dwc_reflect_pad_adjoint_band(const float* dxp, float* dx, int B, int H, int W, int C, int pad, void* stream);
 /* r05: weight gradient of the two 7x7 layer shapes in fp32 as exact split products -- the fp32 twin of dwc_bf16_conv7_smallk_wgrad
  * (reference networks_v2.py:106,159-160, networks.py:432 through autograd): between an NHWC4 fp32 image img4:[B][H][W][4] and a
