@@ -164,12 +164,28 @@ class ResBlock(nn.Module):
             Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation=activation, pad_type=pad_type),
             Conv2dBlock(dim, dim, 3, 1, 1, norm=norm, activation="none", pad_type=pad_type))
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         # the gradient of the identity branch rides on the data gradient of the first convolution (ops.ResGradToken); only when
         # the closing norm takes the residual itself (IN / AdaIN) -- otherwise autograd sums the two gradients as usual
         fused = self.model[1].norm_kind in ("in", "adain")
+        if groups > 1:
+            return self._forward_groups(x, groups)
         token = ops.res_token(x) if fused else None
         return self.model[1](self.model[0](x, conv_token=token), residual=x, res_token=token)
+
+    def _forward_groups(self, x, groups):
+        """The block applied to ``groups`` copies of the batch x that differ only in their AdaIN parameters (the solver decodes one
+        content code with several styles in one pass: reference solver.py:171-190 runs gen.decode three times on c_real): the first
+        convolution sees the same input in every group, so it runs ONCE at batch B and its output is repeated in front of the
+        AdaIN -- a third of its forward, data-gradient and weight-gradient work at three groups.  Same value as the block on
+        torch.cat([x] * groups) up to fp32 summation order (the three groups' gradients meet before the convolution instead of
+        inside its batch)."""
+        c0, c1 = self.model[0], self.model[1]
+        if c0.norm_kind != "adain" or c0.act_kind != "relu" or c0.pad_type != "reflect" or c1.norm_kind != "adain":
+            return self.forward(torch.cat([x] * groups), 1)
+        y = ops.conv2d(x, c0.conv.weight, c0.conv.bias, c0.stride, c0.padding, "none", bias_grad=False)
+        h = c0.norm(torch.cat([y] * groups), relu=True)
+        return c1(h, residual=torch.cat([x] * groups))
 
 
 class ResBlocks(nn.Module):
@@ -178,7 +194,12 @@ class ResBlocks(nn.Module):
         self.model = nn.Sequential(*[ResBlock(dim, norm=norm, activation=activation, pad_type=pad_type)
                                      for _ in range(num_blocks)])
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
+        if groups > 1 and len(self.model) > 0:        # (see ResBlock._forward_groups: x is ONE copy of the batch)
+            x = self.model[0](x, groups=groups)
+            for blk in list(self.model)[1:]:
+                x = blk(x)
+            return x
         return self.model(x)
 
 
@@ -263,10 +284,12 @@ class Decoder(nn.Module):
         self.image_content = Conv2dBlock(dim, output_dim, 7, 1, 3, norm="none", activation="tanh", pad_type=pad_type)
         self.image_attention = Conv2dBlock(dim, 1, 7, 1, 3, norm="none", activation="sigmoid", pad_type=pad_type)
 
-    def forward_nhwc4(self, x, attention_used=True):
+    def forward_nhwc4(self, x, attention_used=True, groups=1):
         """``attention_used=False``: the caller will not read plane 3, so the attention head is taken
         off the tape — its parameters then get NO gradient (not a zero one), exactly like the
-        reference, whose optimiser skips gradient-less parameters (no weight decay / momentum)."""
+        reference, whose optimiser skips gradient-less parameters (no weight decay / momentum).
+        ``groups`` > 1: x is ONE copy of a batch that is decoded with ``groups`` sets of AdaIN parameters (assigned for
+        groups * B samples); the result has groups * B samples (ResBlock._forward_groups)."""
         if self.output_dim != 3:
             raise NotImplementedError("fused heads assume a 3-channel image")
         wc, bc = self.image_content.conv.weight, self.image_content.conv.bias
@@ -275,7 +298,12 @@ class Decoder(nn.Module):
         if not attention_used:
             wa, ba = wa.detach(), ba.detach()
         with ops.scope("decode"):        # label for the profiler's decode-stack roofline figure
-            feat = self.model(x)
+            if groups > 1 and isinstance(self.model[0], ResBlocks):
+                feat = self.model[0](x, groups=groups)
+                for layer in list(self.model)[1:]:
+                    feat = layer(feat)
+            else:
+                feat = self.model(x if groups == 1 else torch.cat([x] * groups))
             ws, bs = [wc, wa], [bc, ba]
             extra = ops.image_planes(feat.dtype) - 4         # bf16 images are NHWC8: four zero planes
             if extra:

@@ -246,10 +246,11 @@ class AdaINGen_v2(nn.Module):
         return self.dec(content)
 
     # -- internal 4-plane image API used by the solver ------------------------------------
-    def decode_nhwc4(self, content, style, attention_used=True):
-        """As decode(), returning the fused NHWC4 head buffer (planes 0-2 image, plane 3 attention)."""
+    def decode_nhwc4(self, content, style, attention_used=True, groups=1):
+        """As decode(), returning the fused NHWC4 head buffer (planes 0-2 image, plane 3 attention).  ``groups`` > 1: ``content`` is ONE
+        copy of a batch that is decoded with ``groups`` styles per sample, ``style`` has groups * B rows (group-major)."""
         self.assign_adain_params(self.mlp(style), self.dec)
-        return self.dec.forward_nhwc4(content, attention_used=attention_used)
+        return self.dec.forward_nhwc4(content, attention_used=attention_used, groups=groups)
 
     def assign_adain_params(self, adain_params, model):
         """Hand each AdaIN layer, in module order, its slice of the MLP output: first C columns ->

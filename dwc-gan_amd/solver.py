@@ -44,6 +44,8 @@ def _frozen(module):
             p.requires_grad_(f)
 
 
+GROUPED_DECODE = int(os.environ.get("DWC_GROUPED_DECODE", "1"))    # 0: always decode torch.cat([content] * groups) (ResBlock._forward_groups off)
+
 class Solver(nn.Module):
     def __init__(self, configs, device=None, pretrained_embed=None):
         super().__init__()
@@ -201,9 +203,16 @@ class Solver(nn.Module):
         """gen.encode_txt; returns (result, join) -- ``join()`` is a no-op kept for the call sites' shape."""
         return self.gen.encode_txt(style, txt, lens), (lambda: None)
 
-    def _decode(self, content, style, x_real4):
-        """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out."""
-        heads = self.gen.decode_nhwc4(content, style, attention_used=self.use_attention)
+    def _decode(self, content, style, x_real4, groups=1):
+        """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out.  ``groups`` > 1: ``content`` is one copy
+        of the batch, decoded with ``groups`` styles per sample (``style`` and ``x_real4`` hold groups * B samples, group-major): the
+        decoder's first convolution then runs once instead of once per group (networks.ResBlock._forward_groups)."""
+        # (r05, same box, alternating runs: c2 / bf16 1 344-1 346 images/s grouped against 1 338-1 340; c1 / fp32 343-346 against 345-352
+        # -- there the batch-16 launch of the shared convolution is a contraction-split one, no cheaper per image than the batch-48
+        # launch it replaces, and the repeat / gradient sums come on top: grouped on the bf16 path only)
+        if groups > 1 and not (GROUPED_DECODE and ops.PRECISION == "bf16"):
+            content, groups = torch.cat([content] * groups), 1
+        heads = self.gen.decode_nhwc4(content, style, attention_used=self.use_attention, groups=groups)
         return ops.attention_blend(heads, x_real4) if self.use_attention else heads
 
     def forward(self, x_real, txt_src2trg, txt_lens):
@@ -249,8 +258,7 @@ class Solver(nn.Module):
             content = content_taped.detach()
             join_txt()
             # both fakes in ONE decoder pass (AdaIN parameters are per sample)
-            fakes = self._decode(torch.cat([content, content]), torch.cat([flat_heads(style_txt), style1]),
-                                 torch.cat([x4, x4]))
+            fakes = self._decode(content, torch.cat([flat_heads(style_txt), style1]), torch.cat([x4, x4]), groups=2)
         gw, cw = configs["gan_w"], configs["cls_w"]
         # ONE discriminator pass over [x_fake, x_fake1, x_real]; D(x_real) enters both loss terms as
         # in the reference (which evaluates it twice, with identical values)
@@ -299,7 +307,7 @@ class Solver(nn.Module):
             join_txt()
             s_txt = flat_heads(style_txt)
             # decode [within-domain reconstruction | text-driven fake | random-style fake]
-            x_all = self._decode(torch.cat([content_real] * 3), torch.cat([s_real, s_txt, style1]), torch.cat([x4] * 3))
+            x_all = self._decode(content_real, torch.cat([s_real, s_txt, style1]), torch.cat([x4] * 3), groups=3)
             x_rec, x_fake, x_fake1 = torch.split(x_all, B)
             self.loss_ds = ops.l1_mean(x_fake1, x_fake2, image=True)
             self.init_ds_w = max(self.init_ds_w - 1 / 1e5, 0.0)
@@ -378,7 +386,7 @@ class Solver(nn.Module):
         mus_real, mus_txt = sign(style_real), sign(style_txt)
         z = torch.cat([dist_sampling_split(mus_txt[i:i + 1], self.c_dim, self.stddev, self.device) for i in range(B)])
         z = self.style_replace(mus_real, mus_txt, style_real, z)
-        heads = self.gen.decode_nhwc4(torch.cat([content] * 3), torch.cat([style_real, style_txt, z]))
+        heads = self.gen.decode_nhwc4(content, torch.cat([style_real, style_txt, z]), groups=3)
         out = ops.attention_blend(heads, torch.cat([x4] * 3)) if self.use_attention else heads
         res = [x_real, out[:B, :3].float(), out[B:2 * B, :3].float(), out[2 * B:, :3].float()]
         if self.use_attention:

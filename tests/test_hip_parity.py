@@ -735,6 +735,46 @@ def test_tiny_modules_vs_reference(tiny):
             close(cls, T(tiny["mod/dis%d_cls" % i]), rel=1e-4, msg="dis cls")
 
 
+@pytest.mark.parametrize("size", ["tiny", "full"])
+def test_grouped_decode_equals_concatenated_decode(tiny, size):
+    """r05: the solver decodes ONE content code with two / three styles in one pass (reference solver.py:171-190 calls gen.decode
+    three times on c_real); the decoder's first convolution sees the same input in every group, so it runs once at batch B and its
+    output is repeated in front of the AdaIN (networks.ResBlock._forward_groups).  Same result as decoding torch.cat([content] * 3):
+    image heads within 2e-6 of their scale, gradients w.r.t. the content code, the first and the second convolution's weights and the
+    style within 2e-5 (fp32 summation order: the groups' gradients meet before the convolution instead of inside its batch)."""
+    from solver import Solver
+    if size == "tiny":
+        s, cfg, batch = _tiny_solver(tiny)
+        x = batch["x_real"]
+    else:
+        cfg = synth.make_config(image_size=64)
+        torch.manual_seed(7)
+        s = Solver(cfg, torch.device(DEV), None).to(DEV)
+        x = synth.make_batch(2, 64, seed=3)["x_real"].to(DEV)
+    gen = s.gen
+    B = x.shape[0]
+    with torch.no_grad():
+        content0, mus, _ = gen.encode(ops.pack_image(x))
+        width = torch.cat(list(mus), 1).shape[1]
+    g = torch.Generator().manual_seed(21)
+    style0 = torch.randn(3 * B, width, generator=g).to(DEV)
+    w1 = gen.dec.model[0].model[0].model[0].conv.weight
+    w2 = gen.dec.model[0].model[0].model[1].conv.weight
+    gy = None
+    outs = []
+    for grouped in (True, False):
+        content = content0.detach().clone().requires_grad_(True)
+        style = style0.detach().clone().requires_grad_(True)
+        gen.zero_grad(set_to_none=True)
+        heads = gen.decode_nhwc4(content, style, groups=3) if grouped else gen.decode_nhwc4(torch.cat([content] * 3), style)
+        if gy is None:
+            gy = torch.randn(heads.shape, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        (heads * gy).sum().backward()
+        outs.append([heads.detach(), content.grad.detach(), w1.grad.detach().clone(), w2.grad.detach().clone(), style.grad.detach()])
+    for a, b, name in zip(outs[0], outs[1], ("heads", "d content", "d w (first conv)", "d w (second conv)", "d style")):
+        close(a, b, rel=2e-6 if name == "heads" else 2e-5, msg="grouped vs concatenated decode: " + name)
+
+
 def test_tiny_three_iterations_vs_reference(tiny):
     """Same seed, same random stream (HostNoise), three full iterations: every loss scalar the
     reference printed, its G gradients and its post-Adam weights after iteration 0."""
