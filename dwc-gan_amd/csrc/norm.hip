@@ -1047,7 +1047,9 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
         const int pairs = B * (C / (Raw4<T>::CQ * 4)) / 2;
         const dim3 grid((pairs + 7) / 8 * 16);
         // (r05, bf16 planes without a residual, in-step: 256 threads 58.8 us, 512 threads 54.8, 1 024 threads 64.5; with a residual 512
-        // threads 81.8 against 89.0 on 1 024; fp32 without a residual: 256 threads 16.1 us, 512 threads 16.7)
+        // threads 81.8 against 89.0 on 1 024; fp32 without a residual: 256 threads 16.1 us, 512 threads 16.7.  Whole 128-byte lines per
+        // workgroup (64 bf16 channels, 1 024 threads, no pairing of workgroups over a line): 52.2 against 54.9 us -- not what holds these
+        // kernels at 2.4 TB/s; not kept)
         if (rhw == 1024 && !residual && sizeof(T) == 2) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 512, false>), grid, dim3(512), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
         else if (rhw == 1024 && residual) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 512, true>), grid, dim3(512), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
         else if (rhw == 1024) hipLaunchKernelGGL((in_resident_fwd<T, 1024, 256, false>), grid, dim3(256), 0, st, x, gamma, beta, residual, y, mean, rstd, C, eps, relu, pairs, amax, amax_ep);
