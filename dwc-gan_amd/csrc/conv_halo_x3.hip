@@ -1137,7 +1137,9 @@ void x3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int K, int bn, int np
     // resident workgroups: whole rounds, see wgrad_halo_plan.  The two-plane kernels of K = 3 and K = 4 need 106-124 registers and
     // exactly half of the LDS (81,920 bytes): two workgroups per CU (r05, wgrad + reduce planned for 256 / 512 slots: 3x3 256->256
     // B=48 250 -> 223 us, 4x4 stride 2 200 -> 186 and 184 -> 179 us, B=16 unchanged; K = 5 holds 96 KB and stays at one per CU).
-    const int cus = (npl == 2 && K != 5) ? 512 : 256;
+    // (... unless that leaves a workgroup fewer than 8 units -- 3x3 256->256 at B=16: the kernel takes the same time either way and
+    // twice the slabs cost the reduce 13.5 instead of 9.9 us)
+    const int cus = (npl == 2 && K != 5 && (long)units * roles >= 8L * 512) ? 512 : 256;
     const int smax = units / 4 > 0 ? units / 4 : 1;
     int s = 1;
     double best = 0.0;
