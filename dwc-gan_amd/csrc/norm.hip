@@ -83,8 +83,7 @@ __device__ __forceinline__ void colsum_groups(float (&a)[V], float (&b)[V], floa
 // last-arriving workgroup of a sample summing them -- to save the *_final launch.  r05 measured what that costs at batch 16 on the
 // planes the resident kernels do not take: 2 048 agent-scope acquire/release tickets per launch, in_stats_partial 71.9 us fused
 // against 13.0 + 5.2 us as two launches once the final kernel is parallel over the chunks (in_stats_final_wide), in_bwd_partial 89.0
-// against 21.4 + 4.8.  The mechanism was removed; the `tickets` argument of the entry points is accepted and ignored.)
-constexpr int NORM_TICKET_WORDS = 64;     // dwc_instnorm_ticket_words(): what rounds 3-4 asked callers to keep per stream
+// against 21.4 + 4.8.  The mechanism was removed, and with ABI 8 the `tickets` argument of the entry points.)
 
 // ---------------------------------------------------------------------------------------
 // instance norm
@@ -216,7 +215,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
-    if (rg >= groups) return;
+    // (threads past the last row group -- none while groups * cq == 256 -- walk no rows below but still reach the publish barrier)
     unsigned am = 0;                                       // largest |y| this thread writes (two-plane conv kernels: absmax slot of y)
     const int n = blockIdx.y;
     const size_t s = (size_t)n * C + col * V;
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void in_apply(const T* __restrict__ x, const f
     if (beta) ldf<V>(beta, s, sh);
     const size_t base = (size_t)n * HW * cq + col;
     const int r0 = blockIdx.x * rows_per_chunk;
-    const int r1 = min(HW, r0 + rows_per_chunk);
+    const int r1 = rg < groups ? min(HW, r0 + rows_per_chunk) : r0;
     auto one = [&](const float (&v)[V], const float* res, float (&o)[V]) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
-    if (rg >= groups) return;
+    // (threads past the last row group -- none while groups * cq == 256 -- walk no rows below but still reach the publish barrier)
     unsigned am = 0;
     const int n = blockIdx.y;
     const size_t s = (size_t)n * C + col * V;
@@ -367,7 +366,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply(const T* __restrict__ dy, co
     for (int k = 0; k < V; ++k) k1[k] *= inv_hw, k2[k] *= inv_hw;
     const size_t base = (size_t)n * HW * cq + col;
     const int r0 = blockIdx.x * rows_per_chunk;
-    const int r1 = min(HW, r0 + rows_per_chunk);
+    const int r1 = rg < groups ? min(HW, r0 + rows_per_chunk) : r0;
     auto one = [&](const float (&xv)[V], const float (&dv)[V], float (&o)[V]) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -492,7 +491,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
-    if (rg >= groups) return;
+    // (threads past the last row group -- none while groups * cq == 256 -- walk no rows below but still reach the publish barrier)
     unsigned am = 0;
     const int n = blockIdx.y;
     const float mu = mean[n], iv = inv[n];
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(256) void ln_apply(const T* __restrict__ x, const f
     for (int k = 0; k < V; ++k) sc[k] *= iv;
     const size_t base = (size_t)n * HW * cq + col;
     const int r0 = blockIdx.x * rows_per_chunk;
-    const int r1 = min(HW, r0 + rows_per_chunk);
+    const int r1 = rg < groups ? min(HW, r0 + rows_per_chunk) : r0;
     auto one = [&](const float (&v)[V], float (&o)[V]) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -688,7 +687,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
     const int cq = C / V;
     const int groups = 256 / cq;
     const int col = threadIdx.x % cq, rg = threadIdx.x / cq;
-    if (rg >= groups) return;
+    // (threads past the last row group -- none while groups * cq == 256 -- walk no rows below but still reach the publish barrier)
     unsigned am = 0;
     const int n = blockIdx.y;
     const float N = (float)HW * (float)C;
@@ -702,7 +701,7 @@ __global__ __launch_bounds__(256) void ln_bwd_apply(const T* __restrict__ dy, co
     ldf<V>(beta, (size_t)col * V, be);
     const size_t base = (size_t)n * HW * cq + col;
     const int r0 = blockIdx.x * rows_per_chunk;
-    const int r1 = min(HW, r0 + rows_per_chunk);
+    const int r1 = rg < groups ? min(HW, r0 + rows_per_chunk) : r0;
     auto one = [&](const float (&xv)[V], const float (&dv)[V], float (&o)[V]) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -1038,7 +1037,7 @@ size_t instnorm_ws_bytes(int B, int HW, int C) {
 
 template <typename T>
 int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* residual, T* y, float* mean,
-                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream,
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream,
                      unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
@@ -1075,7 +1074,7 @@ int instnorm_fwd_t(const T* x, const float* gamma, const float* beta, const T* r
 template <typename T>
 int instnorm_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, T* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                     size_t ws_bytes, unsigned* tickets, void* stream, unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
+                     size_t ws_bytes, void* stream, unsigned long long* amax = nullptr, unsigned amax_ep = 0) {
     if (!norm_shape_ok(B, HW, C, VecOf<T>::V)) return DWC_EINVAL;
     if (!ws || ws_bytes < instnorm_ws_bytes(B, HW, C)) return DWC_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1162,17 +1161,16 @@ int layernorm_bwd_t(const T* dy, const T* x, const float* mean, const float* inv
 extern "C" {
 
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C) { return instnorm_ws_bytes(B, HW, C); }
-size_t dwc_instnorm_ticket_words(void) { return NORM_TICKET_WORDS; }
 size_t dwc_layernorm_ws_bytes(int B, int HW, int C) { return layernorm_ws_bytes(B, HW, C); }
 
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream) {
-    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, tickets, stream);
+                     float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
+    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, stream);
 }
 int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                     size_t ws_bytes, unsigned* tickets, void* stream) {
-    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, tickets, stream);
+                     size_t ws_bytes, void* stream) {
+    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, stream);
 }
 int dwc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
                       int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
@@ -1188,15 +1186,15 @@ int dwc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
  * the apply pass, so that a two-plane split-product convolution (dwc_h2_*, include/dwcgan_hip.h) that consumes the tensor needs no
  * dwc_absmax pass of its own.  out_amax NULL: exactly the plain entry point. */
 int dwc_instnorm_fwd_amax(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes,
                           void* out_amax, unsigned out_epoch, void* stream) {
-    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, tickets, stream,
+    return instnorm_fwd_t<float>(x, gamma, beta, residual, y, mean, rstd, B, HW, C, eps, relu, ws, ws_bytes, stream,
                                  (unsigned long long*)out_amax, out_epoch);
 }
 int dwc_instnorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, unsigned* tickets, void* out_amax, unsigned out_epoch, void* stream) {
-    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, tickets, stream,
+                          size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream) {
+    return instnorm_bwd_t<float>(dy, x, mean, rstd, gamma, beta, dx, dgamma, dbeta, B, HW, C, relu, ws, ws_bytes, stream,
                                  (unsigned long long*)out_amax, out_epoch);
 }
 int dwc_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
@@ -1213,16 +1211,15 @@ int dwc_layernorm_bwd_amax(const float* dy, const float* x, const float* mean, c
 
 /* bf16 activations (x, residual, y, dy, dx); statistics, gamma/beta and their gradients stay fp32 */
 int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
-                          void* stream) {
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {
     return instnorm_fwd_t<dwc_bf16>((const dwc_bf16*)x, gamma, beta, (const dwc_bf16*)residual, (dwc_bf16*)y, mean, rstd, B, HW, C,
-                                    eps, relu, ws, ws_bytes, tickets, stream);
+                                    eps, relu, ws, ws_bytes, stream);
 }
 int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, unsigned* tickets, void* stream) {
+                          size_t ws_bytes, void* stream) {
     return instnorm_bwd_t<dwc_bf16>((const dwc_bf16*)dy, (const dwc_bf16*)x, mean, rstd, gamma, beta, (dwc_bf16*)dx, dgamma, dbeta,
-                                    B, HW, C, relu, ws, ws_bytes, tickets, stream);
+                                    B, HW, C, relu, ws, ws_bytes, stream);
 }
 int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
                            int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream) {

@@ -53,9 +53,8 @@ SIGNATURES = {
     "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "dwc_instnorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
-    "dwc_instnorm_ticket_words": (c_sz, []),
-    "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_fp]),
-    "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_fp]),
+    "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "dwc_layernorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
     "dwc_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
@@ -138,8 +137,8 @@ SIGNATURES = {
     "dwc_x3_conv2d_wgrad_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_x3_conv2d_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_absmax": (c_int, [c_fp, c_sz, c_fp, c_u, c_fp]),
-    "dwc_instnorm_fwd_amax": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_fp, c_u, c_fp]),
-    "dwc_instnorm_bwd_amax": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_fp, c_u, c_fp]),
+    "dwc_instnorm_fwd_amax": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_u, c_fp]),
+    "dwc_instnorm_bwd_amax": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_u, c_fp]),
     "dwc_layernorm_fwd_amax": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_u, c_fp]),
     "dwc_layernorm_bwd_amax": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_u, c_fp]),
     "dwc_act_bwd_bias_amax": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_u, c_fp]),
@@ -168,8 +167,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_bwd_weight_ex_ws_bytes": (c_sz, [c_int] * 11),
     "dwc_bf16_conv2d_bwd_weight_ex": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 13 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
-    "dwc_bf16_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp, c_fp]),
-    "dwc_bf16_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_fp]),
+    "dwc_bf16_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
+    "dwc_bf16_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "dwc_bf16_layernorm_fwd": (c_int, [c_fp] * 6 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_bf16_layernorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_bf16_upsample2x_fwd": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
@@ -184,7 +183,7 @@ SIGNATURES = {
     "dwc_bf16_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
 }
 
-ABI_VERSION = 7                # DWC_ABI_VERSION of include/dwcgan_hip.h
+ABI_VERSION = 8                # DWC_ABI_VERSION of include/dwcgan_hip.h
 EINVAL = -1
 _ERRORS = {-1: "DWC_EINVAL (unsupported shape/argument)", -2: "DWC_EWORKSPACE (scratch too small)",
            -3: "DWC_ELAUNCH (kernel launch failed)"}

@@ -23,6 +23,18 @@ ACT = {"none": 0, None: 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4, "head
 PRECISION = "fp32"
 BF16 = torch.bfloat16
 
+# Switches of earlier rounds that no longer select anything: a script or profile recipe that still sets one would
+# otherwise run another configuration than it claims, silently.
+_REMOVED_SWITCHES = ("DWC_WINOGRAD", "DWC_TXT_STREAM", "DWC_NORM_FUSED_FINAL", "DWC_GEMM_TILE", "DWC_STRIP_BM", "DWC_X3_DUO", "DWC_X3_BN",
+                     "DWC_X3_BN32", "DWC_X3_WIDE", "DWC_X3_STAGGER", "DWC_HALO_STAGGER", "DWC_X3_WDUO", "DWC_HALO16", "DWC_HALO_DUO",
+                     "DWC_HALO_BN128", "DWC_BF16_TILE", "DWC_BF16_STAGES3", "DWC_NARROW_ROWS16")
+_set = [k for k in _REMOVED_SWITCHES if k in os.environ]
+if _set:
+    import warnings
+    warnings.warn("hipdwc: %s no longer select%s anything (removed in round 5, DESIGN.md 10.3) and %s ignored" % (
+        ", ".join(_set), "s" if len(_set) == 1 else "", "is" if len(_set) == 1 else "are"), stacklevel=2)
+del _set
+
 
 def set_precision(name):
     """Select "fp32" or "bf16" activations for images packed from now on."""
@@ -587,6 +599,8 @@ def amax_of(t):
     (``set_amax``) if it still describes it, else one pass of dwc_absmax."""
     c = amax_live(t)
     if c is not None:
+        if AMAX_CHECK:
+            _amax_verify(t, c)
         return c
     if t.dtype != torch.float32 or not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
         raise ValueError("amax_of: dense fp32 tensor expected")
@@ -603,8 +617,30 @@ def h2_fits(t):
 
 
 def set_amax(t, slot, ep):
+    """Tag ``t`` with the slot that bounds its magnitude.  INVARIANT the tag rests on: nothing writes into ``t`` after it was tagged.
+    The tag is checked against ``t._version`` and the address, but the HIP entry points write through raw pointers and never bump the
+    version counter -- an op that writes a tensor it did not allocate (in-place add into y, buffer re-use) must clear
+    ``t._dwc_amax`` itself, or the two-plane kernels would scale by a stale, possibly too small bound (f16 overflow to inf; the NaN
+    poison only covers a stale EPOCH).  ``DWC_AMAX_CHECK=1`` re-measures every tagged tensor at the point of use and raises when the
+    tag is smaller than the truth."""
     t._dwc_amax = (slot, ep, t._version, t.data_ptr())
     return t
+
+
+AMAX_CHECK = int(os.environ.get("DWC_AMAX_CHECK", "0"))
+
+
+def _amax_verify(t, c):
+    """DWC_AMAX_CHECK=1 (debugging, synchronises): the slot attached to ``t`` must hold at least max|t|."""
+    pool = _AMAX[t.device.index if t.device.index is not None else torch.cuda.current_device()][0]
+    word = int(pool[(c[0] - pool.data_ptr()) // 8])
+    bits = word & 0xffffffff
+    if (word >> 32) != c[1]:
+        raise RuntimeError("DWC_AMAX_CHECK: slot epoch %d, tag says %d" % (word >> 32, c[1]))
+    true_bits = int(t.detach().abs().max().view(torch.int32)) if t.numel() else 0
+    if true_bits > bits:
+        raise RuntimeError("DWC_AMAX_CHECK: stale absmax tag -- slot holds %g, the tensor's largest magnitude is %g" % (
+            np.uint32(bits).view(np.float32), np.uint32(true_bits).view(np.float32)))
 
 
 def out_amax(t):
@@ -684,6 +720,8 @@ def ksplit_status_poll(wait=False):
     different XCDs; the kernel wrote NaN into that tile.  Raises, after re-zeroing the ticket row so that later launches do not keep
     timing out on it.  Solver calls this once per step."""
     for key, row in list(_X3_TICKETS.items()):
+        if key[1] != _stream():                  # a row is polled -- and, on an error, re-zeroed -- from the stream its launches run on
+            continue
         ent = _KSPLIT_POLL.get(key)
         if ent is None:
             ent = [torch.zeros(1, dtype=torch.int32).pin_memory(), None]
@@ -692,13 +730,14 @@ def ksplit_status_poll(wait=False):
             if wait:
                 ent[1].synchronize()
             ent[1] = None
-            if int(ent[0][0]) != 0:
+            status = int(ent[0][0])
+            if status != 0:
                 row.zero_()
                 ent[0].zero_()
                 raise _lib.HipKernelError(
                     "contraction split of a split-product convolution: the two halves of a tile did not meet (status %d); the tile was "
-                    "overwritten with NaN and the ticket row has been re-zeroed.  DWC_X3_KSPLIT=0 runs these launches unsplit." % 1)
-        if ent[1] is None and key[1] == _stream():          # (a row is polled from the stream its launches run on)
+                    "overwritten with NaN and the ticket row has been re-zeroed.  DWC_X3_KSPLIT=0 runs these launches unsplit." % status)
+        if ent[1] is None:
             ent[0].copy_(row[-1:], non_blocking=True)
             ent[1] = torch.cuda.Event()
             ent[1].record()
@@ -1617,11 +1656,6 @@ def lstm_bidir(x, lens, w_ih, w_hh, b_ih, b_hh, owners=None):
 # --------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------
-def _norm_tickets(device):
-    """The `tickets` argument of dwc_instnorm_*: unused since r05 (the statistics are finalised by their own launch), always NULL."""
-    return None
-
-
 class _InstNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, residual, relu, eps, token=None):
@@ -1643,12 +1677,12 @@ class _InstNorm(torch.autograd.Function):
         if ya is not None:
             _lib.check(lib.dwc_instnorm_fwd_amax(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
                                                  rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(),
-                                                 _norm_tickets(dev), ya, yep, _stream()), "instnorm_fwd")
+                                                 ya, yep, _stream()), "instnorm_fwd")
             set_amax(y, ya, yep)
         else:
             _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
                                                    rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(),
-                                                   _norm_tickets(dev), _stream()), "instnorm_fwd")
+                                                   _stream()), "instnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -1671,12 +1705,12 @@ class _InstNorm(torch.autograd.Function):
         if da is not None:
             _lib.check(lib.dwc_instnorm_bwd_amax(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                                  dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
-                                                 ws.numel(), _norm_tickets(dev), da, dep, _stream()), "instnorm_bwd")
+                                                 ws.numel(), da, dep, _stream()), "instnorm_bwd")
             set_amax(dx, da, dep)
         else:
             _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                                    dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
-                                                   ws.numel(), _norm_tickets(dev), _stream()), "instnorm_bwd")
+                                                   ws.numel(), _stream()), "instnorm_bwd")
         if ctx.token is not None:                 # the first convolution of the block adds it in its data-gradient epilogue
             ctx.token.g = dy
             return dx, dgamma, dbeta, None, None, None, None

@@ -44,6 +44,7 @@ def _frozen(module):
             p.requires_grad_(f)
 
 
+SAMPLE_CHUNK = 32                                                  # images per decode pass of Solver.sample()
 GROUPED_DECODE = int(os.environ.get("DWC_GROUPED_DECODE", "1"))    # 0: always decode torch.cat([content] * groups) (ResBlock._forward_groups off)
 
 class Solver(nn.Module):
@@ -199,10 +200,6 @@ class Solver(nn.Module):
         keep = (c_src == c_trg).repeat_interleave(self.c_dim, dim=1)
         return torch.where(keep, z_src, z_trg)
 
-    def _encode_txt_side(self, style, txt, lens):
-        """gen.encode_txt; returns (result, join) -- ``join()`` is a no-op kept for the call sites' shape."""
-        return self.gen.encode_txt(style, txt, lens), (lambda: None)
-
     def _decode(self, content, style, x_real4, groups=1):
         """decode + (when enabled) the attention blend x*a + x_real*(1-a); NHWC4 in and out.  ``groups`` > 1: ``content`` is one copy
         of the batch, decoded with ``groups`` styles per sample (``style`` and ``x_real4`` hold groups * B samples, group-major): the
@@ -210,10 +207,15 @@ class Solver(nn.Module):
         # (r05, same box, alternating runs: c2 / bf16 1 344-1 346 images/s grouped against 1 338-1 340; c1 / fp32 343-346 against 345-352
         # -- there the batch-16 launch of the shared convolution is a contraction-split one, no cheaper per image than the batch-48
         # launch it replaces, and the repeat / gradient sums come on top: grouped on the bf16 path only)
+        heads = self._decode_heads(content, style, groups, self.use_attention)
+        return ops.attention_blend(heads, x_real4) if self.use_attention else heads
+
+    def _decode_heads(self, content, style, groups=1, attention_used=True):
+        """The decoder's fused heads for ``groups`` styles per content code; the grouped form only where it is the faster one (see
+        _decode), the concatenated decode elsewhere."""
         if groups > 1 and not (GROUPED_DECODE and ops.PRECISION == "bf16"):
             content, groups = torch.cat([content] * groups), 1
-        heads = self.gen.decode_nhwc4(content, style, attention_used=self.use_attention, groups=groups)
-        return ops.attention_blend(heads, x_real4) if self.use_attention else heads
+        return self.gen.decode_nhwc4(content, style, attention_used=attention_used, groups=groups)
 
     def forward(self, x_real, txt_src2trg, txt_lens):
         x4 = ops.pack_image(x_real)
@@ -246,7 +248,7 @@ class Solver(nn.Module):
         with torch.no_grad():
             style_real = flat_heads(style_real)
             style1 = dist_sampling_split(c_trg, self.c_dim, self.stddev, self.device)      # (drawn before the text encoder's draws, as in the reference)
-            (style_txt, _), join_txt = self._encode_txt_side(style_real, txt_src2trg, txt_lens)   # side stream, beside enc_content
+            style_txt, _ = self.gen.encode_txt(style_real, txt_src2trg, txt_lens)
         if tape:
             content_taped = self.gen.enc_content(x4)
             self._content_cache = (x_real, x_real._version, self._gen_steps, content_taped)
@@ -256,7 +258,6 @@ class Solver(nn.Module):
                 content_taped = self.gen.enc_content(x4)
         with torch.no_grad():
             content = content_taped.detach()
-            join_txt()
             # both fakes in ONE decoder pass (AdaIN parameters are per sample)
             fakes = self._decode(content, torch.cat([flat_heads(style_txt), style1]), torch.cat([x4, x4]), groups=2)
         gw, cw = configs["gan_w"], configs["cls_w"]
@@ -290,8 +291,7 @@ class Solver(nn.Module):
             style_real, logvar = gen.enc_style(x4)                               # draw: mapping dropout
             s_real = flat_heads(style_real)
             mask_rec = gen.draw_encode_mask(B, x4.device)                        # draw of encode(x_real_rec)
-            # draws of the text encoder; its kernels run on the side stream beside enc_content / the x_fake2 decode below
-            (style_txt, logvar_txt), join_txt = self._encode_txt_side(s_real, txt_src2trg, txt_lens)
+            style_txt, logvar_txt = self.gen.encode_txt(s_real, txt_src2trg, txt_lens)     # draws of the text encoder
             cache, self._content_cache = self._content_cache, None
             if cache is not None and cache[0] is x_real and cache[1] == x_real._version and cache[2] == self._gen_steps:
                 content_real = cache[3]                                          # taped in dis_update on the same batch and G
@@ -304,7 +304,6 @@ class Solver(nn.Module):
 
             with torch.no_grad():                                                # only ever used detached; independent of the text style
                 x_fake2 = self._decode(content_real, style2, x4)
-            join_txt()
             s_txt = flat_heads(style_txt)
             # decode [within-domain reconstruction | text-driven fake | random-style fake]
             x_all = self._decode(content_real, torch.cat([s_real, s_txt, style1]), torch.cat([x4] * 3), groups=3)
@@ -386,11 +385,20 @@ class Solver(nn.Module):
         mus_real, mus_txt = sign(style_real), sign(style_txt)
         z = torch.cat([dist_sampling_split(mus_txt[i:i + 1], self.c_dim, self.stddev, self.device) for i in range(B)])
         z = self.style_replace(mus_real, mus_txt, style_real, z)
-        heads = self.gen.decode_nhwc4(content, torch.cat([style_real, style_txt, z]), groups=3)
-        out = ops.attention_blend(heads, torch.cat([x4] * 3)) if self.use_attention else heads
-        res = [x_real, out[:B, :3].float(), out[B:2 * B, :3].float(), out[2 * B:, :3].float()]
+        # (through the same gate as the training step's decodes -- DWC_GROUPED_DECODE, bf16 only -- and SAMPLE_CHUNK images at a
+        # time: a display batch of hundreds of images does not become one 3 x B decode)
+        outs, atts = [], []
+        for i in range(0, B, SAMPLE_CHUNK):
+            j = min(B, i + SAMPLE_CHUNK)
+            heads = self._decode_heads(content[i:j], torch.cat([style_real[i:j], style_txt[i:j], z[i:j]]), groups=3)
+            out = ops.attention_blend(heads, torch.cat([x4[i:j]] * 3)) if self.use_attention else heads
+            outs.append(out[:, :3].float().contiguous().view(3, j - i, 3, out.shape[2], out.shape[3]))
+            if self.use_attention:
+                atts.append((heads[j - i:2 * (j - i), 3:4].float().expand(-1, 3, -1, -1) - 0.5) / 0.5)
+        outs = torch.cat(outs, dim=1)
+        res = [x_real, outs[0], outs[1], outs[2]]
         if self.use_attention:
-            res.append((heads[B:2 * B, 3:4].float().expand(-1, 3, -1, -1) - 0.5) / 0.5)
+            res.append(torch.cat(atts))
         self.train()
         return res
 

@@ -48,7 +48,7 @@ extern "C" {
 /* Version of this C ABI: bumped with every change of an entry point's signature or of a structure passed through it (r05: 5 --
  * dwc_weight_refresh_multi gained has_h2 / epoch, the dwc_h2_* / dwc_*_amax entry points).  A binding must refuse a library that
  * reports another number: symbols alone do not tell a changed argument list (hipdwc/_lib.py does). */
-#define DWC_ABI_VERSION 7
+#define DWC_ABI_VERSION 8
 int dwc_version(void);
 /* The fp32 im2col kernels (dwc_conv2d_fwd / _bwd_data* / _bwd_weight*, ring strips) take their inner products as exact three-way
  * bf16 split products on the bf16 matrix cores by default (r04; fp32 operands, results and accumulation -- see
@@ -148,18 +148,17 @@ int dwc_act_bwd_bias(const float* dy, const float* y, float* g, float* db, int r
  *      networks.py:706-719 AdaptiveInstanceNorm2d; residual add networks.py:518-522) --------- */
 /* y = relu?( (x-mean[n,c])*rstd[n,c]*gamma[n,c] + beta[n,c] ) + residual?
  * gamma/beta: [B*C] or NULL (plain IN).  mean/rstd [B*C] are outputs kept for the backward.
- * tickets: accepted and IGNORED since r05 (pass NULL).  Rounds 3-4 finalised the statistics inside the partial launch through a
- * caller-owned ticket row of dwc_instnorm_ticket_words() words; measured at batch 16 that cost 3-5x what a parallel finalise launch
- * costs (csrc/norm.hip), so the statistics are always finalised by their own small launch now.  The library keeps no mutable state. */
+ * (ABI 8 dropped the `tickets` argument of the six instance-norm entry points and the ticket-row size query: rounds 3-4 finalised
+ * the statistics inside the partial launch through a caller-owned ticket row; measured at batch 16 that cost 3-5x what a parallel
+ * finalise launch costs (csrc/norm.hip), so the statistics are finalised by their own small launch.)  The library keeps no mutable state. */
 size_t dwc_instnorm_ws_bytes(int B, int HW, int C);
-size_t dwc_instnorm_ticket_words(void);
 int dwc_instnorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                      float* y, float* mean, float* rstd, int B, int HW, int C, float eps, int relu,
-                     void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+                     void* ws, size_t ws_bytes, void* stream);
 /* dx (and dgamma/dbeta [B*C] when gamma != NULL) given dy w.r.t. the (pre-residual) output. */
 int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
-                     int B, int HW, int C, int relu, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+                     int B, int HW, int C, int relu, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- MUNIT LayerNorm (reference networks.py:736-752: per-sample mean, UNBIASED std,
  *      (x-mean)/(std+eps), per-channel gamma/beta) ------------------------------------------ */
@@ -419,11 +418,11 @@ int dwc_absmax(const float* x, size_t n, void* slot, unsigned epoch, void* strea
  * the fp32 norms' apply kernels (y / dx), the activation backward (g) and the two-plane convolutions themselves (y_amax below).
  * Arguments before `out_amax` as the plain entry points; out_amax NULL: exactly the plain entry point. */
 int dwc_instnorm_fwd_amax(const float* x, const float* gamma, const float* beta, const float* residual, float* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes,
                           void* out_amax, unsigned out_epoch, void* stream);
 int dwc_instnorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, float* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, unsigned* tickets, void* out_amax, unsigned out_epoch, void* stream);
+                          size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream);
 int dwc_layernorm_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* inv, int B, int HW,
                            int C, float eps, int relu, void* ws, size_t ws_bytes, void* out_amax, unsigned out_epoch, void* stream);
 int dwc_layernorm_bwd_amax(const float* dy, const float* x, const float* mean, const float* inv, const float* gamma,
@@ -581,11 +580,10 @@ int dwc_bf16_conv2d_bwd_weight_ex(const void* x, const void* dy, float* dw_oihw,
 int dwc_bf16_act_bwd_bias(const void* dy, const void* y, void* g, float* db, int rows, int C, int act, void* ws,
                           size_t ws_bytes, void* stream);
 int dwc_bf16_instnorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* y, float* mean,
-                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, unsigned* tickets,
-                          void* stream);
+                          float* rstd, int B, int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
 int dwc_bf16_instnorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                           const float* beta, void* dx, float* dgamma, float* dbeta, int B, int HW, int C, int relu, void* ws,
-                          size_t ws_bytes, unsigned* tickets, void* stream);
+                          size_t ws_bytes, void* stream);
 int dwc_bf16_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* inv, int B,
                            int HW, int C, float eps, int relu, void* ws, size_t ws_bytes, void* stream);
 int dwc_bf16_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* inv, const float* gamma,

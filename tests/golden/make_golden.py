@@ -341,25 +341,58 @@ def grad_record(out, prefix, named):
 
 class DiskOffload:
     """saved_tensors_hooks that park every large tensor autograd saves for backward in a file (the unmodified reference at batch 64
-    holds ~60 GB of them; this container has 62 GB and no swap).  Values are unchanged: np.save / np.load of the raw fp32."""
+    holds ~60 GB of them; this container has 62 GB and no swap).  Values are unchanged: the raw fp32 goes to disk, tensors that
+    are at least a quarter exact zeros (ReLU outputs and their padded copies) as a bit mask + the non-zero values (lossless; the
+    batch-128 G step would not fit the disk otherwise), and a tensor that autograd saves twice (the ReLU's output is also the next
+    block's input) is written once."""
 
-    def __init__(self, root, min_bytes=4 << 20):
-        self.root, self.min_bytes, self.n, self.bytes = root, min_bytes, 0, 0
+    def __init__(self, root, min_bytes=4 << 20, min_free=6 << 30):
+        self.root, self.min_bytes, self.min_free, self.n, self.bytes, self.on_disk = root, min_bytes, min_free, 0, 0, 0
+        self.seen = {}
         os.makedirs(root, exist_ok=True)
 
     def pack(self, t):
         if t.device.type != "cpu" or t.numel() * t.element_size() < self.min_bytes or t.dtype not in (torch.float32, torch.int64, torch.bool):
             return t
+        key = (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
+        hit = self.seen.get(key)
+        if hit is not None and hit[1]() is not None:          # the same live tensor, already parked
+            return hit[0]
+        import shutil
+        import weakref
+        if shutil.disk_usage(self.root).free < self.min_free:
+            raise RuntimeError("DiskOffload: less than %d GB free under %s" % (self.min_free >> 30, self.root))
         path = os.path.join(self.root, "t%06d.npy" % self.n)
         self.n += 1
         self.bytes += t.numel() * t.element_size()
-        np.save(path, t.detach().contiguous().numpy())
-        return ("disk", path)
+        a = t.detach().contiguous().numpy()
+        h = ("disk", path, None)
+        if t.dtype == torch.float32:
+            flat = a.reshape(-1)
+            nz = flat.view(np.uint32) != 0                      # (bit pattern: -0.0 stays a value)
+            if int(nz.sum()) * 4 < flat.size * 3:
+                np.save(path, flat[nz])
+                np.save(path + ".mask.npy", np.packbits(nz))
+                self.on_disk += int(nz.sum()) * 4 + flat.size // 8
+                h = ("disk", path, tuple(a.shape))
+        if h[2] is None:
+            np.save(path, a)
+            self.on_disk += a.nbytes
+        try:
+            self.seen[key] = (h, weakref.ref(t))
+        except TypeError:
+            pass
+        return h
 
     def unpack(self, h):
-        if isinstance(h, tuple) and len(h) == 2 and h[0] == "disk":
-            t = torch.from_numpy(np.load(h[1]))
-            return t
+        if isinstance(h, tuple) and len(h) == 3 and h[0] == "disk":
+            if h[2] is None:
+                return torch.from_numpy(np.load(h[1]))
+            n = int(np.prod(h[2]))
+            nz = np.unpackbits(np.load(h[1] + ".mask.npy"), count=n).astype(bool)
+            flat = np.zeros(n, dtype=np.float32)
+            flat[nz] = np.load(h[1])
+            return torch.from_numpy(flat.reshape(h[2]))
         return h
 
 
@@ -400,6 +433,7 @@ def gen_full(ref_solver, S, B, offload=False, dis_only=False):
             if off:
                 shutil.rmtree(root, ignore_errors=True)
                 os.makedirs(root, exist_ok=True)
+                off.seen.clear()
             if not dis_only:
                 trainer.gen_update(*a)
                 losses = read_losses(trainer)
@@ -407,7 +441,7 @@ def gen_full(ref_solver, S, B, offload=False, dis_only=False):
                 print("[full S%d B%d] gen_update %.1fs loss_gen_total %.6f" % (S, B, time.time() - t0, losses["loss_gen_total"]), flush=True)
     finally:
         if off:
-            print("[full S%d B%d] offloaded %d tensors, %.1f GB" % (S, B, off.n, off.bytes / 1e9), flush=True)
+            print("[full S%d B%d] offloaded %d tensors, %.1f GB (%.1f GB on disk)" % (S, B, off.n, off.bytes / 1e9, off.on_disk / 1e9), flush=True)
             shutil.rmtree(root, ignore_errors=True)
     path = os.path.join(HERE, "full_s%d_b%d%s.npz" % (S, B, "_dis" if dis_only else ""))
     np.savez_compressed(path, **out)
@@ -604,3 +638,5 @@ if __name__ == "__main__":
         gen_full(ref_solver, 128, 64, offload=True)
     if "full128b128dis" in what:
         gen_full(ref_solver, 128, 128, offload=True, dis_only=True)
+    if "full128b128" in what:   # D step + G step at BASELINE configs[2]'s batch; ~1 h, needs ~100 GB of /tmp
+        gen_full(ref_solver, 128, 128, offload=True)

@@ -116,8 +116,12 @@ def test_hip_resync_24_steps_s128_b16():
     """24 optimiser steps at BASELINE configs[1] (128x128, batch 16), the headline configuration itself: the 16 scalars within
     1e-3 at 16 of the 24 steps -- 0-6, every second one after that, and 23 (each oracle iteration costs ~7 s of CPU at this size; r03
     checked six, r04 ten; the seconds come from the bf16 full-size cases, which read fixtures since r05)."""
-    worst, _ = _resync_run(128, 16, 24, check=[0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 23])
+    worst, signed = _resync_run(128, 16, 24, check=[0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 14, 16, 18, 20, 22, 23])
     print("worst |rel err| per scalar over 24 steps:", dict(zip(SCALARS, np.round(worst, 7))))
+    # the signed-bias bound of the 64x64 run, at the headline shape (VERDICT r05 "weak" 1): a systematic error of the HIP step would
+    # show as a mean signed error comparable to the worst one, rounding noise averages out
+    print("mean signed rel err per scalar:", dict(zip(SCALARS, np.round(signed.mean(axis=0), 8))))
+    assert np.abs(signed.mean(axis=0)).max() <= 2e-4, signed.mean(axis=0)
 
 
 def test_hip_resync_bf16_24_steps_s64_b4():

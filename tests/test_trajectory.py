@@ -172,6 +172,21 @@ def test_hip_trajectory_s128_b16_100_steps():
     rel = np.array([abs(g - gref) / abs(gref) for _, _, _, g, gref in out])
     print("hip-vs-reference rel deviation of loss_gen_total: max %.4f (reference self-drift max %.4f), tail-20 mean %.4f (%.4f)" % (
         rel.max(), env.max(), rel[-20:].mean(), env[-20:].mean()))
+    # the north star's literal figure ("G/D losses within 1e-3 after 100 steps") on record, next to what the reference does to
+    # itself when only its CPU thread count changes (profiles/r06_free_run_step99.json is a copy of this file)
+    last = out[-1]
+    rec = {"shape": "128x128 batch 16 fp32, 100 free-running steps from the recorded reference's initial state",
+           "step": int(last[0]), "loss_dis_all": {"hip": last[1], "reference": last[2], "abs_diff": abs(last[1] - last[2])},
+           "loss_gen_total": {"hip": last[3], "reference": last[4], "abs_diff": abs(last[3] - last[4])},
+           "reference_self_drift_rel_at_step_99_threads6_vs_threads3": float(env[-1]),
+           "hip_rel_dev_max": float(rel.max()), "reference_self_drift_rel_max": float(env.max())}
+    print("free run, step 99:", json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "r06_free_run_step99.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
     assert rel.max() <= 2.5 * env.max(), (rel.max(), env.max())
     assert rel[-20:].mean() <= 4.0 * env[-20:].mean() + 2e-3, (rel[-20:].mean(), env[-20:].mean())
     for w0 in range(10, 100, 10):
