@@ -384,30 +384,32 @@ def test_bf16_iteration_with_vgg_loss_vs_fp32_oracle(tmp_path):
 
 
 def test_bf16_full_iteration_b128(golden_dir):
-    """BASELINE configs[2] under a whole-iteration checker at ITS OWN batch (128x128, batch 128, bf16 activations):
-    * the D step against the IMPORTED REFERENCE's fp32 D step at batch 128, recorded once in the build container
-      (tests/golden/make_golden.py full128b128dis; reference solver.py:317-353; autograd's saved tensors parked on disk): both loss
-      scalars within 2e-2 relative, sampled entries of four D weight gradients within 8e-2 (rms 2e-2) of the tensor's largest
-      magnitude, their sums of squares within 10 %;
-    * the G step (reference solver.py:151-240) at the same batch against the HIP fp32 path from the same weights, batch and random
-      stream -- the fp32 path itself is held to the reference at batch 64 (tests/test_hip_parity.py::
-      test_full_size_iteration_vs_oracle[128-64-all]); a batch-128 reference G step would need ~110 GB of parked tensors --:
-      the headline loss within 2e-2 relative, every scalar within 3e-2 of max(1, |value|), five G gradients within 1.5e-1 (rms 3e-2)."""
+    """BASELINE configs[2] under a whole-iteration checker at ITS OWN batch (128x128, batch 128, bf16 activations), BOTH steps against
+    the IMPORTED REFERENCE's fp32 iteration at batch 128, recorded once in the build container (tests/golden/make_golden.py
+    full128b128: reference solver.py:317-353 and 151-240; autograd's 125 GB of saved tensors parked on disk, zero-run packed):
+    * D step: both loss scalars within 2e-2 relative, sampled entries of four D weight gradients within 8e-2 (rms 2e-2) of the
+      tensor's largest magnitude, their sums of squares within 10 %;
+    * G step (r06; rounds 4-5 compared it with the HIP fp32 path): the headline loss within 2e-2 relative, each of the 16 scalars within
+      3e-2 of max(1, |value|), sampled entries of the eight recorded G gradients within 1.5e-1 (rms 3e-2) of the largest magnitude;
+    * the fp32 HIP path on the same batch against the same fixture at the gates of test_full_size_iteration_vs_oracle (scalars 2e-4,
+      sampled gradients 1e-2): configs[2]'s shape is held to the reference in both precisions."""
     import json
     import numpy as np
     from solver import Solver
 
     def full_sample_idx(n):          # (tests/golden/make_golden.py sample_idx)
         return torch.arange(n) if n <= 8192 else (torch.arange(8192, dtype=torch.int64) * n) // 8192
-    fx = np.load(os.path.join(golden_dir, "full_s128_b128_dis.npz"))
+    fx = np.load(os.path.join(golden_dir, "full_s128_b128.npz"))
+    ref_losses = json.loads(bytes(fx["losses_json"]).decode())
     S, B = 128, 128
     cfg = synth.make_config(image_size=S, lstm_dropout=0.0)
     dev = torch.device(DEV)
     batch = synth.make_batch(B, S, seed=11)
     db = {k: v.to(dev) for k, v in batch.items()}
     a = (db["x_real"], db["c_src"], db["c_trg"], db["txt"], db["txt_lens"], db["label_src"], db["label_trg"], cfg, 0)
-    names = ("enc_content.model.0.conv.weight", "dec.model.0.model.1.model.0.conv.weight", "dec.model.2.conv.weight",
-             "dec.image_content.conv.weight", "mlp.model.2.fc.weight")
+    gnames = sorted({k.split("/")[1] for k in fx.files if k.startswith("ggrad/")})
+    dnames = sorted({k.split("/")[1] for k in fx.files if k.startswith("dgrad/")})
+    assert len(dnames) == 4 and len(gnames) == 8
 
     def run(precision):
         ops.set_precision(precision)
@@ -417,46 +419,55 @@ def test_bf16_full_iteration_b128(golden_dir):
             s = Solver(cfg, dev, None).to(dev)
             s.copy_nets()
             s.dis_update(*a)
-            dgrads = {k: p.grad.detach().float().cpu().clone() for k, p in s.dis.named_parameters() if p.grad is not None}
+            dp = dict(s.dis.named_parameters())
+            dgrads = {k: dp[k].grad.detach().float().cpu().clone() for k in dnames}
             dl = {k: float(getattr(s, k)) for k in ("loss_dis", "loss_dis_all")}
             s.gen_update(*a)
             torch.cuda.synchronize()
-            gl = {k: float(torch.as_tensor(getattr(s, k)).detach()) for k in LOSS_KEYS}
+            gl = {k: float(torch.as_tensor(getattr(s, k)).detach()) for k in ref_losses if k not in dl}
             gp = dict(s.gen.named_parameters())
-            gg = {k: gp[k].grad.detach().float().cpu().clone() for k in names}
+            gg = {k: gp[k].grad.detach().float().cpu().clone() for k in gnames}
             return dl, dgrads, gl, gg
         finally:
             host.set_noise(host.DeviceNoise())
+
+    def sampled(prefix, name, g):
+        flat = g.reshape(-1)
+        want = torch.from_numpy(fx["%s/%s/sample" % (prefix, name)])
+        amax, _, sumsq = (float(v) for v in fx["%s/%s/stats" % (prefix, name)])
+        diff = flat[full_sample_idx(flat.numel())] - want
+        return diff.abs().max().item(), diff.double().pow(2).mean().sqrt().item(), amax, float(flat.double().pow(2).sum()), sumsq
 
     dl, dgrads, gl, gg = run("bf16")
     for k in ("loss_dis", "loss_dis_all"):
         want = float(fx[k])
         assert abs(dl[k] - want) <= 2e-2 * abs(want), (k, dl[k], want)
-    dnames = sorted({k.split("/")[1] for k in fx.files if k.startswith("dgrad/")})
-    assert len(dnames) == 4
     for name in dnames:
-        flat = dgrads[name].reshape(-1)
-        want = torch.from_numpy(fx["dgrad/%s/sample" % name])
-        amax, _, sumsq = (float(v) for v in fx["dgrad/%s/stats" % name])
-        diff = flat[full_sample_idx(flat.numel())] - want
-        err, rms = diff.abs().max().item(), diff.double().pow(2).mean().sqrt().item()
+        err, rms, amax, sq, sumsq = sampled("dgrad", name, dgrads[name])
         print("bf16 B=128 D gradient %s: max err %.2e rms %.2e of the largest magnitude" % (name, err / amax, rms / amax))
         # whole-network gradients five bf16 layers deep (single bf16 layers: 1e-2 ... 3e-2 in this file): the worst entry within 8e-2
         # of the tensor's largest magnitude, the rms error within 2e-2 of it, the sum of squares within 10 %
         assert err <= 8e-2 * amax and rms <= 2e-2 * amax, (name, err, rms, amax)
-        assert abs(float(flat.double().pow(2).sum()) - sumsq) <= 0.1 * sumsq, name
-    dl32, _, gl32, gg32 = run("fp32")
+        assert abs(sq - sumsq) <= 0.1 * sumsq, name
+    want = ref_losses["loss_gen_total"]
+    assert abs(gl["loss_gen_total"] - want) <= 2e-2 * abs(want), (gl["loss_gen_total"], want)
+    for k, v in gl.items():
+        assert abs(v - ref_losses[k]) <= 3e-2 * max(1.0, abs(ref_losses[k])), (k, v, ref_losses[k])
+    for name in gnames:
+        err, rms, amax, sq, sumsq = sampled("ggrad", name, gg[name])
+        print("bf16 vs reference B=128 G gradient %s: max err %.2e rms %.2e of the largest magnitude" % (name, err / amax, rms / amax))
+        # gradients through the whole generator + discriminator in bf16 (~25 layers deep at the content stem): worst sampled entry
+        # within 1.5e-1 of the tensor's largest magnitude, rms error within 3e-2 of it
+        assert err <= 1.5e-1 * amax and rms <= 3e-2 * amax, (name, err, rms, amax)
+    dl32, dg32, gl32, gg32 = run("fp32")
     ops.set_precision("bf16")
-    for k in ("loss_dis", "loss_dis_all"):                       # the fp32 path itself against the batch-128 reference: 2e-4
+    for k in ("loss_dis", "loss_dis_all"):                       # the fp32 path itself against the batch-128 reference
         want = float(fx[k])
         assert abs(dl32[k] - want) <= 2e-4 * max(1.0, abs(want)), (k, dl32[k], want)
-    assert abs(gl["loss_gen_total"] - gl32["loss_gen_total"]) <= 2e-2 * abs(gl32["loss_gen_total"]), (gl["loss_gen_total"], gl32["loss_gen_total"])
-    for k in LOSS_KEYS:
-        assert abs(gl[k] - gl32[k]) <= 3e-2 * max(1.0, abs(gl32[k])), (k, gl[k], gl32[k])
-    for k in names:
-        d = (gg[k] - gg32[k]).double()
-        amax = gg32[k].abs().max().item()
-        print("bf16 vs fp32 B=128 G gradient %s: max err %.2e rms %.2e of the largest magnitude" % (k, d.abs().max().item() / amax, d.pow(2).mean().sqrt().item() / amax))
-        # gradients through the whole generator + discriminator in bf16 (~25 layers deep at the content stem): worst entry within
-        # 1.5e-1 of the tensor's largest magnitude, rms error within 3e-2 of it
-        assert d.abs().max().item() <= 1.5e-1 * amax and d.pow(2).mean().sqrt().item() <= 3e-2 * amax, k
+    for k, v in gl32.items():
+        assert abs(v - ref_losses[k]) <= 2e-4 * max(1.0, abs(ref_losses[k])), (k, v, ref_losses[k])
+    for prefix, names, grads in (("dgrad", dnames, dg32), ("ggrad", gnames, gg32)):
+        for name in names:
+            err, _, amax, sq, sumsq = sampled(prefix, name, grads[name])
+            assert err <= 1e-2 * amax + 1e-6, (name, err, amax)
+            assert abs(sq - sumsq) <= 4e-2 * sumsq, (name, sq, sumsq)
