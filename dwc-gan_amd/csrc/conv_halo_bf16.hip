@@ -414,6 +414,41 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
     return DWC_OK;
 }
 
+/* DATA GRADIENT of a reflect-padded stride-1 "same" convolution in ONE launch (r06; reference networks.py:579-585 through autograd):
+ * dx[B,H,W,Cin] = interior of the padded gradient image (zero-rule convolution of dy[B,H,W,Cout] with the rotated filter, w_dgrad =
+ * dwc_bf16_weight_prepare_dgrad layout) + its border ring folded back by the reflect rule, the ring computed by the border tiles
+ * themselves (conv_halo16_bf16.inc, RING) -- replaces dwc_bf16_conv2d_same_halo_add(reflect = 0) + dwc_bf16_conv2d_bwd_data_ring.
+ * `add` ([B,H,W,Cin] bf16 or NULL) is added behind it as in dwc_bf16_conv2d_same_halo_add.  Handled: K = 3 with Cin a multiple of 128
+ * above 128, K = 5 with Cin a multiple of 64 above 64, H and W multiples of 16 and >= 32, launches of at least 512 four-wave
+ * workgroups (the forms two of which share a CU); _ok == 0: use the two-call form. */
+int dwc_bf16_conv2d_bwd_data_same_fused_ok(int B, int H, int W, int Cin, int Cout, int K) {
+    if (!halo_ok(B, H, W, Cout, Cin, K) || H < 2 * TB || W < 2 * TB) return 0;
+    const long nblk = (long)B * (H / TB) * (W / TB);
+    if (nblk * (Cin / 64) < 512) return 0;
+    return (K == 3 ? (Cin > 128 && Cin % 128 == 0) : (Cin > 64 && Cin % 64 == 0)) ? 1 : 0;
+}
+
+int dwc_bf16_conv2d_bwd_data_same_fused(const void* dy, const void* w_dgrad, const void* add, void* dx, int B, int H, int W, int Cin,
+                                        int Cout, int K, void* stream) {
+    if (!dy || !w_dgrad || !dx || !dwc_bf16_conv2d_bwd_data_same_fused_ok(B, H, W, Cin, Cout, K)) return DWC_EINVAL;
+    HaloArgs a;
+    a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.bias = nullptr; a.add = (const bf16*)add; a.y = (bf16*)dx;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cout; a.logCin = dwc_ilog2_exact(Cout); a.N = Cin; a.K = K;
+    a.Kp = (K * K * Cout + BK - 1) / BK * BK; a.act = DWC_ACT_NONE; a.reflect = 0;
+    a.blocks_x = W / TB; a.blocks_per_img = (H / TB) * (W / TB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B * a.blocks_per_img;
+    if (K == 3) {
+        a.tiles_n = Cin / 128;
+        hipLaunchKernelGGL((conv_halo16_kernel<3, 128, 2, 2, 1, 0, 0, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    } else {
+        a.tiles_n = Cin / 64;
+        hipLaunchKernelGGL((conv_halo16_kernel<5, 64, 2, 2, 1, 0, 0, 1>), dim3(nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 /* INTERIOR of the data gradient of the 4x4, stride-2, reflect-pad-1 convolutions (conv_halo16_bf16.inc, S2 == 2): dy:[B,H/2,W/2,Cout]
  * bf16 -> the H x W pixels of dx:[B,H,W,Cin] (every pixel written, no accumulation); w_dgrad = dwc_bf16_weight_prepare_dgrad(KH = KW = 4,
  * stride 2, cout_pad = Cout, cin_pad = Cin): four class matrices [Cin][Kp].  The border ring of the padded gradient image still has to

@@ -93,6 +93,8 @@ SIGNATURES = {
     "dwc_bf16_conv2d_same_halo_ok": (c_int, [c_int] * 6),
     "dwc_bf16_conv2d_same_halo": (c_int, [c_fp] * 4 + [c_int] * 8 + [c_fp]),
     "dwc_bf16_conv2d_same_halo_add": (c_int, [c_fp] * 5 + [c_int] * 8 + [c_fp]),
+    "dwc_bf16_conv2d_bwd_data_same_fused_ok": (c_int, [c_int] * 6),
+    "dwc_bf16_conv2d_bwd_data_same_fused": (c_int, [c_fp] * 4 + [c_int] * 6 + [c_fp]),
     "dwc_weight_refresh_multi": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_u, c_fp]),
     "dwc_bf16_conv2d_fwd_zeropad": (c_int, [c_fp, c_fp, c_fp, c_fp] + [c_int] * 10 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_bwd_data_zeropad_ws_bytes": (c_sz, [c_int] * 8),

@@ -553,6 +553,7 @@ X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 fo
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
 X3_WGRAD_HALO3 = int(os.environ.get("DWC_X3_WGRAD_HALO3", "1"))   # 0: 3x3 weight gradients on the im2col kernel (split-product inner product)
+RING_FUSED = int(os.environ.get("DWC_RING_FUSED", "1"))   # stride-1 data gradients: border ring inside the halo launch (0: strip GEMM + fold launches)
 S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
 
 
@@ -981,7 +982,7 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[0] and same and min(H, W) >= 2 * pad + 2 and (not half or cop >= 64):
             # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
             w_dg = _prepped(w, "dgrad", cop, Cx, 1, owner, half)
-            w_dg_t = _prepped(w, "dgrad_t", cop, Cx, 1, owner, half)
+            w_dg_t = lambda: _prepped(w, "dgrad_t", cop, Cx, 1, owner, half).data_ptr()     # (only the strip GEMMs of the ring read it)
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
             nws = _fn(lib, "conv2d_bwd_data_same_ws_bytes", x)(B, H, W, Cx, cop, KH, KW, pad)
@@ -1006,8 +1007,15 @@ class _Conv2d(torch.autograd.Function):
                         g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, ws.data_ptr(), ks_n,
                         ks_t, st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
                 _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
+                g_res = None                                   # consumed by the kernel's epilogue
+            elif half and HALO and RING_FUSED and lib.dwc_bf16_conv2d_bwd_data_same_fused_ok(B, H, W, Cx, cop, KH):
+                # interior AND border ring in one launch: the border tiles of the halo kernel fold the ring in as extra MFMAs (r06)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_bwd_data_same_fused(
+                    g.data_ptr(), w_dg.data_ptr(), _p(g_res), dx.data_ptr(), B, H, W, Cx, cop, KH, st),
+                    scope_name=ctx.bscope, detail="dgrad-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
+                    "conv2d_bwd_data_same_fused")
                 g_res = None                                   # consumed by the kernel's epilogue
             elif half and HALO and lib.dwc_bf16_conv2d_same_halo_ok(B, H, W, cop, Cx, KH):
                 # interior on the halo-tiled kernel (zero rule, dgrad weights), the ring stays on the strip GEMMs
@@ -1018,13 +1026,13 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st),
                     scope_name=ctx.bscope, detail="dgrad-halo" + shape), "conv2d_same_halo dgrad")
                 _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_bf16_conv2d_bwd_data_ring(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
             else:
                 ws = workspace(nws, dev)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_same", x)(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
+                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_same")
         elif (ctx.needs_input_grad[0] and S2DGRAD and stride == 2 and KH == 4 and KW == 4 and pad == 1

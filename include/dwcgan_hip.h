@@ -511,6 +511,15 @@ int dwc_bf16_conv2d_same_halo(const void* x, const void* w_prepared, const float
  * gradient of a ResBlock (reference networks.py:521) rides on the data gradient of its first convolution. */
 int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const float* bias, const void* add, void* y, int B, int H,
                                   int W, int Cin, int Cout, int K, int act, int reflect, void* stream);
+/* (r06, ABI 8) The DATA GRADIENT of those layers in ONE launch: dx[B,H,W,Cin] = interior (zero-rule convolution of dy[B,H,W,Cout]
+ * with w_dgrad) + the border ring of the padded gradient image folded back by the reflect rule (reference networks.py:579-585 through
+ * autograd) + `add` (NULL or [B,H,W,Cin] bf16, as above).  The border tiles compute the ring pixels that fold onto them as extra
+ * MFMAs of the step whose weights they need (csrc/conv_halo16_bf16.inc, RING): replaces dwc_bf16_conv2d_same_halo_add(reflect = 0)
+ * + dwc_bf16_conv2d_bwd_data_ring (strip GEMM + fold launch).  _ok: K = 3 with Cin a multiple of 128 above 128 / K = 5 with Cin a
+ * multiple of 64 above 64, H, W multiples of 16 and >= 32, Cout a power of two >= 64, at least 512 four-wave workgroups. */
+int dwc_bf16_conv2d_bwd_data_same_fused_ok(int B, int H, int W, int Cin, int Cout, int K);
+int dwc_bf16_conv2d_bwd_data_same_fused(const void* dy, const void* w_dgrad, const void* add, void* dx, int B, int H, int W, int Cin,
+                                        int Cout, int K, void* stream);
 
 /* The stride-2 4x4 reflect-pad-1 convolutions (reference networks.py:90,94,437 -- content encoder / discriminator --,
  * networks_v2.py:107-111 -- style encoder), forward, bf16 NHWC: x [B,H,W,Cin] -> y [B,H/2,W/2,Cout], halo form over the
