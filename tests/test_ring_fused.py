@@ -42,7 +42,7 @@ CASES = [
     (32, 256, 256, 32, 32, 3, False),     # ResBlock 3x3 at 32 x 32: every tile a corner tile
     (32, 256, 256, 32, 32, 3, True),      # ... with the identity-branch gradient riding on it
     (16, 256, 256, 32, 64, 3, False),     # left / right tiles with interior columns between them
-    (8, 256, 256, 64, 32, 3, False),      # top / bottom tiles with interior rows
+    (16, 256, 256, 64, 32, 3, False),     # top / bottom tiles with interior rows
     (8, 256, 128, 64, 64, 5, False),      # first 5x5 (x: 256 channels at 64 x 64): corner, edge and interior tiles
     (4, 128, 64, 128, 128, 5, False),     # second 5x5 (x: 128 channels at 128 x 128)
     (8, 128, 64, 64, 128, 5, True),
