@@ -145,7 +145,17 @@ struct X3Args {
 // 256 stragglers run one per CU): tiles [0, split_from) run whole and are dispatched first, only the tail is split.
 // NPL: planes per operand -- 3: exact bf16 split, six products; 2: f16 hi / lo split with per-tensor power-of-two scales, three
 // products (see h2_scale above).
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3>
+// RING (r06; two-plane form, stride-1 data gradients, a.reflect == 0): the border ring of the padded gradient image -- the reflect
+// rule's adjoint, rounds 2-5: an im2col strip GEMM + a fold launch behind every data gradient -- comes out of THIS launch.  Ring row -m
+// folds onto block row m (top tiles), ring column -x onto block column x (left tiles; bottom / right mirrored): under the taps that
+// reach real dY pixels (kh >= p + m, kw >= p + x) such a pixel needs, besides its regular patch pixel (m + kh, x + kw), the pixels
+// (kh - m, x + kw), (m + kh, kw - x) and -- in a corner -- (kh - m, kw - x).  The MFMA is linear in the pixel operand and a lane owns a
+// pixel, so those lanes simply read a PRE-SUMMED pixel: after every patch conversion a border tile adds the n = p(p+1)/2 row / column
+// pairs in fp32 (from the raw fp32 patch in LDS: exact up to one fp32 rounding of the sum), splits the sums into the two planes and
+// stores them as n extra patch rows and columns; the fragment address of lane (row, column) under tap (kh, kw) gets a per-lane offset
+// (two registers per pixel tile for the rows, two for the columns, selected by the tap).  No extra MFMA.  See conv_halo16_bf16.inc
+// for the bf16 twin.
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3, int RING = 0>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_x3_kernel(X3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 8 waves, two per SIMD, one workgroup per CU -- or 4 waves and two workgroups per CU (PB == 1).  (4 "fat" waves, one per
@@ -158,15 +168,18 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
     static_assert(!S2 || KS == 2, "stride-2 form: 2x2 taps per parity");
     static_assert(KSP == 1 || (KSP == 2 && S2 != 2 && NW == 4 && TM * TN <= 4), "contraction split: the two-per-CU tile only");
+    static_assert(!RING || (NPL == 2 && PB == 1 && S2 == 0 && (KS == 3 || KS == 5)), "fused border ring: two-plane stride-1 form");
     constexpr int PW = TB + KS - 1;                    // patch edge
+    constexpr int NALT = RING ? ((KS - 1) / 2) * ((KS - 1) / 2 + 1) / 2 : 0;     // RING: pre-summed rows / columns behind the PW real ones
+    constexpr int PWA = PW + NALT;
     constexpr int PPIX = PW * PW;                      // patch pixels
     constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
     // LDS image of a patch plane: pixel (py, px) at py*PITCH + px*16 elements, PITCH = PW*16 + 8: consecutive patch rows are
     // offset by HALF a 32-byte pixel slot.  A ds_read_b128 is served in lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}
     // (MI355X_MICROARCH.md), i.e. 8 pixels of one patch row + 8 of the next: with a plain pixel-linear image both rows hit
     // the same eight 16-byte bank slots (every fragment read 2-way conflicted); with the half-slot offset all 16 differ.
-    constexpr int PITCH = PW * CS + 8;
-    constexpr int P_PLANE = PW * PITCH;                // elements per plane of a patch buffer
+    constexpr int PITCH = PWA * CS + 8;
+    constexpr int P_PLANE = PWA * PITCH;               // elements per plane of a patch buffer
     constexpr int W_CHUNKS = NPL * BN * 2;             // 16-byte chunks of one tap's weight slab (NPL planes x BN rows x 32 B)
     constexpr int W_INSTR = (W_CHUNKS + THREADS - 1) / THREADS;    // LDS-DMA instructions per thread and tap
     constexpr int W_SLOT = W_INSTR * THREADS * 8;      // elements per ring slot (whole instructions)
@@ -376,6 +389,99 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     // weight rows: the two 16-byte halves of row r are stored swapped when (r>>3)&1 (dwc_x3_weight_prepare), same reason
     const int b_row = (wn * TN * 32 + l31) * CS + ((hi ^ ((l31 >> 3) & 1)) * 8);
 
+    // ---- RING: which border this tile touches, and the per-lane offsets that send a ring pixel's lane to its pre-summed pixel -------
+    // slot(m, kl): the extra patch row (column) that holds row m + kh plus row kh - m for a top (left) tile under tap row (column) kl =
+    // kh; bottom / right tiles are the mirror image (m counted from the far edge, kl = K - 1 - kh).  kl takes the values 2p and, for
+    // p = 2, 2p - 1: "A" and "B" below.
+    int row_side = 0, col_side = 0;                    // 1: top / left border tile, 2: bottom / right (workgroup-uniform)
+    int khA = -1, khB = -1, kwA = -1, kwB = -1;        // the tap rows / columns that have redirected lanes in this tile
+    int dRA[TM], dRB[TM], dCA = 0, dCB = 0;            // element offsets of those lanes under tap row khA / khB, tap column kwA / kwB
+    auto ring_slot = [](int m, int kl) {
+        int off = 0;
+        for (int q = 1; q < m; ++q) off += PAD - q + 1;
+        return off + kl - (PAD + m);
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) dRA[i] = dRB[i] = 0;
+    if constexpr (RING) {
+        row_side = y0 == 0 ? 1 : (y0 + TB == a.H ? 2 : 0);
+        col_side = x0 == 0 ? 1 : (x0 + TB == a.W ? 2 : 0);
+        if (row_side) {
+            khA = row_side == 1 ? KS - 1 : 0;
+            khB = PAD == 2 ? (row_side == 1 ? KS - 2 : 1) : -1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = ((wm * TM + i) * 32 + l31) >> 4;
+                const int m = row_side == 1 ? r : 15 - r;
+                if (m >= 1 && m <= PAD) {
+                    dRA[i] = (PW + ring_slot(m, KS - 1) - (r + khA)) * PITCH;
+                    if (PAD == 2 && m == 1) dRB[i] = (PW + ring_slot(m, KS - 2) - (r + khB)) * PITCH;
+                }
+            }
+        }
+        if (col_side) {
+            kwA = col_side == 1 ? KS - 1 : 0;
+            kwB = PAD == 2 ? (col_side == 1 ? KS - 2 : 1) : -1;
+            const int x = l31 & 15;
+            const int m = col_side == 1 ? x : 15 - x;
+            if (m >= 1 && m <= PAD) {
+                dCA = (PW + ring_slot(m, KS - 1) - (x + kwA)) * CS;
+                if (PAD == 2 && m == 1) dCB = (PW + ring_slot(m, KS - 2) - (x + kwB)) * CS;
+            }
+        }
+    }
+    const bool ring_tile = RING && (row_side | col_side);
+    // the pre-summed rows / columns of the slab whose raw fp32 patch sits in sR (every wave's DMA has landed and passed a barrier).
+    // One item = 4 channels of one extra pixel: rows {r1[, r2]} x columns {c1[, c2]} of the raw patch added in fp32, split, stored.
+    auto ring_presum = [&]() {
+        if constexpr (RING) {
+            const int ncol = col_side ? NALT * PW : 0;                        // extra columns, real rows
+            const int wrow = PW + (col_side ? NALT : 0);                      // pixels of one extra row
+            const int items = (ncol + (row_side ? NALT * wrow : 0)) * 4;
+            auto pair = [&](int sl, int side, int& u, int& v, int base) {   // slot -> the two source rows / columns of block row / column `base`
+                int m = 1, kl = PAD + 1 + sl;
+                if (PAD == 2 && sl == 2) m = 2, kl = 4;
+                const int k = side == 1 ? kl : KS - 1 - kl;
+                (void)base;
+                u = side == 1 ? m + k : 15 - m + k;
+                v = side == 1 ? k - m : 15 + m + k;
+            };
+            bf16* dst = sP;
+            for (int it = t; it < items; it += THREADS) {
+                const int q = it & 3, px_ = it >> 2;
+                int ty, tx, r1, r2, c1, c2;
+                if (px_ < ncol) {                                             // extra column sl, real row ty
+                    const int sl = px_ / PW;
+                    ty = px_ - sl * PW;
+                    tx = PW + sl;
+                    r1 = r2 = ty;
+                    pair(sl, col_side, c1, c2, 0);
+                } else {                                                      // extra row sl, column tx (real, or an extra column)
+                    const int e = px_ - ncol, sl = e / wrow;
+                    tx = e - sl * wrow;
+                    ty = PW + sl;
+                    pair(sl, row_side, r1, r2, 0);
+                    if (tx < PW) c1 = c2 = tx;
+                    else pair(tx - PW, col_side, c1, c2, 0);
+                }
+                auto raw = [&](int r, int c) {
+                    const int pp = r * PW + c;
+                    const int ps = pp / PPT, tt = (pp - ps * PPT) * 4 + q;
+                    return *reinterpret_cast<const f32x4*>(sR + (ps * THREADS + tt) * 8);
+                };
+                f32x4 v = raw(r1, c1);
+                if (c2 != c1) v += raw(r1, c2);
+                if (r2 != r1) {
+                    v += raw(r2, c1);
+                    if (c2 != c1) v += raw(r2, c2);
+                }
+                const Planes<NPL> pl2 = split_planes<NPL>(v, sx.s);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<u32x2*>(dst + pl * P_PLANE + ty * PITCH + tx * CS + q * 4) = pl2.p[pl];
+            }
+        }
+    };
+
     // acc: the leading products a0*b0; lo: the five correction products (2^-8 and 2^-16 of the leading one).  Kept apart,
     // the corrections are rounded at THEIR magnitude and the main accumulator sees one rounding per 16-channel step instead of
     // six; merged once in the epilogue.  (The 4x2-tile instantiation has no registers for a second set and adds all six in
@@ -411,6 +517,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     write_patch(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (ring_tile) {                                    // (every wave's raw patch has landed: the barrier above)
+        ring_presum();
+        __syncthreads();
+    }
 
     // ---- main loop: one step = one filter tap of one 16-channel slab, one barrier per step -----------------------------------
     // (r02 ablation of the unpipelined loop: kernel time = MFMA time + everything else, no overlap at all; r05 ablation of the
@@ -425,9 +535,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     bf16x8 fa[PIPE ? 2 : 1][NPL][TM], fb[PIPE ? 2 : 1][NPL][TN];
     auto read_frags = [&](auto setc, int tap_, int pbuf_, int slot_) {
         constexpr int set = decltype(setc)::value;
-        const int d = (tap_ / KS) * PITCH + (tap_ % KS) * CS;
+        const int kh_ = tap_ / KS, kw_ = tap_ - kh_ * KS;
+        const int d = kh_ * PITCH + kw_ * CS;
         const bf16* p = sP + pbuf_ * NPL * P_PLANE + d;
         const bf16* w = sW + slot_ * W_SLOT + b_row;
+        int ring_d[TM];                                 // RING: ring pixels' lanes read their pre-summed pixel under this tap
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ring_d[i] = 0;
+        if constexpr (RING) {
+            if (ring_tile) {
+                const int dc = kw_ == kwA ? dCA : (kw_ == kwB ? dCB : 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ring_d[i] = dc + (kh_ == khA ? dRA[i] : (kh_ == khB ? dRB[i] : 0));
+            }
+        }
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
@@ -438,7 +559,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (DBG & 2) { for (int e = 0; e < 8; ++e) fa[set][pl][i][e] = (bf16)(float)(lane + i + pl); }
-                else fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(p + pl * P_PLANE + pp0[i]);
+                else fa[set][pl][i] = *reinterpret_cast<const bf16x8*>(p + pl * P_PLANE + pp0[i] + ring_d[i]);
             }
         }
     };
@@ -521,6 +642,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
                     }
                 }
                 if (!(DBG & 32)) write_patch(0);
+                if (ring_tile) ring_presum();         // (reads the raw patch only: needs no barrier behind write_patch)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -1157,9 +1279,9 @@ bool x3_ok(int B, int H, int W, int Cin, int N, int K) {
            !(N % 4);
 }
 
-template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3>
+template <int KS, int BN, int WM, int WN, int TM, int TN, int DBG = 0, int PB = 2, int S2 = 0, int KSP = 1, int NPL = 3, int RING = 0>
 void x3_launch(const X3Args& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2, KSP, NPL>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((conv_halo_x3_kernel<KS, BN, WM, WN, TM, TN, DBG, PB, S2, KSP, NPL, RING>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 // 16-bit elements of the two-plane prepared filter ({s_w, 1 / s_w} follow as two floats: + 4 elements)
 size_t h2_w_elems(int rows, int kdim, int K) { return (size_t)K * K * ((kdim + CS - 1) / CS) * 2 * rows * CS; }
@@ -1257,10 +1379,12 @@ int dwc_x3_conv2d_ksplit_ticket_words(void) { return X3_KSPLIT_TICKETS + 1; }   
 template <int NPL>
 static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch, const void* w_prepared, const float* bias, const float* add,
                                float* y, int B, int H, int W, int Cin, int N, int rows, int K, int act, int reflect, void* ws,
-                               size_t ws_bytes, unsigned* tickets, void* stream, void* ys = nullptr, unsigned ys_epoch = 0) {
+                               size_t ws_bytes, unsigned* tickets, void* stream, void* ys = nullptr, unsigned ys_epoch = 0, bool ring = false) {
     // (two planes: x is addressed through 31-bit buffer offsets)
     if (!x || !w_prepared || !y || !x3_ok(B, H, W, Cin, N, K) || rows < N || (NPL == 2 && (!xs || (size_t)B * H * W * Cin * 4 >= 0x80000000ull)))
         return DWC_EINVAL;
+    // (ring: the reflect adjoint's border ring inside the launch -- two-plane data gradients on images of at least two tiles per side)
+    if (ring && (NPL != 2 || reflect || H < 2 * TB || W < 2 * TB)) return DWC_EINVAL;
     X3Args a;
     a.x = x; a.w = (const bf16*)w_prepared; a.bias = bias; a.add = add; a.y = y;
     a.xs = (const unsigned long long*)xs; a.xs_epoch = xs_epoch; a.w_elems = h2_w_elems(rows, Cin, K);
@@ -1282,7 +1406,12 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
         a.status = tickets + X3_KSPLIT_TICKETS;
         a.split_from = (int)x3_ksplit_from(g2.x, Cin / CS);
         const dim3 g4(2 * g2.x - a.split_from);
-        if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
+        if constexpr (NPL == 2) {
+            if (ring && K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, 2, 1>(a, g4, (hipStream_t)stream);
+            else if (ring) x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, 2, 1>(a, g4, (hipStream_t)stream);
+        }
+        if (ring) {
+        } else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
         else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 2, NPL>(a, g4, (hipStream_t)stream);
     }
 #ifdef DWC_DEV_ABLATIONS      // timing-only ablations (WRONG results): compiled only with -DDWC_DEV_ABLATIONS, never in the shipped .so
@@ -1326,6 +1455,12 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
         }
     }
 #endif
+    else if (ring) {
+        if constexpr (NPL == 2) {
+            if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, 2, 1>(a, g2, (hipStream_t)stream);
+            else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, 2, 1>(a, g2, (hipStream_t)stream);
+        }
+    }
     else if (K == 3) x3_launch<3, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
     else x3_launch<5, 64, 4, 1, 2, 2, 0, 1, 0, 1, NPL>(a, g2, (hipStream_t)stream);
     DWC_LAUNCH_CHECK();
@@ -1333,6 +1468,19 @@ static int x3_same_add_ws_impl(const float* x, const void* xs, unsigned xs_epoch
 }
 
 extern "C" {
+
+/* (r06, ABI 8) DATA GRADIENT of a reflect-padded stride-1 "same" 3x3 / 5x5 convolution in ONE launch, two-plane split products:
+ * dx[B,H,W,N] = interior (zero-rule convolution of dy[B,H,W,Cout] with w_prepared = dwc_h2_weight_prepare(dgrad = 1, `rows` rows)) +
+ * the border ring of the padded gradient image folded back by the reflect rule (reference networks.py:579-585 through autograd) +
+ * `add` (NULL or [B,H,W,N]).  The border tiles read pre-summed patch pixels for the rows / columns the ring folds onto
+ * (conv_halo_x3_kernel, RING): replaces dwc_h2_conv2d_same_add_ws(reflect = 0) + dwc_conv2d_bwd_data_ring.  dy_amax / dy_epoch, ws,
+ * ws_bytes, tickets as there.  H, W multiples of 16 and >= 32; otherwise as dwc_h2_conv2d_same_add_ws (DWC_EINVAL: use the two calls). */
+int dwc_h2_conv2d_bwd_data_same_fused(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, const float* add,
+                                      float* dx, int B, int H, int W, int Cout, int N, int rows, int K, void* ws, size_t ws_bytes,
+                                      unsigned* tickets, void* stream) {
+    return x3_same_add_ws_impl<2>(dy, dy_amax, dy_epoch, w_prepared, nullptr, add, dx, B, H, W, Cout, N, rows, K, DWC_ACT_NONE, 0, ws, ws_bytes,
+                                  tickets, stream, nullptr, 0, true);
+}
 
 int dwc_x3_conv2d_same_add_ws(const float* x, const void* w_prepared, const float* bias, const float* add, float* y, int B, int H, int W,
                               int Cin, int N, int rows, int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets,

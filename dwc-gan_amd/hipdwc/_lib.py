@@ -147,6 +147,7 @@ SIGNATURES = {
     "dwc_h2_weight_prepared_elems": (c_sz, [c_int] * 3),
     "dwc_h2_weight_prepare": (c_int, [c_fp, c_fp] + [c_int] * 5 + [c_fp, c_u, c_fp]),
     "dwc_h2_conv2d_same_add_ws": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 4 + [c_fp, c_u] + [c_int] * 9 + [c_fp, c_sz, c_fp, c_fp]),
+    "dwc_h2_conv2d_bwd_data_same_fused": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 3 + [c_int] * 7 + [c_fp, c_sz, c_fp, c_fp]),
     "dwc_h2_conv2d_s2_ws": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 3 + [c_fp, c_u] + [c_int] * 7 + [c_fp, c_sz, c_fp, c_fp]),
     "dwc_h2_conv2d_s2_bwd_data": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp] + [c_int] * 6 + [c_fp]),
     "dwc_h2_conv2d_wgrad": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp, c_u, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),

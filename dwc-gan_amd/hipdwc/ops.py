@@ -981,7 +981,7 @@ class _Conv2d(torch.autograd.Function):
                     "conv2d_bwd_data_image")
         elif ctx.needs_input_grad[0] and same and min(H, W) >= 2 * pad + 2 and (not half or cop >= 64):
             # "same" convolutions: interior on the H x W grid straight into dx + the thin border ring (no padded image)
-            w_dg = _prepped(w, "dgrad", cop, Cx, 1, owner, half)
+            w_dg = lambda: _prepped(w, "dgrad", cop, Cx, 1, owner, half).data_ptr()        # (lazily: the fused fp32 form reads neither)
             w_dg_t = lambda: _prepped(w, "dgrad_t", cop, Cx, 1, owner, half).data_ptr()     # (only the strip GEMMs of the ring read it)
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
@@ -991,11 +991,20 @@ class _Conv2d(torch.autograd.Function):
                 # interior = zero-padded convolution of dY with the rotated filter on the split-product kernel; ring direct
                 w_x3 = _prepped(w, "x3_dgrad", cop, Cx, 1, owner) if not h2_fits(g) else None
                 # (one arena: the interior's half sums -- small launches, contraction split -- are dead when the ring strips start)
-                ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1, at_least=nws)
+                fused = bool(RING_FUSED and h2_fits(g) and min(H, W) >= 32)
+                ws, ks_n, ks_t = _x3_ksplit(lib, dev, B, H, W, cop, Cx, KH, 1, at_least=0 if fused else nws)
 
                 shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
                 # (two spans: the interior launch carries the layer's flops, the ring strips + fold are time on top of it)
-                if h2_fits(g):
+                if fused:
+                    # interior AND border ring in one launch: border tiles read pre-summed patch pixels (r06, conv_halo_x3_kernel RING)
+                    w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
+                    ga = amax_of(g)
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_bwd_data_same_fused(
+                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH,
+                        _p(ws), ks_n, ks_t, st), scope_name=ctx.bscope, exec_flops=3 * flops, detail="dgrad-h2" + shape),
+                        "h2_conv2d_bwd_data_same_fused")
+                elif h2_fits(g):
                     w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
                     ga = amax_of(g)
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_same_add_ws(
@@ -1006,14 +1015,15 @@ class _Conv2d(torch.autograd.Function):
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_same_add_ws(
                         g.data_ptr(), w_x3.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, Cx, KH, 0, 0, ws.data_ptr(), ks_n,
                         ks_t, st), scope_name=ctx.bscope, exec_flops=6 * flops, detail="dgrad-x3" + shape), "x3_conv2d_same dgrad")
-                _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
-                    scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
+                if not fused:
+                    _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_ring(
+                        g.data_ptr(), w_dg(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                        scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
             elif half and HALO and RING_FUSED and lib.dwc_bf16_conv2d_bwd_data_same_fused_ok(B, H, W, Cx, cop, KH):
                 # interior AND border ring in one launch: the border tiles of the halo kernel fold the ring in as extra MFMAs (r06)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_bwd_data_same_fused(
-                    g.data_ptr(), w_dg.data_ptr(), _p(g_res), dx.data_ptr(), B, H, W, Cx, cop, KH, st),
+                    g.data_ptr(), w_dg(), _p(g_res), dx.data_ptr(), B, H, W, Cx, cop, KH, st),
                     scope_name=ctx.bscope, detail="dgrad-halo B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_same_fused")
                 g_res = None                                   # consumed by the kernel's epilogue
@@ -1023,16 +1033,16 @@ class _Conv2d(torch.autograd.Function):
 
                 shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_same_halo_add(
-                    g.data_ptr(), w_dg.data_ptr(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st),
+                    g.data_ptr(), w_dg(), None, _p(g_res), dx.data_ptr(), B, H, W, cop, Cx, KH, 0, 0, st),
                     scope_name=ctx.bscope, detail="dgrad-halo" + shape), "conv2d_same_halo dgrad")
                 _lib.check(_timed("conv_gemm_kernel", 0.0, lambda: lib.dwc_bf16_conv2d_bwd_data_ring(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
+                    g.data_ptr(), w_dg(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(), nws, st),
                     scope_name=ctx.bscope, detail="dgrad-ring" + shape), "conv2d_bwd_data_ring")
                 g_res = None                                   # consumed by the kernel's epilogue
             else:
                 ws = workspace(nws, dev)
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: _fn(lib, "conv2d_bwd_data_same", x)(
-                    g.data_ptr(), w_dg.data_ptr(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
+                    g.data_ptr(), w_dg(), w_dg_t(), dx.data_ptr(), B, H, W, Cx, cop, KH, KW, pad, ws.data_ptr(),
                     ws.numel(), st), scope_name=ctx.bscope, detail="dgrad B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)),
                     "conv2d_bwd_data_same")
         elif (ctx.needs_input_grad[0] and S2DGRAD and stride == 2 and KH == 4 and KW == 4 and pad == 1

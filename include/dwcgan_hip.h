@@ -437,6 +437,14 @@ int dwc_h2_weight_prepare(const float* w_oihw, void* out, int Cout, int Cin, int
 int dwc_h2_conv2d_same_add_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias,
                               const float* add, float* y, void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows,
                               int K, int act, int reflect, void* ws, size_t ws_bytes, unsigned* tickets, void* stream);
+/* (r06, ABI 8) The DATA GRADIENT of those layers in ONE launch: dx[B,H,W,N] = interior (zero-rule convolution of dy[B,H,W,Cout] with
+ * w_prepared = dwc_h2_weight_prepare(dgrad = 1)) + the border ring of the padded gradient image folded back by the reflect rule
+ * (reference networks.py:579-585 through autograd) + `add` (NULL or [B,H,W,N]).  Border tiles read pre-summed patch pixels on the rows /
+ * columns the ring folds onto (csrc/conv_halo_x3.hip, RING; no extra MFMA): replaces dwc_h2_conv2d_same_add_ws(reflect = 0) +
+ * dwc_conv2d_bwd_data_ring.  H, W multiples of 16 and >= 32, dy below 2 GB; scratch / tickets as dwc_h2_conv2d_same_add_ws. */
+int dwc_h2_conv2d_bwd_data_same_fused(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, const float* add,
+                                      float* dx, int B, int H, int W, int Cout, int N, int rows, int K, void* ws, size_t ws_bytes,
+                                      unsigned* tickets, void* stream);
 int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, const void* w_prepared, const float* bias, float* y,
                         void* y_amax, unsigned y_epoch, int B, int H, int W, int Cin, int N, int rows, int act, void* ws, size_t ws_bytes,
                         unsigned* tickets, void* stream);

@@ -132,7 +132,14 @@ def test_bf16_hot_shapes_at_bench_batch(shape):
     # rounding where the fp32 sums were associated differently
     assert relerr(y_big, y_c) <= 4e-3, ("y big vs chunks", relerr(y_big, y_c))
     if plain:
-        assert relerr(dx_big, dx_c) <= 4e-3, ("dx big vs chunks", relerr(dx_big, dx_c))
+        # (r06: the big launch of a stride-1 layer folds the border ring inside the halo kernel -- one rounding of interior + ring --, the
+        # chunks of 4 take the strip GEMM + fold launch, which adds the ring to the ROUNDED interior: two roundings apart on the rows /
+        # columns the ring folds onto, one elsewhere)
+        ring = k in (3, 5) and s == 1
+        assert relerr(dx_big, dx_c) <= (8e-3 if ring else 4e-3), ("dx big vs chunks", relerr(dx_big, dx_c))
+        if ring:
+            inner = (slice(None), slice(None), slice(p + 1, H - 1 - p), slice(p + 1, H - 1 - p))
+            assert relerr(dx_big[inner], dx_c[inner]) <= 4e-3, ("dx big vs chunks, off the ring", relerr(dx_big[inner], dx_c[inner]))
     else:
         # behind ReLU / LeakyReLU the derivative is taken from the stored output's sign: where the fp32 sum is within rounding
         # noise of zero the two launches (different split-K / tile plans) can land on opposite signs, which changes ONE term

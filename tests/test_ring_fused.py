@@ -94,3 +94,56 @@ def test_fused_ring_matches_fp32_and_the_two_call_form(case):
         assert ef <= 6e-3, (name, ef, eu)
         assert ef <= 1.25 * eu + 5e-4, (name, ef, eu)
     assert torch.equal(dw_f, dw_u)
+
+
+# fp32 path (two-plane split products, csrc/conv_halo_x3.hip RING): (B, channels of x / dx, channels of y / dY, H, W, K, residual add)
+CASES_F32 = [
+    (16, 256, 256, 32, 32, 3, False),     # c1's ResBlock launch: 256 tiles, contraction split (two workgroups per tile)
+    (16, 256, 256, 32, 32, 3, True),
+    (48, 256, 256, 32, 32, 3, False),     # the 3B passes: whole tiles
+    (8, 256, 256, 32, 64, 3, False),
+    (8, 256, 256, 64, 32, 3, True),
+    (16, 256, 128, 64, 64, 5, False),     # first 5x5 (x: 256 channels at 64 x 64)
+    (16, 128, 64, 128, 128, 5, False),    # second 5x5 (x: 128 channels at 128 x 128)
+    (2, 64, 64, 32, 48, 5, True),         # a small launch, three tiles across
+]
+
+
+@pytest.mark.parametrize("case", CASES_F32, ids=lambda c: "x".join(str(v) for v in c))
+def test_fused_ring_fp32_matches_float64_and_the_two_call_form(case):
+    B, Cx, Cy, H, W, K, res = case
+    p = (K - 1) // 2
+    ops.set_precision("fp32")
+    g = torch.Generator().manual_seed(B + Cx + Cy + H + W + K + 1)
+    x = torch.randn(B, Cx, H, W, generator=g)
+    w = torch.randn(Cy, Cx, K, K, generator=g) / (Cx * K * K) ** 0.5
+    gy = torch.randn(B, Cy, H, W, generator=g)
+    r = torch.randn(B, Cx, H, W, generator=g) if res else None
+    # float64 on the host for a sample of the images (samples are independent through a convolution)
+    idx = sorted({0, B // 2, B - 1})
+    xr = x[idx].double().requires_grad_(True)
+    F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), w.double()).backward(gy[idx].double())
+    want = xr.grad + (r[idx].double() if res else 0.0)
+
+    def run(fused):
+        ops.RING_FUSED = fused
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(DEV).requires_grad_(True)
+        tok = ops.ResGradToken() if res else None
+        y = ops.conv2d(xd, wd, None, 1, p, "none", token=tok)
+        if res:
+            tok.g = r.to(DEV).contiguous(memory_format=torch.channels_last)
+        y.backward(gy.to(DEV).contiguous(memory_format=torch.channels_last))
+        return xd.grad.detach().cpu(), wd.grad.detach().cpu()
+
+    dx_f, dw_f = run(1)
+    dx_u, dw_u = run(0)
+    scale = want.abs().max().item()
+    for name, mask in _regions(H, W, p).items():
+        ef = ((dx_f[idx].double() - want).abs() * mask).max().item() / scale
+        eu = ((dx_u[idx].double() - want).abs() * mask).max().item() / scale
+        d = ((dx_f - dx_u).abs() * mask).max().item() / scale
+        print("%-13s fused %.2e  two-call %.2e  fused vs two-call (all images) %.2e  (of max |dx|)" % (name, ef, eu, d))
+        assert ef <= 5e-6 and ef <= 2.0 * eu + 3e-7, (name, ef, eu)
+        assert d <= 3e-6, (name, d)
+    assert torch.equal(dw_f, dw_u)
