@@ -479,6 +479,29 @@ int dwc_bf16_conv2d_s2_halo_bwd_data(const void* dy, const void* w_dgrad, void* 
     return DWC_OK;
 }
 
+/* (r06, ABI 8) dwc_bf16_conv2d_s2_halo_bwd_data with the border ring of the padded gradient image folded in by the launch itself (the
+ * reflect-pad-1 adjoint: padded row 0 onto dx row 1, row H+1 onto H-2, columns alike; conv_halo16_bf16.inc RING, S2 == 2): the WHOLE data
+ * gradient, no dwc_bf16_conv2d_bwd_data_s2_ring behind it.  Same shapes as dwc_bf16_conv2d_s2_halo_bwd_data_ok. */
+int dwc_bf16_conv2d_s2_halo_bwd_data_fused(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, void* stream) {
+    if (!dy || !w_dgrad || !dx || !dwc_bf16_conv2d_s2_halo_bwd_data_ok(B, H, W, Cin, Cout)) return DWC_EINVAL;
+    HaloArgs a;
+    a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.bias = nullptr; a.add = nullptr; a.y = (bf16*)dx;
+    a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.logCin = dwc_ilog2_exact(Cout); a.N = Cin; a.K = 4;
+    a.Kp = (4 * Cout + BK - 1) / BK * BK; a.act = DWC_ACT_NONE; a.reflect = 0;
+    a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B * a.blocks_per_img;
+    if (Cin % 128 == 0) {
+        a.tiles_n = Cin / 128;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 128, 2, 2, 1, 0, 2, 1>), dim3(4 * nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    } else {
+        a.tiles_n = Cin / 64;
+        hipLaunchKernelGGL((conv_halo16_kernel<2, 64, 2, 2, 1, 0, 2, 1>), dim3(4 * nblk * a.tiles_n), dim3(256), 0, st, a, nullptr);
+    }
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+
 /* 1 when dwc_bf16_conv2d_s2_halo handles this 4x4, stride-2, reflect-pad-1 convolution (else dwc_bf16_conv2d_fwd): H and W
  * multiples of 32 (16x16 output blocks), Cin a power of two >= 64, Cout a multiple of 64 */
 int dwc_bf16_conv2d_s2_halo_ok(int B, int H, int W, int Cin, int Cout) {

@@ -168,9 +168,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     static_assert((NW == 8 || NW == 4) && WM * TM * 32 == 256 && WN * TN * 32 == BN, "tile shape");
     static_assert(!S2 || KS == 2, "stride-2 form: 2x2 taps per parity");
     static_assert(KSP == 1 || (KSP == 2 && S2 != 2 && NW == 4 && TM * TN <= 4), "contraction split: the two-per-CU tile only");
-    static_assert(!RING || (NPL == 2 && PB == 1 && S2 == 0 && (KS == 3 || KS == 5)), "fused border ring: two-plane stride-1 form");
+    static_assert(!RING || (NPL == 2 && PB == 1 && ((S2 == 0 && (KS == 3 || KS == 5)) || S2 == 2)), "fused border ring: two-plane data gradients");
     constexpr int PW = TB + KS - 1;                    // patch edge
-    constexpr int NALT = RING ? ((KS - 1) / 2) * ((KS - 1) / 2 + 1) / 2 : 0;     // RING: pre-summed rows / columns behind the PW real ones
+    // RING: pre-summed rows / columns behind the PW real ones (stride 1: p (p + 1) / 2; the stride-2 data gradient: one)
+    constexpr int NALT = RING ? (S2 == 2 ? 1 : ((KS - 1) / 2) * ((KS - 1) / 2 + 1) / 2) : 0;
     constexpr int PWA = PW + NALT;
     constexpr int PPIX = PW * PW;                      // patch pixels
     constexpr int PPASS = (PPIX + PPT - 1) / PPT;      // gather passes
@@ -403,7 +404,27 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
     };
 #pragma unroll
     for (int i = 0; i < TM; ++i) dRA[i] = dRB[i] = 0;
-    if constexpr (RING) {
+    if constexpr (RING && S2 == 2) {
+        // Stride-2 4x4 layers (a.H x a.W = the dY grid, one output parity class (ry, rx) per workgroup): padded row 0 = dY[0] . W[kh = 0]
+        // folds onto dx row 1 = class row 0 of ry = 1, whose tap a = 1 carries W[kh = 0] and regularly reads dY row 1: its lanes read
+        // dY[1] + dY[0] = patch rows 1 + 0.  Padded row H + 1 = dY[last] . W[kh = 3] folds onto dx row H - 2 = the last class row of
+        // ry = 0, tap a = 0 (W[kh = 3], regular source patch row 15): patch rows 15 + 16.  Columns alike with rx.
+        row_side = (y0 == 0 && ry == 1) ? 1 : ((y0 + TB == a.H && ry == 0) ? 2 : 0);
+        col_side = (x0 == 0 && rx == 1) ? 1 : ((x0 + TB == a.W && rx == 0) ? 2 : 0);
+        if (row_side) {
+            khA = row_side == 1 ? 1 : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = ((wm * TM + i) * 32 + l31) >> 4;
+                if (r == (row_side == 1 ? 0 : 15)) dRA[i] = (PW - (r + khA)) * PITCH;
+            }
+        }
+        if (col_side) {
+            kwA = col_side == 1 ? 1 : 0;
+            const int x = l31 & 15;
+            if (x == (col_side == 1 ? 0 : 15)) dCA = (PW - (x + kwA)) * CS;
+        }
+    } else if constexpr (RING) {
         row_side = y0 == 0 ? 1 : (y0 + TB == a.H ? 2 : 0);
         col_side = x0 == 0 ? 1 : (x0 + TB == a.W ? 2 : 0);
         if (row_side) {
@@ -439,10 +460,15 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_halo_
             const int wrow = PW + (col_side ? NALT : 0);                      // pixels of one extra row
             const int items = (ncol + (row_side ? NALT * wrow : 0)) * 4;
             auto pair = [&](int sl, int side, int& u, int& v, int base) {   // slot -> the two source rows / columns of block row / column `base`
+                (void)base;
+                if constexpr (S2 == 2) {
+                    u = side == 1 ? 1 : 15;
+                    v = side == 1 ? 0 : 16;
+                    return;
+                }
                 int m = 1, kl = PAD + 1 + sl;
                 if (PAD == 2 && sl == 2) m = 2, kl = 4;
                 const int k = side == 1 ? kl : KS - 1 - kl;
-                (void)base;
                 u = side == 1 ? m + k : 15 - m + k;
                 v = side == 1 ? k - m : 15 + m + k;
             };
@@ -1569,7 +1595,7 @@ static int x3_s2_ws_impl(const float* x, const void* xs, unsigned xs_epoch, cons
 
 template <int NPL>
 static int x3_s2_bwd_data_impl(const float* dy, const void* ds, unsigned ds_epoch, const void* w_prepared, float* dx, int B, int H, int W,
-                               int Cin, int Cout, int rows, void* stream) {
+                               int Cin, int Cout, int rows, void* stream, bool ring = false) {
     if (!dy || !w_prepared || !dx || !dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cin, Cout) || rows < Cin ||
         (NPL == 2 && (!ds || (size_t)B * (H / 2) * (W / 2) * Cout * 4 >= 0x80000000ull)))
         return DWC_EINVAL;
@@ -1579,7 +1605,12 @@ static int x3_s2_bwd_data_impl(const float* dy, const void* ds, unsigned ds_epoc
     a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout; a.N = Cin; a.rows = rows; a.act = DWC_ACT_NONE; a.reflect = 0;
     a.blocks_x = (W / 2) / TB; a.blocks_per_img = ((H / 2) / TB) * ((W / 2) / TB);
     a.tiles_n = Cin / 64;
-    x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2, 1, NPL>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    if (ring) {
+        if constexpr (NPL == 2) x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2, 1, 2, 1>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+        else return DWC_EINVAL;
+    } else {
+        x3_launch<2, 64, 4, 1, 2, 2, 0, 1, 2, 1, NPL>(a, dim3(4 * B * a.blocks_per_img * a.tiles_n), (hipStream_t)stream);
+    }
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }
@@ -1614,6 +1645,14 @@ int dwc_x3_conv2d_s2_bwd_data(const float* dy, const void* w_prepared, float* dx
 int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H, int W,
                               int Cin, int Cout, int rows, void* stream) {
     return x3_s2_bwd_data_impl<2>(dy, dy_amax, dy_epoch, w_prepared, dx, B, H, W, Cin, Cout, rows, stream);
+}
+
+/* (r06, ABI 8) ... with the border ring of the padded gradient image folded in by the same launch (the reflect-pad-1 adjoint: padded row 0
+ * onto dx row 1, row H+1 onto H-2, columns alike; conv_halo_x3_kernel RING, S2 == 2): the WHOLE data gradient of a 4x4 stride-2
+ * reflect-pad-1 convolution, no dwc_conv2d_bwd_data_s2_ring behind it.  Arguments and shapes as dwc_h2_conv2d_s2_bwd_data. */
+int dwc_h2_conv2d_s2_bwd_data_fused(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H,
+                                    int W, int Cin, int Cout, int rows, void* stream) {
+    return x3_s2_bwd_data_impl<2>(dy, dy_amax, dy_epoch, w_prepared, dx, B, H, W, Cin, Cout, rows, stream, true);
 }
 
 size_t dwc_x3_conv2d_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int K) {

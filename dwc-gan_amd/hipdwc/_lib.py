@@ -135,6 +135,7 @@ SIGNATURES = {
     "dwc_conv2d_bwd_data_s2_ring": (c_int, [c_fp] * 4 + [c_int] * 5 + [c_fp]),
     "dwc_bf16_conv2d_s2_halo_bwd_data_ok": (c_int, [c_int] * 5),
     "dwc_bf16_conv2d_s2_halo_bwd_data": (c_int, [c_fp] * 3 + [c_int] * 5 + [c_fp]),
+    "dwc_bf16_conv2d_s2_halo_bwd_data_fused": (c_int, [c_fp] * 3 + [c_int] * 5 + [c_fp]),
     "dwc_bf16_conv2d_bwd_data_s2_ring": (c_int, [c_fp] * 4 + [c_int] * 5 + [c_fp]),
     "dwc_x3_conv2d_wgrad_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_x3_conv2d_wgrad": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
@@ -150,6 +151,7 @@ SIGNATURES = {
     "dwc_h2_conv2d_bwd_data_same_fused": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 3 + [c_int] * 7 + [c_fp, c_sz, c_fp, c_fp]),
     "dwc_h2_conv2d_s2_ws": (c_int, [c_fp, c_fp, c_u] + [c_fp] * 3 + [c_fp, c_u] + [c_int] * 7 + [c_fp, c_sz, c_fp, c_fp]),
     "dwc_h2_conv2d_s2_bwd_data": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp] + [c_int] * 6 + [c_fp]),
+    "dwc_h2_conv2d_s2_bwd_data_fused": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp] + [c_int] * 6 + [c_fp]),
     "dwc_h2_conv2d_wgrad": (c_int, [c_fp, c_fp, c_u, c_fp, c_fp, c_u, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),
     "dwc_bf16_conv2d_wgrad_halo_ws_bytes": (c_sz, [c_int] * 6),
     "dwc_bf16_conv2d_wgrad_halo": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 8 + [c_fp, c_sz, c_fp]),

@@ -1051,12 +1051,18 @@ class _Conv2d(torch.autograd.Function):
                    or ((not half) and X3 and lib.dwc_x3_conv2d_s2_bwd_data_ok(B, H, W, Cx, cop)))):
             # stride-2 4x4 layers: the interior (all H x W pixels of dx) as four output-parity classes of 2x2-tap halo convolutions
             # over dY, then the border ring of the padded image as eight thin GEMM strips + band fold (reflect-pad adjoint)
-            w_dg = _prepped(w, "dgrad", cop, Cx, 2, owner, half)
+            fused = bool(RING_FUSED and (half or h2_fits(g)))
+            # (the fused fp32 form reads neither the im2col data-gradient layout nor the padded scratch image)
+            w_dg = _prepped(w, "dgrad", cop, Cx, 2, owner, half) if half or not fused else None
             dx = empty_cl(B, Cx, H, W, dev, dt)
             flops = 2.0 * rows * Cout * Cin * KH * KW
-            dxp = workspace(B * (H + 2) * (W + 2) * Cx * (2 if half else 4), dev)
+            dxp = None if fused else workspace(B * (H + 2) * (W + 2) * Cx * (2 if half else 4), dev)
             shape = " B%d %dx%d %d>%d k%d s%d" % (B, H, W, Cx, cop, KH, stride)
-            if half:
+            if half and fused:     # interior + border ring in one launch (r06: conv_halo16_bf16.inc RING, S2 == 2)
+                _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_s2_halo_bwd_data_fused(
+                    g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
+                    detail="dgrad-s2halo" + shape), "conv2d_s2_halo_bwd_data_fused")
+            elif half:
                 _lib.check(_timed("conv_gemm_kernel", flops, lambda: lib.dwc_bf16_conv2d_s2_halo_bwd_data(
                     g.data_ptr(), w_dg.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
                     detail="dgrad-s2halo" + shape), "conv2d_s2_halo_bwd_data")
@@ -1064,7 +1070,13 @@ class _Conv2d(torch.autograd.Function):
                     g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
                     detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
             else:
-                if h2_fits(g):
+                if fused:          # interior + border ring in one launch (r06: pre-summed patch rows / columns, conv_halo_x3_kernel RING)
+                    w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
+                    ga = amax_of(g)
+                    _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_bwd_data_fused(
+                        g.data_ptr(), ga[0], ga[1], w_h2.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope,
+                        exec_flops=3 * flops, detail="dgrad-h2s2" + shape), "h2_conv2d_s2_bwd_data_fused")
+                elif h2_fits(g):
                     w_h2 = _prepped(w, "h2_dgrad", cop, Cx, 1, owner)
                     ga = amax_of(g)
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_h2_conv2d_s2_bwd_data(
@@ -1075,9 +1087,10 @@ class _Conv2d(torch.autograd.Function):
                     _lib.check(_timed("conv_halo_x3_kernel", flops, lambda: lib.dwc_x3_conv2d_s2_bwd_data(
                         g.data_ptr(), w_x3.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, Cx, st), scope_name=ctx.bscope,
                         exec_flops=6 * flops, detail="dgrad-x3s2" + shape), "x3_conv2d_s2_bwd_data")
-                _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_s2_ring(
-                    g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
-                    detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
+                if not fused:
+                    _lib.check(_timed("conv_halo_x3_kernel", 0.0, lambda: lib.dwc_conv2d_bwd_data_s2_ring(
+                        g.data_ptr(), w_dg.data_ptr(), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cx, cop, st), scope_name=ctx.bscope,
+                        detail="dgrad-ring" + shape), "conv2d_bwd_data_s2_ring")
         elif ctx.needs_input_grad[0]:
             w_dg = _prepped(w, "dgrad", cop, Cx, stride, owner, half)
             dx = empty_cl(B, Cx, H, W, dev, dt)

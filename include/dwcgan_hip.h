@@ -450,6 +450,10 @@ int dwc_h2_conv2d_s2_ws(const float* x, const void* x_amax, unsigned x_epoch, co
                         unsigned* tickets, void* stream);
 int dwc_h2_conv2d_s2_bwd_data(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H, int W,
                               int Cin, int Cout, int rows, void* stream);
+/* (r06, ABI 8) the same with the border ring of the padded gradient image folded in by the launch itself (reflect-pad-1 adjoint; no
+ * dwc_conv2d_bwd_data_s2_ring behind it): the whole data gradient of a 4x4 stride-2 reflect-pad-1 convolution. */
+int dwc_h2_conv2d_s2_bwd_data_fused(const float* dy, const void* dy_amax, unsigned dy_epoch, const void* w_prepared, float* dx, int B, int H,
+                                    int W, int Cin, int Cout, int rows, void* stream);
 int dwc_h2_conv2d_wgrad(const float* x, const void* x_amax, unsigned x_epoch, const float* dy, const void* dy_amax, unsigned dy_epoch,
                         float* dw_oihw, int B, int H, int W, int Cin, int Cout, int K, int cin_real, int cout_real, void* ws, size_t ws_bytes,
                         void* stream);
@@ -541,6 +545,9 @@ int dwc_bf16_conv2d_s2_halo(const void* x, const void* w_prepared, const float* 
  * both calls; dxp: bf16 scratch image [B][H+2][W+2][Cin]). */
 int dwc_bf16_conv2d_s2_halo_bwd_data_ok(int B, int H, int W, int Cin, int Cout);
 int dwc_bf16_conv2d_s2_halo_bwd_data(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, void* stream);
+/* (r06, ABI 8) the same with the border ring of the padded gradient image folded in by the launch itself (reflect-pad-1 adjoint; no
+ * dwc_bf16_conv2d_bwd_data_s2_ring behind it): the whole data gradient of a 4x4 stride-2 reflect-pad-1 convolution. */
+int dwc_bf16_conv2d_s2_halo_bwd_data_fused(const void* dy, const void* w_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, void* stream);
 int dwc_bf16_conv2d_bwd_data_s2_ring(const void* dy, const void* w_dgrad, void* dxp, void* dx, int B, int H, int W, int Cin, int Cout,
                                      void* stream);
 /* Halo form of the weight gradient of the same layers (reflect padding): a workgroup stages the (8+K-1)x(16+K-1) patch of x

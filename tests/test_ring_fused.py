@@ -147,3 +147,57 @@ def test_fused_ring_fp32_matches_float64_and_the_two_call_form(case):
         assert ef <= 5e-6 and ef <= 2.0 * eu + 3e-7, (name, ef, eu)
         assert d <= 3e-6, (name, d)
     assert torch.equal(dw_f, dw_u)
+
+
+# ---- the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111): padded row 0 folds onto dx row 1,
+# row H + 1 onto H - 2, columns alike.  (B, channels of x / dx, channels of y / dY, H = W of x)
+S2_CASES = [(16, 64, 128, 128), (16, 128, 256, 64), (48, 256, 256, 32), (4, 64, 128, 64), (128, 64, 128, 32)]
+
+
+def _s2_regions(H):
+    rows = torch.zeros(H, H, dtype=torch.bool)
+    cols = torch.zeros(H, H, dtype=torch.bool)
+    rows[1] = rows[H - 2] = True
+    cols[:, 1] = cols[:, H - 2] = True
+    return {"interior": ~(rows | cols), "ring rows": rows & ~cols, "ring columns": cols & ~rows, "corners": rows & cols}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("case", S2_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_fused_ring_stride2(case, precision):
+    B, Cx, Cy, H = case
+    half = precision == "bf16"
+    ops.set_precision(precision)
+    g = torch.Generator().manual_seed(B + Cx + Cy + H + 5)
+    x = torch.randn(B, Cx, H, H, generator=g)
+    w = torch.randn(Cy, Cx, 4, 4, generator=g) / (Cx * 16) ** 0.5
+    gy = torch.randn(B, Cy, H // 2, H // 2, generator=g)
+    if half:
+        x, gy = x.to(BF).float(), gy.to(BF).float()
+    idx = sorted({0, B // 2, B - 1})
+    xr = x[idx].double().requires_grad_(True)
+    wr = (w.to(BF).float() if half else w).double()
+    F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, stride=2).backward(gy[idx].double())
+    want = xr.grad
+
+    def run(fused):
+        ops.RING_FUSED = fused
+        xd = x.to(DEV).to(BF if half else torch.float32).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wd = w.to(DEV).requires_grad_(True)
+        y = ops.conv2d(xd, wd, None, 2, 1, "none")
+        y.backward(gy.to(DEV).to(y.dtype).contiguous(memory_format=torch.channels_last))
+        return xd.grad.detach().float().cpu(), wd.grad.detach().cpu()
+
+    dx_f, dw_f = run(1)
+    dx_u, dw_u = run(0)
+    scale = want.abs().max().item()
+    for name, mask in _s2_regions(H).items():
+        ef = ((dx_f[idx].double() - want).abs() * mask).max().item() / scale
+        eu = ((dx_u[idx].double() - want).abs() * mask).max().item() / scale
+        d = ((dx_f - dx_u).abs() * mask).max().item() / scale
+        print("%-13s fused %.2e  two-call %.2e  fused vs two-call (all images) %.2e  (of max |dx|)" % (name, ef, eu, d))
+        if half:
+            assert ef <= 6e-3 and ef <= 1.25 * eu + 5e-4, (name, ef, eu)
+        else:
+            assert ef <= 5e-6 and ef <= 2.0 * eu + 3e-7 and d <= 3e-6, (name, ef, eu, d)
+    assert torch.equal(dw_f, dw_u)
