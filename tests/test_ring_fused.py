@@ -151,7 +151,7 @@ def test_fused_ring_fp32_matches_float64_and_the_two_call_form(case):
 
 # ---- the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111): padded row 0 folds onto dx row 1,
 # row H + 1 onto H - 2, columns alike.  (B, channels of x / dx, channels of y / dY, H = W of x)
-S2_CASES = [(16, 64, 128, 128), (16, 128, 256, 64), (48, 256, 256, 32), (4, 64, 128, 64), (128, 64, 128, 32)]
+S2_CASES = [(16, 64, 128, 128), (16, 128, 256, 64), (48, 256, 256, 32), (16, 64, 128, 64), (128, 64, 128, 32)]
 
 
 def _s2_regions(H):
