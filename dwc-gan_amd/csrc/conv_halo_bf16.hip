@@ -404,7 +404,11 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
         else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
         else HALO16_LAUNCH(3, 64, 4, 2, 2);
     } else {
-        if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
+        // (r06 laboratory knob: the two-per-CU 5x5 tile as 4 x 1 waves -- 4 block rows x 64 channels per wave, 8 fragment reads per 16 MFMAs
+        // instead of 10 -- for every 64-channel-tiled launch incl. the 128->64 layer, which otherwise runs the 8-wave tile)
+        static const int wm4 = getenv("DWC_H16_WM4") ? atoi(getenv("DWC_H16_WM4")) : 0;
+        if (wm4 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 4, 1, 1);
+        else if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
         else if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
         else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
         else HALO16_LAUNCH(5, 64, 4, 2, 1);
