@@ -404,10 +404,12 @@ int dwc_bf16_conv2d_same_halo_add(const void* x, const void* w_prepared, const f
         else if (Cout > 64) HALO16_LAUNCH(3, 128, 4, 2, 2);
         else HALO16_LAUNCH(3, 64, 4, 2, 2);
     } else {
-        // (r06 laboratory knob: the two-per-CU 5x5 tile as 4 x 1 waves -- 4 block rows x 64 channels per wave, 8 fragment reads per 16 MFMAs
-        // instead of 10 -- for every 64-channel-tiled launch incl. the 128->64 layer, which otherwise runs the 8-wave tile)
-        static const int wm4 = getenv("DWC_H16_WM4") ? atoi(getenv("DWC_H16_WM4")) : 0;
-        if (wm4 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 4, 1, 1);
+        // (r06: the two-per-CU tile as 4 x 1 waves -- 4 block rows x 64 channels per wave, 8 fragment reads per 16 MFMAs instead of the 10 of
+        // the 2 x 2 form / 6 per 8 of the 8-wave tile -- for the 64-output-channel layer, which ran the 8-wave tile: 128->64 at 128 x 128
+        // B=128 698-705 -> 650-671 us, B=384 1852-1855 -> 1802-1820 (profiles/r06_halo5_tile_bench.txt); on the wider layers within
+        // +-1.5 % of the 2 x 2 form, which stays.  DWC_H16_WM4=1: everywhere, =0: nowhere.)
+        static const int wm4 = getenv("DWC_H16_WM4") ? atoi(getenv("DWC_H16_WM4")) : -1;
+        if (duo && Cout % 64 == 0 && (wm4 == 1 || (wm4 < 0 && Cout == 64))) HALO16_LAUNCH(5, 64, 4, 1, 1);
         else if (Cout > 64 && duo && Cout % 64 == 0) HALO16_LAUNCH(5, 64, 2, 2, 1);
         else if (Cout > 128) HALO16_LAUNCH(5, 256, 2, 4, 1);
         else if (Cout > 64) HALO16_LAUNCH(5, 128, 4, 2, 1);
