@@ -495,7 +495,8 @@ def measure(args, config_name, steps, warmup, dev, dist, rank, world, force_dp):
     if getattr(args, "ledger", None):
         with open(args.ledger if config_name == args.config else args.ledger + "." + config_name, "w") as f:
             json.dump({"config": config_name, "precision": precision, "per_gpu_batch": per_gpu_batch, "image_size": image_size,
-                       "ledger": ledger, "kernels": kernel_table(ledger, precision)}, f, indent=1)
+                       "ledger": ledger, "kernels": kernel_table(ledger, precision),
+                       "hbm_ops": timer.hbm_ledger() if timer is not None else {}}, f, indent=1)
     dom = total(lambda t: t.endswith(DOMINANT))
     x3 = total(lambda t: t.endswith(X3))
     # the generator decode conv stack (8 AdaIN-ResBlock 3x3 convs, two 5x5 upsampling convs, fused heads)

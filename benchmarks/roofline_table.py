@@ -89,6 +89,36 @@ def main():
             "products_per_mac": None if al_fl <= 0 else round(ex_fl / al_fl, 2),
             "frac_algorithmic_of_pipe": None if (ms_iter <= 0 or not peak) else round(al_fl / (ms_iter * 1e-3) / 1e12 / peak, 4),
             "span_avg_us_hip_events": k["avg_launch_us"]})
+    # HBM-bound op families (r06): bench.py's ledger carries their calls and ALGORITHMIC bytes per iteration (each operand read once, each
+    # result written once: hipdwc.ops._hbm); all kernels of a family together give its effective bandwidth against the 8 TB/s spec and
+    # the 6.3 TB/s a float4 copy reaches (MI355X_MICROARCH.md)
+    HBM_FAMILIES = {
+        "instnorm_fwd": r"in_resident_fwd|in_stats_partial|in_stats_final|in_apply",
+        "instnorm_bwd": r"in_resident_bwd|in_bwd_partial|in_bwd_final|in_bwd_apply",
+        "layernorm_fwd": r"ln_stats_partial|ln_stats_final|ln_apply",
+        "layernorm_bwd": r"ln_bwd_partial|ln_bwd_final|ln_bwd_apply",
+        "upsample2x_fwd": r"upsample2x_fwd_kernel", "upsample2x_bwd": r"upsample2x_bwd_kernel",
+        "avgpool2_fwd": r"avgpool2_fwd_kernel", "avgpool2_bwd": r"avgpool2_bwd_kernel",
+        "act_bwd_bias": r"act_bwd_partial|colsum_final",
+        "adam_multi": r"adam_multi_kernel", "ema_multi": r"ema_multi_kernel",
+    }
+    for fam, ent in (led.get("hbm_ops") or {}).items():
+        rx = HBM_FAMILIES.get(fam)
+        match = [r for r in rows_csv if rx and re.search(rx, r["Name"]) and r["Name"] not in used]
+        if not match:
+            continue
+        ns = sum(int(r["TotalDurationNs"]) for r in match)
+        calls = sum(int(r["Calls"]) for r in match)
+        used.update(r["Name"] for r in match)
+        ms_iter = ns / 1e6 / iters
+        gbps = ent["bytes"] / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else None
+        table.append({"kernel": fam + " (" + ", ".join(sorted({re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", r["Name"].replace("void ", "").replace(
+                          "(anonymous namespace)::", "").split("(")[0].split("<")[0])[:24] for r in match})) + ")",
+                      "pipe": None, "bound": "hbm", "launches_per_iter": round(calls / iters, 2), "op_calls_per_iter": ent["calls"],
+                      "avg_us": round(ns / 1e3 / calls, 2), "ms_per_iter": round(ms_iter, 3), "share_of_kernel_time": round(ns / total_ns, 4),
+                      "algorithmic_mbytes_per_iter": round(ent["bytes"] / 1e6, 1), "gbps": None if gbps is None else round(gbps, 1),
+                      "frac_of_hbm_spec_8TBs": None if gbps is None else round(gbps / 8000.0, 4),
+                      "frac_of_hbm_achievable_6p3TBs": None if gbps is None else round(gbps / 6300.0, 4)})
     rest = {}
     for r in rows_csv:
         if r["Name"] in used:
@@ -115,6 +145,10 @@ def main():
         json.dump(res, f, indent=1)
     for r in table[:14]:
         print("%-58s %8.3f ms/iter %8.1f us  frac %s" % (r["kernel"][:58], r["ms_per_iter"], r["avg_us"], r.get("frac")))
+    hb = [r for r in table if r.get("bound") == "hbm"]
+    print("HBM-bound op families: %.2f ms per iteration" % sum(r["ms_per_iter"] for r in hb))
+    for r in hb:
+        print("%-58s %8.3f ms/iter %8.1f GB/s  %.2f of 8 TB/s" % (r["kernel"][:58], r["ms_per_iter"], r["gbps"], r["frac_of_hbm_spec_8TBs"]))
 
 
 if __name__ == "__main__":

@@ -23,6 +23,11 @@ networks_v2.py:249): an N-rank run equals N independent local batches, not one g
 import torch
 import torch.distributed as dist
 
+# Flat gradient buckets of this size: D's 53.4 MB of gradients make 3 buckets, G's 77.6 MB 4 (r05 shipped 64 MB: D was ONE bucket, whose
+# all-reduce could only start when D's whole backward was done -- the overlap the reducer is built for needs several).  A ring all-reduce
+# over the 7 xGMI links of a GPU moves a 20 MB message in ~0.3 ms: still bandwidth-, not latency-bound.
+BUCKET_BYTES = 20 << 20
+
 
 class GradAllReduce:
     """Callable handed to ``Solver`` (``solver.grad_sync``): averages the gradients of the given
@@ -34,7 +39,7 @@ class GradAllReduce:
     "skip parameters without grad" behaviour (SURVEY.md section 7 quirk viii) is preserved.
     """
 
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES):
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
@@ -88,7 +93,7 @@ class OverlappedGradReducer:
     (SURVEY.md section 7 quirk viii: no weight decay / momentum for gradient-less parameters).  Averaging uses
     ReduceOp.AVG where the backend has it (RCCL) and SUM followed by one scale per bucket otherwise (gloo)."""
 
-    def __init__(self, params, group=None, bucket_bytes=64 << 20):
+    def __init__(self, params, group=None, bucket_bytes=BUCKET_BYTES):
         self.group = group
         self.world = dist.get_world_size(group)
         self.params = [p for p in params if p.requires_grad]
@@ -143,6 +148,9 @@ class OverlappedGradReducer:
     @torch.no_grad()
     def prepare(self, skip=()):
         skip_ids = {id(p) for p in skip}
+        # (biases whose gradient is identically zero -- hipdwc.ops marks them `_dwc_zero_grad` on their first forward -- receive no
+        # gradient from autograd: not waited for either; their zero-filled bucket slice is all-reduced as zeros)
+        skip_ids |= {id(p) for p in self.params if getattr(p, "_dwc_zero_grad", False)}
         self.touched.clear()
         for b in self.buckets:
             b["flat"].zero_()

@@ -111,6 +111,7 @@ class KernelTimer:
         self.spans = []   # (kernel tag, algorithmic flops, start event, end event)
         self.details = []  # problem shape of each span (benchmarks/step_breakdown.py)
         self.executed = []  # multiply-add flops the matrix cores actually issued (< algorithmic for Winograd launches)
+        self.hbm = {}       # HBM-bound op family -> [calls, algorithmic bytes] (benchmarks/roofline_table.py: GB/s of those kernels)
 
     def run(self, tag, flops, fn, detail="", exec_flops=None):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,6 +143,10 @@ class KernelTimer:
             ent["shape_ms"][det] = round(ent["shape_ms"].get(det, 0.0) + ms, 4)
         return out
 
+    def hbm_ledger(self):
+        """HBM-bound op families of the instrumented step: calls and algorithmic bytes (see _hbm)."""
+        return {k: {"calls": v[0], "bytes": v[1]} for k, v in self.hbm.items()}
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
@@ -155,6 +160,15 @@ class KernelTimer:
 
 
 TIMER = None   # set to a KernelTimer to collect spans
+
+
+def _hbm(family, nbytes):
+    """Bookkeeping for the roofline table: the ALGORITHMIC bytes an HBM-bound op moves (each operand read once, each result written
+    once), counted while bench.py's timer is on; no events, no launches."""
+    if TIMER is not None:
+        e = TIMER.hbm.setdefault(family, [0, 0])
+        e[0] += 1
+        e[1] += int(nbytes)
 SCOPE = ""     # optional label (e.g. "decode") prefixed to the span tags of launches made inside it
 
 
@@ -553,6 +567,7 @@ X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 fo
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
 X3_WGRAD_HALO3 = int(os.environ.get("DWC_X3_WGRAD_HALO3", "1"))   # 0: 3x3 weight gradients on the im2col kernel (split-product inner product)
+ZERO_GRAD_BY_FLAG = int(os.environ.get("DWC_ZERO_GRAD_FLAG", "1"))   # biases whose gradient is identically zero: flagged, not filled (0: torch.zeros per use)
 RING_FUSED = int(os.environ.get("DWC_RING_FUSED", "1"))   # stride-1 data gradients: border ring inside the halo launch (0: strip GEMM + fold launches)
 S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
 
@@ -760,6 +775,7 @@ class _Conv2d(torch.autograd.Function):
         if Cin > Cx:
             raise ValueError("input has %d channels, weight expects %d" % (Cx, Cin))
         ctx.bias_grad = bias_grad
+        ctx.zero_flag = bool(b is not None and getattr(b, "_dwc_zero_grad", False))
         ctx.owner = owner
         cop = _padc(Cout, x.dtype)
         Ho = (H + 2 * pad - KH) // stride + 1
@@ -872,8 +888,10 @@ class _Conv2d(torch.autograd.Function):
         db = None
         if need_db and not ctx.bias_grad:
             # the output goes straight into an instance norm: a per-channel constant is removed by its mean
-            # subtraction, so this gradient is identically zero (the reference computes rounding noise here)
-            db, need_db = torch.zeros(Cout, dtype=torch.float32, device=dev), False
+            # subtraction, so this gradient is identically zero (the reference computes rounding noise here).  The parameter carries
+            # `_dwc_zero_grad` (set in forward): FusedAdam steps it with a shared zero vector, the data-parallel reducer does not wait for
+            # it -- no gradient tensor, no fill launch (r05: 38 per iteration).  Anything else asks for a real zero tensor.
+            db, need_db = (None if ctx.zero_flag else torch.zeros(Cout, dtype=torch.float32, device=dev)), False
         if act != 0 or need_db:
             db_full = torch.empty(cop, dtype=torch.float32, device=dev) if need_db else None
             g_out = empty_cl(B, cop, Ho, Wo, dev, dt) if act != 0 else None
@@ -887,6 +905,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _lib.check(_fn(lib, "act_bwd_bias", x)(dy.data_ptr(), _p(y), _p(g_out), _p(db_full), rows, cop, act, ws.data_ptr(),
                                                        ws.numel(), st), "act_bwd_bias")
+            _hbm("act_bwd_bias", dy.numel() * dy.element_size() * ((1 if y is None else 2) + (1 if g_out is not None else 0)))
             if g_out is not None:
                 g = g_out
             if need_db:
@@ -1123,6 +1142,8 @@ def conv2d(x, w, b, stride, pad, act="none", bias_grad=True, owner=None, token=N
     slice of the 4-aligned buffer when Cout is not a multiple of 4).  ``bias_grad=False``: the caller feeds the
     result to an instance norm, whose mean subtraction makes the bias gradient identically zero -- it is returned
     as zeros instead of being reduced from dY."""
+    if not bias_grad and ZERO_GRAD_BY_FLAG and isinstance(b, torch.nn.Parameter):
+        b._dwc_zero_grad = True            # (see _Conv2d.backward: no gradient tensor for it; FusedAdam / the DP reducer know the flag)
     y = _Conv2d.apply(x, w, b, int(stride), int(pad), ACT[act], bool(bias_grad), owner, token, not torch.is_grad_enabled())
     return y if y.shape[1] == w.shape[0] else y[:, :w.shape[0]]
 
@@ -1714,6 +1735,7 @@ class _InstNorm(torch.autograd.Function):
             _lib.check(_fn(lib, "instnorm_fwd", x)(x.data_ptr(), _p(gamma), _p(beta), _p(residual), y.data_ptr(), mean.data_ptr(),
                                                    rstd.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(),
                                                    _stream()), "instnorm_fwd")
+        _hbm("instnorm_fwd", x.numel() * x.element_size() * (3 if residual is not None else 2))
         ctx.save_for_backward(x, mean, rstd, gamma, beta)
         ctx.relu = int(relu)
         ctx.has_res = residual is not None
@@ -1742,6 +1764,7 @@ class _InstNorm(torch.autograd.Function):
             _lib.check(_fn(lib, "instnorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _p(gamma), _p(beta),
                                                    dx.data_ptr(), _p(dgamma), _p(dbeta), B, H * W, C, ctx.relu, ws.data_ptr(),
                                                    ws.numel(), _stream()), "instnorm_bwd")
+        _hbm("instnorm_bwd", x.numel() * x.element_size() * 3)
         if ctx.token is not None:                 # the first convolution of the block adds it in its data-gradient epilogue
             ctx.token.g = dy
             return dx, dgamma, dbeta, None, None, None, None
@@ -1777,6 +1800,7 @@ class _LayerNorm(torch.autograd.Function):
             _lib.check(_fn(lib, "layernorm_fwd", x)(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(),
                                                     inv.data_ptr(), B, H * W, C, eps, int(relu), ws.data_ptr(), ws.numel(), _stream()),
                        "layernorm_fwd")
+        _hbm("layernorm_fwd", x.numel() * x.element_size() * 2)
         ctx.save_for_backward(x, mean, inv, g, b)
         ctx.relu, ctx.eps = int(relu), eps
         return y
@@ -1802,6 +1826,7 @@ class _LayerNorm(torch.autograd.Function):
             _lib.check(_fn(lib, "layernorm_bwd", x)(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), inv.data_ptr(), g.data_ptr(),
                                                     b.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), B, H * W, C,
                                                     ctx.eps, ctx.relu, ws.data_ptr(), ws.numel(), _stream()), "layernorm_bwd")
+        _hbm("layernorm_bwd", x.numel() * x.element_size() * 3)
         return dx, dgamma, dbeta, None, None
 
 
@@ -1826,6 +1851,7 @@ class _Resample(torch.autograd.Function):
         else:
             y = empty_cl(B, C, H // 2, W // 2, x.device, x.dtype)
             _lib.check(_fn(lib, "avgpool2_fwd", x)(x.data_ptr(), y.data_ptr(), B, H, W, C, _stream()), "avgpool2_fwd")
+        _hbm("upsample2x_fwd" if up else "avgpool2_fwd", (x.numel() + y.numel()) * x.element_size())
         return pass_amax(x, y)
 
     @staticmethod
@@ -1838,6 +1864,7 @@ class _Resample(torch.autograd.Function):
             _lib.check(_fn(lib, "upsample2x_bwd", dy)(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "upsample2x_bwd")
         else:
             _lib.check(_fn(lib, "avgpool2_bwd", dy)(dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream()), "avgpool2_bwd")
+        _hbm("upsample2x_bwd" if ctx.up else "avgpool2_bwd", (dx.numel() + dy.numel()) * dy.element_size())
         return dx, None
 
 

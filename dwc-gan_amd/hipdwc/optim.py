@@ -45,6 +45,18 @@ class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._maps = {}
+        self._zeros = {}       # device -> a zero vector that stands in for the gradient of `_dwc_zero_grad` parameters
+
+    def _zero_grad_for(self, p):
+        """Parameters marked ``_dwc_zero_grad`` by the op that consumes them (convolution biases in front of an instance norm: the mean
+        subtraction removes them, their gradient is identically zero, hipdwc.ops._Conv2d) get NO gradient tensor from autograd -- no fill
+        launch per layer and use -- and are stepped here with a shared zero vector: the same update an explicit zero gradient gave
+        (weight decay included)."""
+        z = self._zeros.get(p.device)
+        if z is None or z.numel() < p.numel():
+            z = torch.zeros(max(4096, p.numel()), dtype=torch.float32, device=p.device)
+            self._zeros[p.device] = z
+        return z
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -72,6 +84,8 @@ class FusedAdam(torch.optim.Adam):
                 desc[i]["p"], desc[i]["m"], desc[i]["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 desc[i]["n"] = p.numel()
                 g = p.grad
+                if g is None and getattr(p, "_dwc_zero_grad", False):
+                    g = self._zero_grad_for(p)
                 if g is None:
                     continue                                  # g stays NULL: tensor skipped, step not advanced
                 if g.dtype != torch.float32 or not g.is_contiguous():
@@ -93,9 +107,12 @@ class FusedAdam(torch.optim.Adam):
                                           group["eps"], group["weight_decay"], torch.cuda.current_stream().cuda_stream),
                        "adam_multi")
             del keep
+            from . import ops as _ops
+            stepped = [p for p in params if p.grad is not None or getattr(p, "_dwc_zero_grad", False)]
+            _ops._hbm("adam_multi", 28 * sum(p.numel() for p in stepped))                              # p, g, m, v read; p, m, v written
             # the kernel wrote through raw pointers: tell autograd (and the prepared-weight cache in
             # hipdwc.ops, which keys on the version counter) that these tensors changed
-            touched = [p for p in params if p.grad is not None]
+            touched = stepped
             torch.autograd.graph.increment_version(touched)
             # ... and rebuild every prepared layout of the updated weights in ONE launch, here, instead of one launch per layout
             # at each layer's next use (Adam + weight refresh as one pass over the parameters)
@@ -133,4 +150,6 @@ class FusedEMA:
         lib = _lib.load()
         _lib.check(lib.dwc_ema_multi(self.desc.data_ptr(), self.tid.data_ptr(), self.start.data_ptr(), self.n_chunks,
                                      beta, torch.cuda.current_stream().cuda_stream), "ema_multi")
+        from . import ops as _ops
+        _ops._hbm("ema_multi", 12 * sum(p.numel() for p in self.src))                                # p, copy read; copy written
         torch.autograd.graph.increment_version(self.dst)

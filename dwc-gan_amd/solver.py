@@ -45,6 +45,7 @@ def _frozen(module):
 
 
 SAMPLE_CHUNK = 32                                                  # images per decode pass of Solver.sample()
+DP_BUCKET_BYTES = 20 << 20                                          # hipdwc.dp.BUCKET_BYTES: D 3 buckets, G 4
 GROUPED_DECODE = int(os.environ.get("DWC_GROUPED_DECODE", "1"))    # 0: always decode torch.cat([content] * groups) (ResBlock._forward_groups off)
 
 class Solver(nn.Module):
@@ -105,7 +106,7 @@ class Solver(nn.Module):
                 param.requires_grad = False
 
     # ---- data parallel -----------------------------------------------------------------------
-    def enable_data_parallel(self, group=None, bucket_bytes=64 << 20):
+    def enable_data_parallel(self, group=None, bucket_bytes=DP_BUCKET_BYTES):
         """One process per GPU (torch.distributed initialised by the caller, backend nccl = RCCL): gradients of D / G become
         views of flat buckets that are all-reduced (averaged) as backward completes them (hipdwc.dp.OverlappedGradReducer)."""
         from hipdwc import dp
