@@ -59,6 +59,8 @@ def compare(dev):
     for step in g_plain:
         if set(g_plain[step]) != set(g_dp[step]):          # same parameters gradient-less (attention head while attention is off)
             res["grad_keys_equal"] = False
+            res.setdefault("key_diff", {})[step] = {"only_plain": sorted(set(g_plain[step]) - set(g_dp[step]))[:6],
+                                                    "only_dp": sorted(set(g_dp[step]) - set(g_plain[step]))[:6]}
         for k in g_plain[step]:
             if k in g_dp[step]:
                 res["max_grad_diff"] = max(res["max_grad_diff"], float((g_plain[step][k] - g_dp[step][k]).abs().max()))

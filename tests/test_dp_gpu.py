@@ -49,7 +49,7 @@ def test_one_rank_rccl_path_equals_plain_trainer(tmp_path):
         r = dp_force_worker.compare(dev)
     finally:
         dist.destroy_process_group()
-    assert r["avg_op"] and r["grad_keys_equal"], r
+    assert r["avg_op"] and r["grad_keys_equal"], (r.get("key_diff"), r)
     assert r["buckets"]["gen"] >= 2 and r["all_reduces"]["gen"] >= 2 * r["buckets"]["gen"], r
     assert r["launched_early"]["gen"] >= 1 and r["launched_early"]["dis"] >= 1, r
     assert r["max_grad_diff"] == 0.0 and r["max_param_diff"] == 0.0, r
