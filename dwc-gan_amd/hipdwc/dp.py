@@ -136,7 +136,9 @@ class OverlappedGradReducer:
         self.bytes += b["flat"].numel() * 4
 
     def _hook(self, p):
-        if not self.active or id(p) in self.touched:
+        # (the hook also fires when autograd had NO gradient for p -- an op returned None: parameters flagged `_dwc_zero_grad` are
+        # not counted, they end the step gradient-less as in a single-process run and FusedAdam steps them with zeros)
+        if not self.active or id(p) in self.touched or getattr(p, "_dwc_zero_grad", False):
             return
         self.touched.add(id(p))
         b = self.buckets[self.where[id(p)]]
