@@ -90,7 +90,8 @@ def test_conv_forward_backward(shape):
 def test_stride2_data_gradient_halo_form(B, ci, co, H, W, prec, monkeypatch):
     """Data gradient of the 4x4 stride-2 reflect-pad-1 layers (reference networks.py:90,94,437, networks_v2.py:107-111) in halo
     form (r04): interior as four output-parity classes of 2x2-tap convolutions over dY (split products in fp32, bf16 MFMA on the
-    bf16 path), border ring of the padded image as eight GEMM strips + band fold.  Against the float64 gradient of the
+    bf16 path), border ring of the padded image as eight GEMM strips + band fold -- since r06 inside the same launch (pre-summed patch
+    rows / columns, virtual block rows; DWC_RING_FUSED=0 brings the strips back).  Against the float64 gradient of the
     reflect-padded convolution -- every pixel, with the image border (where the ring folds) checked separately --, for square
     and rectangular images, one and several tiles per image."""
     monkeypatch.setattr(ops, "S2DGRAD_MIN_WGS", 0)
@@ -108,6 +109,8 @@ def test_stride2_data_gradient_halo_form(B, ci, co, H, W, prec, monkeypatch):
         lib = _lib_mod.load()
         name = "dwc_bf16_conv2d_s2_halo_bwd_data" if prec == "bf16" else (
             "dwc_h2_conv2d_s2_bwd_data" if ops.X3_PLANES == 2 else "dwc_x3_conv2d_s2_bwd_data")
+        if ops.RING_FUSED and (prec == "bf16" or ops.X3_PLANES == 2):
+            name += "_fused"          # (r06: the border ring inside the same launch, tests/test_ring_fused.py)
         real = getattr(lib, name)
         monkeypatch.setattr(lib, name, lambda *a: (calls.append(1), real(*a))[1])
         xd = x.to(DEV).to(ops.act_dtype()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
