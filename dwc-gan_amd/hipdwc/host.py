@@ -15,6 +15,9 @@ from torch.optim import lr_scheduler
 # --------------------------------------------------------------------------------------
 # random draws
 # --------------------------------------------------------------------------------------
+_STYLE_NORMAL_CHECKED = int(__import__("os").environ.get("DWC_STYLE_NORMAL", "0"))
+
+
 class DeviceNoise:
     """Default: draw on the tensor's own device, like the reference does on its GPU."""
     align_stream = False     # draws whose result is unused may be skipped
@@ -28,7 +31,13 @@ class DeviceNoise:
 
     def style_sample(self, mu, c_dim, stddev):
         shape = (1, c_dim) + tuple(mu.shape)
-        draw = torch.normal(mu.expand(shape), torch.full_like(mu, stddev).expand(shape))
+        # (r06: torch.normal(mean tensor, std TENSOR) checks `std.min() >= 0` on the host -- a device synchronisation in the middle of
+        # the step, three per iteration, each of which drains the launch queue (profiles/r05_torch_kernel_sites_c1.txt: 6
+        # _local_scalar_dense).  Same distribution, same generator, no check: standard normal draws scaled by the scalar stddev.)
+        if _STYLE_NORMAL_CHECKED:       # (A/B switch DWC_STYLE_NORMAL=1: the synchronising form of rounds 1-5)
+            draw = torch.normal(mu.expand(shape), torch.full_like(mu, stddev).expand(shape))
+        else:
+            draw = torch.randn(shape, dtype=mu.dtype, device=mu.device) * float(stddev) + mu
         return draw.permute(0, 2, 3, 1).reshape(mu.shape[0], -1)
 
 
