@@ -567,6 +567,7 @@ X3_S2 = int(os.environ.get("DWC_X3_S2", "1"))             # fp32 stride-2 4x4 fo
 S2HALO = int(os.environ.get("DWC_BF16_S2_HALO", "1"))     # stride-2 4x4 forwards on the halo kernel over the space-to-depth image
 S2DGRAD = int(os.environ.get("DWC_S2_DGRAD_HALO", "1"))   # stride-2 4x4 DATA GRADIENTS in halo form (interior) + ring strips, both precisions
 X3_WGRAD_HALO3 = int(os.environ.get("DWC_X3_WGRAD_HALO3", "1"))   # 0: 3x3 weight gradients on the im2col kernel (split-product inner product)
+PINNED_STAGE = int(os.environ.get("DWC_PINNED_STAGE", "1"))        # small host->device tables through pinned staging (0: pageable copies, which wait for the stream)
 ZERO_GRAD_BY_FLAG = int(os.environ.get("DWC_ZERO_GRAD_FLAG", "1"))   # biases whose gradient is identically zero: flagged, not filled (0: torch.zeros per use)
 RING_FUSED = int(os.environ.get("DWC_RING_FUSED", "1"))   # stride-1 data gradients: border ring inside the halo launch (0: strip GEMM + fold launches)
 S2DGRAD_MIN_WGS = 192        # below this many workgroups (4 classes x blocks x 64-channel tiles) the im2col GEMM keeps the layer
@@ -2047,7 +2048,9 @@ class _WeightedSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weights, *terms):
-        w = torch.tensor(weights, dtype=torch.float32).to(terms[0].device, non_blocking=True)
+        # (pinned staging: a copy from pageable memory makes the host wait for the stream -- here for the whole G forward, r06)
+        w = torch.tensor(weights, dtype=torch.float32)
+        w = (w.pin_memory() if terms[0].is_cuda and PINNED_STAGE else w).to(terms[0].device, non_blocking=True)
         ctx.save_for_backward(w)
         return torch.dot(torch.stack([t.float().reshape(()) for t in terms]), w)
 

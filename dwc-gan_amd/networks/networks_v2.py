@@ -146,8 +146,17 @@ class TxtEncoder(nn.Module):
         seq_len, bsz = tokens.shape
         lens_host = src_lengths.detach().to("cpu")               # kept on the host: no device sync per call
         lens_sorted, order_host = torch.sort(lens_host, descending=True)
-        order = order_host.to(tokens.device)
-        unsort = torch.sort(order_host)[1].to(tokens.device)      # inverse permutation
+        # order, its inverse, the sorted lengths and the last-token index travel in ONE pinned staging block, asynchronously (r06: four
+        # separate copies from pageable memory made the host wait for the stream four times per call -- with torch.normal's check that was
+        # why the host could never run ahead of the GPU, benchmarks/host_vs_gpu.py)
+        if tokens.is_cuda and ops.PINNED_STAGE:
+            stage = torch.empty(4, bsz, dtype=torch.int64).pin_memory()
+            stage[0], stage[1], stage[2], stage[3] = order_host, torch.sort(order_host)[1], lens_sorted, lens_sorted - 1
+            on_dev = stage.to(tokens.device, non_blocking=True)
+            order, unsort, lens_dev, last = on_dev[0], on_dev[1], on_dev[2].to(torch.int32), on_dev[3]
+        else:
+            order, unsort = order_host.to(tokens.device), torch.sort(order_host)[1].to(tokens.device)
+            lens_dev, last = lens_sorted.to(torch.int32).to(tokens.device), (lens_sorted - 1).to(tokens.device)
         emb = self.embed_tokens(tokens.index_select(1, order))
         emb = noise.dropout(emb, self.dropout_in, self.training)
         sty = _Permute.apply(style_ord, 0, order, unsort)
@@ -155,9 +164,7 @@ class TxtEncoder(nn.Module):
         # lengths instead of a PackedSequence; T = longest sequence of the batch, as pack_padded_sequence would cut it.
         lens_list = lens_sorted.tolist()
         t_max = int(lens_list[0])
-        lens_dev = lens_sorted.to(torch.int32).to(tokens.device, non_blocking=True)
         data = torch.cat([emb, sty.expand(seq_len, -1, -1)], -1)[:t_max]
-        last = (lens_sorted - 1).to(tokens.device, non_blocking=True)
         cols = torch.arange(bsz, device=tokens.device)
         suffixes = ("", "_reverse") if self.bidirectional else ("",)
         if not self.bidirectional:
