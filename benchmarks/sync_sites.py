@@ -48,6 +48,8 @@ def main():
             if "/dwc-gan_amd/" in fs.filename or fs.filename.endswith("bench.py"):
                 frame = "%s:%d %s" % (fs.filename.split("/repo/")[-1], fs.lineno, fs.name)
                 break
+        if frame == "?":
+            frame = "? " + " <- ".join("%s:%d" % (fs.filename.split("/")[-1], fs.lineno) for fs in reversed(traceback.extract_stack(limit=12)[:-1]))
         sites[frame] += 1
     old = warnings.showwarning
     warnings.showwarning = hook

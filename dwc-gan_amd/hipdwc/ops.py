@@ -343,7 +343,8 @@ def _prepped(w, kind, cout_pad, cin_pad, stride, owner=None, half=False):
         bank[:, :49, :pl] = wf.permute(0, 2, 3, 1).reshape(64, 49, pl)
         steps = bank.view(64, 25, 2, 8).permute(1, 0, 2, 3).contiguous()           # [j][co][h][p]
         swap = ((torch.arange(64, device=w.device) >> 3) & 1).bool()
-        steps[:, swap] = steps[:, swap].flip(2)
+        # (torch.where, not boolean-mask indexing: a mask index is a nonzero() = a host synchronisation, six per c2 iteration -- r06)
+        steps = torch.where(swap.view(1, 64, 1, 1), steps.flip(2), steps)
         out = steps.reshape(25, 64, 16).to(BF16).contiguous()
         ent[key] = (stamp, out)
         return out
