@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import ops as _ops
 
 CHUNK = 8192           # must equal DWC_OPT_CHUNK in include/dwcgan_hip.h
 REFRESH_WITH_STEP = True   # FusedAdam.step() ends with hipdwc.ops.refresh_prepared (False: every layout lazily at its next use)
@@ -104,10 +105,9 @@ class FusedAdam(torch.optim.Adam):
                 self._maps[gi] = maps
             ddev = _to_device_bytes(desc, dev)
             _lib.check(lib.dwc_adam_multi(ddev.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(), maps[2], b1, b2,
-                                          group["eps"], group["weight_decay"], torch.cuda.current_stream().cuda_stream),
+                                          group["eps"], group["weight_decay"], _ops._stream()),
                        "adam_multi")
             del keep
-            from . import ops as _ops
             stepped = [p for p in params if p.grad is not None or getattr(p, "_dwc_zero_grad", False)]
             _ops._hbm("adam_multi", 28 * sum(p.numel() for p in stepped))                              # p, g, m, v read; p, m, v written
             # the kernel wrote through raw pointers: tell autograd (and the prepared-weight cache in
@@ -149,7 +149,6 @@ class FusedEMA:
     def step(self, beta=0.999):
         lib = _lib.load()
         _lib.check(lib.dwc_ema_multi(self.desc.data_ptr(), self.tid.data_ptr(), self.start.data_ptr(), self.n_chunks,
-                                     beta, torch.cuda.current_stream().cuda_stream), "ema_multi")
-        from . import ops as _ops
+                                     beta, _ops._stream()), "ema_multi")
         _ops._hbm("ema_multi", 12 * sum(p.numel() for p in self.src))                                # p, copy read; copy written
         torch.autograd.graph.increment_version(self.dst)
