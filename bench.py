@@ -63,28 +63,29 @@ DOMINANT = "conv_gemm_kernel"            # the forward / data-gradient GEMM fami
 # several launches of comparable weight (ring strips + fold) are labelled as such and never chosen as
 # "the" roofline kernel; small helper launches inside a call (split-K / slab reduces, folds) are part of its span time.
 KIND_KERNEL = {
-    "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
-    "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
+    "fwd-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3, 0>\(", "bf16x3"),
+    "dgrad-x3": ("conv_halo_x3_kernel<{k}>", r"conv_halo_x3_kernel<{k}, .*, 3, 0>\(", "bf16x3"),
     "fwd-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
     "dgrad-heads-stem-x3": ("conv_stem_x3_kernel", r"conv_stem_x3_kernel", "bf16x3"),
     "fwd-heads-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
     "dgrad-image-nx3": ("conv_narrow_x3_kernel", r"conv_narrow_x3_kernel<", "bf16x3"),
-    # (template arguments: ..., PB, S2, KSP -- S2 is the last but one: 1 = stride-2 forward, 2 = its data gradient)
-    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 3>\(", "bf16x3"),
-    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1, 3>\(", "bf16x3"),
-    "dgrad-s2halo": ("conv_halo16_kernel<2,S2-dgrad>", r"conv_halo16_kernel<2, .*, 2>\(", "bf16"),
+    # (template arguments: ..., PB, S2, KSP, NPL, RING -- S2: 1 = stride-2 forward, 2 = its data gradient; RING (r06, last): the border ring
+    # of the data gradient inside the launch; conv_halo16_kernel: ..., PROBE, S2, RING)
+    "fwd-x3s2": ("conv_halo_x3_kernel<2,S2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 3, 0>\(", "bf16x3"),
+    "dgrad-x3s2": ("conv_halo_x3_kernel<2,S2-dgrad>", r"conv_halo_x3_kernel<2, .*, 2, 1, 3, 0>\(", "bf16x3"),
+    "dgrad-s2halo": ("conv_halo16_kernel<2,S2-dgrad>", r"conv_halo16_kernel<2, .*, 2, [01]>\(", "bf16"),
     "wgrad-x3": ("wgrad_x3_kernel<{k}>", r"wgrad_x3_kernel<{k}, .*, 3>\(", "bf16x3"),
     # r05: the same kernels with TWO f16 planes per operand (template argument NPL = 2, the last one): 3 MFMAs per fp32 multiply-add
-    "fwd-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2>\(", "f16x2"),
-    "dgrad-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2>\(", "f16x2"),
-    "fwd-h2s2": ("conv_halo_x3_kernel<2,S2,h2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 2>\(", "f16x2"),
-    "dgrad-h2s2": ("conv_halo_x3_kernel<2,S2-dgrad,h2>", r"conv_halo_x3_kernel<2, .*, 2, 1, 2>\(", "f16x2"),
+    "fwd-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2, [01]>\(", "f16x2"),
+    "dgrad-h2": ("conv_halo_x3_kernel<{k},h2>", r"conv_halo_x3_kernel<{k}, .*, 2, [01]>\(", "f16x2"),
+    "fwd-h2s2": ("conv_halo_x3_kernel<2,S2,h2>", r"conv_halo_x3_kernel<2, .*, 1, [12], 2, 0>\(", "f16x2"),
+    "dgrad-h2s2": ("conv_halo_x3_kernel<2,S2-dgrad,h2>", r"conv_halo_x3_kernel<2, .*, 2, 1, 2, [01]>\(", "f16x2"),
     "wgrad-h2": ("wgrad_x3_kernel<{k},h2>", r"wgrad_x3_kernel<{k}, .*, 2>\(", "f16x2"),
     "fwd-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
     "dgrad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
     "fwd-zeropad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
     "dgrad-zeropad-halo": ("conv_halo16_kernel<{k}>", r"conv_halo16_kernel<{k}, ", "bf16"),
-    "fwd-s2halo": ("conv_halo16_kernel<2,S2>", r"conv_halo16_kernel<2, .*, 1>\(", "bf16"),
+    "fwd-s2halo": ("conv_halo16_kernel<2,S2>", r"conv_halo16_kernel<2, .*, 1, 0>\(", "bf16"),
     "wgrad-halo": ("wgrad_halo_kernel<{k}>", r"wgrad_halo_kernel<{k}, ", "bf16"),
     "fwd-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),
     "dgrad-heads-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),

@@ -112,8 +112,11 @@ def main():
         used.update(r["Name"] for r in match)
         ms_iter = ns / 1e6 / iters
         gbps = ent["bytes"] / (ms_iter * 1e-3) / 1e9 if ms_iter > 0 else None
-        table.append({"kernel": fam + " (" + ", ".join(sorted({re.sub(r"^_ZN12_GLOBAL__N_1\d+", "", r["Name"].replace("void ", "").replace(
-                          "(anonymous namespace)::", "").split("(")[0].split("<")[0])[:24] for r in match})) + ")",
+        def short(name):
+            name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+            m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+            return name[len(m.group(0)):len(m.group(0)) + int(m.group(1))] if m else name
+        table.append({"kernel": fam + " (" + ", ".join(sorted({short(r["Name"]) for r in match})) + ")",
                       "pipe": None, "bound": "hbm", "launches_per_iter": round(calls / iters, 2), "op_calls_per_iter": ent["calls"],
                       "avg_us": round(ns / 1e3 / calls, 2), "ms_per_iter": round(ms_iter, 3), "share_of_kernel_time": round(ns / total_ns, 4),
                       "algorithmic_mbytes_per_iter": round(ent["bytes"] / 1e6, 1), "gbps": None if gbps is None else round(gbps, 1),
