@@ -29,6 +29,10 @@ class DeviceNoise:
         """Scaled keep-mask (0 or 1/(1-p)) drawn now, to be multiplied in later."""
         return F.dropout(torch.ones(tuple(shape), dtype=torch.float32, device=device), p=p, training=True)
 
+    def rand(self, shape, device):
+        """U[0, 1) draws (the interpolation weights of the gradient penalty, reference solver.py:339)."""
+        return torch.rand(tuple(shape), device=device)
+
     def style_sample(self, mu, c_dim, stddev):
         shape = (1, c_dim) + tuple(mu.shape)
         # (r06: torch.normal(mean tensor, std TENSOR) checks `std.min() >= 0` on the host -- a device synchronisation in the middle of
@@ -63,6 +67,9 @@ class HostNoise:
         shape = (1, c_dim) + tuple(m.shape)
         draw = torch.normal(m.expand(shape), torch.full_like(m, stddev).expand(shape))
         return draw.permute(0, 2, 3, 1).reshape(m.shape[0], -1).to(mu.device)
+
+    def rand(self, shape, device):
+        return torch.rand(tuple(shape)).to(device)
 
 
 _NOISE = DeviceNoise()

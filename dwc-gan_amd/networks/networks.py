@@ -362,6 +362,26 @@ class MsImageDis(nn.Module):
                 x = ops.downsample_half(x)
         return outputs
 
+    def forward_src_scale0_torch(self, x):
+        """The first scale's 'src' map -- ``self(x, False)[0][0]`` -- on stock torch device ops (F.pad / F.conv2d / activation), for the
+        two callers that differentiate it TWICE: Solver.gradient_penalty / r1_penalty (reference solver.py:291-315,338-350; off in the
+        shipped configuration).  The HIP autograd Functions are once-differentiable; these penalties are an O(B) side branch of the D
+        step, so they take torch's own double backward on the same parameters instead.  x: [B, 3, H, W] fp32."""
+        if self.norm != "none" or self.pad_type not in ("reflect", "zero", "replicate"):
+            raise NotImplementedError("gradient penalties: discriminator norm %r / pad %r" % (self.norm, self.pad_type))
+        mode = {"reflect": "reflect", "zero": "constant", "replicate": "replicate"}[self.pad_type]
+        h = x.float()
+        for blk in self.cnns_feat[0]:
+            p = blk.padding
+            h = F.conv2d(F.pad(h, (p, p, p, p), mode=mode) if p else h, blk.conv.weight, blk.conv.bias, stride=blk.stride)
+            if blk.act_kind == "relu":
+                h = torch.relu(h)
+            elif blk.act_kind == "lrelu":
+                h = F.leaky_relu(h, 0.1)
+            elif blk.act_kind != "none":
+                h = blk._torch_act(h)
+        return F.conv2d(h, self.cnns_src[0].weight, self.cnns_src[0].bias)
+
     def _classification_loss(self, logit, target, dataset="CelebA"):
         if dataset in ("CelebA", "CUB200"):
             return F.binary_cross_entropy_with_logits(logit, target, reduction="mean")

@@ -224,13 +224,24 @@ class Solver(nn.Module):
         style_txt, _ = self.gen.encode_txt(flat_heads(style_src), txt_src2trg, txt_lens)
         return self._decode(content, flat_heads(style_txt), x4)[:, :3].float()
 
+    # ---- penalties (reference solver.py:291-315) --------------------------------------------------
+    def gradient_penalty(self, y, x):
+        """(||dy/dx||_2 - 1)^2, mean over the batch (reference solver.py:291-304)."""
+        dydx = torch.autograd.grad(outputs=y, inputs=x, grad_outputs=torch.ones_like(y), retain_graph=True, create_graph=True,
+                                   only_inputs=True)[0]
+        dydx = dydx.reshape(dydx.size(0), -1)
+        return torch.mean((torch.sqrt(torch.sum(dydx ** 2, dim=1)) - 1) ** 2)
+
+    def r1_penalty(self, y, x):
+        """mean over the batch of (||dy/dx||_2^2)^2 -- the reference squares the squared norm (solver.py:306-315); kept."""
+        dydx = torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y), create_graph=True, only_inputs=True)[0]
+        dydx = dydx.reshape(dydx.size(0), -1)
+        return torch.mean(torch.sum(dydx ** 2, dim=1) ** 2)
+
     # ---- D step (reference solver.py:317-353) ---------------------------------------------------
     def dis_update(self, x_real, c_src, c_trg, txt_src2trg, txt_lens, label_src, label_trg, configs, iters, tape_content=None):
         """``tape_content`` (not in the reference's signature): True / False = whether a gen_update on this batch follows this
         call (its enc_content(x_real) is then computed once, here, on the tape); None = decide from set_n_critic()."""
-        if configs["gp_w"] > 0.0 or configs["use_r1"]:
-            raise NotImplementedError("gradient / R1 penalties need double backward through the HIP ops "
-                                      "(off in the shipped config: gp_w 0, use_r1 False)")
         self._zero_grad("dis")
         x4 = ops.pack_image(x_real)
         ops.lstm_status_poll(x4.device)     # persistent text-encoder kernels: raise if a hand-off of an earlier step timed out
@@ -274,6 +285,20 @@ class Solver(nn.Module):
             self.loss_dis = self.dis.dis_loss_terms(o_fake, o_real, label_src, gw, cw) + \
                 self.dis.dis_loss_terms(o_fake1, o_real, label_src, gw, cw)
         self.loss_dis_all = self.loss_dis
+        # Gradient / R1 penalties (reference solver.py:337-350; gp_w 0 and use_r1 False in the shipped configuration).  Both differentiate
+        # the first scale's src map w.r.t. its INPUT and then that gradient w.r.t. D's weights: a double backward, taken on stock torch
+        # device ops over the same parameters (MsImageDis.forward_src_scale0_torch) -- the HIP Functions are once-differentiable.
+        # The reference adds them IN PLACE to the tensor both names refer to (`self.loss_dis_all = self.loss_dis; ... += ...`): loss_dis
+        # reads the penalised value afterwards too; kept.
+        if configs["gp_w"] > 0.0:
+            alpha = host.noise().rand((x_real.size(0), 1, 1, 1), x_real.device)
+            x_hat = (alpha * x_real.detach()[:, :3].float() + (1 - alpha) * fakes[:B, :3].detach().float()).requires_grad_(True)
+            self.loss_gp = self.gradient_penalty(self.dis.forward_src_scale0_torch(x_hat), x_hat) * configs["gp_w"]
+            self.loss_dis_all = self.loss_dis = self.loss_dis_all + self.loss_gp
+        if configs["use_r1"] and (iters + 1) % self.d_reg_every == 0:
+            x_r = x_real.detach()[:, :3].float().requires_grad_(True)
+            self.loss_r1 = self.r1_penalty(self.dis.forward_src_scale0_torch(x_r), x_r) * 10. / 2
+            self.loss_dis_all = self.loss_dis = self.loss_dis_all + self.loss_r1
         self.loss_dis_all.backward()
         self._sync_grads("dis")             # data parallel: average D's gradients over the ranks
         self.dis_opt.step()

@@ -159,6 +159,10 @@ class GlobalCpuNoise:
         draw = torch.normal(mu.expand(shape), (torch.ones_like(mu) * stddev).expand(shape))
         return draw.permute(0, 2, 3, 1).reshape(mu.shape[0], -1)
 
+    def rand(self, shape):
+        """torch.rand(...) of the gradient penalty's interpolation weights (reference solver.py:339)."""
+        return torch.rand(tuple(shape))
+
 
 # --------------------------------------------------------------------------------------
 # generator
@@ -493,6 +497,27 @@ class OracleSolver:
             x_fake1 = self._blend(*gen_decode(G, content, style1, g), x_real)
         loss = calc_dis_loss(D, x_fake, x_real, label_src, cfg["gan_w"], cfg["cls_w"], d) + \
             calc_dis_loss(D, x_fake1, x_real, label_src, cfg["gan_w"], cfg["cls_w"], d)
+        # gradient / R1 penalties on the first scale's src map (reference solver.py:337-350, :291-315): a gradient w.r.t. the INPUT,
+        # differentiated again w.r.t. D's weights by the backward below.  Both are added in place to the tensor that loss_dis and
+        # loss_dis_all name in the reference, so both scalars read the penalised value.
+        one_scale = dict(d, num_scales=1)
+        if cfg.get("gp_w", 0.0) > 0.0:
+            alpha = self.noise.rand((x_real.shape[0], 1, 1, 1))
+            x_hat = (alpha * x_real.detach() + (1 - alpha) * x_fake.detach()).requires_grad_(True)
+            y = dis_forward(D, x_hat, one_scale)[0][0]
+            dydx = torch.autograd.grad(y, x_hat, grad_outputs=torch.ones_like(y), retain_graph=True, create_graph=True)[0]
+            norm = torch.sqrt(torch.sum(dydx.reshape(dydx.shape[0], -1) ** 2, dim=1))
+            loss_gp = torch.mean((norm - 1) ** 2) * cfg["gp_w"]
+            self.losses["loss_gp"] = float(loss_gp.detach())
+            loss = loss + loss_gp
+        if cfg.get("use_r1", False) and (iters + 1) % 16 == 0:                       # d_reg_every = 16 (reference solver.py:54)
+            x_r = x_real.detach().clone().requires_grad_(True)
+            y = dis_forward(D, x_r, one_scale)[0][0]
+            dydx = torch.autograd.grad(y, x_r, grad_outputs=torch.ones_like(y), create_graph=True)[0]
+            sq = torch.sum(dydx.reshape(dydx.shape[0], -1) ** 2, dim=1)
+            loss_r1 = torch.mean(sq ** 2) * 10. / 2                                  # (the square of the squared norm: as written, :313-314)
+            self.losses["loss_r1"] = float(loss_r1.detach())
+            loss = loss + loss_r1
         self.losses["loss_dis"] = self.losses["loss_dis_all"] = float(loss.detach())
         grads = self._grads(loss, D)
         self.last_dis_grads = grads

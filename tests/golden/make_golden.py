@@ -275,6 +275,35 @@ def gen_tiny(ref_solver):
     print("tiny_dis_grads.npz written")
 
 
+def gen_penalties(ref_solver):
+    """dis_update of the imported reference with BOTH penalties on (reference solver.py:337-350; gp_w 0 / use_r1 False in the shipped
+    configuration): tiny networks from the seed-1234 initialisation, the tiny fixture's batch, iteration 15 (so that (iters + 1) %
+    d_reg_every == 0 and the R1 term is live).  Scalars and every D gradient, grabbed in front of dis_opt.step."""
+    cfg = synth.make_config(image_size=32, tiny=True)
+    cfg["gp_w"], cfg["use_r1"] = 10.0, True
+    trainer = build_ref_solver(ref_solver, cfg)
+    batch = synth.make_batch(3, 32, seed=4321)
+    out = {"rng_state_after_init": torch.get_rng_state().numpy().copy()}
+    grabbed = {}
+    real_step = trainer.dis_opt.step
+
+    def grab_then_step(*args, **kw):
+        for k, p in trainer.dis.named_parameters():
+            grabbed["grad/" + k] = t2n(p.grad)
+        return real_step(*args, **kw)
+    trainer.dis_opt.step = grab_then_step
+    x_real = batch["x_real"].clone()                  # (the reference sets requires_grad on the tensor it is handed)
+    trainer.dis_update(x_real, batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"], batch["label_src"],
+                       batch["label_trg"], cfg, 15)
+    out.update(grabbed)
+    for k in ("loss_dis", "loss_dis_all", "loss_gp", "loss_r1"):
+        out[k] = np.float64(float(getattr(trainer, k)))
+    out["meta"] = np.frombuffer(json.dumps({"gp_w": 10.0, "use_r1": True, "iters": 15, "B": 3, "S": 32, "batch_seed": 4321,
+                                            "seed": 1234}).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "tiny_penalties.npz"), **out)
+    print("tiny_penalties.npz written:", {k: float(out[k]) for k in ("loss_dis", "loss_dis_all", "loss_gp", "loss_r1")})
+
+
 def gen_init_checksums(ref_solver):
     res = {}
     for S in (64, 128):
@@ -602,6 +631,8 @@ if __name__ == "__main__":
         gen_tiny(ref_solver)
     if "init" in what:
         gen_init_checksums(ref_solver)
+    if "penalties" in what:
+        gen_penalties(ref_solver)
     if "reach" in what:
         gen_reach(ref_nets)
     if "vgg" in what:

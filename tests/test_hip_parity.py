@@ -971,6 +971,33 @@ def test_tiny_dis_gradients_vs_reference(tiny, golden_dir):
         host.set_noise(host.DeviceNoise())
 
 
+def test_tiny_dis_penalties_vs_reference(tiny, golden_dir):
+    """Solver.dis_update with the gradient penalty and the R1 penalty on (reference solver.py:291-315,337-350; r06 -- rounds 1-5 raised
+    NotImplementedError): the HIP D step plus the two double-backward side branches on torch device ops, against the imported reference
+    (gp_w = 10, use_r1 = True, iteration 15): scalars and every D gradient."""
+    ref = np.load(os.path.join(golden_dir, "tiny_penalties.npz"))
+    host.set_noise(host.HostNoise())
+    try:
+        s, cfg, batch = _tiny_solver(tiny)
+        cfg = dict(cfg, gp_w=10.0, use_r1=True)
+        grabbed = {}
+        real_step = s.dis_opt.step
+
+        def grab(*a, **k):
+            grabbed.update({n: p.grad.detach().clone() for n, p in s.dis.named_parameters()})
+            return real_step(*a, **k)
+        s.dis_opt.step = grab
+        s.dis_update(batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+                     batch["label_src"], batch["label_trg"], cfg, 15)
+        for k in ("loss_dis", "loss_dis_all", "loss_gp", "loss_r1"):
+            got, want = float(getattr(s, k)), float(ref[k])
+            assert abs(got - want) <= 2e-4 * max(abs(want), 1e-12) + (2e-4 if k != "loss_r1" else 0.0), (k, got, want)
+        for k, g in grabbed.items():
+            close(g, T(ref["grad/" + k]), rel=2e-3, msg=k)
+    finally:
+        host.set_noise(host.DeviceNoise())
+
+
 # ---- VGG16 perceptual loss (reference networks.py:639-688, solver.py:242-247; SURVEY.md section 8(f) rank 2) ----------
 @pytest.mark.parametrize("B,C,H", [(2, 64, 16), (1, 8, 6), (3, 4, 10)])
 def test_max_pool2_and_zeropad_conv(B, C, H):

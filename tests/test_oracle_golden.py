@@ -204,6 +204,27 @@ def test_tiny_dis_grads(tiny, golden_dir):
         close_scaled(g, T(ref[k]), 1e-3, msg=k)
 
 
+def test_tiny_dis_penalties(tiny, golden_dir):
+    """Gradient penalty + R1 penalty of the D step (reference solver.py:291-315,337-350; both off in the shipped configuration) against
+    the imported reference run with gp_w = 10, use_r1 = True at iteration 15 (tests/golden/make_golden.py penalties): the four
+    scalars -- loss_dis carries the penalties too, the reference adds them in place to the tensor both names refer to -- and every
+    D gradient (a double backward)."""
+    ref = np.load(os.path.join(golden_dir, "tiny_penalties.npz"))
+    cfg = synth.make_config(image_size=32, tiny=True)
+    cfg["gp_w"], cfg["use_r1"] = 10.0, True
+    batch = {k[len("batch/"):]: T(tiny[k]) for k in tiny.files if k.startswith("batch/")}
+    solver = orc.OracleSolver(cfg, _sd(tiny, "init/gen/"), _sd(tiny, "init/dis/"))
+    torch.set_rng_state(T(ref["rng_state_after_init"]))
+    solver.dis_update(batch["x_real"], batch["c_src"], batch["c_trg"], batch["txt"], batch["txt_lens"],
+                      batch["label_src"], batch["label_trg"], cfg, 15)
+    for k in ("loss_dis", "loss_dis_all", "loss_gp", "loss_r1"):
+        want = float(ref[k])
+        assert abs(solver.losses[k] - want) <= 1e-4 * max(abs(want), 1e-12) + (1e-5 if k != "loss_r1" else 0.0), (k, solver.losses[k], want)
+    assert float(ref["loss_gp"]) > 1.0 and float(ref["loss_r1"]) > 0.0
+    for k, g in solver.last_dis_grads.items():
+        close_scaled(g, T(ref["grad/" + k]), 1e-3, msg=k)
+
+
 # ---- VGG16 perceptual loss (SURVEY.md section 8(f) rank 2) ----------------------------------------------------------
 def _seeded_vgg_state():
     """The product's Vgg16 built under the fixture's seed: same constructor order as the reference's, so the same
