@@ -52,6 +52,9 @@ SIGNATURES = {
     "dwc_conv2d_bwd_weight_ex": (c_int, [c_fp, c_fp, c_fp] + [c_int] * 13 + [c_fp, c_sz, c_fp]),
     "dwc_act_bwd_bias_ws_bytes": (c_sz, [c_int, c_int]),
     "dwc_act_bwd_bias": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "dwc_linear_small_ok": (c_int, [c_int] * 3),
+    "dwc_linear_small_fwd": (c_int, [c_fp] * 4 + [c_int] * 4 + [c_fp]),
+    "dwc_linear_small_bwd": (c_int, [c_fp] * 7 + [c_int] * 3 + [c_fp]),
     "dwc_instnorm_ws_bytes": (c_sz, [c_int, c_int, c_int]),
     "dwc_instnorm_fwd": (c_int, [c_fp] * 7 + [c_int, c_int, c_int, c_f, c_int, c_fp, c_sz, c_fp]),
     "dwc_instnorm_bwd": (c_int, [c_fp] * 9 + [c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),

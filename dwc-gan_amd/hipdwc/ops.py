@@ -1448,9 +1448,52 @@ def max_pool2(x):
     return _MaxPool2.apply(x)
 
 
+LINEAR_SMALL = int(os.environ.get("DWC_LINEAR_SMALL", "1"))      # nn.Linear on few rows on csrc/linear_small.hip (0: the 1x1-convolution path)
+
+
+class _LinearSmall(torch.autograd.Function):
+    """y = relu?(x w^T + b) for fp32 activations of a few rows: one launch forward, two backward (csrc/linear_small.hip; r06).  The
+    weights are read as nn.Linear stores them: no prepared layout to refresh."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        lib = _lib.load()
+        x, w = x.contiguous(), w.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+        _lib.check(_timed("linear_small_kernel", 2.0 * M * N * K, lambda: lib.dwc_linear_small_fwd(
+            x.data_ptr(), w.data_ptr(), _p(b), y.data_ptr(), M, N, K, int(relu), _stream()),
+            detail="fwd-lin B%d 1x1 %d>%d k1 s1" % (M, K, N)), "linear_small_fwd")
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2] and dw is not None) else None
+        _lib.check(_timed("linear_small_kernel", 2.0 * M * N * K * ((dx is not None) + (dw is not None)), lambda: lib.dwc_linear_small_bwd(
+            dy.data_ptr(), _p(y), x.data_ptr(), w.data_ptr(), _p(dx), _p(dw), _p(db), M, N, K, _stream()),
+            scope_name=("bwd:" + SCOPE) if SCOPE else "", detail="bwd-lin B%d 1x1 %d>%d k1 s1" % (M, K, N)), "linear_small_bwd")
+        if ctx.has_b and ctx.needs_input_grad[2] and db is None:        # (bias gradient alone: column sums of the masked dy)
+            g = dy if y is None else dy * (y > 0)
+            db = g.sum(0)
+        return dx, dw, db, None
+
+
 def linear(x, w, b, act="none", owner=None):
-    """nn.Linear (+ReLU) as a 1x1 convolution over a 1x1 image (reference networks.py:587-634).
-    Input width must be a power of two >= 4."""
+    """nn.Linear (+ReLU) (reference networks.py:587-634): on csrc/linear_small.hip where the shape fits (fp32, widths multiples of 16,
+    at most 4096 rows), else as a 1x1 convolution over a 1x1 image (input width a power of two >= 4)."""
+    if (LINEAR_SMALL and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and w.dtype == torch.float32 and act in ("none", "relu", None)
+            and _lib.load().dwc_linear_small_ok(x.shape[0], w.shape[0], x.shape[1])):
+        return _LinearSmall.apply(x, w, b, act == "relu")
     y = conv2d(x.reshape(x.shape[0], x.shape[1], 1, 1), w.reshape(w.shape[0], w.shape[1], 1, 1), b, 1, 0, act, owner=owner or w)
     return y.reshape(x.shape[0], -1)
 

@@ -160,6 +160,18 @@ int dwc_instnorm_bwd(const float* dy, const float* x, const float* mean, const f
                      const float* gamma, const float* beta, float* dx, float* dgamma, float* dbeta,
                      int B, int HW, int C, int relu, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- nn.Linear (+ ReLU) on few rows (r06, ABI 8): the style -> AdaIN-parameter MLP (reference networks.py:491-503, LinearBlock
+ *      :587-634) and the style encoder's mapping (networks_v2.py:116-121) ------------------------------------------------------
+ * y[M][N] = act(x[M][K] . w[N][K]^T + bias[N]), fp32 row-major, w as nn.Linear stores it (no prepared layout); relu != 0: ReLU.
+ * One wave per 16 x 16 output tile on the exact fp32 matrix instruction (v_mfma_f32_16x16x4_f32), operands straight from memory: no
+ * LDS, no scratch.  _ok: N and K multiples of 16, M <= 4096 (larger problems belong on dwc_conv2d_fwd as a 1x1 convolution).
+ * dwc_linear_small_bwd: dx[M][K] (NULL: skipped), dw[N][K] and db[N] (NULL: skipped) from dy[M][N]; y_relu = the forward's output when
+ * it had the ReLU (the mask is applied while dy is read), else NULL. */
+int dwc_linear_small_ok(int M, int N, int K);
+int dwc_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int relu, void* stream);
+int dwc_linear_small_bwd(const float* dy, const float* y_relu, const float* x, const float* w, float* dx, float* dw, float* db, int M,
+                         int N, int K, void* stream);
+
 /* ---- MUNIT LayerNorm (reference networks.py:736-752: per-sample mean, UNBIASED std,
  *      (x-mean)/(std+eps), per-channel gamma/beta) ------------------------------------------ */
 size_t dwc_layernorm_ws_bytes(int B, int HW, int C);
