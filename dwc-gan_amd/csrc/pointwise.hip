@@ -799,9 +799,64 @@ int l1_mean_bwd_t(const T* a, const T* b, const float* dout, T* da, T* db, size_
     return DWC_OK;
 }
 
+// ---- GMM style-space KL term (reference gmm.py:13-22; r06) ---------------------------------------------------------------
+// sum_k mean_b sum_d 0.5 (log(sigma / e^lv) + (e^lv + (mu - c[b][k])^2) / sigma - 1) over [B][K][D] heads: the reference's (and rounds 1-5's)
+// dozen elementwise launches forward and two dozen backward on 16 x 8 x 8 numbers.  One workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void gmm_kl_sp_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                             const float* __restrict__ centre, int centre_stride, int B, int K, int D,
+                                                             float sigma, float* __restrict__ out) {
+    __shared__ float red[1024];
+    const int n = B * K * D;
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const int b = e / (K * D), k = (e / D) % K;
+        const float c = centre[(size_t)b * centre_stride + k], var = expf(lv[e]), d = mu[e] - c;
+        s += 0.5f * (logf(sigma / var) + (var + d * d) / sigma - 1.0f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)B;
+}
+
+__global__ __launch_bounds__(256) void gmm_kl_sp_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                            const float* __restrict__ centre, int centre_stride, int B, int K, int D,
+                                                            float sigma, const float* __restrict__ dout, float* __restrict__ dmu,
+                                                            float* __restrict__ dlv) {
+    const int n = B * K * D, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int b = e / (K * D), k = (e / D) % K;
+    const float g = dout[0] / (float)B;
+    if (dmu) dmu[e] = g * (mu[e] - centre[(size_t)b * centre_stride + k]) / sigma;
+    if (dlv) dlv[e] = g * 0.5f * (expf(lv[e]) / sigma - 1.0f);
+}
+
 }  // namespace
 
 extern "C" {
+
+int dwc_gmm_kl_sp_fwd(const float* mu, const float* lv, const float* centre, int centre_stride, int B, int K, int D, float sigma,
+                      float* out, void* stream) {
+    if (!mu || !lv || !centre || !out || B <= 0 || K <= 0 || D <= 0 || centre_stride < K || !(sigma > 0.f) ||
+        (long long)B * K * D > (1 << 24))
+        return DWC_EINVAL;
+    hipLaunchKernelGGL(gmm_kl_sp_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mu, lv, centre, centre_stride, B, K, D, sigma, out);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
+int dwc_gmm_kl_sp_bwd(const float* mu, const float* lv, const float* centre, int centre_stride, int B, int K, int D, float sigma,
+                      const float* dout, float* dmu, float* dlv, void* stream) {
+    if (!mu || !lv || !centre || !dout || B <= 0 || K <= 0 || D <= 0 || centre_stride < K || !(sigma > 0.f) ||
+        (long long)B * K * D > (1 << 24))
+        return DWC_EINVAL;
+    hipLaunchKernelGGL(gmm_kl_sp_bwd_kernel, dim3((B * K * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, mu, lv, centre,
+                       centre_stride, B, K, D, sigma, dout, dmu, dlv);
+    DWC_LAUNCH_CHECK();
+    return DWC_OK;
+}
 
 int dwc_adv_tail_fwd(const float* src, const float* cls, const float* labels, float* out, int segs, int B, int src_per_sample, int ncls,
                      dwc_adv_spec spec, void* stream) {

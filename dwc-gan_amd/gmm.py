@@ -6,6 +6,8 @@ N(c_i, sigma^2) with c_i = +-1 taken from the label (reference gmm.py:13-22, :33
 """
 import torch
 
+from hipdwc import ops
+
 
 def _stack(heads):
     """list of K tensors [B, D] -> [B, K, D].  A networks_v2.HeadList carries the [B, K*D] tensor its entries were cut from:
@@ -24,6 +26,8 @@ def gmm_kl_distance(pred_mu, pred_sigma, mus, sigma):
 def gmm_kl_distance_sp(pred_mus, pred_sigma, mus, sigma):
     """Per-attribute KL with log-variance heads: sum_i mean_n sum_d KL(N(mu, e^lv) || N(c_i, sigma))."""
     mu, lv = _stack(pred_mus), _stack(pred_sigma)          # [B, K, D]
+    if mu.is_cuda and ops.GMM_FUSED and mu.dtype == torch.float32 and lv.dtype == torch.float32:
+        return ops.gmm_kl_sp(mu, lv, mus, sigma)           # one launch each way (hipdwc.ops._GmmKlSp)
     var = lv.exp()
     centre = mus[:, :mu.shape[1]].unsqueeze(-1)            # [B, K, 1]
     kl = 0.5 * (torch.log(sigma / var) + (var + (mu - centre) ** 2) / sigma - 1.0)

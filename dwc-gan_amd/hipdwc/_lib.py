@@ -70,6 +70,8 @@ SIGNATURES = {
     "dwc_blend_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_fp]),
     "dwc_blend_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_fp]),
     "dwc_l1_ws_bytes": (c_sz, [c_sz]),
+    "dwc_gmm_kl_sp_fwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_fp, c_fp]),
+    "dwc_gmm_kl_sp_bwd": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_fp]),
     "dwc_l1_mean_fwd": (c_int, [c_fp, c_fp, c_fp, c_sz, c_int, c_fp, c_sz, c_fp]),
     "dwc_l1_mean_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_sz, c_int, c_fp]),
     "dwc_lstm_fwd": (c_int, [c_fp] * 6 + [c_int] * 4 + [c_fp]),

@@ -22,12 +22,21 @@ class DeviceNoise:
     """Default: draw on the tensor's own device, like the reference does on its GPU."""
     align_stream = False     # draws whose result is unused may be skipped
 
+    def __init__(self):
+        self._ones = {}
+
     def dropout(self, x, p, training=True):
         return F.dropout(x, p=p, training=training)
 
     def dropout_mask(self, shape, p, device):
         """Scaled keep-mask (0 or 1/(1-p)) drawn now, to be multiplied in later."""
-        return F.dropout(torch.ones(tuple(shape), dtype=torch.float32, device=device), p=p, training=True)
+        key = (tuple(shape), str(device))
+        ones = self._ones.get(key)
+        if ones is None:               # (a constant input of the draw: filled once per shape, not once per call)
+            if len(self._ones) > 64:
+                self._ones.clear()
+            ones = self._ones[key] = torch.ones(tuple(shape), dtype=torch.float32, device=device)
+        return F.dropout(ones, p=p, training=True)
 
     def rand(self, shape, device):
         """U[0, 1) draws (the interpolation weights of the gradient penalty, reference solver.py:339)."""
@@ -40,9 +49,11 @@ class DeviceNoise:
         # _local_scalar_dense).  Same distribution, same generator, no check: standard normal draws scaled by the scalar stddev.)
         if _STYLE_NORMAL_CHECKED:       # (A/B switch DWC_STYLE_NORMAL=1: the synchronising form of rounds 1-5)
             draw = torch.normal(mu.expand(shape), torch.full_like(mu, stddev).expand(shape))
-        else:
-            draw = torch.randn(shape, dtype=mu.dtype, device=mu.device) * float(stddev) + mu
-        return draw.permute(0, 2, 3, 1).reshape(mu.shape[0], -1)
+            return draw.permute(0, 2, 3, 1).reshape(mu.shape[0], -1)
+        # drawn in the layout it is used in ([B, A, c_dim]: the entries are i.i.d., so WHICH draw lands where is immaterial on the
+        # device generator): randn + one fused multiply-add, no transposing copy
+        eps = torch.randn(tuple(mu.shape) + (c_dim,), dtype=mu.dtype, device=mu.device)
+        return torch.add(mu.unsqueeze(-1), eps, alpha=float(stddev)).reshape(mu.shape[0], -1)
 
 
 class HostNoise:

@@ -469,12 +469,32 @@ class _CatParams(torch.autograd.Function):
         return (None,) + tuple(parts)
 
 
+_PCAT_LIVE = {}     # (stack, ids of the parameters) -> (stamp, weakrefs, graph-attached result)
+
+
 def cat_params(params, stack=False):
-    """Concatenation (``stack=True``: stack) along dim 0 of parameters of one module, cached across calls."""
+    """Concatenation (``stack=True``: stack) along dim 0 of parameters of one module, cached across calls.
+
+    Under autograd the RESULT (with its graph node) is cached too while the parameters are unchanged: a module used k times in one graph
+    (the style encoder on x_real and on x_fake) then hangs off ONE node, the engine sums the k concatenated gradients (k - 1 adds) and
+    every parameter receives one view -- instead of k views per parameter and (k - 1) adds for EACH of them (r06: 32 of the 478 stock
+    launches of a c1 iteration).  The node saves no tensors, so it may be walked by several backward calls."""
     params = list(params)
     if not params[0].is_cuda:
         return torch.stack(params) if stack else torch.cat(params, 0)
-    return _CatParams.apply(stack, *params)
+    if not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+        return _CatParams.apply(stack, *params)
+    key = (bool(stack), tuple(id(p) for p in params))
+    stamp = tuple((p._version, p.data_ptr(), p.requires_grad) for p in params)
+    ent = _PCAT_LIVE.get(key)
+    if ent is not None and ent[0] == stamp and all(r() is p for r, p in zip(ent[1], params)):
+        return ent[2]
+    out = _CatParams.apply(stack, *params)
+    if len(_PCAT_LIVE) > 256:          # (ids of dead parameters: entries are small, but do not let them pile up)
+        for k in [k for k, e in _PCAT_LIVE.items() if any(r() is None for r in e[1])]:
+            del _PCAT_LIVE[k]
+    _PCAT_LIVE[key] = (stamp, [weakref.ref(p) for p in params], out)
+    return out
 
 
 def _shifted_bank(w, px):
@@ -2049,6 +2069,58 @@ def l1_mean(a, b, image=False):
     """mean |a-b| (reference solver.py:113-114).  image=True: internal image buffers (NHWC4 / NHWC8), mean over
     planes 0..2 only."""
     return _L1Mean.apply(a, b, a.shape[1] if image else 0)
+
+
+GMM_FUSED = int(os.environ.get("DWC_GMM_FUSED", "1"))      # the KL style-space term on dwc_gmm_kl_sp_* (0: torch's elementwise algebra)
+_SIGMA_F = {}                                               # id(sigma tensor) -> (weakref, version, python float)
+
+
+def _scalar_value(t):
+    """Python float of a 0-dim CONSTANT tensor (Solver.sigma), read from the device once per tensor and version -- not once per call,
+    which would make the host wait for the stream inside every iteration."""
+    if not torch.is_tensor(t):
+        return float(t)
+    ent = _SIGMA_F.get(id(t))
+    if ent is None or ent[0]() is not t or ent[1] != t._version:
+        ent = (weakref.ref(t), t._version, float(t.detach().float().item()))
+        _SIGMA_F[id(t)] = ent
+    return ent[2]
+
+
+class _GmmKlSp(torch.autograd.Function):
+    """sum_k mean_b sum_d KL(N(mu, e^lv) || N(centre[b][k], sigma)) over [B, K, D] heads (reference gmm.py:13-22): one launch forward,
+    one backward (r06; the batched torch expression was 12 + 24 launches on 16 x 8 x 8 numbers, twice per iteration)."""
+
+    @staticmethod
+    def forward(ctx, mu, lv, centre, sigma):
+        lib = _lib.load()
+        mu, lv, centre = mu.contiguous(), lv.contiguous(), centre.float()
+        if centre.stride(-1) != 1:
+            centre = centre.contiguous()
+        B, K, D = mu.shape
+        out = torch.empty((), dtype=torch.float32, device=mu.device)
+        _lib.check(lib.dwc_gmm_kl_sp_fwd(mu.data_ptr(), lv.data_ptr(), centre.data_ptr(), centre.stride(0), B, K, D, sigma, out.data_ptr(),
+                                         _stream()), "gmm_kl_sp_fwd")
+        ctx.save_for_backward(mu, lv, centre)
+        ctx.sigma = sigma
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        mu, lv, centre = ctx.saved_tensors
+        B, K, D = mu.shape
+        dout = dout.float().contiguous()
+        dmu = torch.empty_like(mu) if ctx.needs_input_grad[0] else None
+        dlv = torch.empty_like(lv) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.dwc_gmm_kl_sp_bwd(mu.data_ptr(), lv.data_ptr(), centre.data_ptr(), centre.stride(0), B, K, D, ctx.sigma,
+                                         dout.data_ptr(), _p(dmu), _p(dlv), _stream()), "gmm_kl_sp_bwd")
+        return dmu, dlv, None, None
+
+
+def gmm_kl_sp(mu, lv, centre, sigma):
+    """mu, lv: [B, K, D] fp32 device tensors; centre: [B, >= K]; sigma: python number or 0-dim tensor (a constant)."""
+    return _GmmKlSp.apply(mu, lv, centre, _scalar_value(sigma))
 
 
 # --------------------------------------------------------------------------------------

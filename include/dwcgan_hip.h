@@ -214,6 +214,14 @@ int dwc_blend_fwd(const float* heads, const float* real, float* out, int npix, v
 int dwc_blend_bwd(const float* dout, const float* heads, const float* real, float* dheads, int npix,
                   void* stream);
 
+/* ---- GMM style-space KL term, all attributes at once (reference gmm.py:13-22, called at solver.py:218-219; r06) ----
+ * out[0] = sum_k mean_b sum_d 0.5 (log(sigma / e^lv) + (e^lv + (mu - centre[b][k])^2) / sigma - 1); mu, lv: [B][K][D] contiguous,
+ * centre: [B][centre_stride >= K] (the +-1 component centres from the labels).  One launch each way; dmu / dlv may be NULL. */
+int dwc_gmm_kl_sp_fwd(const float* mu, const float* lv, const float* centre, int centre_stride, int B, int K, int D, float sigma,
+                      float* out_scalar, void* stream);
+int dwc_gmm_kl_sp_bwd(const float* mu, const float* lv, const float* centre, int centre_stride, int B, int K, int D, float sigma,
+                      const float* dout_scalar, float* dmu, float* dlv, void* stream);
+
 /* ---- mean |a-b| (reference solver.py:113-114) ----------------------------------------------
  * skip4 != 0: the buffers are NHWC4 images; every 4th element (the pad / attention plane) is
  * ignored and the mean is over the 3 image planes only (n*3/4 elements). */

@@ -202,38 +202,3 @@ def test_fused_ring_stride2(case, precision):
             assert ef <= 5e-6 and ef <= 2.0 * eu + 3e-7 and d <= 3e-6, (name, ef, eu, d)
     assert torch.equal(dw_f, dw_u)
 
-
-# ---- nn.Linear on few rows (csrc/linear_small.hip, r06): the AdaIN-parameter MLP and the style mapping (reference networks.py:491-503,
-# 587-634, networks_v2.py:116-121) on the exact fp32 matrix instruction, against float64
-@pytest.mark.parametrize("M,K,N,relu,bias", [(16, 64, 256, True, True), (16, 256, 256, True, True), (16, 256, 4096, False, True),
-                                             (48, 256, 128, False, True), (3, 64, 32, True, False), (384, 256, 4096, False, True),
-                                             (130, 48, 80, True, True), (32, 256, 256, False, False)])
-def test_linear_small_matches_float64(M, K, N, relu, bias):
-    ops.set_precision("fp32")
-    lib = _lib.load()
-    assert lib.dwc_linear_small_ok(M, N, K) == 1
-    g = torch.Generator().manual_seed(M + K + N)
-    x = torch.randn(M, K, generator=g)
-    w = torch.randn(N, K, generator=g) / K ** 0.5
-    b = torch.randn(N, generator=g) * 0.1 if bias else None
-    gy = torch.randn(M, N, generator=g)
-    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
-    br = b.double().requires_grad_(True) if bias else None
-    yr = F.linear(xr, wr, br)
-    yr = torch.relu(yr) if relu else yr
-    (yr * gy.double()).sum().backward()
-    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    bd = b.to(DEV).requires_grad_(True) if bias else None
-    calls = []
-    real = lib.dwc_linear_small_fwd
-    try:
-        lib.dwc_linear_small_fwd = lambda *a: (calls.append(1), real(*a))[1]
-        yd = ops.linear(xd, wd, bd, "relu" if relu else "none")
-    finally:
-        lib.dwc_linear_small_fwd = real
-    assert calls, "the small-linear kernel was not taken"
-    (yd * gy.to(DEV)).sum().backward()
-    for name, got, want in (("y", yd, yr), ("dx", xd.grad, xr.grad), ("dw", wd.grad, wr.grad)) + ((("db", bd.grad, br.grad),) if bias else ()):
-        err = (got.detach().cpu().double() - want.detach()).abs().max().item() / max(want.detach().abs().max().item(), 1e-30)
-        print("%-3s max err %.2e of the largest magnitude" % (name, err))
-        assert err <= 2e-6, (name, err)
