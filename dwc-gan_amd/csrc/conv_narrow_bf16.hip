@@ -36,6 +36,7 @@ struct NarrowArgs {
     bf16* y;             // [B][OH][OWg][32]
     int B, IH, IW, OH, OWg, off_h, off_w, act, reflect;
     int blocks_x, blocks_y;
+    // (timing-only ablations: -DDWC_DEV_ABLATIONS -DDWC_NARROW_DBG=<bits>: 1 no MFMA, 2 no fragment reads, 4 no patch staging, 8 no reduction)
 };
 
 // NB_ROWS = 8: 73.5 KB of LDS and <= 128 registers, so TWO workgroups share a CU and one's patch staging / reduction runs beside
@@ -61,6 +62,11 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
     bid /= a.blocks_x;
     const int by = bid % a.blocks_y, n = bid / a.blocks_y;
     const int oy0 = by * NB_ROWS, gx0 = bx * NB_GROUPS;
+#if defined(DWC_DEV_ABLATIONS) && defined(DWC_NARROW_DBG)       // compile-time: a run-time switch in the tap loop disturbs its schedule
+    constexpr int DBG = DWC_NARROW_DBG;
+#else
+    constexpr int DBG = 0;
+#endif
 
     // ---- patch: one LDS-DMA pass per 64 pixels; chunk swizzle by (patch column >> 2) ----------------------------------------
     const unsigned x_bytes = (unsigned)a.B * a.IH * a.IW * NCH * 2u;
@@ -86,8 +92,9 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
             w = min(max(w, 0), a.IW - 1);
             const int lc = (t & 7) ^ ((pc >> 2) & 7);
             const unsigned off = ((unsigned)((n * a.IH + h) * a.IW + w) * NCH + (unsigned)(lc * 8)) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * 64 * NCH), 16,
-                                                     ok ? off : OOB, 0, 0, 0);
+            if (!(DBG & 4))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(lp + i * 64 * NCH), 16,
+                                                         ok ? off : OOB, 0, 0, 0);
         }
     }
 
@@ -142,8 +149,11 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
             const bf16* p = sP + pp * NCH;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(p + (((2 * q + hi) ^ sw) << 3));
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[q], fa, acc[m], 0, 0, 0);      // D[column][group]
+                bf16x8 fa;
+                if (DBG & 2) fa = fb[(q + 1) & 3];
+                else fa = *reinterpret_cast<const bf16x8*>(p + (((2 * q + hi) ^ sw) << 3));
+                if (DBG & 1) asm volatile("" ::"v"(fa));
+                else acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[q], fa, acc[m], 0, 0, 0);      // D[column][group]
             }
         }
     }
@@ -157,6 +167,10 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
     }
 #pragma unroll
     for (int round = 0; round < MT / 2; ++round) {
+        if (DBG & 8) {                                  // (ablation: no exchange; wave 0's own sums are stored)
+            if (wave == 0 && oy0 < a.OH) a.y[(size_t)blockIdx.x * 64 + lane] = (bf16)(acc[0][lane & 15] + acc[MT - 1][lane & 15]);
+            break;
+        }
         __syncthreads();                                // patch (round 0) / previous round's sums fully read
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm)
@@ -184,6 +198,311 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
             o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
             *reinterpret_cast<bf16x4*>(a.y + ((size_t)(n * a.OH + oy) * a.OWg + gx) * 32 + c0) = o;
         }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// The same layer as a PERSISTENT workgroup (r06).  Ablations of the kernel above at B = 384 (profiles/r06_narrow_ablation.txt, 647 us on
+// that box): no patch staging -231, no MFMAs and no fragment reads -204, no partial-sum exchange -54, and the remaining skeleton alone
+// 231 us -- the parts ADD: a workgroup stages, waits, multiplies, exchanges, and two workgroups per CU do not interleave enough to hide any
+// of it; and the skeleton is mostly filter traffic: every wave re-reads its 9 taps x 4 KB from L2 for every 256-pixel block (288 KB per
+// block against 74 KB of patch).  Here ONE workgroup per CU walks over the blocks:
+//  * a wave's filter taps (9 x 4 fragments = 144 registers) are loaded ONCE and stay in registers for every block;
+//  * two patch buffers: the next block's patch is requested (LDS-DMA) before the tap loop of the current one and lands behind it;
+//  * the fragment reads are asm ds_read_b128 with counted lgkmcnt, one item (tap, group tile) ahead of the MFMAs -- as compiler-visible LDS
+//    reads every one of them would be made to wait for the DMA in flight (vmcnt(0): the compiler cannot tell the buffers apart);
+//  * the partial-sum exchange aliases the patch buffer just consumed, as above.
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define NRW_DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+
+template <int N, class F>
+__device__ __forceinline__ void nrw_for(F&& f) {
+    if constexpr (N > 0) {
+        nrw_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int KH, int KWW>
+__global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NB_ROWS = 8, MT = NB_ROWS / 4;
+    constexpr int PR = NB_ROWS + KH - 1, PC = 4 * NB_GROUPS + KWW - 1, PPIX = PR * PC;
+    constexpr int PPASS = (PPIX + 63) / 64;
+    constexpr int NTAP = KH * KWW, NT_W = (NTAP + 7) / 8, NITEM = NT_W * MT;
+    constexpr int PBUF = PPASS * 64 * NCH;              // elements of one patch buffer (73 728 bytes)
+    constexpr int RED = 8 * 2 * 16 * 64;                // floats of the exchange: [wave][tile][reg][lane]
+    static_assert(RED * 4 <= PBUF * 2 && MT == 2, "the exchange aliases one patch buffer; one round of two tiles");
+    __shared__ __attribute__((aligned(128))) unsigned char smem_raw[2 * PBUF * 2];
+    bf16* sP = reinterpret_cast<bf16*>(smem_raw);
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+#if defined(DWC_DEV_ABLATIONS) && defined(DWC_NARROW_DBG)       // timing-only ablations (WRONG results), as in conv_narrow_kernel
+    constexpr int DBG = DWC_NARROW_DBG;
+#else
+    constexpr int DBG = 0;
+#endif
+    long long probe[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define NRW_PROBE(i)                                        \
+    do {                                                    \
+        if constexpr ((DBG & 32) != 0) {                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+            probe[i] = (long long)clock64();                \
+        }                                                   \
+    } while (0)
+
+    // ---- this wave's taps, once -----------------------------------------------------------------------------------------------
+    bf16x8 wreg[NT_W][4];
+    {
+        const bf16* wlane = a.w + lane * 8;
+        nrw_for<NT_W * 4>([&](auto K) {
+            constexpr int j = decltype(K)::value / 4, q = decltype(K)::value % 4;
+            wreg[j][q] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)(wave + 8 * j) * 4 + q) * 512);
+        });
+    }
+    const unsigned x_bytes = (unsigned)a.B * a.IH * a.IW * NCH * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.x), 0, x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    // Patch staging, one patch ROW per wave and turn (rows wave and wave + 8), 8 pixels (1 KB) per LDS-DMA instruction.  The address work is
+    // what the first persistent version lost its time on: one instruction per 64 consecutive patch pixels cost a division by the patch
+    // width, two reflections, clamps and three multiplies per lane and instruction -- 339 vector instructions per wave and block against 72
+    // MFMAs, and with all waves of the workgroup in the same phase nothing overlapped them.  Row-wise, the row's base is scalar arithmetic
+    // and the column term (reflected column x 128 B + swizzled 16-byte chunk) is a per-lane constant of the block COLUMN, kept in six
+    // registers while the workgroup walks down that column: one add and one select per instruction.
+    constexpr int NJ = (PC + 7) / 8;                    // instructions per row; the last one holds PC - 8 (NJ - 1) pixels
+    constexpr int TAIL_PIX = PC - 8 * (NJ - 1);
+    int wq[NJ];                                         // byte offset of this lane's pixel / chunk inside an image row, or -1: no data
+    auto column_terms = [&](int bx) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pc = 8 * j + (lane >> 3);
+            int w = 4 * bx * NB_GROUPS + pc + a.off_w;
+            bool ok = pc < PC;
+            if (a.reflect) w = reflect_idx(w, a.IW);
+            else ok = ok && (unsigned)w < (unsigned)a.IW;
+            w = min(max(w, 0), a.IW - 1);
+            const int lc = (lane & 7) ^ ((pc >> 2) & 7);
+            wq[j] = ok ? w * (NCH * 2) + lc * 16 : -1;
+        }
+    };
+    // A row's scalar part: source byte offset of the row start, or OOB (zero rule, row outside the image).
+    auto row_base = [&](int n, int by, int pr) -> unsigned {
+        int h = by * NB_ROWS + pr + a.off_h;
+        bool okh = true;
+        if (a.reflect) h = reflect_idx(h, a.IH);
+        else okh = (unsigned)h < (unsigned)a.IH;
+        h = min(max(h, 0), a.IH - 1);
+        return okh ? (unsigned)((n * a.IH + h) * a.IW) * (NCH * 2u) : OOB;
+    };
+    // DMA instruction j of patch row pr: 8 pixels.  (The vector-memory path takes ~150 cycles per such instruction when all eight waves
+    // issue their 12 back to back: 1.8 of the 10.3 thousand cycles of a block by the shader-clock probes (-DDWC_NARROW_DBG=32).  Issued one
+    // at a time between the MFMAs of the tap loop they cost the same -- the issuing wave is held, not the queue -- so they stay in front.)
+    auto stage_one = [&](unsigned rowbase, int pr, int j, int buf) {
+        const unsigned off = (rowbase != OOB && wq[j] >= 0) ? rowbase + (unsigned)wq[j] : OOB;
+        bf16* lp = sP + buf * PBUF + (pr * PC + j * 8) * NCH;
+        if (DBG & 4) return;
+        if (j + 1 < NJ || TAIL_PIX == 8) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)lp, 16, off, 0, 0, 0);
+        } else if (lane < 8 * TAIL_PIX) {               // (the lanes past the row's end must write NOTHING: the next row starts there)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)lp, 16, off, 0, 0, 0);
+        }
+    };
+    const bool two_rows = wave + 8 < PR;                // (scalar) rows wave and wave + 8 of the patch
+    auto stage = [&](int n, int by, int buf) {
+        const unsigned rb0 = row_base(n, by, wave), rb1 = two_rows ? row_base(n, by, wave + 8) : OOB;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) stage_one(rb0, wave, j, buf);
+        if (two_rows) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) stage_one(rb1, wave + 8, j, buf);
+        }
+    };
+    // fragment addresses (bytes inside a patch buffer) of item (tap slot j, tile m), 16-channel step 0: the other steps XOR (q << 5)
+    int g_base[MT], g_col[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int g = m * 32 + l31;
+        g_base[m] = (g >> 3) * PC + 4 * (g & 7);
+        g_col[m] = 4 * (g & 7);
+    }
+    auto frag_addr = [&](int j, int m, unsigned base) -> unsigned {
+        const int tp = wave + 8 * j;
+        int kh = tp / KWW, u = tp - kh * KWW;
+        if (tp >= NTAP) kh = 0, u = 0;                  // padding tap: zero weights, any patch pixel
+        const int pp = g_base[m] + kh * PC + u;
+        const int sw = ((g_col[m] + u) >> 2) & 7;
+        return base + (unsigned)(pp * NCH + ((hi ^ sw) << 3)) * 2u;
+    };
+    const int tile2 = t >> 8, rb = (t >> 6) & 3;        // epilogue thread: tile, register block
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bq[k] = a.bias[8 * rb + 4 * hi + k];
+    }
+
+    // XCD-aware walk: workgroup w runs on XCD w % 8 (round-robin dispatch).  Each XCD owns a contiguous eighth of the IMAGES; each of its
+    // workgroups walks block COLUMNS of them top to bottom, one after the other.  The 6 halo rows a block shares with the block below are
+    // then re-read a few microseconds later by the same CU, the halo columns by a neighbour CU of the same XCD: both from that XCD's L2.
+    // (With blk = w + k * grid the vertical neighbour ran on another XCD and every halo row came from HBM / MALL again: 2.2x the tensor.)
+    const int xcd = blockIdx.x & 7, slot = (int)blockIdx.x >> 3, per_x = (int)gridDim.x >> 3;
+    const int imgs = (a.B + 7) >> 3, n_first = xcd * imgs, n_imgs = min(imgs, a.B - n_first);
+    const int ncols = n_imgs > 0 ? n_imgs * a.blocks_x : 0;      // block columns of this XCD
+    // step k of this workgroup: column slot + per_x * (k / blocks_y), block row k % blocks_y
+    auto locate = [&](int k, int& n, int& by, int& bx) -> bool {
+        const int col = slot + per_x * (k / a.blocks_y);
+        by = k % a.blocks_y;
+        n = n_first + col / a.blocks_x;
+        bx = col % a.blocks_x;
+        return col < ncols;
+    };
+    int n, by, bx;
+    if (!locate(0, n, by, bx)) return;
+    int bx_terms = bx;
+    column_terms(bx);
+    stage(n, by, 0);
+    int cur = 0;
+    for (int k = 0;; ++k, cur ^= 1) {
+        if (!locate(k, n, by, bx)) break;
+        int n2, by2, bx2;
+        const bool more = locate(k + 1, n2, by2, bx2);
+        const int oy0 = by * NB_ROWS, gx0 = bx * NB_GROUPS;
+        NRW_PROBE(0);
+        if (!(DBG & 16) || k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's patch (own share); the first time, the filter taps
+        __builtin_amdgcn_s_barrier();                                 // ... everyone's share; the other buffer's exchange is fully read
+        NRW_PROBE(1);
+        if (more) {
+            if (bx2 != bx_terms) {                                    // (the walk entered another block column: once per blocks_y blocks)
+                bx_terms = bx2;
+                column_terms(bx2);
+            }
+            stage(n2, by2, cur ^ 1);
+        }
+        NRW_PROBE(2);
+        const unsigned pbase = lds0 + (unsigned)cur * (PBUF * 2u);
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        // 72 fragment reads per block, a ring of four registers, three reads ahead of the MFMA that consumes them
+        constexpr int NRD = NITEM * 4, AHEAD = 3;
+        bf16x8 fr[AHEAD + 1];
+        unsigned ad_item = frag_addr(0, 0, pbase);
+        nrw_for<AHEAD>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            bf16x8& dst = fr[k];                          // (asm operands inside a generic lambda: through local names)
+            const unsigned adr = ad_item ^ (unsigned)(k << 5);
+            NRW_DSR(dst, adr);
+        });
+        unsigned ad_next = ad_item;
+        nrw_for<NRD>([&](auto K) {                       // (compile-time indices: the filter taps and the ring must stay registers)
+            constexpr int k = decltype(K)::value;
+            constexpr int it = k / 4, q = k % 4, j = it / MT, m = it % MT, kn = k + AHEAD;
+            if constexpr (kn < NRD) {
+                if constexpr (kn % 4 == 0) ad_next = frag_addr((kn / 4) / MT, (kn / 4) % MT, pbase);
+                bf16x8& dst = fr[kn % (AHEAD + 1)];
+                const unsigned adr = ad_next ^ (unsigned)((kn % 4) << 5);
+                NRW_DSR(dst, adr);
+            }
+            bf16x8& fa = fr[k % (AHEAD + 1)];
+            if constexpr (kn < NRD) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa));
+            else if constexpr (NRD - 1 - k == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa));
+            else if constexpr (NRD - 1 - k == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa));
+            if constexpr (DBG & 1) asm volatile("" ::"v"(fa));
+            else acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[j][q], fa, acc[m], 0, 0, 0);      // D[column][group]
+        });
+        if constexpr (DBG & 8) {                        // (ablation: no exchange)
+            if (wave == 0 && k == 0) a.y[(size_t)blockIdx.x * 64 + lane] = (bf16)(acc[0][lane & 15] + acc[1][lane & 15]);
+            continue;
+        }
+
+        // ---- the 8 partial sums meet in the patch buffer just consumed ---------------------------------------------------------
+        // (asm LDS stores and loads, like the fragment reads: as compiler-visible LDS accesses they would be made to wait for the next block's
+        // patch -- vmcnt(0) -- which then could no longer land behind the exchange and the epilogue, only behind the tap loop)
+        // (the MFMA results feed asm statements: the wait states between a matrix instruction and a reader of its result, which the
+        // compiler inserts for instructions it knows, are spelled out -- 8-pass MFMA -> LDS data operand: 18)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+        NRW_PROBE(3);
+        __builtin_amdgcn_s_barrier();
+        NRW_PROBE(4);                   // every wave is past its fragment reads of this buffer (lgkmcnt(0) above).  A bare
+                                                        // barrier: __syncthreads() carries a fence that waits for the DMA in flight
+        {
+            const unsigned wad = pbase + (unsigned)(wave * 2 * 16 * 64 + lane) * 4u;      // [wave][tile][reg][lane] floats
+            nrw_for<16>([&](auto I) {                   // two registers per store, 256 bytes (one register row) apart
+                constexpr int i = 2 * decltype(I)::value;
+                const float v0 = acc[i / 16][i % 16], v1 = acc[i / 16][i % 16 + 1];
+                const unsigned adr = wad;
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(adr), "v"(v0), "v"(v1), "i"(i), "i"(i + 1));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        NRW_PROBE(5);
+        __builtin_amdgcn_s_barrier();
+        NRW_PROBE(6);
+        float v[4];
+        {
+            // thread (tile2, rb, lane): registers 4 rb + k of the eight waves' tile `tile2`; wave w8's copy is 32 register rows further on
+            const unsigned rad = pbase + (unsigned)((tile2 * 16 + 4 * rb) * 64 + lane) * 4u;
+            f32x2 pv[4][4];                             // [k][pair of waves]
+            nrw_for<16>([&](auto I) {
+                constexpr int k = decltype(I)::value / 4, pr2 = decltype(I)::value % 4;
+                f32x2& dst = pv[k][pr2];
+                const unsigned adr = rad;
+                asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(adr), "i"(2 * pr2 * 32 + k), "i"((2 * pr2 + 1) * 32 + k));
+            });
+            nrw_for<4>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                f32x2 (&p4)[4] = pv[k];
+                if constexpr (k == 0) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(p4[0]), "+v"(p4[1]), "+v"(p4[2]), "+v"(p4[3]));
+                else if constexpr (k == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(p4[0]), "+v"(p4[1]), "+v"(p4[2]), "+v"(p4[3]));
+                else if constexpr (k == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(p4[0]), "+v"(p4[1]), "+v"(p4[2]), "+v"(p4[3]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p4[0]), "+v"(p4[1]), "+v"(p4[2]), "+v"(p4[3]));
+                float sum = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) sum = (sum + p4[w2][0]) + p4[w2][1];             // waves 0..7 in order
+                v[k] = sum;
+            });
+        }
+        NRW_PROBE(7);
+        const int g = tile2 * 32 + l31;
+        const int oy = oy0 + (g >> 3), gx = gx0 + (g & 7);
+        if (oy < a.OH && gx < a.OWg) {
+            const int c0 = 8 * rb + 4 * hi;
+            if (a.act == DWC_ACT_HEADS8) {
+                // tanh on planes 0..2, sigmoid on plane 3, planes 4..7 zero -- for a bf16 result (relative 4e-3): tanh x = 2 sigmoid(2x) - 1
+                // on the hardware exp2 / rcp (absolute 2e-7), the odd cubic below 1/16 where that form cancels (relative 2e-6).  The
+                // library tanhf / expf / IEEE division of dwc_act_apply were 1.0 of the 10.3 thousand cycles of a block.
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float x = v[k] + bq[k];
+                    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(k < 3 ? -2.f * x : -x));
+                    const float th = fabsf(x) < 0.0625f ? x * (1.f - x * x * 0.33333334f) : 2.f * sg - 1.f;
+                    v[k] = hi ? 0.f : (k < 3 ? th : sg);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k] + bq[k], a.act, c0 + k);
+            }
+            bf16x4 o;
+            o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+            *reinterpret_cast<bf16x4*>(a.y + ((size_t)(n * a.OH + oy) * a.OWg + gx) * 32 + c0) = o;
+        }
+        NRW_PROBE(8);
+#if defined(DWC_DEV_ABLATIONS) && defined(DWC_NARROW_DBG)
+        if constexpr ((DBG & 32) != 0) {
+            if (blockIdx.x == 8 && t == 0 && (k == 6 || k == 7 || k == 20))
+                printf("k %d: wait %lld barrier %lld stage %lld taps %lld bar %lld xwrite %lld bar %lld xread %lld epilogue %lld | whole %lld\n", k,
+                       probe[1] - probe[0], 0ll, probe[2] - probe[1], probe[3] - probe[2], probe[4] - probe[3], probe[5] - probe[4],
+                       probe[6] - probe[5], probe[7] - probe[6], probe[8] - probe[7], probe[8] - probe[0]);
+        }
+#endif
     }
 #endif
 }
@@ -626,7 +945,21 @@ int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias3
     a.B = B; a.IH = IH; a.IW = IW; a.OH = OH; a.OWg = OWg;
     a.off_h = off_h; a.off_w = off_w; a.act = act; a.reflect = reflect;
     a.blocks_x = (OWg + NB_GROUPS - 1) / NB_GROUPS; a.blocks_y = (OH + 7) / 8;      // (8-row blocks; 16-row blocks measured equal, not instantiated)
-    hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(a.blocks_x * a.blocks_y * B), dim3(512), 0, (hipStream_t)stream, a);
+    const int nblocks = a.blocks_x * a.blocks_y * B;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const char* e = getenv("DWC_NARROW_PERSIST");       // (read per call: tests / A-B runs switch it between launches)
+    const int persist = e ? atoi(e) : 1;
+    // (r06) one persistent workgroup per CU where every workgroup of an XCD gets at least two block columns of that XCD's images
+    // (B >= 128 at 128 x 128); shorter launches keep the block-per-workgroup form
+    if (persist && cus >= 8 && ((B + 7) / 8) * a.blocks_x >= 2 * (cus / 8))
+        hipLaunchKernelGGL((conv_narrow_persist_kernel<7, 10>), dim3(cus & ~7), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, a);
     DWC_LAUNCH_CHECK();
     return DWC_OK;
 }

@@ -249,3 +249,35 @@ def test_bf16_forward_passes_b128_vs_oracle_chunks():
         print("B=128 forward vs fp32 oracle (worst, mean, worst per-sample mean; relative to max|ref|):", report)
     finally:
         host.set_noise(host.DeviceNoise())
+
+
+def test_bf16_narrow_persistent_form_equals_block_form(monkeypatch):
+    """conv_narrow_persist_kernel (r06: one workgroup per CU walks block columns, filter taps in registers, next patch by LDS-DMA behind
+    the tap loop) against the block-per-workgroup kernel it replaces at B >= 128, on the same operands: the image gradient of a 7x7
+    stem (no activation, same summation order) bit for bit, the tanh / sigmoid heads within one bf16 step (hardware exp2 / rcp there)."""
+    B, C, H = 128, 64, 128
+    g = torch.Generator().manual_seed(77)
+    x = _gpu_randn((B, C, H, H), 5).to(BF).contiguous(memory_format=torch.channels_last)
+    w8 = torch.cat([torch.randn(4, C, 7, 7, generator=g) * (1.0 / (C * 49) ** 0.5), torch.zeros(4, C, 7, 7)], 0).to(DEV)
+    b8 = torch.cat([torch.randn(4, generator=g) * 0.1, torch.zeros(4)]).to(DEV)
+    img = _gpu_randn((B, 8, H, H), 6)
+    img[:, 3:] = 0
+    img = img.to(BF).contiguous(memory_format=torch.channels_last)
+    ws = (torch.randn(64, 3, 7, 7, generator=g) * 0.05).to(DEV)
+    gz = _gpu_randn((B, 64, H, H), 7).to(BF).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("DWC_NARROW_PERSIST", form)
+        with torch.no_grad():
+            y = ops.conv2d_heads(x, w8, b8).float()
+        xi = img.clone().requires_grad_(True)
+        ops.conv2d(xi, ws, None, 1, 3, "none").backward(gz)
+        res[form] = (y, xi.grad.float())
+    y0, dx0 = res["0"]
+    y1, dx1 = res["1"]
+    assert torch.equal(dx0, dx1), "image gradient: persistent vs block form"
+    assert float(y1[:, 4:].abs().max()) == 0.0
+    d = (y0 - y1).abs()
+    step = y0.abs().clamp_min(2.0 ** -126) * 2.0 ** -7          # one bf16 step at the value's magnitude (8 bits of significand)
+    assert bool((d <= step).all()), ("heads: more than one bf16 step apart", float((d / step).max()))
+    print("heads: %.4f %% of the values differ by one bf16 step" % (100.0 * float((d > 0).float().mean())))
