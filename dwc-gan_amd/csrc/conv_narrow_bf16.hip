@@ -39,6 +39,20 @@ struct NarrowArgs {
     // (timing-only ablations: -DDWC_DEV_ABLATIONS -DDWC_NARROW_DBG=<bits>: 1 no MFMA, 2 no fragment reads, 4 no patch staging, 8 no reduction)
 };
 
+// tanh on planes 0..2, sigmoid on plane 3, planes 4..7 zero (DWC_ACT_HEADS8) for a bf16 RESULT (relative 4e-3): tanh x = 2 sigmoid(2x) - 1 on
+// the hardware exp2 / rcp (absolute 2e-7), the odd cubic below 1/16 where that form cancels (relative 2e-6).  The library tanhf / expf /
+// IEEE division of dwc_act_apply were 1.0 of the 10.3 thousand cycles a 256-pixel block took (r06, shader-clock probes).  v: the four
+// values of planes 4 hi .. 4 hi + 3 of one pixel, bias added.
+__device__ __forceinline__ void narrow_heads8_bf16(float (&v)[4], int hi) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x = v[k];
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(k < 3 ? -2.f * x : -x));
+        const float th = fabsf(x) < 0.0625f ? x * (1.f - x * x * 0.33333334f) : 2.f * sg - 1.f;
+        v[k] = hi ? 0.f : (k < 3 ? th : sg);
+    }
+}
+
 // NB_ROWS = 8: 73.5 KB of LDS and <= 128 registers, so TWO workgroups share a CU and one's patch staging / reduction runs beside
 // the other's tap loop (16 rows, one workgroup per CU: 14.5 us per 512-pixel block, most of it exposed staging latency).
 template <int KH, int KWW, int NB_ROWS>
@@ -191,8 +205,12 @@ __global__ __launch_bounds__(512, NB_ROWS == 8 ? 2 : 1) void conv_narrow_kernel(
         if (oy < a.OH && gx < a.OWg) {
             const int c0 = 8 * rb + 4 * hi;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = dwc_act_apply(v[k] + bq[k], a.act, c0 + k);
+            for (int k = 0; k < 4; ++k) v[k] += bq[k];
+            if (a.act == DWC_ACT_HEADS8) {
+                narrow_heads8_bf16(v, hi);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], a.act, c0 + k);
             }
             bf16x4 o;
             o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
@@ -475,20 +493,13 @@ __global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs 
         const int oy = oy0 + (g >> 3), gx = gx0 + (g & 7);
         if (oy < a.OH && gx < a.OWg) {
             const int c0 = 8 * rb + 4 * hi;
-            if (a.act == DWC_ACT_HEADS8) {
-                // tanh on planes 0..2, sigmoid on plane 3, planes 4..7 zero -- for a bf16 result (relative 4e-3): tanh x = 2 sigmoid(2x) - 1
-                // on the hardware exp2 / rcp (absolute 2e-7), the odd cubic below 1/16 where that form cancels (relative 2e-6).  The
-                // library tanhf / expf / IEEE division of dwc_act_apply were 1.0 of the 10.3 thousand cycles of a block.
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float x = v[k] + bq[k];
-                    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(k < 3 ? -2.f * x : -x));
-                    const float th = fabsf(x) < 0.0625f ? x * (1.f - x * x * 0.33333334f) : 2.f * sg - 1.f;
-                    v[k] = hi ? 0.f : (k < 3 ? th : sg);
-                }
+            for (int k = 0; k < 4; ++k) v[k] += bq[k];
+            if (a.act == DWC_ACT_HEADS8) {
+                narrow_heads8_bf16(v, hi);
             } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k] + bq[k], a.act, c0 + k);
+                for (int k = 0; k < 4; ++k) v[k] = dwc_act_apply(v[k], a.act, c0 + k);
             }
             bf16x4 o;
             o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
@@ -954,9 +965,11 @@ int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias3
     }
     const char* e = getenv("DWC_NARROW_PERSIST");       // (read per call: tests / A-B runs switch it between launches)
     const int persist = e ? atoi(e) : 1;
-    // (r06) one persistent workgroup per CU where every workgroup of an XCD gets at least two block columns of that XCD's images
-    // (B >= 128 at 128 x 128); shorter launches keep the block-per-workgroup form
-    if (persist && cus >= 8 && ((B + 7) / 8) * a.blocks_x >= 2 * (cus / 8))
+    // (r06) one persistent workgroup per CU where the block columns of an XCD's images fill the rounds of its workgroups to >= 85 %
+    // (128 x 128: B = 64, 128, 192, 256, 384 ... fill them exactly); other launches keep the block-per-workgroup form
+    const int ncols = ((B + 7) / 8) * a.blocks_x, per_x = cus / 8;
+    const int rounds = per_x > 0 ? (ncols + per_x - 1) / per_x : 0;
+    if (persist && per_x > 0 && ncols >= per_x && 100 * ncols >= 85 * rounds * per_x)
         hipLaunchKernelGGL((conv_narrow_persist_kernel<7, 10>), dim3(cus & ~7), dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((conv_narrow_kernel<7, 10, 8>), dim3(nblocks), dim3(512), 0, (hipStream_t)stream, a);
