@@ -89,8 +89,8 @@ KIND_KERNEL = {
     "wgrad-halo": ("wgrad_halo_kernel<{k}>", r"wgrad_halo_kernel<{k}, ", "bf16"),
     "fwd-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),
     "dgrad-heads-stem": ("conv_stem_kernel", r"conv_stem_kernel", "bf16"),
-    "fwd-heads-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
-    "dgrad-image-narrow": ("conv_narrow_kernel", r"conv_narrow_kernel", "bf16"),
+    "fwd-heads-narrow": ("conv_narrow_kernel", r"conv_narrow(_persist)?_kernel", "bf16"),
+    "dgrad-image-narrow": ("conv_narrow_kernel", r"conv_narrow(_persist)?_kernel", "bf16"),
     "wgrad-stem": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
     "wgrad-heads-small": ("smallk_wgrad_kernel", r"smallk_wgrad_kernel", "bf16"),
     "wgrad-stem-x3": ("smallk_wgrad_x3_kernel", r"smallk_wgrad_x3_kernel", "bf16x3"),

@@ -16,7 +16,7 @@ f = glob.glob('/tmp/psq_$CFG/**/*counter_collection.csv', recursive=True)
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(f[0])):
     k = r['Kernel_Name']
-    m = re.search(r'(conv_halo16_kernel|wgrad_halo_kernel|conv_halo_x3_kernel|wgrad_x3_kernel|conv_narrow_kernel|conv_stem_kernel|smallk_wgrad_kernel|gemm_kernel_h|conv_gemm_kernel)(<[^>]*>)?', k)
+    m = re.search(r'(conv_halo16_kernel|wgrad_halo_kernel|conv_halo_x3_kernel|wgrad_x3_kernel|conv_narrow_kernel|conv_narrow_persist_kernel|conv_stem_kernel|smallk_wgrad_kernel|gemm_kernel_h|conv_gemm_kernel)(<[^>]*>)?', k)
     if not m:
         continue
     key = "%s%s grid %s wg %s" % (m.group(1), m.group(2) or "", r['Grid_Size'], r['Workgroup_Size'])
