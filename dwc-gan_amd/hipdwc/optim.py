@@ -46,6 +46,7 @@ class FusedAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._maps = {}
+        self._host = {}        # group index -> host-side tables of step() (_host_tables)
         self._zeros = {}       # device -> a zero vector that stands in for the gradient of `_dwc_zero_grad` parameters
 
     def _zero_grad_for(self, p):
@@ -58,6 +59,39 @@ class FusedAdam(torch.optim.Adam):
             z = torch.zeros(max(4096, p.numel()), dtype=torch.float32, device=p.device)
             self._zeros[p.device] = z
         return z
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._host = {}            # step counts and moment pointers are re-read from the loaded state
+
+    def _host_tables(self, gi, params):
+        """Per group, built once (and again when the parameter list or a loaded state changes it): the descriptor array with the constant
+        fields filled in, the step counts as a numpy vector mirroring ``state[p]['step']``, the element counts.  step() used to do all of
+        this per parameter and call in Python -- ~1 ms per call for G's ~130 tensors, at a moment when the GPU has just drained the
+        backward's last small kernels and sits idle (r06, `benchmarks/gpu_idle_gaps.py`: an 850 us gap per iteration in front of the
+        descriptor upload)."""
+        key = tuple(p.data_ptr() for p in params)
+        ent = self._host.get(gi)
+        if ent is not None and ent["key"] == key:
+            return ent
+        desc = np.zeros(len(params), dtype=_ADAM_DT)
+        steps = np.zeros(len(params), dtype=np.float64)
+        for i, p in enumerate(params):
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            if not p.is_contiguous():
+                raise RuntimeError("FusedAdam expects contiguous parameters")
+            desc[i]["p"], desc[i]["m"], desc[i]["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            desc[i]["n"] = p.numel()
+            steps[i] = float(st["step"])
+        ent = {"key": key, "desc": desc, "steps": steps, "numel": desc["n"].astype(np.int64),
+               "step_tensors": [self.state[p]["step"] for p in params],
+               "flagged": np.array([bool(getattr(p, "_dwc_zero_grad", False)) for p in params])}
+        self._host[gi] = ent
+        return ent
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -72,44 +106,45 @@ class FusedAdam(torch.optim.Adam):
             if not params[0].is_cuda:
                 raise RuntimeError("FusedAdam needs device parameters: the product path has no CPU fallback")
             b1, b2 = group["betas"]
-            desc = np.zeros(len(params), dtype=_ADAM_DT)
+            tab = self._host_tables(gi, params)
+            desc = tab["desc"].copy()
             keep = []          # keeps contiguous gradient copies alive until the launch is queued
+            gptr = np.zeros(len(params), dtype=np.uint64)
+            flagged = tab["flagged"]
             for i, p in enumerate(params):
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                if not p.is_contiguous():
-                    raise RuntimeError("FusedAdam expects contiguous parameters")
-                desc[i]["p"], desc[i]["m"], desc[i]["v"] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                desc[i]["n"] = p.numel()
                 g = p.grad
-                if g is None and getattr(p, "_dwc_zero_grad", False):
-                    g = self._zero_grad_for(p)
                 if g is None:
-                    continue                                  # g stays NULL: tensor skipped, step not advanced
-                if g.dtype != torch.float32 or not g.is_contiguous():
+                    if not flagged[i]:
+                        if getattr(p, "_dwc_zero_grad", False):          # (flag set after the tables were built: first iteration)
+                            flagged[i] = True
+                        else:
+                            continue                                      # g stays NULL: tensor skipped, step not advanced
+                    g = self._zero_grad_for(p)
+                elif g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.to(torch.float32).contiguous()
                     keep.append(g)
-                st["step"] += 1
-                t = float(st["step"])
-                desc[i]["g"] = g.data_ptr()
-                desc[i]["step_size"] = group["lr"] / (1.0 - b1 ** t)
-                desc[i]["bc2_sqrt"] = math.sqrt(1.0 - b2 ** t)
+                gptr[i] = g.data_ptr()
+            has = gptr != 0
+            steps = tab["steps"]
+            steps[has] += 1.0
+            torch._foreach_add_([t for t, h in zip(tab["step_tensors"], has) if h], 1.0)      # state_dict()'s view of the counts
+            t = np.where(has, steps, 1.0)
+            desc["g"] = gptr
+            desc["step_size"] = np.where(has, group["lr"] / (1.0 - np.power(b1, t)), 0.0)
+            desc["bc2_sqrt"] = np.where(has, np.sqrt(1.0 - np.power(b2, t)), 0.0)
             maps = self._maps.get(gi)
-            if maps is None or maps[3] != [p.numel() for p in params]:
-                sizes = [p.numel() for p in params]
+            if maps is None or maps[4] != tab["key"]:
+                sizes = [int(n) for n in tab["numel"]]
                 tid, start, n = _chunk_maps(sizes, dev)
-                maps = (tid, start, n, sizes)
+                maps = (tid, start, n, sizes, tab["key"])
                 self._maps[gi] = maps
             ddev = _to_device_bytes(desc, dev)
             _lib.check(lib.dwc_adam_multi(ddev.data_ptr(), maps[0].data_ptr(), maps[1].data_ptr(), maps[2], b1, b2,
                                           group["eps"], group["weight_decay"], _ops._stream()),
                        "adam_multi")
             del keep
-            stepped = [p for p in params if p.grad is not None or getattr(p, "_dwc_zero_grad", False)]
-            _ops._hbm("adam_multi", 28 * sum(p.numel() for p in stepped))                              # p, g, m, v read; p, m, v written
+            stepped = [p for p, h in zip(params, has) if h]
+            _ops._hbm("adam_multi", 28 * int(tab["numel"][has].sum()))                                # p, g, m, v read; p, m, v written
             # the kernel wrote through raw pointers: tell autograd (and the prepared-weight cache in
             # hipdwc.ops, which keys on the version counter) that these tensors changed
             touched = stepped
