@@ -584,7 +584,11 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
  * rule; dwc_bf16_conv2d_bwd_data_image_narrow = that + the reflect fold).  Patch staged once per 16x32-pixel block, taps dealt
  * to the waves, weight fragments straight from L2 in fragment order w_frag[tap][q][hi][row][8] (the [32][Kp] layout of
  * dwc_bf16_weight_prepare_fwd permuted by the caller; r04: the tap count rounded up to a multiple of 8 with ZERO taps, 72 for
- * KH x KWW = 7 x 10, so that every wave walks the same number of taps).  y: [B][OH][OWg][32] bf16. */
+ * KH x KWW = 7 x 10, so that every wave walks the same number of taps).  y: [B][OH][OWg][32] bf16.
+ * r06: where the block columns of the images fill the rounds of one workgroup per CU (B = 64, 128, 192 ... at 128 x 128) the
+ * launch is ONE persistent workgroup per CU (filter taps in registers, the next block's patch by LDS-DMA behind the tap loop,
+ * XCD-aware walk down block columns); same results bit for bit.  DWC_ACT_HEADS8 rounds tanh / sigmoid for the bf16 result from
+ * the hardware exp2 / rcp (absolute 2e-7).  DWC_NARROW_PERSIST=0 (environment, read per call) keeps the block-per-workgroup form. */
 int dwc_bf16_conv2d_narrow_ok(int B, int IH, int IW, int Cin, int OH, int OWg, int KH, int KWW);
 int dwc_bf16_conv2d_narrow(const void* x, const void* w_frag, const float* bias32, void* y, int B, int IH, int IW, int Cin, int OH,
                            int OWg, int KH, int KWW, int off_h, int off_w, int act, int reflect, void* stream);
