@@ -613,16 +613,27 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
             bvs[c][q4] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c * 32 + 8 * q4 + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int buf = 0;
+#if defined(DWC_DEV_ABLATIONS) && defined(DWC_STEM_DBG)
+    long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int kiter = 0;
+#define STEM_PROBE(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); probe[i] = (long long)clock64(); } while (0)
+#else
+#define STEM_PROBE(i) do { } while (0)
+#endif
     for (int blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
         int bid = blk;
         const int bx = bid % a.blocks_x;
         bid /= a.blocks_x;
         const int by = bid % a.blocks_y, n = bid / a.blocks_y;
         const int oy0 = by * 16, ox0 = bx * 16;
+        STEM_PROBE(0);
         __syncthreads();                                              // every wave is past the previous block's reads
+        STEM_PROBE(1);
         stage_patch(blk, 0);
+        STEM_PROBE(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this block's patch (and, the first time, the filter)
         __syncthreads();
+        STEM_PROBE(3);
         const bf16* p = sP + buf * P_EL;
 
         f32x16 acc[2][2];
@@ -647,8 +658,24 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[c], fa[i], acc[i][c], 0, 0, 0);
         }
+        STEM_PROBE(4);
         // ---- epilogue: D[channel][pixel]: lane = pixel, 4 consecutive channels per register quad -> LDS -> 16-byte chunks,
         // 128 pixels (the tiles of two waves) per phase -----------------------------------------------------------------------
+        // (bias, activation and rounding by ALL four waves at once, results packed in registers: the staging buffer holds 128 pixels, so the
+        // waves write it in two turns -- and with the arithmetic inside the turn, 2 300 cycles of vector work per turn by the shader-clock
+        // probes, the other pair of waves stood at the barrier for it: 4 600 of a block's 13 000 cycles.  r06.)
+        bf16x4 packed[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v = {acc[i][c][4 * q4], acc[i][c][4 * q4 + 1], acc[i][c][4 * q4 + 2], acc[i][c][4 * q4 + 3]};
+                    v += bvs[c][q4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) packed[i][c][q4][k] = (bf16)dwc_act_simple(v[k], slope);
+                }
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             if ((wm >> 1) == ph) {
@@ -658,18 +685,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const int col = c * 32 + 8 * q4 + 4 * hi;
-                            f32x4 v = {acc[i][c][4 * q4], acc[i][c][4 * q4 + 1], acc[i][c][4 * q4 + 2], acc[i][c][4 * q4 + 3]};
-                            v += bvs[c][q4];
-                            bf16x4 o;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) o[k] = (bf16)dwc_act_simple(v[k], slope);
-                            *reinterpret_cast<bf16x4*>(sC + row * LDC + col) = o;
-                        }
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            *reinterpret_cast<bf16x4*>(sC + row * LDC + c * 32 + 8 * q4 + 4 * hi) = packed[i][c][q4];
                 }
             }
+            if (ph == 0) STEM_PROBE(6);
             __syncthreads();
+            if (ph == 0) STEM_PROBE(7);
             for (int idx = t; idx < 128 * 8; idx += 256) {
                 const int row = idx >> 3, ch = idx & 7;
                 const int pb = ph * 128 + row;
@@ -686,6 +708,13 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(StemArgs a) {
             }
             if (ph == 0) __syncthreads();
         }
+        STEM_PROBE(5);
+#if defined(DWC_DEV_ABLATIONS) && defined(DWC_STEM_DBG)
+        if (blockIdx.x == 9 && t == 0 && (kiter == 5 || kiter == 6 || kiter == 12))
+            printf("stem k %d: barrier %lld stage-issue %lld patch-wait %lld taps %lld epilogue %lld (phase-0 convert+write %lld, barrier %lld, rest %lld) | whole %lld\n", kiter, probe[1] - probe[0],
+                   probe[2] - probe[1], probe[3] - probe[2], probe[4] - probe[3], probe[5] - probe[4], probe[6] - probe[4], probe[7] - probe[6], probe[5] - probe[7], probe[5] - probe[0]);
+        ++kiter;
+#endif
     }
 #endif
 }
