@@ -76,7 +76,12 @@ struct WgradHaloArgs {
 // PROBE (the round-3 laboratory benchmarks/halo_lab.hip, removed in round 5, instantiated it): s_memtime stamps of wave 0 -- start / first unit staged / loop done / slabs stored.
 // DBG (timing only, results wrong; lab and -DDWC_DEV_ABLATIONS builds): 1 no MFMA, 2 no fragment reads, 4 no staging in the
 // loop, 8 no wait + barrier per unit.
-template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 0>
+// HALF (r06): the next unit's staging pieces are issued by ONE half of the waves (waves 0-3 for odd units, 4-7 for even ones: a wave and
+// its SIMD partner are in different halves), each covering its partner's share too.  A wave issuing LDS-DMA instructions is held by the
+// vector-memory path for ~140 cycles per instruction when all eight waves issue at once (7 pieces per thread and unit: ~1 100 cycles per unit
+// with no MFMA running, by the probes of conv_narrow_persist_kernel); with one half issuing, the other half's MFMAs run meanwhile.  Worth
+// 3-4 % on the 5x5 form (LDS read bandwidth still bounds it), nothing on the stride-2 one: instantiated for KS == 5 only.
+template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 0, int HALF = 0>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsigned long long* probe = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long stamp[4] = {0, 0, 0, 0};
@@ -140,8 +145,13 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     // staging of one unit = PPASS + D_PASSES LDS-DMA pieces per thread; their global offsets first (unit_offsets), the pieces
     // themselves one at a time (dma_piece) so the main loop can place them between the MFMAs of successive patch rows
     constexpr int NPIECE = PPASS + D_PASSES;
-    unsigned s_off[NPIECE];
-    auto unit_offsets = [&](int u) {
+    unsigned s_off_all[HALF ? 2 : 1][NPIECE];           // [own share / the SIMD partner's share]
+    typedef std::integral_constant<int, 0> Own;
+    typedef std::integral_constant<int, 1> Partner;
+    auto unit_offsets = [&](int u, auto whoc) {
+        constexpr int who = HALF ? decltype(whoc)::value : 0;
+        const int t = who ? (int)(threadIdx.x ^ 256u) : (int)threadIdx.x;      // (who = 1: the thread of wave ^ 4 at this lane)
+        unsigned (&s_off)[NPIECE] = s_off_all[who];
         const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
         const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
         const int y0 = uy * UH, x0 = ux * UW;
@@ -163,14 +173,17 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
             s_off[PPASS + p] = (pix * a.N + tn * BN + lc * 8) * 2u;
         }
     };
-    auto dma_piece = [&](auto ic, int buf) {
+    auto dma_piece = [&](auto ic, int buf, auto whoc) {
         constexpr int i = decltype(ic)::value;
+        constexpr int who = HALF ? decltype(whoc)::value : 0;
+        const int wv = who ? (wave ^ 4) : wave;
+        const unsigned off = s_off_all[who][i < NPIECE ? i : 0];
         if constexpr (i < PPASS)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sP + buf * P_TILE + wave * 512 + i * P_RPP * CIW),
-                                                     16, s_off[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sP + buf * P_TILE + wv * 512 + i * P_RPP * CIW),
+                                                     16, off, 0, 0, 0);
         else if constexpr (i < NPIECE)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (__attribute__((address_space(3))) void*)(sD + buf * D_TILE + wave * 512 + (i - PPASS) * D_RPP * BN),
-                                                     16, s_off[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_d, (__attribute__((address_space(3))) void*)(sD + buf * D_TILE + wv * 512 + (i - PPASS) * D_RPP * BN),
+                                                     16, off, 0, 0, 0);
     };
 
     f32x16 acc[NT];
@@ -208,8 +221,8 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     };
 
     if (u0 < u1) {
-        unit_offsets(u0);
-        h16_for<NPIECE>([&](auto ic) { dma_piece(ic, 0); });
+        unit_offsets(u0, Own{});
+        h16_for<NPIECE>([&](auto ic) { dma_piece(ic, 0, Own{}); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if constexpr (PROBE) stamp[1] = __builtin_amdgcn_s_memtime();
@@ -218,9 +231,15 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
             // the next unit's pieces, issued as one burst here (SPREAD, lab only: one piece behind each patch row's MFMAs -- measured
             // 5-30 % slower: the pieces then queue behind a busy LDS instead of in front of it)
             const bool stage_next = u + 1 < u1 && !(DBG & 4);
-            if (stage_next) {
-                unit_offsets(u + 1);
-                if constexpr (!SPREAD) h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1); });
+            if constexpr (HALF) {
+                if (stage_next && (wave >> 2) == ((u - u0) & 1)) {       // (wave-uniform)
+                    unit_offsets(u + 1, Own{});
+                    unit_offsets(u + 1, Partner{});
+                    h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1, Own{}); dma_piece(ic, buf ^ 1, Partner{}); });
+                }
+            } else if (stage_next) {
+                unit_offsets(u + 1, Own{});
+                if constexpr (!SPREAD) h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1, Own{}); });
             }
             const unsigned pbase = lds0 + (unsigned)(buf * P_TILE) * 2u, dbase = lds0 + (unsigned)(2 * P_TILE + buf * D_TILE) * 2u;
             // Fragment reads run PF patch rows ahead of the MFMAs that use them (register rings).
@@ -269,7 +288,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
                 if constexpr (SPREAD) {
                     static_assert(NPIECE <= PH, "one staging piece per patch row");
                     __builtin_amdgcn_sched_barrier(0);
-                    if (stage_next) dma_piece(rc, buf ^ 1);
+                    if (stage_next) dma_piece(rc, buf ^ 1, Own{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -570,9 +589,15 @@ int dwc_bf16_conv2d_wgrad_halo(const void* x, const void* dy, float* dw_oihw, in
     if (K == 3 && dbg == 4) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128, 4>), grid, dim3(512), 0, st, a);
     else
 #endif
+    // (HALF: measured at B=128 on one box, alternating: 5x5 256->128 735 / 739 -> 711 / 704 us, 128->64 742 / 750 -> 733 / 714 us; the
+    // stride-2 form 160 -> 166 us and stays as it was, profiles/r06_wgrad_half_ab.txt.  DWC_WGRAD_HALF=0 restores the all-waves burst.)
+    const char* he = getenv("DWC_WGRAD_HALF");
+    const int half = he ? atoi(he) : 1;
     if (K == 3) hipLaunchKernelGGL((wgrad_halo_kernel<3, 128>), grid, dim3(512), 0, st, a);
     else if (K == 4) hipLaunchKernelGGL((wgrad_halo_kernel<4, 128>), grid, dim3(512), 0, st, a);
+    else if (bn == 128 && half) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128, 0, 0, -1, 0, 1>), grid, dim3(512), 0, st, a);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_halo_kernel<5, 128>), grid, dim3(512), 0, st, a);
+    else if (half) hipLaunchKernelGGL((wgrad_halo_kernel<5, 64, 0, 0, -1, 0, 1>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((wgrad_halo_kernel<5, 64>), grid, dim3(512), 0, st, a);
     DWC_LAUNCH_CHECK();
     const size_t total = (size_t)K * K * Cin * Cout;
