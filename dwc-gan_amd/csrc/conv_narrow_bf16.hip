@@ -253,6 +253,11 @@ __global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs 
     constexpr int PBUF = PPASS * 64 * NCH;              // elements of one patch buffer (73 728 bytes)
     constexpr int RED = 8 * 2 * 16 * 64;                // floats of the exchange: [wave][tile][reg][lane]
     static_assert(RED * 4 <= PBUF * 2 && MT == 2, "the exchange aliases one patch buffer; one round of two tiles");
+#ifdef DWC_NARROW_ALL_STAGE                             // (A/B build: every wave stages its own rows)
+    constexpr bool HALF_STAGE = false;
+#else
+    constexpr bool HALF_STAGE = true;
+#endif
     __shared__ __attribute__((aligned(128))) unsigned char smem_raw[2 * PBUF * 2];
     bf16* sP = reinterpret_cast<bf16*>(smem_raw);
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)smem_raw;
@@ -330,14 +335,14 @@ __global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)lp, 16, off, 0, 0, 0);
         }
     };
-    const bool two_rows = wave + 8 < PR;                // (scalar) rows wave and wave + 8 of the patch
-    auto stage = [&](int n, int by, int buf) {
-        const unsigned rb0 = row_base(n, by, wave), rb1 = two_rows ? row_base(n, by, wave + 8) : OOB;
+    auto stage = [&](int n, int by, int buf, int wv) {  // the rows wave wv stages: wv and wv + 8 (scalar)
+        const bool two_rows = wv + 8 < PR;
+        const unsigned rb0 = row_base(n, by, wv), rb1 = two_rows ? row_base(n, by, wv + 8) : OOB;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) stage_one(rb0, wave, j, buf);
+        for (int j = 0; j < NJ; ++j) stage_one(rb0, wv, j, buf);
         if (two_rows) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) stage_one(rb1, wave + 8, j, buf);
+            for (int j = 0; j < NJ; ++j) stage_one(rb1, wv + 8, j, buf);
         }
     };
     // fragment addresses (bytes inside a patch buffer) of item (tap slot j, tile m), 16-channel step 0: the other steps XOR (q << 5)
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs 
     if (!locate(0, n, by, bx)) return;
     int bx_terms = bx;
     column_terms(bx);
-    stage(n, by, 0);
+    stage(n, by, 0, wave);
     int cur = 0;
     for (int k = 0;; ++k, cur ^= 1) {
         if (!locate(k, n, by, bx)) break;
@@ -398,7 +403,17 @@ __global__ __launch_bounds__(512, 1) void conv_narrow_persist_kernel(NarrowArgs 
                 bx_terms = bx2;
                 column_terms(bx2);
             }
-            stage(n2, by2, cur ^ 1);
+            // ONE half of the waves requests the next patch -- its own rows and its SIMD partner's (wave ^ 4), the halves taking turns --
+            // while the other half is already in the tap loop: a wave issuing LDS-DMA instructions is held ~140 cycles per instruction
+            // when all eight issue at once (the "stage" probe: 1.2-1.8 of a block's 8.6 thousand cycles with no MFMA running).
+            if (HALF_STAGE) {
+                if ((wave >> 2) == (k & 1)) {
+                    stage(n2, by2, cur ^ 1, wave);
+                    stage(n2, by2, cur ^ 1, wave ^ 4);
+                }
+            } else {
+                stage(n2, by2, cur ^ 1, wave);
+            }
         }
         NRW_PROBE(2);
         const unsigned pbase = lds0 + (unsigned)cur * (PBUF * 2u);
