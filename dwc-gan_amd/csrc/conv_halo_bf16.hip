@@ -80,7 +80,8 @@ struct WgradHaloArgs {
 // its SIMD partner are in different halves), each covering its partner's share too.  A wave issuing LDS-DMA instructions is held by the
 // vector-memory path for ~140 cycles per instruction when all eight waves issue at once (7 pieces per thread and unit: ~1 100 cycles per unit
 // with no MFMA running, by the probes of conv_narrow_persist_kernel); with one half issuing, the other half's MFMAs run meanwhile.  Worth
-// 3-4 % on the 5x5 form (LDS read bandwidth still bounds it), nothing on the stride-2 one: instantiated for KS == 5 only.
+// 3-4 % on the 5x5 form (LDS read bandwidth still bounds it), nothing on the stride-2 one, and the 3x3 form has no register left for
+// it (256 in use: 11 spilled, 166 -> 179 us): instantiated for KS == 5 only.
 template <int KS, int BN, int DBG = 0, int PROBE = 0, int PFT = -1, int SPREAD = 0, int HALF = 0>
 __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsigned long long* probe = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -145,13 +146,13 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
     // staging of one unit = PPASS + D_PASSES LDS-DMA pieces per thread; their global offsets first (unit_offsets), the pieces
     // themselves one at a time (dma_piece) so the main loop can place them between the MFMAs of successive patch rows
     constexpr int NPIECE = PPASS + D_PASSES;
-    unsigned s_off_all[HALF ? 2 : 1][NPIECE];           // [own share / the SIMD partner's share]
+    unsigned s_off_all[1][NPIECE];                      // (HALF: the own share's offsets, then -- once those pieces are issued -- the partner's)
     typedef std::integral_constant<int, 0> Own;
     typedef std::integral_constant<int, 1> Partner;
     auto unit_offsets = [&](int u, auto whoc) {
         constexpr int who = HALF ? decltype(whoc)::value : 0;
         const int t = who ? (int)(threadIdx.x ^ 256u) : (int)threadIdx.x;      // (who = 1: the thread of wave ^ 4 at this lane)
-        unsigned (&s_off)[NPIECE] = s_off_all[who];
+        unsigned (&s_off)[NPIECE] = s_off_all[0];
         const int n = u / a.units_per_img, ur = u - n * a.units_per_img;
         const int uy = ur / a.units_x, ux = ur - uy * a.units_x;
         const int y0 = uy * UH, x0 = ux * UW;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
         constexpr int i = decltype(ic)::value;
         constexpr int who = HALF ? decltype(whoc)::value : 0;
         const int wv = who ? (wave ^ 4) : wave;
-        const unsigned off = s_off_all[who][i < NPIECE ? i : 0];
+        const unsigned off = s_off_all[0][i < NPIECE ? i : 0];
         if constexpr (i < PPASS)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(sP + buf * P_TILE + wv * 512 + i * P_RPP * CIW),
                                                      16, off, 0, 0, 0);
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(512) void wgrad_halo_kernel(WgradHaloArgs a, unsign
             if constexpr (HALF) {
                 if (stage_next && (wave >> 2) == ((u - u0) & 1)) {       // (wave-uniform)
                     unit_offsets(u + 1, Own{});
+                    h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1, Own{}); });
                     unit_offsets(u + 1, Partner{});
-                    h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1, Own{}); dma_piece(ic, buf ^ 1, Partner{}); });
+                    h16_for<NPIECE>([&](auto ic) { dma_piece(ic, buf ^ 1, Partner{}); });
                 }
             } else if (stage_next) {
                 unit_offsets(u + 1, Own{});
